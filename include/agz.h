@@ -1,0 +1,227 @@
+/*
+ * agz.h — C ABI of libagz.so: the MI355X-native replacement for agogo's self-play hot path.
+ *
+ * Everything here is plain C (opaque handles, plain pointers and sizes, int error codes); no C++
+ * or torch types cross this boundary.  Each entry point cites the reference interface it
+ * replaces (paths are relative to the gorgonia/agogo tree).  The cgo binding a maintainer would
+ * add on the reference side is in INTEGRATION.md / go/agzhip.
+ *
+ * Threading: an agz_ctx owns one HIP device + one stream and is NOT thread-safe (reference:
+ * under `-tags cuda` agogo serialises on a single VM, const_cuda.go:5).  Drive one ctx from one
+ * OS thread (Go: runtime.LockOSThread); different ctxs may be driven concurrently.
+ *
+ * Ownership: the caller allocates every output buffer; the library never returns interior
+ * pointers (the reference's Inferencer.Infer returns a slice aliasing the VM output,
+ * dualnet/meta.go:186-189 — a latent race this ABI does not reproduce).
+ *
+ * Errors: 0 = ok, <0 = AGZ_E_*; agz_last_error() returns a thread-local message.
+ */
+#ifndef AGZ_H
+#define AGZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGZ_OK 0
+#define AGZ_E_INVALID (-1)   /* bad argument / invalid config (reference: Config.IsValid, agogo.go:42-47 panics) */
+#define AGZ_E_HIP (-2)       /* HIP runtime failure */
+#define AGZ_E_NOMEM (-3)
+#define AGZ_E_STATE (-4)     /* call sequence error (e.g. infer before commit) */
+#define AGZ_E_TREE_FULL (-5) /* a tree's node pool overflowed (reference cap: MAXTREESIZE, mcts/search.go:23) */
+#define AGZ_E_UNSUPPORTED (-6)
+
+typedef struct agz_ctx agz_ctx;
+typedef struct agz_net agz_net;
+typedef struct agz_arena agz_arena;
+
+/* game.Colour / game.Player values (game/state.go:9-13) */
+#define AGZ_NONE 0
+#define AGZ_BLACK 1
+#define AGZ_WHITE 2
+/* game.Single special moves (mcts/mcts.go:21-22) */
+#define AGZ_PASS (-1)
+#define AGZ_RESIGN (-2)
+
+const char* agz_last_error(void);
+/* library / build info string ("libagz <ver> gfx950 ...") */
+const char* agz_version(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* One HIP device + stream.  Replaces the implicit gorgonia VM/engine an Agent owns (agent.go:44-53). */
+int agz_ctx_create(int device, agz_ctx** out);
+void agz_ctx_destroy(agz_ctx* ctx);
+int agz_ctx_sync(agz_ctx* ctx);
+/* raw hipStream_t the ctx launches on (for callers that want to record their own events) */
+void* agz_ctx_stream(agz_ctx* ctx);
+/* kernel-class timers: HIP events recorded on the ctx stream around every launch of a class.
+ * enable=1 starts collecting (and clears), enable=0 stops.  agz_ctx_prof_read syncs and returns
+ * the launch count and summed milliseconds of one class. */
+#define AGZ_PROF_CONV 0    /* 3x3 conv tower kernels (dominant) */
+#define AGZ_PROF_HEADS 1   /* policy/value head kernel */
+#define AGZ_PROF_SELECT 2  /* MCTS select/apply/encode */
+#define AGZ_PROF_EXPAND 3  /* MCTS expand/backup */
+#define AGZ_PROF_MOVE 4    /* root update / best move / apply */
+#define AGZ_PROF_NCLASS 5
+int agz_ctx_prof_enable(agz_ctx* ctx, int enable);
+int agz_ctx_prof_read(agz_ctx* ctx, int klass, int64_t* launches, double* total_ms);
+
+/* ---- dual network ------------------------------------------------------------------------- */
+/* Fields 1:1 with dual.Config (dualnet/config.go:4-16); bn_* pin the BatchNorm inference
+ * semantics that live in un-vendored gorgonia. */
+#define AGZ_BN_DEGENERATE_EPS 0 /* x / sqrt(0 + eps) * gamma + beta  (op.Reset() before every Infer, meta.go:170-172) */
+#define AGZ_BN_RUNNING 1        /* (x - mean_c) / sqrt(var_c + eps) * gamma + beta, stats via agz_net_set_bn_stats */
+#define AGZ_BN_IDENTITY 2       /* x * gamma + beta */
+typedef struct agz_net_conf {
+  int32_t K;            /* filters */
+  int32_t SharedLayers; /* dual-branch blocks */
+  int32_t FC;           /* value hidden width */
+  int32_t BatchSize;    /* only used for Glorot fan computation of batch-shaped params (App. B b5) */
+  int32_t Width, Height;
+  int32_t Features;
+  int32_t ActionSpace;  /* policy width (moves + pass) */
+  int32_t bn_mode;      /* AGZ_BN_* */
+  float bn_eps;         /* 1e-5 in the reference (ermahagerdmonards.go:54) */
+} agz_net_conf;
+
+/* dual.New + (*Dual).Init (dualnet/dual.go:33-47). Parameters are created zeroed. */
+int agz_net_create(agz_ctx* ctx, const agz_net_conf* conf, agz_net** out);
+void agz_net_destroy(agz_net* net);
+/* (*Dual).Model() (dualnet/dual.go:134-142): learnables in creation order of Dual.fwd:
+ *   Init{filter,gamma,beta}, per shared layer {L1 filter,gamma,beta, L2 filter,gamma,beta},
+ *   PolicyHead{filter,gamma,beta}, Policy_w, Policy_b, ValueHead{filter,gamma,beta}, Value_w, Value_b,
+ *   ValueOutput_w, ValueOutput_b.
+ * Row-0 shapes are stored: conv filter [out,in,k,k]; BN gamma/beta [C,H,W]; FC w [in,units]; FC b [units]. */
+int agz_net_num_params(const agz_net* net);
+int agz_net_param_info(const agz_net* net, int index, char* name, size_t name_cap, size_t* n_elems);
+/* G.Let on a learnable / the copy loop of dual.Infer (dualnet/meta.go:141-146).  n may exceed the
+ * row-0 size (batch-shaped reference tensors): the first n_elems floats (= row 0) are taken, as Go
+ * copy() + "only row 0 is ever real" does (App. B b5).  For BN params n == C broadcasts per channel. */
+int agz_net_set_param(agz_net* net, int index, const float* host, size_t n);
+int agz_net_get_param(const agz_net* net, int index, float* host, size_t n);
+/* per-channel running statistics for AGZ_BN_RUNNING; bn_index counts BN ops in Dual.ops order
+ * (dual.go:59-100: Init, L1/L2 of each shared layer, then policy, value). */
+int agz_net_set_bn_stats(agz_net* net, int bn_index, const float* mean, const float* var, size_t C);
+/* Random init with the reference's initialiser KINDS (GlorotU conv, GlorotN FC + BN gamma/beta,
+ * zero FC bias; ermahagerdmonards.go:39,80,82) from the build's own RNG (Go's math/rand stream is
+ * not reproducible here). */
+int agz_net_init_random(agz_net* net, uint64_t seed);
+/* Upload + repack to device layouts (folds BN into per-(c,h,w) scale/shift). Must follow any set_param. */
+int agz_net_commit(agz_net* net);
+/* dual.Infer + (*Inferencer).Infer (dualnet/meta.go:125-190), batched: planes [B,F,H,W] fp32 NCHW
+ * (every board evaluated with row-0 parameters), policy [B,ActionSpace] softmax, value [B] tanh.
+ * Host buffers (pageable ok). */
+int agz_net_infer(agz_net* net, const float* planes, int B, float* policy, float* value);
+/* same with device pointers, asynchronous on the ctx stream */
+int agz_net_infer_dev(agz_net* net, const float* planes_dev, int B, float* policy_dev, float* value_dev);
+/* FLOPs of one evaluation (SURVEY App. D formula) */
+double agz_net_flops_per_eval(const agz_net* net);
+
+/* ---- batched self-play arenas: game.State + mcts.MCTS + agogo.Arena on device ---------------- */
+#define AGZ_GAME_MNK 0  /* game/mnk  (m,n,k) */
+#define AGZ_GAME_C4 1   /* game/c4   (rows=m, cols=n, k in a row) */
+#define AGZ_GAME_KOMI 2 /* game/komi (m,n, capture-k) */
+#define AGZ_GAME_WQ 3   /* game/wq   (m=n=size, komi) */
+typedef struct agz_game_conf {
+  int32_t kind;
+  int32_t m, n, k;
+  float komi;        /* wq: AdditionalScore (game/wq/game.go:181) */
+  int32_t max_moves; /* arena safety cap on game length (the reference has no ko rule; 0 = 2*m*n) */
+  int32_t encoder;   /* AGZ_ENC_* */
+} agz_game_conf;
+#define AGZ_ENC_TWOPLANE 0 /* cmd/tictactoe/main.go:26-47 : board(+-1, 0->0.001) + to-move plane, F=2 */
+#define AGZ_ENC_WQ 1       /* WQEncoder, encoding_helper.go:29-68, F=18 */
+
+/* mcts.Config (mcts/tree.go:15-29); Timeout is replaced by "exactly Budget simulations"  */
+#define AGZ_DONT_PREFER_PASS 0
+#define AGZ_PREFER_PASS 1
+#define AGZ_DONT_RESIGN 2
+typedef struct agz_mcts_conf {
+  float PUCT;
+  int32_t M, N;
+  int32_t RandomCount;
+  int32_t Budget;
+  uint32_t RandomMinVisits;
+  float RandomTemperature;
+  int32_t DumbPass;
+  float ResignPercentage;
+  int32_t PassPreference;
+} agz_mcts_conf;
+
+/* Inferencer kinds an Agent can hold (mcts.Inferencer, mcts/mcts.go:15-18) */
+#define AGZ_INF_NET 0    /* Agent.Infer over a dual net (agent.go:60-74) */
+#define AGZ_INF_DUMMY 1  /* agogo.dummyInferer: uniform 1/ActionSpace policy, value +1 Black / -1 White agent (dummy.go:10-23) */
+#define AGZ_INF_SCRIPT 2 /* mcts/example_test.go:40-72 dummyNN (tic-tac-toe script by move number) */
+#define AGZ_INF_HASH 3   /* deterministic synthetic inferencer (integer hash of the position): parity tests */
+#define AGZ_INF_UNIFORM 4 /* mcts/example_test.go:158-166 dummyNN2: 1/25 policy (len 25), value 1/25 */
+
+/* MakeArena × n_games (arena.go:42-70): n_games independent games, each with agents A and B, each
+ * agent with its own search tree (mcts.New, mcts/tree.go:80-103).  max_nodes = node-pool capacity per
+ * tree (0 = default from Budget and action space). */
+int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_conf* mcts, int n_games,
+                     uint64_t seed, int max_nodes, agz_arena** out);
+void agz_arena_destroy(agz_arena* arena);
+/* Agent.NN / SwitchToInference / useDummy (agent.go:42-57,105-113): agent 0 = A, 1 = B. net may be NULL
+ * for the non-NET kinds. */
+int agz_arena_set_inferencer(agz_arena* arena, int agent, int kind, agz_net* net);
+/* Start new games: fresh trees, empty boards, colour assignment.  a_is_black: per game 0/1, or NULL to
+ * draw it from the arena RNG (arena.go:81-89 draws a.r.Intn(2)). */
+int agz_arena_reset(agz_arena* arena, const uint8_t* a_is_black);
+/* Arena.Play loop body for every unfinished game (arena.go:96-138): current agent Search
+ * (mcts/search.go:92-164) -> record example -> Apply -> switch player -> Ended / two passes.
+ * n_moves = how many plies to advance (<=0: until all games ended). */
+int agz_arena_play(agz_arena* arena, int n_moves, int record);
+/* Finer steps of one ply, for benchmarks and parity tests:
+ *   begin_move   = updateRoot + prepareRoot (search.go:94-109)
+ *   simulate(k)  = k x { pipeline (search.go:209-257) for every game, leaves coalesced into one
+ *                  batched inference }
+ *   end_move     = bestMove + Policies + Apply (search.go:151-161, arena.go:105-138) */
+int agz_arena_begin_move(agz_arena* arena);
+int agz_arena_simulate(agz_arena* arena, int k);
+int agz_arena_end_move(agz_arena* arena, int record);
+
+/* --- observers (all copy into caller buffers) --- */
+typedef struct agz_arena_stats {
+  int64_t sims_total;    /* pipeline invocations (iter, search.go:181) */
+  int64_t sims_nonnull;  /* playouts: non-null results (search.go:175-178) */
+  int64_t nn_evals;      /* inferencer evaluations */
+  int64_t moves_played;
+  int64_t games_finished;
+  int64_t examples;
+  int32_t n_games;
+  int32_t n_active;      /* games not yet ended */
+  int32_t tree_full;     /* number of trees that overflowed their pool */
+  int32_t reserved;
+} agz_arena_stats;
+int agz_arena_get_stats(agz_arena* arena, agz_arena_stats* out);
+/* game state of game g: board [m*n] colours, to_move, move number, passes, ended, winner, a_is_black,
+ * last best move */
+typedef struct agz_game_state {
+  int32_t to_move, move_number, passes, ended, winner, a_is_black, last_move, reserved;
+  float score_black, score_white;
+} agz_game_state;
+int agz_arena_get_game(agz_arena* arena, int g, int32_t* board, agz_game_state* st);
+/* moves played so far in game g (game.Single per ply); returns count via *n */
+int agz_arena_get_history(agz_arena* arena, int g, int32_t* moves, int cap, int* n);
+/* root children of agent's tree in game g after a search, in bestMove's fancySort order
+ * (search.go:353): move, visits, blackScores, prior. Returns the number of children in *n. */
+int agz_arena_root_children(agz_arena* arena, int g, int agent, int32_t* moves, uint32_t* visits,
+                            float* black_scores, float* priors, int cap, int* n);
+/* mcts.Nodes() analogue: nodes allocated in the tree pool */
+int agz_arena_tree_nodes(agz_arena* arena, int g, int agent, int* n_nodes);
+/* examples recorded so far (arena.go:105-123,146-155): planes [n, F*m*n], policy [n, A+1], value [n]
+ * (labelled +1/-1/0 once the game has ended; before that the raw mover colour 1/2), game index [n].
+ * Pass NULL buffers to query the count. */
+int agz_arena_get_examples(agz_arena* arena, float* planes, float* policy, float* value, int32_t* game_idx,
+                           int cap, int* n);
+int agz_arena_clear_examples(agz_arena* arena);
+/* device pointers of the example buffers (for an RCCL all-gather before dual.Train) */
+int agz_arena_examples_dev(agz_arena* arena, float** planes, float** policy, float** value, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGZ_H */

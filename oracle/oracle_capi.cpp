@@ -1,0 +1,298 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  C entry points (ctypes) over the CPU restatement.
+// Loaded only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+
+#include "arena.hpp"
+
+using namespace oracle;
+
+namespace {
+StatePtr make_game(int kind, int m, int n, int k, double komi) {
+  switch (kind) {
+    case 0: return std::make_shared<MNK>(m, n, k);
+    case 1: return std::make_shared<C4>(m, n, k);
+    case 2: return std::make_shared<Komi>(m, n, k);
+    case 3: return std::make_shared<WQ>(m, 0, komi);
+  }
+  return nullptr;
+}
+GameEncoder make_enc(int enc) {
+  if (enc == 1) return [](const State& s) { return WQEncoder(s); };
+  return [](const State& s) { return EncodeTwoPlane(s); };
+}
+std::vector<Colour>& raw_board(State* s) {
+  if (auto* g = dynamic_cast<MNK*>(s)) return g->board;
+  if (auto* g = dynamic_cast<C4*>(s)) return g->data;
+  if (auto* g = dynamic_cast<Komi*>(s)) return g->board;
+  return dynamic_cast<WQ*>(s)->board.data;
+}
+struct ArenaBox {
+  std::unique_ptr<Arena> arena;
+  std::unique_ptr<Inferencer> inf[2];
+  int kind, m, n, k, enc;
+  double komi;
+};
+}  // namespace
+
+extern "C" {
+
+int orc_round(int a) { return dual_round(a); }
+
+// ---- games ----
+void* orc_game_new(int kind, int m, int n, int k, double komi) {
+  StatePtr g = make_game(kind, m, n, k, komi);
+  if (!g) return nullptr;
+  return new StatePtr(g);
+}
+void orc_game_free(void* h) { delete (StatePtr*)h; }
+void orc_game_set_board(void* h, const int32_t* b, int n) {
+  auto& v = raw_board(((StatePtr*)h)->get());
+  for (int i = 0; i < n && i < (int)v.size(); i++) v[i] = b[i];
+}
+void orc_game_get_board(void* h, int32_t* b) {
+  const auto& v = (*(StatePtr*)h)->Board();
+  for (size_t i = 0; i < v.size(); i++) b[i] = v[i];
+}
+void orc_game_set_to_move(void* h, int p) { (*(StatePtr*)h)->SetToMove(p); }
+int orc_game_to_move(void* h) { return (*(StatePtr*)h)->ToMove(); }
+int orc_game_move_number(void* h) { return (*(StatePtr*)h)->MoveNumber(); }
+int orc_game_passes(void* h) { return (*(StatePtr*)h)->Passes(); }
+int orc_game_action_space(void* h) { return (*(StatePtr*)h)->ActionSpace(); }
+uint32_t orc_game_hash(void* h) { return (*(StatePtr*)h)->Hash(); }
+int orc_game_check(void* h, int player, int move) { return (*(StatePtr*)h)->Check(PlayerMove{player, move}) ? 1 : 0; }
+// game.State.Apply; the handle follows the returned state
+void orc_game_apply(void* h, int player, int move) {
+  StatePtr* sp = (StatePtr*)h;
+  *sp = (*sp)->Apply(PlayerMove{player, move});
+}
+// komi: Game.Apply then (taken, err) as komi_test.go:186-190 reads them. returns taken, or -1 on error
+int orc_komi_apply(void* h, int player, int move) {
+  Komi* g = dynamic_cast<Komi*>(((StatePtr*)h)->get());
+  if (!g) return -2;
+  g->Apply(PlayerMove{player, move});
+  return g->err ? -1 : g->taken;
+}
+// wq: Board.Apply as wq_test.go:206 calls it. returns taken, or -1 on error
+int orc_wq_board_apply(void* h, int player, int move) {
+  WQ* g = dynamic_cast<WQ*>(((StatePtr*)h)->get());
+  if (!g) return -2;
+  return g->board.Apply(PlayerMove{player, move});
+}
+float orc_wq_board_score(void* h, int player) {  // Board.Score (wq.go:173-202)
+  WQ* g = dynamic_cast<WQ*>(((StatePtr*)h)->get());
+  return g ? g->board.Score(player) : -1.f;
+}
+float orc_game_score(void* h, int player) { return (*(StatePtr*)h)->Score(player); }
+int orc_game_ended(void* h, int* winner) {
+  Player w = None;
+  bool e = (*(StatePtr*)h)->Ended(&w);
+  if (winner) *winner = w;
+  return e ? 1 : 0;
+}
+int orc_mnk_is_winner(void* h, int player) {
+  MNK* g = dynamic_cast<MNK*>(((StatePtr*)h)->get());
+  return g && g->isWinner(player) ? 1 : 0;
+}
+void* orc_game_clone(void* h) { return new StatePtr((*(StatePtr*)h)->Clone()); }
+int orc_game_eq(void* a, void* b) { return (*(StatePtr*)a)->Eq(((StatePtr*)b)->get()) ? 1 : 0; }
+void orc_game_reset(void* h) { (*(StatePtr*)h)->Reset(); }
+void orc_game_undo(void* h) { (*(StatePtr*)h)->UndoLastMove(); }
+void orc_game_fwd(void* h) { (*(StatePtr*)h)->Fwd(); }
+int orc_game_encode(void* h, int enc, float* out, int cap) {
+  std::vector<float> r = make_enc(enc)(**(StatePtr*)h);
+  if ((int)r.size() > cap) return -(int)r.size();
+  memcpy(out, r.data(), r.size() * sizeof(float));
+  return (int)r.size();
+}
+
+// ---- dual net ----
+void* orc_net_new(int K, int L, int FC, int BatchSize, int W, int H, int F, int A, int bn_mode, float bn_eps) {
+  DualConfig c;
+  c.K = K; c.SharedLayers = L; c.FC = FC; c.BatchSize = BatchSize; c.Width = W; c.Height = H; c.Features = F;
+  c.ActionSpace = A; c.bn_mode = bn_mode; c.bn_eps = bn_eps;
+  if (!c.IsValid()) return nullptr;
+  return new Dual(c);
+}
+void orc_net_free(void* h) { delete (Dual*)h; }
+int orc_net_num_params(void* h) { return (int)((Dual*)h)->params.size(); }
+int64_t orc_net_param_size(void* h, int i) { return (int64_t)((Dual*)h)->params.at(i).v.size(); }
+const char* orc_net_param_name(void* h, int i) { return ((Dual*)h)->params.at(i).name.c_str(); }
+void orc_net_get_param(void* h, int i, float* out) {
+  auto& v = ((Dual*)h)->params.at(i).v;
+  memcpy(out, v.data(), v.size() * sizeof(float));
+}
+void orc_net_set_param(void* h, int i, const float* in) {
+  auto& v = ((Dual*)h)->params.at(i).v;
+  memcpy(v.data(), in, v.size() * sizeof(float));
+}
+void orc_net_set_bn_stats(void* h, int bi, const float* mean, const float* var, int C) {
+  auto& st = ((Dual*)h)->bn.at(bi);
+  st.mean.assign(mean, mean + C);
+  st.var.assign(var, var + C);
+}
+void orc_net_init_random(void* h, uint64_t seed) { ((Dual*)h)->InitRandom(seed); }
+double orc_net_flops_per_eval(void* h) { return ((Dual*)h)->FlopsPerEval(); }
+// planes [B,F,H,W] -> policy [B,A], value [B]; each board evaluated independently with the row-0 parameters
+void orc_net_infer(void* h, const float* planes, int B, float* policy, float* value) {
+  Dual* d = (Dual*)h;
+  size_t per = (size_t)d->conf.Features * d->HW();
+  for (int b = 0; b < B; b++) {
+    std::vector<float> p;
+    float v;
+    d->Infer(planes + per * b, &p, &v);
+    memcpy(policy + (size_t)b * d->conf.ActionSpace, p.data(), p.size() * sizeof(float));
+    value[b] = v;
+  }
+}
+
+// ---- arena (one game, two agents) ----
+void* orc_arena_new(int kind, int m, int n, int k, double komi, int enc, float PUCT, int M, int N, int RandomCount,
+                    int Budget, uint32_t RandomMinVisits, float RandomTemperature, int DumbPass,
+                    float ResignPercentage, int PassPreference, uint64_t seed, int max_moves) {
+  StatePtr g = make_game(kind, m, n, k, komi);
+  if (!g) return nullptr;
+  MCTSConfig c;
+  c.PUCT = PUCT; c.M = M; c.N = N; c.RandomCount = RandomCount; c.Budget = Budget; c.RandomMinVisits = RandomMinVisits;
+  c.RandomTemperature = RandomTemperature; c.DumbPass = DumbPass != 0; c.ResignPercentage = ResignPercentage;
+  c.PassPreference = PassPreference;
+  if (!c.IsValid()) return nullptr;
+  auto* box = new ArenaBox();
+  box->kind = kind; box->m = m; box->n = n; box->k = k; box->komi = komi; box->enc = enc;
+  if (max_moves <= 0) max_moves = 2 * m * n;
+  box->arena.reset(new Arena(g, c, make_enc(enc), seed, max_moves));
+  return box;
+}
+void orc_arena_free(void* h) { delete (ArenaBox*)h; }
+// kind: AGZ_INF_* ; net = orc_net handle for AGZ_INF_NET; dummy_player for AGZ_INF_DUMMY; policy_len for HASH/UNIFORM
+int orc_arena_set_inferencer(void* h, int agent, int kind, void* net, int dummy_player, int policy_len) {
+  ArenaBox* b = (ArenaBox*)h;
+  Inferencer* inf = nullptr;
+  int A = b->arena->game->ActionSpace();
+  switch (kind) {
+    case 0: if (!net) return -1; inf = new NetInferencer((Dual*)net, make_enc(b->enc)); break;
+    case 1: inf = new DummyInferer(A, dummy_player); break;
+    case 2: inf = new ScriptNN(); break;
+    case 3: inf = new HashNN(policy_len > 0 ? policy_len : A + 1); break;
+    case 4: inf = new UniformNN(policy_len > 0 ? policy_len : 25); break;
+    default: return -1;
+  }
+  b->inf[agent].reset(inf);
+  (agent == 0 ? b->arena->A : b->arena->B).nn = inf;
+  return 0;
+}
+int orc_arena_set_callback(void* h, int agent, infer_cb cb, void* user, int policy_len) {
+  ArenaBox* b = (ArenaBox*)h;
+  Inferencer* inf = new CallbackInferencer(cb, user, make_enc(b->enc), policy_len);
+  b->inf[agent].reset(inf);
+  (agent == 0 ? b->arena->A : b->arena->B).nn = inf;
+  return 0;
+}
+void orc_arena_begin(void* h, int a_is_black) { ((ArenaBox*)h)->arena->Begin(a_is_black); }
+int orc_arena_step(void* h, int record) { return ((ArenaBox*)h)->arena->Step(record != 0) ? 1 : 0; }
+// plays up to n_moves plies (<=0: to the end); returns plies played
+int orc_arena_play(void* h, int n_moves, int record) {
+  Arena* a = ((ArenaBox*)h)->arena.get();
+  int played = 0;
+  while (!a->ended && (n_moves <= 0 || played < n_moves)) { a->Step(record != 0); played++; }
+  return played;
+}
+int orc_arena_history(void* h, int32_t* moves, int cap) {
+  Arena* a = ((ArenaBox*)h)->arena.get();
+  int n = (int)a->moves.size();
+  for (int i = 0; i < n && i < cap; i++) moves[i] = a->moves[i];
+  return n;
+}
+// out: [to_move, move_number, passes, ended, winner, a_is_black]
+void orc_arena_state(void* h, int32_t* board, int32_t* out) {
+  Arena* a = ((ArenaBox*)h)->arena.get();
+  if (board) { const auto& v = a->game->Board(); for (size_t i = 0; i < v.size(); i++) board[i] = v[i]; }
+  out[0] = a->game->ToMove(); out[1] = a->game->MoveNumber(); out[2] = a->game->Passes();
+  out[3] = a->ended ? 1 : 0; out[4] = a->winner; out[5] = a->A.player == Black ? 1 : 0;
+}
+// root children of an agent's tree in their current order (bestMove sorts them in place, search.go:353)
+int orc_arena_root_children(void* h, int agent, int32_t* moves, uint32_t* visits, float* bscores, float* priors, int cap) {
+  Arena* a = ((ArenaBox*)h)->arena.get();
+  MCTS* t = (agent == 0 ? a->A : a->B).mcts.get();
+  if (!t || t->root == nilNode) return 0;
+  const auto& kids = t->children.at(t->root);
+  int n = (int)kids.size();
+  for (int i = 0; i < n && i < cap; i++) {
+    const Node& nd = t->N(kids[i]);
+    moves[i] = nd.move; visits[i] = nd.visits; bscores[i] = nd.blackScores; priors[i] = nd.score;
+  }
+  return n;
+}
+// out: [nnEvals, playouts, lastIter, nodes, rootVisits] ; root blackScores via *root_bs
+void orc_arena_tree_stats(void* h, int agent, int64_t* out, float* root_bs) {
+  Arena* a = ((ArenaBox*)h)->arena.get();
+  MCTS* t = (agent == 0 ? a->A : a->B).mcts.get();
+  out[0] = t->nnEvals; out[1] = t->playouts; out[2] = t->lastIter; out[3] = t->Nodes();
+  out[4] = t->root == nilNode ? 0 : t->N(t->root).visits;
+  if (root_bs) *root_bs = t->root == nilNode ? 0.f : t->N(t->root).blackScores;
+}
+int orc_arena_num_examples(void* h) { return (int)((ArenaBox*)h)->arena->examples.size(); }
+void orc_arena_get_example(void* h, int i, float* board, float* policy, float* value) {
+  const Example& e = ((ArenaBox*)h)->arena->examples.at(i);
+  memcpy(board, e.Board.data(), e.Board.size() * sizeof(float));
+  memcpy(policy, e.Policy.data(), e.Policy.size() * sizeof(float));
+  *value = e.Value;
+}
+int orc_arena_example_sizes(void* h, int* board_len, int* policy_len) {
+  Arena* a = ((ArenaBox*)h)->arena.get();
+  if (a->examples.empty()) return 0;
+  *board_len = (int)a->examples[0].Board.size();
+  *policy_len = (int)a->examples[0].Policy.size();
+  return 1;
+}
+
+
+// ---- mcts/example_test.go:74-103 pattern: ONE tree searched alternately for both players ----
+struct ExampleBox {
+  StatePtr g;
+  std::unique_ptr<Inferencer> inf;
+  std::unique_ptr<MCTS> t;
+  Player player;
+};
+void* orc_example_new(int kind, int m, int n, int k, double komi, float PUCT, int Budget, int inf_kind, int policy_len,
+                      int first_player, uint64_t seed) {
+  auto* b = new ExampleBox();
+  b->g = make_game(kind, m, n, k, komi);
+  MCTSConfig c;
+  c.PUCT = PUCT; c.M = m; c.N = n; c.Budget = Budget; c.DumbPass = true; c.PassPreference = DontPreferPass; c.RandomCount = 0;
+  int A = b->g->ActionSpace();
+  switch (inf_kind) {
+    case 2: b->inf.reset(new ScriptNN()); break;
+    case 3: b->inf.reset(new HashNN(policy_len > 0 ? policy_len : A + 1)); break;
+    case 4: b->inf.reset(new UniformNN(policy_len > 0 ? policy_len : 25)); break;
+    default: b->inf.reset(new DummyInferer(A, 0)); break;
+  }
+  b->t.reset(new MCTS(b->g, c, b->inf.get(), seed));
+  b->player = first_player;
+  return b;
+}
+void orc_example_free(void* h) { delete (ExampleBox*)h; }
+// one loop iteration of Example(): returns best move; *ended / *winner evaluated after the Apply
+int orc_example_turn(void* h, int* ended, int* winner) {
+  ExampleBox* b = (ExampleBox*)h;
+  Single best = b->t->Search(b->player);
+  b->g = b->g->Apply(PlayerMove{b->player, best});
+  b->t->SetGame(b->g);
+  b->player = Opponent(b->player);
+  Player w = None;
+  *ended = b->g->Ended(&w) ? 1 : 0;
+  *winner = w;
+  return best;
+}
+int orc_example_root_children(void* h, int32_t* moves, uint32_t* visits, float* bscores, int cap) {
+  MCTS* t = ((ExampleBox*)h)->t.get();
+  const auto& kids = t->children.at(t->root);
+  int n = (int)kids.size();
+  for (int i = 0; i < n && i < cap; i++) { const Node& nd = t->N(kids[i]); moves[i] = nd.move; visits[i] = nd.visits; bscores[i] = nd.blackScores; }
+  return n;
+}
+int64_t orc_example_nn_evals(void* h) { return ((ExampleBox*)h)->t->nnEvals; }
+
+}  // extern "C"
