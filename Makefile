@@ -1,0 +1,34 @@
+# Builds libagz.so (HIP, gfx950) and the CPU oracle (test infrastructure).
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CS := agogo_amd/csrc
+OUT := agogo_amd/lib
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Iinclude
+# engine.hip holds the bit-exact MCTS arithmetic: no fused multiply-add contraction (Go/amd64 never fuses)
+ENGINE_FLAGS := -ffp-contract=off
+
+SRCS := $(CS)/ctx.hip $(CS)/net.hip $(CS)/engine.hip
+OBJS := $(OUT)/ctx.o $(OUT)/net.o $(OUT)/engine.o
+HDRS := $(wildcard $(CS)/*.hpp) include/agz.h
+
+all: $(OUT)/libagz.so oracle
+
+$(OUT)/ctx.o: $(CS)/ctx.hip $(HDRS)
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(OUT)/net.o: $(CS)/net.hip $(HDRS)
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(OUT)/engine.o: $(CS)/engine.hip $(HDRS)
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) $(ENGINE_FLAGS) -c $< -o $@
+$(OUT)/libagz.so: $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(OUT)/*.o $(OUT)/libagz.so
+	$(MAKE) -C oracle clean
+.PHONY: all oracle clean

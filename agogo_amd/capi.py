@@ -1,0 +1,337 @@
+"""ctypes binding of libagz.so (include/agz.h).  No compute happens in Python and nothing here falls
+back to the CPU: if the HIP library or a GPU is missing, calls raise AgzError."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# constants from include/agz.h
+NONE, BLACK, WHITE = 0, 1, 2
+PASS, RESIGN = -1, -2
+GAME_MNK, GAME_C4, GAME_KOMI, GAME_WQ = 0, 1, 2, 3
+ENC_TWOPLANE, ENC_WQ = 0, 1
+INF_NET, INF_DUMMY, INF_SCRIPT, INF_HASH, INF_UNIFORM = 0, 1, 2, 3, 4
+BN_DEGENERATE_EPS, BN_RUNNING, BN_IDENTITY = 0, 1, 2
+PROF_CONV, PROF_HEADS, PROF_SELECT, PROF_EXPAND, PROF_MOVE = 0, 1, 2, 3, 4
+DONT_PREFER_PASS, PREFER_PASS, DONT_RESIGN = 0, 1, 2
+
+
+class AgzError(RuntimeError):
+    pass
+
+
+class NetConf(C.Structure):
+    """agz_net_conf == dual.Config (dualnet/config.go:4-16)."""
+    _fields_ = [("K", C.c_int32), ("SharedLayers", C.c_int32), ("FC", C.c_int32), ("BatchSize", C.c_int32),
+                ("Width", C.c_int32), ("Height", C.c_int32), ("Features", C.c_int32), ("ActionSpace", C.c_int32),
+                ("bn_mode", C.c_int32), ("bn_eps", C.c_float)]
+
+
+class GameConf(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("komi", C.c_float),
+                ("max_moves", C.c_int32), ("encoder", C.c_int32)]
+
+
+class MctsConf(C.Structure):
+    """agz_mcts_conf == mcts.Config (mcts/tree.go:15-29), Timeout -> Budget simulations."""
+    _fields_ = [("PUCT", C.c_float), ("M", C.c_int32), ("N", C.c_int32), ("RandomCount", C.c_int32),
+                ("Budget", C.c_int32), ("RandomMinVisits", C.c_uint32), ("RandomTemperature", C.c_float),
+                ("DumbPass", C.c_int32), ("ResignPercentage", C.c_float), ("PassPreference", C.c_int32)]
+
+
+class ArenaStats(C.Structure):
+    _fields_ = [("sims_total", C.c_int64), ("sims_nonnull", C.c_int64), ("nn_evals", C.c_int64),
+                ("moves_played", C.c_int64), ("games_finished", C.c_int64), ("examples", C.c_int64),
+                ("n_games", C.c_int32), ("n_active", C.c_int32), ("tree_full", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GameState(C.Structure):
+    _fields_ = [("to_move", C.c_int32), ("move_number", C.c_int32), ("passes", C.c_int32), ("ended", C.c_int32),
+                ("winner", C.c_int32), ("a_is_black", C.c_int32), ("last_move", C.c_int32), ("reserved", C.c_int32),
+                ("score_black", C.c_float), ("score_white", C.c_float)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libagz.so")
+
+
+def lib():
+    """Load libagz.so (built in-tree by `make` / __graft_entry__.build())."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise AgzError("libagz.so not built (%s): run `make` or __graft_entry__.build(); there is no CPU fallback"
+                       % path)
+    L = C.CDLL(path)
+    vp, i32, u64, f64 = C.c_void_p, C.c_int, C.c_uint64, C.c_double
+    pvp = C.POINTER(C.c_void_p)
+    pf, pi, pu, pu8 = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("agz_last_error", C.c_char_p)
+    sig("agz_version", C.c_char_p)
+    sig("agz_ctx_create", i32, i32, pvp)
+    sig("agz_ctx_destroy", None, vp)
+    sig("agz_ctx_sync", i32, vp)
+    sig("agz_ctx_stream", vp, vp)
+    sig("agz_ctx_prof_enable", i32, vp, i32)
+    sig("agz_ctx_prof_read", i32, vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_double))
+    sig("agz_net_create", i32, vp, C.POINTER(NetConf), pvp)
+    sig("agz_net_destroy", None, vp)
+    sig("agz_net_num_params", i32, vp)
+    sig("agz_net_param_info", i32, vp, i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t))
+    sig("agz_net_set_param", i32, vp, i32, pf, C.c_size_t)
+    sig("agz_net_get_param", i32, vp, i32, pf, C.c_size_t)
+    sig("agz_net_set_bn_stats", i32, vp, i32, pf, pf, C.c_size_t)
+    sig("agz_net_init_random", i32, vp, u64)
+    sig("agz_net_commit", i32, vp)
+    sig("agz_net_infer", i32, vp, pf, i32, pf, pf)
+    sig("agz_net_infer_dev", i32, vp, vp, i32, vp, vp)
+    sig("agz_net_flops_per_eval", f64, vp)
+    sig("agz_arena_create", i32, vp, C.POINTER(GameConf), C.POINTER(MctsConf), i32, u64, i32, pvp)
+    sig("agz_arena_destroy", None, vp)
+    sig("agz_arena_set_inferencer", i32, vp, i32, i32, vp)
+    sig("agz_arena_reset", i32, vp, pu8)
+    sig("agz_arena_play", i32, vp, i32, i32)
+    sig("agz_arena_begin_move", i32, vp)
+    sig("agz_arena_simulate", i32, vp, i32)
+    sig("agz_arena_end_move", i32, vp, i32)
+    sig("agz_arena_get_stats", i32, vp, C.POINTER(ArenaStats))
+    sig("agz_arena_get_game", i32, vp, i32, pi, C.POINTER(GameState))
+    sig("agz_arena_get_history", i32, vp, i32, pi, i32, pi)
+    sig("agz_arena_root_children", i32, vp, i32, i32, pi, pu, pf, pf, i32, pi)
+    sig("agz_arena_tree_nodes", i32, vp, i32, i32, pi)
+    sig("agz_arena_get_examples", i32, vp, pf, pf, pf, pi, i32, pi)
+    sig("agz_arena_clear_examples", i32, vp)
+    sig("agz_arena_examples_dev", i32, vp, pvp, pvp, pvp, pi)
+    _LIB = L
+    return L
+
+
+def _check(r, what=""):
+    if r != 0:
+        raise AgzError("%s failed (%d): %s" % (what, r, lib().agz_last_error().decode(errors="replace")))
+
+
+def _pf(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _pi(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Ctx:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _check(lib().agz_ctx_create(device, C.byref(self.h)), "agz_ctx_create")
+
+    def close(self):
+        if self.h:
+            lib().agz_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(lib().agz_ctx_sync(self.h), "agz_ctx_sync")
+
+    def stream(self):
+        return lib().agz_ctx_stream(self.h)
+
+    def prof_enable(self, on=True):
+        _check(lib().agz_ctx_prof_enable(self.h, int(on)), "agz_ctx_prof_enable")
+
+    def prof_read(self, klass):
+        n, ms = C.c_int64(0), C.c_double(0)
+        _check(lib().agz_ctx_prof_read(self.h, klass, C.byref(n), C.byref(ms)), "agz_ctx_prof_read")
+        return n.value, ms.value
+
+
+class Net:
+    """dual.Dual + dual.Inferencer over libagz (dualnet/dual.go, dualnet/meta.go:125-190)."""
+
+    def __init__(self, ctx, K, SharedLayers, FC, Width, Height, Features, ActionSpace, BatchSize=256,
+                 bn_mode=BN_DEGENERATE_EPS, bn_eps=1e-5):
+        self.ctx = ctx
+        self.conf = NetConf(K, SharedLayers, FC, BatchSize, Width, Height, Features, ActionSpace, bn_mode, bn_eps)
+        self.h = C.c_void_p()
+        _check(lib().agz_net_create(ctx.h, C.byref(self.conf), C.byref(self.h)), "agz_net_create")
+
+    def close(self):
+        if self.h:
+            lib().agz_net_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_params(self):
+        return lib().agz_net_num_params(self.h)
+
+    def param_info(self, i):
+        name = C.create_string_buffer(128)
+        n = C.c_size_t(0)
+        _check(lib().agz_net_param_info(self.h, i, name, 128, C.byref(n)), "agz_net_param_info")
+        return name.value.decode(), n.value
+
+    def set_param(self, i, v):
+        a = np.ascontiguousarray(v, dtype=np.float32).ravel()
+        _check(lib().agz_net_set_param(self.h, i, _pf(a), a.size), "agz_net_set_param")
+
+    def get_param(self, i):
+        _, n = self.param_info(i)
+        a = np.zeros(n, dtype=np.float32)
+        _check(lib().agz_net_get_param(self.h, i, _pf(a), a.size), "agz_net_get_param")
+        return a
+
+    def set_bn_stats(self, bi, mean, var):
+        m = np.ascontiguousarray(mean, dtype=np.float32)
+        v = np.ascontiguousarray(var, dtype=np.float32)
+        _check(lib().agz_net_set_bn_stats(self.h, bi, _pf(m), _pf(v), m.size), "agz_net_set_bn_stats")
+
+    def init_random(self, seed):
+        _check(lib().agz_net_init_random(self.h, seed), "agz_net_init_random")
+
+    def commit(self):
+        _check(lib().agz_net_commit(self.h), "agz_net_commit")
+
+    def infer(self, planes):
+        c = self.conf
+        x = np.ascontiguousarray(planes, dtype=np.float32).reshape(-1, c.Features, c.Height, c.Width)
+        B = x.shape[0]
+        pol = np.zeros((B, c.ActionSpace), dtype=np.float32)
+        val = np.zeros(B, dtype=np.float32)
+        _check(lib().agz_net_infer(self.h, _pf(x), B, _pf(pol), _pf(val)), "agz_net_infer")
+        return pol, val
+
+    def infer_dev(self, planes_ptr, B, policy_ptr, value_ptr):
+        """device pointers (ints); asynchronous on the ctx stream"""
+        _check(lib().agz_net_infer_dev(self.h, C.c_void_p(planes_ptr), B, C.c_void_p(policy_ptr),
+                                       C.c_void_p(value_ptr)), "agz_net_infer_dev")
+
+    def flops_per_eval(self):
+        return lib().agz_net_flops_per_eval(self.h)
+
+
+class Arena:
+    """n_games x agogo.Arena (arena.go:20-179): batched self-play with per-agent mcts.MCTS trees on device."""
+
+    def __init__(self, ctx, kind, m, n, k=0, komi=0.0, encoder=ENC_TWOPLANE, n_games=1, seed=1337, max_nodes=0,
+                 max_moves=0, PUCT=1.0, M=None, N=None, RandomCount=0, Budget=100, RandomMinVisits=0,
+                 RandomTemperature=0.0, DumbPass=True, ResignPercentage=0.0, PassPreference=DONT_PREFER_PASS):
+        self.ctx = ctx
+        self.kind, self.m, self.n, self.n_games = kind, m, n, n_games
+        self.features = 18 if encoder == ENC_WQ else 2
+        self.action_space = n if kind == GAME_C4 else m * n
+        self.gconf = GameConf(kind, m, n, k, komi, max_moves, encoder)
+        self.mconf = MctsConf(PUCT, M if M is not None else m, N if N is not None else n, RandomCount, Budget,
+                              RandomMinVisits, RandomTemperature, int(DumbPass), ResignPercentage, PassPreference)
+        self.h = C.c_void_p()
+        self._nets = []
+        _check(lib().agz_arena_create(ctx.h, C.byref(self.gconf), C.byref(self.mconf), n_games, seed, max_nodes,
+                                      C.byref(self.h)), "agz_arena_create")
+
+    def close(self):
+        if self.h:
+            lib().agz_arena_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_inferencer(self, agent, kind, net=None):
+        _check(lib().agz_arena_set_inferencer(self.h, agent, kind, net.h if net is not None else None),
+               "agz_arena_set_inferencer")
+        if net is not None:
+            self._nets.append(net)
+
+    def reset(self, a_is_black=None):
+        if a_is_black is None:
+            _check(lib().agz_arena_reset(self.h, None), "agz_arena_reset")
+        else:
+            a = np.ascontiguousarray(a_is_black, dtype=np.uint8)
+            assert a.size == self.n_games
+            _check(lib().agz_arena_reset(self.h, a.ctypes.data_as(C.POINTER(C.c_uint8))), "agz_arena_reset")
+
+    def play(self, n_moves=0, record=True):
+        _check(lib().agz_arena_play(self.h, n_moves, int(record)), "agz_arena_play")
+
+    def begin_move(self):
+        _check(lib().agz_arena_begin_move(self.h), "agz_arena_begin_move")
+
+    def simulate(self, k):
+        _check(lib().agz_arena_simulate(self.h, k), "agz_arena_simulate")
+
+    def end_move(self, record=True):
+        _check(lib().agz_arena_end_move(self.h, int(record)), "agz_arena_end_move")
+
+    def stats(self):
+        s = ArenaStats()
+        _check(lib().agz_arena_get_stats(self.h, C.byref(s)), "agz_arena_get_stats")
+        return {f: getattr(s, f) for f, _ in ArenaStats._fields_ if f != "reserved"}
+
+    def game(self, g):
+        board = np.zeros(self.m * self.n, dtype=np.int32)
+        st = GameState()
+        _check(lib().agz_arena_get_game(self.h, g, _pi(board), C.byref(st)), "agz_arena_get_game")
+        return board, {f: getattr(st, f) for f, _ in GameState._fields_ if f != "reserved"}
+
+    def history(self, g):
+        a = np.zeros(4096, dtype=np.int32)
+        n = C.c_int32(0)
+        _check(lib().agz_arena_get_history(self.h, g, _pi(a), a.size, C.byref(n)), "agz_arena_get_history")
+        return a[:n.value].copy()
+
+    def root_children(self, g, agent):
+        cap = self.m * self.n + 2
+        mv = np.zeros(cap, dtype=np.int32)
+        vis = np.zeros(cap, dtype=np.uint32)
+        bs = np.zeros(cap, dtype=np.float32)
+        pr = np.zeros(cap, dtype=np.float32)
+        n = C.c_int32(0)
+        _check(lib().agz_arena_root_children(self.h, g, agent, _pi(mv), vis.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                             _pf(bs), _pf(pr), cap, C.byref(n)), "agz_arena_root_children")
+        k = n.value
+        return mv[:k].copy(), vis[:k].copy(), bs[:k].copy(), pr[:k].copy()
+
+    def tree_nodes(self, g, agent):
+        n = C.c_int32(0)
+        _check(lib().agz_arena_tree_nodes(self.h, g, agent, C.byref(n)), "agz_arena_tree_nodes")
+        return n.value
+
+    def examples(self):
+        n = C.c_int32(0)
+        _check(lib().agz_arena_get_examples(self.h, None, None, None, None, 0, C.byref(n)), "agz_arena_get_examples")
+        k = n.value
+        cells = self.m * self.n
+        planes = np.zeros((k, self.features * cells), np.float32)
+        policy = np.zeros((k, self.action_space + 1), np.float32)
+        value = np.zeros(k, np.float32)
+        gidx = np.zeros(k, np.int32)
+        if k:
+            _check(lib().agz_arena_get_examples(self.h, _pf(planes), _pf(policy), _pf(value), _pi(gidx), k,
+                                                C.byref(n)), "agz_arena_get_examples")
+        return planes, policy, value, gidx
+
+    def clear_examples(self):
+        _check(lib().agz_arena_clear_examples(self.h), "agz_arena_clear_examples")

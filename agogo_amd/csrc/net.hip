@@ -1,0 +1,650 @@
+// Dual network on gfx950: fp32 MFMA implicit-GEMM 3x3 conv tower + fused heads.
+//
+// Reference path replaced: dualnet/dual.go:50-103 (graph), dualnet/ermahagerdmonards.go:33-104 (layers),
+// dualnet/meta.go:125-190 (Inferencer).  The reference evaluates ONE real board in row 0 of an
+// ActionSpace-row batch per leaf (meta.go:128,175-177); here every row of the batch is a real leaf.
+//
+// Data layout in HBM
+//   activations  padded NHWC fp32  [B][H+2][W+2][Cp]  (Cp = channels rounded up to 32; the 1-cell halo is
+//                zero and never written, so the 3x3 taps need no bounds checks)
+//   conv weights [tap 9][n][Cin_p] fp32, Cin contiguous (both GEMM operands are "rows of 32 contiguous k")
+//                dual-branch blocks: n ordered per block tile as [a-channels | matching b-channels] so one
+//                wave holds conv_a and conv_b of the same (pixel, channel) in matching MFMA accumulators
+//   epilogue     per (position, channel) {scale, shift} (BN folded; gorgonia's gamma/beta are [B,C,H,W]-shaped,
+//                row 0 is what inference uses — SURVEY App. B b3-b5)
+//
+// Kernel K1/K2: implicit GEMM  D[m, n] = sum_{tap, c} X[pix(m)+off(tap)][c] * Wt[tap][n][c]
+//   M = B*H*W pixels, N = out channels (x2 for the dual block), K = 9*Cin
+//   v_mfma_f32_32x32x2_f32 (exact fp32; 64 FLOP/clk/SIMD = 157.3 TF chip peak) — bound: MFMA.
+//   256 threads = 4 waves; each wave owns MT x 2 tiles of 32x32; BK = 32; LDS double-buffered with a
+//   16-byte-chunk XOR swizzle ((row>>1)&7) so the ds_read_b128 operand reads are bank-conflict free.
+//   Algorithmic FLOPs per launch: 2 * M * N * 9 * Cin.
+#include "net.hpp"
+
+#include <cmath>
+#include <cstring>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace agz {
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const void* ep;
+  float* y;
+  int M, HW, W, Wp, HpWp;
+  int Cin_p, Cout_p, Ntot;
+  int n_mtiles, n_ntiles;
+};
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+// WM x WN waves, each wave MT x 2 MFMA tiles.  BM = WM*MT*32 rows (pixels), BNT = WN*64 GEMM columns.
+template <int WM, int WN, int MT, bool DUAL>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
+  constexpr int BM = WM * MT * 32;
+  constexpr int BNT = WN * 64;
+  constexpr int A_PER_T = BM * 8 / 256;   // 16-byte chunks per thread per tile
+  constexpr int B_PER_T = BNT * 8 / 256;
+  static_assert(WM * WN == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BNT) * 32];
+  constexpr int STAGE = (BM + BNT) * 32;  // floats per pipeline stage: A tile then B tile
+
+  // XCD-aware tile mapping (bijective): consecutive block ids land on different XCDs; give each XCD a
+  // contiguous run of tiles so the n-tiles of one m-tile (same A rows) share an L2.
+  const int nblk = a.n_mtiles * a.n_ntiles;
+  int tile;
+  {
+    int id = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = id & 7, slot = id >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int m_tile = tile / a.n_ntiles, n_tile = tile - m_tile * a.n_ntiles;
+  const int m0 = m_tile * BM, n0 = n_tile * BNT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+
+  // --- per-thread staging assignments
+  const int chunk = tid & 7;
+  int a_goff[A_PER_T];  // float offset of (row pixel, chunk) in x for tap (0,0) centre
+  int a_loff[A_PER_T];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; i++) {
+    int row = (tid >> 3) + 32 * i;
+    int m = m0 + row;
+    if (m >= a.M) m = a.M - 1;
+    int b = m / a.HW, p = m - b * a.HW;
+    int h = p / a.W, w = p - h * a.W;
+    a_goff[i] = ((b * a.HpWp) + (h + 1) * a.Wp + (w + 1)) * a.Cin_p + chunk * 4;
+    a_loff[i] = swz_off(row, chunk);
+  }
+  int b_goff[B_PER_T];
+  int b_loff[B_PER_T];
+#pragma unroll
+  for (int i = 0; i < B_PER_T; i++) {
+    int row = (tid >> 3) + 32 * i;
+    int n = n0 + row;
+    if (n >= a.Ntot) n = a.Ntot - 1;
+    b_goff[i] = n * a.Cin_p + chunk * 4;
+    b_loff[i] = swz_off(row, chunk);
+  }
+
+  const int NC = a.Cin_p >> 5;
+  const int NK = 9 * NC;
+  const int w_tap_stride = a.Ntot * a.Cin_p;
+
+  float4 ra[A_PER_T], rb[B_PER_T];
+  // (macros, not lambdas: by-reference captures of ra/rb make LLVM promote them to LDS instead of VGPRs)
+#define AGZ_GLOAD(IT)                                                                                     \
+  {                                                                                                       \
+    int tap_ = (IT) / NC, cc_ = (IT) - tap_ * NC;                                                         \
+    int ky_ = tap_ / 3, kx_ = tap_ - ky_ * 3;                                                             \
+    int xo_ = ((ky_ - 1) * a.Wp + (kx_ - 1)) * a.Cin_p + cc_ * 32;                                        \
+    int wo_ = tap_ * w_tap_stride + cc_ * 32;                                                             \
+    _Pragma("unroll") for (int i = 0; i < A_PER_T; i++) ra[i] =                                           \
+        *reinterpret_cast<const float4*>(a.x + a_goff[i] + xo_);                                          \
+    _Pragma("unroll") for (int i = 0; i < B_PER_T; i++) rb[i] =                                           \
+        *reinterpret_cast<const float4*>(a.w + b_goff[i] + wo_);                                          \
+  }
+#define AGZ_LSTORE(BUF)                                                                                   \
+  {                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < A_PER_T; i++)                                                   \
+        *reinterpret_cast<float4*>(lds + (BUF) * STAGE + a_loff[i]) = ra[i];                              \
+    _Pragma("unroll") for (int i = 0; i < B_PER_T; i++)                                                   \
+        *reinterpret_cast<float4*>(lds + (BUF) * STAGE + BM * 32 + b_loff[i]) = rb[i];                    \
+  }
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // operand rows of this lane
+  int a_row[MT], b_row[2];
+#pragma unroll
+  for (int i = 0; i < MT; i++) a_row[i] = (wm * MT + i) * 32 + (lane & 31);
+  if (DUAL) {
+    b_row[0] = wn * 32 + (lane & 31);            // branch a channels
+    b_row[1] = WN * 32 + wn * 32 + (lane & 31);  // matching branch b channels
+  } else {
+    b_row[0] = (wn * 2 + 0) * 32 + (lane & 31);
+    b_row[1] = (wn * 2 + 1) * 32 + (lane & 31);
+  }
+  const int khalf = lane >> 5;
+
+  AGZ_GLOAD(0);
+  AGZ_LSTORE(0);
+  __syncthreads();
+#define AGZ_COMPUTE(BUF)                                                                                          \
+  {                                                                                                               \
+    const float* Ab = lds + (BUF) * STAGE;                                                                        \
+    const float* Bb = Ab + BM * 32;                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ks++) {                                                            \
+      float4 av[MT], bv[2];                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < MT; i++) av[i] =                                                      \
+          *reinterpret_cast<const float4*>(Ab + swz_off(a_row[i], 2 * ks + khalf));                               \
+      _Pragma("unroll") for (int j = 0; j < 2; j++) bv[j] =                                                       \
+          *reinterpret_cast<const float4*>(Bb + swz_off(b_row[j], 2 * ks + khalf));                               \
+      _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < 2; j++) {              \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);                   \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+  for (int it = 0; it < NK - 1; it++) {
+    const int buf = it & 1;
+    AGZ_GLOAD(it + 1);
+    AGZ_COMPUTE(buf);
+    AGZ_LSTORE(buf ^ 1);
+    __syncthreads();
+  }
+  AGZ_COMPUTE((NK - 1) & 1);
+#undef AGZ_COMPUTE
+#undef AGZ_GLOAD
+#undef AGZ_LSTORE
+  // --- epilogue: BN(scale,shift) + ReLU (+ dual add + ReLU), store interior of padded NHWC
+  // C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < MT; i++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      int m = m0 + row;
+      const bool mvalid = m < a.M;
+      if (!mvalid) m = a.M - 1;
+      int b = m / a.HW, p = m - b * a.HW;
+      int h = p / a.W, w = p - h * a.W;
+      size_t obase = ((size_t)b * a.HpWp + (h + 1) * a.Wp + (w + 1)) * a.Cout_p;
+      if (DUAL) {
+        int c = n_tile * (BNT / 2) + wn * 32 + (lane & 31);
+        if (mvalid && c < a.Cout_p) {
+          float4 e = reinterpret_cast<const float4*>(a.ep)[(size_t)p * a.Cout_p + c];
+          float va = acc[i][0][r] * e.x + e.y;
+          float vb = acc[i][1][r] * e.z + e.w;
+          va = va > 0.f ? va : 0.f;
+          vb = vb > 0.f ? vb : 0.f;
+          float s = va + vb;
+          a.y[obase + c] = s > 0.f ? s : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          int c = n0 + (wn * 2 + j) * 32 + (lane & 31);
+          if (mvalid && c < a.Cout_p) {
+            float2 e = reinterpret_cast<const float2*>(a.ep)[(size_t)p * a.Cout_p + c];
+            float v = acc[i][j][r] * e.x + e.y;
+            a.y[obase + c] = v > 0.f ? v : 0.f;
+          }
+        }
+      }
+    }
+  }
+}
+
+// planes NCHW [B,F,H,W] -> padded NHWC [B][Hp][Wp][32] (channels >= F zero)
+__global__ void pack_planes_kernel(const float* __restrict__ planes, float* __restrict__ out, int B, int F, int H, int W,
+                                   int Fp) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (b, h, w, c)
+  int total = B * H * W * Fp;
+  if (idx >= total) return;
+  int c = idx % Fp;
+  int p = idx / Fp;
+  int w = p % W, h = (p / W) % H, b = p / (W * H);
+  float v = c < F ? planes[((size_t)(b * F + c) * H + h) * W + w] : 0.f;
+  out[(((size_t)b * (H + 2) + h + 1) * (W + 2) + w + 1) * Fp + c] = v;
+}
+
+struct HeadArgs {
+  const float* x;  // padded NHWC [B][Hp][Wp][Kp]
+  const float* conv;  // [3][Kp]
+  const float* bn;    // [3][HW][2]
+  const float* Wp; const float* bp; const float* W1; const float* b1; const float* W2; const float* b2;
+  float* policy; float* value;
+  int H, W, HW, Wp_, HpWp, Kp, A, FC;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// K4+K5: both heads for one board per workgroup (dual.go:72-97)
+__global__ __launch_bounds__(256) void heads_kernel(HeadArgs a) {
+  extern __shared__ float sm[];
+  float* feat = sm;                  // [3][HW]  relu(bn(conv1x1)) : policy c0, policy c1, value
+  float* red = sm + 3 * a.HW;        // [8]
+  float* hid = red + 8;              // [FC]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // phase 1: 1x1 convs — a wave per pixel, lanes over channels (coalesced 16 B per lane)
+  for (int p = wid; p < a.HW; p += 4) {
+    int h = p / a.W, w = p - h * a.W;
+    const float* xp = a.x + ((size_t)b * a.HpWp + (h + 1) * a.Wp_ + (w + 1)) * a.Kp;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < a.Kp; c += 256) {
+      float4 xv = *reinterpret_cast<const float4*>(xp + c);
+      float4 w0 = *reinterpret_cast<const float4*>(a.conv + c);
+      float4 w1 = *reinterpret_cast<const float4*>(a.conv + a.Kp + c);
+      float4 w2 = *reinterpret_cast<const float4*>(a.conv + 2 * a.Kp + c);
+      s0 += xv.x * w0.x + xv.y * w0.y + xv.z * w0.z + xv.w * w0.w;
+      s1 += xv.x * w1.x + xv.y * w1.y + xv.z * w1.z + xv.w * w1.w;
+      s2 += xv.x * w2.x + xv.y * w2.y + xv.z * w2.z + xv.w * w2.w;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+      float v0 = s0 * a.bn[(0 * a.HW + p) * 2] + a.bn[(0 * a.HW + p) * 2 + 1];
+      float v1 = s1 * a.bn[(1 * a.HW + p) * 2] + a.bn[(1 * a.HW + p) * 2 + 1];
+      float v2 = s2 * a.bn[(2 * a.HW + p) * 2] + a.bn[(2 * a.HW + p) * 2 + 1];
+      feat[p] = v0 > 0.f ? v0 : 0.f;
+      feat[a.HW + p] = v1 > 0.f ? v1 : 0.f;
+      feat[2 * a.HW + p] = v2 > 0.f ? v2 : 0.f;
+    }
+  }
+  __syncthreads();
+  // phase 2: policy logits = feat[0:2HW] . Wp[2HW, A] + bp ; softmax
+  float lmax = -INFINITY;
+  float logit[2];  // A <= 512 supported per 256 threads x 2
+  for (int r = 0, j = tid; r < 2; r++, j += 256) {
+    float s = 0.f;
+    if (j < a.A) {
+      for (int i = 0; i < 2 * a.HW; i++) s += feat[i] * a.Wp[(size_t)i * a.A + j];
+      s += a.bp[j];
+      lmax = fmaxf(lmax, s);
+    }
+    logit[r] = s;
+  }
+  for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+  if (lane == 0) red[wid] = lmax;
+  __syncthreads();
+  float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float lsum = 0.f;
+  for (int r = 0, j = tid; r < 2; r++, j += 256) {
+    if (j < a.A) { logit[r] = expf(logit[r] - mx); lsum += logit[r]; }
+  }
+  lsum = wave_sum(lsum);
+  if (lane == 0) red[4 + wid] = lsum;
+  __syncthreads();
+  float tot = red[4] + red[5] + red[6] + red[7];
+  for (int r = 0, j = tid; r < 2; r++, j += 256)
+    if (j < a.A) a.policy[(size_t)b * a.A + j] = logit[r] / tot;
+  // phase 3: value = tanh( relu(feat[2] . W1 + b1) . W2 + b2 )
+  for (int j = tid; j < a.FC; j += 256) {
+    float s = 0.f;
+    const float* f2 = feat + 2 * a.HW;
+    for (int i = 0; i < a.HW; i++) s += f2[i] * a.W1[(size_t)i * a.FC + j];
+    s += a.b1[j];
+    hid[j] = s > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  float o = 0.f;
+  for (int j = tid; j < a.FC; j += 256) o += hid[j] * a.W2[j];
+  o = wave_sum(o);
+  __syncthreads();
+  if (lane == 0) red[wid] = o;
+  __syncthreads();
+  if (tid == 0) a.value[b] = tanhf(red[0] + red[1] + red[2] + red[3] + a.b2[0]);
+}
+
+}  // namespace agz
+
+using namespace agz;
+
+// ------------------------------------------------------------------------------------------------
+void agz_net::free_device() {
+  auto f = [](float*& p) { if (p) { hipFree(p); p = nullptr; } };
+  f(d_w_init); f(d_ep_init);
+  for (auto& p : d_w_dual) f(p);
+  for (auto& p : d_ep_dual) f(p);
+  d_w_dual.clear(); d_ep_dual.clear();
+  f(d_head_conv); f(d_head_bn); f(d_Wp); f(d_bp); f(d_W1); f(d_b1); f(d_W2); f(d_b2);
+  f(d_act_in); f(d_actA); f(d_actB); f(d_planes); f(d_policy); f(d_value);
+  max_batch = 0;
+}
+
+int agz_net::ensure_batch(int B) {
+  if (B <= max_batch) return AGZ_OK;
+  auto f = [](float*& p) { if (p) { hipFree(p); p = nullptr; } };
+  f(d_act_in); f(d_actA); f(d_actB); f(d_planes); f(d_policy); f(d_value);
+  size_t px = (size_t)B * Hp * Wp;
+  AGZ_HIP_TRY(hipMalloc(&d_act_in, px * Fp * sizeof(float)));
+  AGZ_HIP_TRY(hipMalloc(&d_actA, px * Kp * sizeof(float)));
+  AGZ_HIP_TRY(hipMalloc(&d_actB, px * Kp * sizeof(float)));
+  AGZ_HIP_TRY(hipMalloc(&d_planes, (size_t)B * conf.Features * HW * sizeof(float)));
+  AGZ_HIP_TRY(hipMalloc(&d_policy, (size_t)B * conf.ActionSpace * sizeof(float)));
+  AGZ_HIP_TRY(hipMalloc(&d_value, (size_t)B * sizeof(float)));
+  // zero halos once; kernels only ever write the interior
+  AGZ_HIP_TRY(hipMemsetAsync(d_act_in, 0, px * Fp * sizeof(float), ctx->stream));
+  AGZ_HIP_TRY(hipMemsetAsync(d_actA, 0, px * Kp * sizeof(float), ctx->stream));
+  AGZ_HIP_TRY(hipMemsetAsync(d_actB, 0, px * Kp * sizeof(float), ctx->stream));
+  max_batch = B;
+  return AGZ_OK;
+}
+
+template <int WM, int WN, int MT, bool DUAL>
+static void launch_conv(agz_ctx* ctx, ConvArgs& a) {
+  constexpr int BM = WM * MT * 32, BNT = WN * 64;
+  a.n_mtiles = ceil_div(a.M, BM);
+  a.n_ntiles = ceil_div(a.Ntot, BNT);
+  dim3 grid(a.n_mtiles * a.n_ntiles), block(256);
+  ProfScope ps(ctx, AGZ_PROF_CONV);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, MT, DUAL>), grid, block, 0, ctx->stream, a);
+}
+
+int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
+  AGZ_REQUIRE(committed, AGZ_E_STATE, "agz_net: infer before agz_net_commit");
+  AGZ_REQUIRE(B >= 1 && B <= max_batch, AGZ_E_INVALID, "agz_net: batch %d exceeds allocated %d", B, max_batch);
+  ConvArgs a{};
+  a.M = B * HW; a.HW = HW; a.W = W; a.Wp = Wp; a.HpWp = Hp * Wp;
+  // K1: init conv  F -> K  (+BN+ReLU)
+  a.x = d_act_in; a.w = d_w_init; a.ep = d_ep_init; a.y = d_actA;
+  a.Cin_p = Fp; a.Cout_p = Kp; a.Ntot = Kp;
+  if (cfg == 0) launch_conv<2, 2, 2, false>(ctx, a); else launch_conv<4, 1, 1, false>(ctx, a);
+  // K2: SharedLayers x fused dual-branch block
+  float* cur = d_actA;
+  float* nxt = d_actB;
+  for (int l = 0; l < conf.SharedLayers; l++) {
+    a.x = cur; a.w = d_w_dual[l]; a.ep = d_ep_dual[l]; a.y = nxt;
+    a.Cin_p = Kp; a.Cout_p = Kp; a.Ntot = 2 * Kp;
+    if (cfg == 0) launch_conv<2, 2, 2, true>(ctx, a); else launch_conv<4, 1, 1, true>(ctx, a);
+    std::swap(cur, nxt);
+  }
+  // K4+K5 heads
+  HeadArgs h{};
+  h.x = cur; h.conv = d_head_conv; h.bn = d_head_bn; h.Wp = d_Wp; h.bp = d_bp; h.W1 = d_W1; h.b1 = d_b1; h.W2 = d_W2;
+  h.b2 = d_b2; h.policy = policy_dev; h.value = value_dev;
+  h.H = H; h.W = W; h.HW = HW; h.Wp_ = Wp; h.HpWp = Hp * Wp; h.Kp = Kp; h.A = conf.ActionSpace; h.FC = conf.FC;
+  size_t smem = (size_t)(3 * HW + 8 + conf.FC) * sizeof(float);
+  {
+    ProfScope ps(ctx, AGZ_PROF_HEADS);
+    hipLaunchKernelGGL(heads_kernel, dim3(B), dim3(256), smem, ctx->stream, h);
+  }
+  AGZ_HIP_TRY(hipGetLastError());
+  return AGZ_OK;
+}
+
+int agz_net::forward_dev(const float* planes_dev, int B, float* policy_dev, float* value_dev) {
+  AGZ_REQUIRE(committed, AGZ_E_STATE, "agz_net: infer before agz_net_commit");
+  int r = ensure_batch(B);
+  if (r != AGZ_OK) return r;
+  int total = B * HW * Fp;
+  hipLaunchKernelGGL(pack_planes_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, planes_dev, d_act_in, B,
+                     conf.Features, H, W, Fp);
+  return forward_packed(B, policy_dev, value_dev);
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int agz_net_create(agz_ctx* ctx, const agz_net_conf* c, agz_net** out) {
+  AGZ_REQUIRE(ctx && c && out, AGZ_E_INVALID, "agz_net_create: NULL argument");
+  // dual.Config.IsValid (dualnet/config.go:33-42)
+  AGZ_REQUIRE(c->K >= 1 && c->ActionSpace >= 3 && c->SharedLayers >= 0 && c->FC > 1 && c->BatchSize >= 1 && c->Features > 0,
+              AGZ_E_INVALID, "agz_net_create: NNConf is not valid");
+  AGZ_REQUIRE(c->Width >= 1 && c->Height >= 1, AGZ_E_INVALID, "agz_net_create: bad board size");
+  AGZ_REQUIRE(c->Features <= 32, AGZ_E_UNSUPPORTED, "agz_net_create: Features > 32 unsupported");
+  AGZ_REQUIRE(c->ActionSpace <= 512, AGZ_E_UNSUPPORTED, "agz_net_create: ActionSpace > 512 unsupported");
+  AGZ_REQUIRE(c->bn_mode >= 0 && c->bn_mode <= 2, AGZ_E_INVALID, "agz_net_create: bad bn_mode");
+  agz_net* n = new agz_net();
+  n->ctx = ctx;
+  n->conf = *c;
+  n->H = c->Height; n->W = c->Width; n->HW = n->H * n->W; n->Hp = n->H + 2; n->Wp = n->W + 2;
+  n->Kp = round_up(c->K, 32);
+  n->cfg = (n->Kp % 64 == 0) ? 0 : 1;
+  int K = c->K, F = c->Features, H = n->H, W = n->W, hw = n->HW, B = c->BatchSize;
+  auto conv = [&](const std::string& nm, int o, int i, int k) {
+    n->params.push_back(Param{"Filter" + nm, std::vector<float>((size_t)o * i * k * k, 0.f), {o, i, k, k}, 0});
+  };
+  auto bnp = [&](const std::string& nm, int C) {
+    n->params.push_back(Param{nm + "_gamma", std::vector<float>((size_t)C * hw, 0.f), {B, C, H, W}, 1});
+    n->params.push_back(Param{nm + "_beta", std::vector<float>((size_t)C * hw, 0.f), {B, C, H, W}, 1});
+    n->bn.push_back(BNStats{std::vector<float>(C, 0.f), std::vector<float>(C, 1.f)});
+  };
+  auto fc = [&](const std::string& nm, int in, int units) {
+    n->params.push_back(Param{nm + "_w", std::vector<float>((size_t)in * units, 0.f), {in, units}, 2});
+    n->params.push_back(Param{nm + "_b", std::vector<float>((size_t)units, 0.f), {B, units}, 3});
+  };
+  conv("Init", K, F, 3); bnp("Init", K);
+  for (int i = 0; i < c->SharedLayers; i++) {
+    std::string s = std::to_string(i);
+    conv("Layer1 of Shared Layer " + s, K, K, 3); bnp("L1_" + s, K);
+    conv("Layer2 of Shared Layer " + s, K, K, 3); bnp("L2_" + s, K);
+  }
+  conv("PolicyHead", 2, K, 1); bnp("PolicyHead", 2);
+  fc("Policy", 2 * hw, c->ActionSpace);
+  conv("ValueHead", 1, K, 1); bnp("ValueHead", 1);
+  fc("Value", hw, c->FC);
+  fc("ValueOutput", c->FC, 1);
+  *out = n;
+  return AGZ_OK;
+}
+
+void agz_net_destroy(agz_net* n) {
+  if (!n) return;
+  hipStreamSynchronize(n->ctx->stream);
+  n->free_device();
+  delete n;
+}
+
+int agz_net_num_params(const agz_net* n) { return n ? (int)n->params.size() : 0; }
+
+int agz_net_param_info(const agz_net* n, int i, char* name, size_t cap, size_t* n_elems) {
+  AGZ_REQUIRE(n && i >= 0 && i < (int)n->params.size(), AGZ_E_INVALID, "agz_net_param_info: bad index %d", i);
+  if (name && cap) { strncpy(name, n->params[i].name.c_str(), cap - 1); name[cap - 1] = 0; }
+  if (n_elems) *n_elems = n->params[i].v.size();
+  return AGZ_OK;
+}
+
+int agz_net_set_param(agz_net* n, int i, const float* host, size_t cnt) {
+  AGZ_REQUIRE(n && host && i >= 0 && i < (int)n->params.size(), AGZ_E_INVALID, "agz_net_set_param: bad argument");
+  Param& p = n->params[i];
+  if (p.kind == 1 && cnt == (size_t)p.ref_shape[1]) {  // per-channel broadcast
+    int C = p.ref_shape[1], hw = n->HW;
+    for (int c = 0; c < C; c++) for (int q = 0; q < hw; q++) p.v[(size_t)c * hw + q] = host[c];
+  } else {
+    AGZ_REQUIRE(cnt >= p.v.size(), AGZ_E_INVALID, "agz_net_set_param(%s): need >= %zu floats, got %zu", p.name.c_str(),
+                p.v.size(), cnt);
+    memcpy(p.v.data(), host, p.v.size() * sizeof(float));  // row 0 of a batch-shaped tensor
+  }
+  n->committed = false;
+  return AGZ_OK;
+}
+
+int agz_net_get_param(const agz_net* n, int i, float* host, size_t cnt) {
+  AGZ_REQUIRE(n && host && i >= 0 && i < (int)n->params.size(), AGZ_E_INVALID, "agz_net_get_param: bad argument");
+  const Param& p = n->params[i];
+  AGZ_REQUIRE(cnt >= p.v.size(), AGZ_E_INVALID, "agz_net_get_param: buffer too small");
+  memcpy(host, p.v.data(), p.v.size() * sizeof(float));
+  return AGZ_OK;
+}
+
+int agz_net_set_bn_stats(agz_net* n, int bi, const float* mean, const float* var, size_t C) {
+  AGZ_REQUIRE(n && mean && var && bi >= 0 && bi < (int)n->bn.size(), AGZ_E_INVALID, "agz_net_set_bn_stats: bad argument");
+  AGZ_REQUIRE(C == n->bn[bi].mean.size(), AGZ_E_INVALID, "agz_net_set_bn_stats: C mismatch");
+  n->bn[bi].mean.assign(mean, mean + C);
+  n->bn[bi].var.assign(var, var + C);
+  n->committed = false;
+  return AGZ_OK;
+}
+
+int agz_net_init_random(agz_net* n, uint64_t seed) {
+  AGZ_REQUIRE(n, AGZ_E_INVALID, "net is NULL");
+  SplitMix64 r(seed);
+  for (Param& p : n->params) {
+    double field = 1;
+    for (size_t i = 2; i < p.ref_shape.size(); i++) field *= p.ref_shape[i];
+    double fan = (double)(p.ref_shape[0] + p.ref_shape[1]) * field;
+    double stdev = std::sqrt(2.0 / fan);
+    if (p.kind == 0) {  // GlorotU(1.0), ermahagerdmonards.go:39
+      double lim = stdev * std::sqrt(3.0);
+      for (float& x : p.v) x = (float)((r.float64() * 2.0 - 1.0) * lim);
+    } else if (p.kind == 1 || p.kind == 2) {  // GlorotN(1.0), ermahagerdmonards.go:80 (+ BN gamma/beta, App. B b3)
+      for (size_t i = 0; i < p.v.size(); i += 2) {
+        double u1 = 1.0 - r.float64(), u2 = r.float64();
+        double rad = std::sqrt(-2.0 * std::log(u1)), th = 6.283185307179586476925 * u2;
+        p.v[i] = (float)(rad * std::cos(th) * stdev);
+        if (i + 1 < p.v.size()) p.v[i + 1] = (float)(rad * std::sin(th) * stdev);
+      }
+    } else {  // Zeroes, ermahagerdmonards.go:82
+      for (float& x : p.v) x = 0.f;
+    }
+  }
+  n->committed = false;
+  return AGZ_OK;
+}
+
+static int upload(float** dptr, const std::vector<float>& h, hipStream_t s) {
+  if (*dptr) { hipFree(*dptr); *dptr = nullptr; }
+  AGZ_HIP_TRY(hipMalloc(dptr, h.size() * sizeof(float)));
+  AGZ_HIP_TRY(hipMemcpyAsync(*dptr, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));  // h may be a temporary
+  return AGZ_OK;
+}
+
+int agz_net_commit(agz_net* n) {
+  AGZ_REQUIRE(n, AGZ_E_INVALID, "net is NULL");
+  const agz_net_conf& c = n->conf;
+  const int K = c.K, F = c.Features, hw = n->HW, Kp = n->Kp, Fp = n->Fp, A = c.ActionSpace, FCn = c.FC;
+  hipStream_t s = n->ctx->stream;
+  AGZ_HIP_TRY(hipSetDevice(n->ctx->device));
+  // BN fold: y = ((x-mean)*inv)*gamma + beta  ->  x*scale + shift
+  auto fold = [&](int bi, int ch, const Param& g, const Param& b, int p, float* scale, float* shift) {
+    float mean = 0.f, inv = 1.f;
+    if (c.bn_mode == AGZ_BN_DEGENERATE_EPS) inv = 1.0f / std::sqrt(0.0f + c.bn_eps);
+    else if (c.bn_mode == AGZ_BN_RUNNING) { mean = n->bn[bi].mean[ch]; inv = 1.0f / std::sqrt(n->bn[bi].var[ch] + c.bn_eps); }
+    float gm = g.v[(size_t)ch * hw + p], bt = b.v[(size_t)ch * hw + p];
+    *scale = inv * gm;
+    *shift = bt - mean * inv * gm;
+  };
+  size_t pi = 0;
+  int bi = 0;
+  // --- init conv: Wt[tap][n<Kp][c<Fp]
+  {
+    const Param& w = n->params[pi];
+    std::vector<float> wt((size_t)9 * Kp * Fp, 0.f);
+    for (int o = 0; o < K; o++) for (int ci = 0; ci < F; ci++) for (int t = 0; t < 9; t++)
+      wt[((size_t)t * Kp + o) * Fp + ci] = w.v[((size_t)o * F + ci) * 9 + t];
+    std::vector<float> ep((size_t)hw * Kp * 2, 0.f);
+    for (int p = 0; p < hw; p++) for (int o = 0; o < K; o++)
+      fold(bi, o, n->params[pi + 1], n->params[pi + 2], p, &ep[((size_t)p * Kp + o) * 2], &ep[((size_t)p * Kp + o) * 2 + 1]);
+    int r;
+    if ((r = upload(&n->d_w_init, wt, s)) != AGZ_OK) return r;
+    if ((r = upload(&n->d_ep_init, ep, s)) != AGZ_OK) return r;
+    pi += 3; bi++;
+  }
+  // --- dual blocks: n ordered per block tile [a-channels | b-channels]
+  for (auto& p : n->d_w_dual) if (p) hipFree(p);
+  for (auto& p : n->d_ep_dual) if (p) hipFree(p);
+  n->d_w_dual.assign(c.SharedLayers, nullptr);
+  n->d_ep_dual.assign(c.SharedLayers, nullptr);
+  const int half = (n->cfg == 0) ? 64 : 32;  // channels per block tile (BNT/2)
+  for (int l = 0; l < c.SharedLayers; l++) {
+    const Param& wa = n->params[pi];
+    const Param& wb = n->params[pi + 3];
+    std::vector<float> wt((size_t)9 * 2 * Kp * Kp, 0.f);
+    for (int br = 0; br < 2; br++) {
+      const Param& w = br == 0 ? wa : wb;
+      for (int o = 0; o < K; o++) {
+        int tile = o / half, j = o % half;
+        int nidx = tile * 2 * half + br * half + j;
+        for (int ci = 0; ci < K; ci++) for (int t = 0; t < 9; t++)
+          wt[((size_t)t * 2 * Kp + nidx) * Kp + ci] = w.v[((size_t)o * K + ci) * 9 + t];
+      }
+    }
+    std::vector<float> ep((size_t)hw * Kp * 4, 0.f);
+    for (int p = 0; p < hw; p++) for (int o = 0; o < K; o++) {
+      float* e = &ep[((size_t)p * Kp + o) * 4];
+      fold(bi, o, n->params[pi + 1], n->params[pi + 2], p, &e[0], &e[1]);
+      fold(bi + 1, o, n->params[pi + 4], n->params[pi + 5], p, &e[2], &e[3]);
+    }
+    int r;
+    if ((r = upload(&n->d_w_dual[l], wt, s)) != AGZ_OK) return r;
+    if ((r = upload(&n->d_ep_dual[l], ep, s)) != AGZ_OK) return r;
+    pi += 6; bi += 2;
+  }
+  // --- heads
+  {
+    std::vector<float> hc((size_t)3 * Kp, 0.f), hb((size_t)3 * hw * 2, 0.f);
+    const Param& pw = n->params[pi];  // PolicyHead filter [2,K,1,1]
+    for (int o = 0; o < 2; o++) for (int ci = 0; ci < K; ci++) hc[(size_t)o * Kp + ci] = pw.v[(size_t)o * K + ci];
+    for (int o = 0; o < 2; o++) for (int p = 0; p < hw; p++)
+      fold(bi, o, n->params[pi + 1], n->params[pi + 2], p, &hb[((size_t)o * hw + p) * 2], &hb[((size_t)o * hw + p) * 2 + 1]);
+    pi += 3; bi++;
+    int r;
+    if ((r = upload(&n->d_Wp, n->params[pi].v, s)) != AGZ_OK) return r;
+    if ((r = upload(&n->d_bp, n->params[pi + 1].v, s)) != AGZ_OK) return r;
+    pi += 2;
+    const Param& vw = n->params[pi];  // ValueHead filter [1,K,1,1]
+    for (int ci = 0; ci < K; ci++) hc[(size_t)2 * Kp + ci] = vw.v[ci];
+    for (int p = 0; p < hw; p++)
+      fold(bi, 0, n->params[pi + 1], n->params[pi + 2], p, &hb[((size_t)2 * hw + p) * 2], &hb[((size_t)2 * hw + p) * 2 + 1]);
+    pi += 3; bi++;
+    if ((r = upload(&n->d_W1, n->params[pi].v, s)) != AGZ_OK) return r;
+    if ((r = upload(&n->d_b1, n->params[pi + 1].v, s)) != AGZ_OK) return r;
+    pi += 2;
+    if ((r = upload(&n->d_W2, n->params[pi].v, s)) != AGZ_OK) return r;
+    if ((r = upload(&n->d_b2, n->params[pi + 1].v, s)) != AGZ_OK) return r;
+    pi += 2;
+    if ((r = upload(&n->d_head_conv, hc, s)) != AGZ_OK) return r;
+    if ((r = upload(&n->d_head_bn, hb, s)) != AGZ_OK) return r;
+    (void)A; (void)FCn;
+  }
+  n->committed = true;
+  return AGZ_OK;
+}
+
+int agz_net_infer_dev(agz_net* n, const float* planes_dev, int B, float* policy_dev, float* value_dev) {
+  AGZ_REQUIRE(n && planes_dev && policy_dev && value_dev && B >= 1, AGZ_E_INVALID, "agz_net_infer_dev: bad argument");
+  AGZ_HIP_TRY(hipSetDevice(n->ctx->device));
+  return n->forward_dev(planes_dev, B, policy_dev, value_dev);
+}
+
+int agz_net_infer(agz_net* n, const float* planes, int B, float* policy, float* value) {
+  AGZ_REQUIRE(n && planes && policy && value && B >= 1, AGZ_E_INVALID, "agz_net_infer: bad argument");
+  AGZ_REQUIRE(n->committed, AGZ_E_STATE, "agz_net_infer: call agz_net_commit first");
+  AGZ_HIP_TRY(hipSetDevice(n->ctx->device));
+  int r = n->ensure_batch(B);
+  if (r != AGZ_OK) return r;
+  hipStream_t s = n->ctx->stream;
+  size_t per = (size_t)n->conf.Features * n->HW;
+  AGZ_HIP_TRY(hipMemcpyAsync(n->d_planes, planes, (size_t)B * per * sizeof(float), hipMemcpyHostToDevice, s));
+  r = n->forward_dev(n->d_planes, B, n->d_policy, n->d_value);
+  if (r != AGZ_OK) return r;
+  AGZ_HIP_TRY(hipMemcpyAsync(policy, n->d_policy, (size_t)B * n->conf.ActionSpace * sizeof(float), hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(value, n->d_value, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  return AGZ_OK;
+}
+
+double agz_net_flops_per_eval(const agz_net* n) {
+  if (!n) return 0;
+  double K = n->conf.K, F = n->conf.Features, hw = n->HW, A = n->conf.ActionSpace, L = n->conf.SharedLayers, FCn = n->conf.FC;
+  return 2 * F * K * 9 * hw + L * 2 * (2 * K * K * 9 * hw) + (2 * K * 2 * hw + 2 * 2 * hw * A) + (2 * K * hw + 2 * hw * FCn + 2 * FCn);
+}
+
+}  // extern "C"

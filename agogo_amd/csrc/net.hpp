@@ -1,0 +1,61 @@
+// agz_net: the dual network (dualnet/dual.go:50-103) as device-resident parameters + HIP launch chain.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace agz {
+struct Param {
+  std::string name;
+  std::vector<float> v;        // row-0 values (see include/agz.h)
+  std::vector<int> ref_shape;  // reference tensor shape (batch-shaped for BN/bias) for the Glorot fan
+  int kind;                    // 0 conv filter, 1 BN gamma/beta, 2 FC weight, 3 FC bias
+};
+struct BNStats { std::vector<float> mean, var; };
+}  // namespace agz
+
+struct agz_net {
+  agz_ctx* ctx = nullptr;
+  agz_net_conf conf{};
+  std::vector<agz::Param> params;
+  std::vector<agz::BNStats> bn;
+  bool committed = false;
+
+  // geometry
+  int H = 0, W = 0, HW = 0, Hp = 0, Wp = 0;
+  int Kp = 0;    // K rounded up to 32
+  int Fp = 32;   // input planes padded to 32 channels
+  int cfg = 0;   // 0: 128x128 block tile (K%64==0), 1: 128x64 block tile (K%32==0)
+
+  // device parameters (repacked)
+  float* d_w_init = nullptr;    // [9][Ntot_init][Fp]
+  float* d_ep_init = nullptr;   // float2 {scale,shift} [HW][Kp]
+  std::vector<float*> d_w_dual;   // per layer [9][2*Kp][Kp] in block-tile order
+  std::vector<float*> d_ep_dual;  // per layer float4 {sa,ta,sb,tb} [HW][Kp]
+  float* d_head_conv = nullptr;  // [3][Kp] policy ch0, ch1, value ch0 (1x1 filters)
+  float* d_head_bn = nullptr;    // [3][HW][2] scale, shift
+  float* d_Wp = nullptr;         // [2HW][A]
+  float* d_bp = nullptr;         // [A]
+  float* d_W1 = nullptr;         // [HW][FC]
+  float* d_b1 = nullptr;         // [FC]
+  float* d_W2 = nullptr;         // [FC]
+  float* d_b2 = nullptr;         // [1]
+
+  // activations (padded NHWC, zero halo)
+  int max_batch = 0;
+  float* d_act_in = nullptr;  // [B][Hp][Wp][Fp]
+  float* d_actA = nullptr;    // [B][Hp][Wp][Kp]
+  float* d_actB = nullptr;
+  // staging for the host-pointer entry point
+  float* d_planes = nullptr;  // [B][F][H][W]
+  float* d_policy = nullptr;  // [B][A]
+  float* d_value = nullptr;   // [B]
+
+  int ensure_batch(int B);
+  void free_device();
+  // planes_dev NCHW [B,F,H,W] -> policy_dev [B,A], value_dev [B]; async on ctx stream
+  int forward_dev(const float* planes_dev, int B, float* policy_dev, float* value_dev);
+  // same but the input already sits in d_act_in (padded NHWC, written by the MCTS encoder)
+  int forward_packed(int B, float* policy_dev, float* value_dev);
+};

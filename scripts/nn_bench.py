@@ -1,0 +1,47 @@
+"""NN-only micro-benchmark of the conv tower on the BASELINE 19x19 config (K=256, L=20, B=512)."""
+import argparse
+import json
+import sys
+import os
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import agogo_amd as A
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--K", type=int, default=256)
+ap.add_argument("--L", type=int, default=20)
+ap.add_argument("--B", type=int, default=512)
+ap.add_argument("--size", type=int, default=19)
+ap.add_argument("--iters", type=int, default=5)
+args = ap.parse_args()
+ctx = A.Ctx(0)
+S = args.size
+net = A.Net(ctx, args.K, args.L, 2 * args.K, S, S, 18, S * S + 1)
+net.init_random(1337)
+net.commit()
+x = torch.randint(-1, 2, (args.B, 18, S, S), device="cuda").float()
+pol = torch.empty((args.B, S * S + 1), device="cuda")
+val = torch.empty((args.B,), device="cuda")
+torch.cuda.synchronize()
+for _ in range(2):
+    net.infer_dev(x.data_ptr(), args.B, pol.data_ptr(), val.data_ptr())
+ctx.sync()
+ctx.prof_enable(True)
+t0 = time.perf_counter()
+for _ in range(args.iters):
+    net.infer_dev(x.data_ptr(), args.B, pol.data_ptr(), val.data_ptr())
+ctx.sync()
+t1 = time.perf_counter()
+ctx.prof_enable(False)
+n_conv, ms_conv = ctx.prof_read(A.capi.PROF_CONV)
+n_head, ms_head = ctx.prof_read(A.capi.PROF_HEADS)
+flops = net.flops_per_eval() * args.B
+dt = (t1 - t0) / args.iters
+print(json.dumps({"B": args.B, "K": args.K, "L": args.L, "ms_per_pass": dt * 1e3, "evals_per_s": args.B / dt,
+                  "tflops": flops / dt / 1e12, "frac_fp32_peak": flops / dt / 157.3e12,
+                  "conv_launches": n_conv, "conv_ms_avg": ms_conv / max(n_conv, 1), "heads_ms_avg": ms_head / max(n_head, 1),
+                  "policy_sum": float(pol.sum().item()), "value_mean": float(val.mean().item())}))

@@ -1,0 +1,123 @@
+"""GPU parity: libagz dual-net forward (HIP, fp32 MFMA) vs the CPU oracle restatement.
+
+Tolerance: fp32 — |policy - oracle| <= 2e-5 absolute (+1e-4 relative), |value - oracle| <= 1e-4.
+Both sides compute in fp32; they differ only in summation order (MFMA k-pair order vs sequential),
+BN folding (scale/shift vs normalise-then-affine) and expf/tanhf implementations.
+"""
+import numpy as np
+import pytest
+
+import agogo_amd as A
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+POL_ATOL, POL_RTOL, VAL_ATOL = 2e-5, 1e-4, 1e-4
+
+
+def make_pair(ctx, K, L, FC, W, H, F, Aspace, bn_mode=0, seed=1337):
+    onet = O.Net(K, L, FC, W, H, F, Aspace, bn_mode=bn_mode)
+    onet.init_random(seed)
+    gnet = A.Net(ctx, K, L, FC, W, H, F, Aspace, bn_mode=bn_mode)
+    assert gnet.num_params() == onet.num_params()
+    for i in range(onet.num_params()):
+        name, n = gnet.param_info(i)
+        p = onet.get_param(i)
+        assert n == p.size, (name, n, p.size)
+        gnet.set_param(i, p)
+    if bn_mode == A.capi.BN_RUNNING:
+        rng = np.random.default_rng(seed)
+        chans = [K] + [K, K] * L + [2, 1]
+        for bi, c in enumerate(chans):
+            mean = rng.normal(0, 0.1, c).astype(np.float32)
+            var = rng.uniform(0.5, 1.5, c).astype(np.float32)
+            onet.set_bn_stats(bi, mean, var)
+            gnet.set_bn_stats(bi, mean, var)
+    gnet.commit()
+    return onet, gnet
+
+
+def rand_planes(B, F, H, W, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.choice(np.array([-1.0, 0.0, 1.0, 0.001], dtype=np.float32), size=(B, F, H, W))
+    return x.astype(np.float32)
+
+
+CASES = [
+    # K, L, FC, W, H, F, A, B, bn_mode
+    (3, 3, 8, 3, 3, 2, 10, 7, 0),        # TTT config #1 (README.md:90-109): K=3 -> padded 32, cfg1 kernel
+    (64, 2, 128, 7, 6, 2, 8, 5, 0),      # C4-shaped, cfg0 kernel, partial M tile
+    (32, 2, 64, 9, 9, 18, 82, 4, 0),     # 9x9 Go, K=32 (cfg1)
+    (128, 2, 256, 9, 9, 18, 82, 3, 0),   # 9x9 Go K=128 (config #3 width)
+    (64, 1, 128, 19, 19, 18, 362, 3, 2),  # 19x19, identity BN
+    (64, 1, 128, 19, 19, 18, 362, 2, 1),  # 19x19, running-stats BN
+]
+
+
+@pytest.mark.parametrize("K,L,FC,W,H,F,Aspace,B,bn_mode", CASES)
+def test_infer_matches_oracle(ctx, K, L, FC, W, H, F, Aspace, B, bn_mode):
+    onet, gnet = make_pair(ctx, K, L, FC, W, H, F, Aspace, bn_mode)
+    x = rand_planes(B, F, H, W, seed=K * 100 + B)
+    pol_o, val_o = onet.infer(x)
+    pol_g, val_g = gnet.infer(x)
+    assert np.all(np.isfinite(pol_g)) and np.all(np.isfinite(val_g))
+    np.testing.assert_allclose(pol_g.sum(axis=1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(pol_g, pol_o, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(val_g, val_o, atol=VAL_ATOL)
+    # not a degenerate comparison: outputs differ across boards
+    assert np.abs(pol_o[0] - pol_o[-1]).max() > 1e-6
+
+
+def test_batch_independence(ctx):
+    """meta.go:175-189: every board is its own row-0 evaluation — results must not depend on batch composition."""
+    onet, gnet = make_pair(ctx, 64, 2, 128, 9, 9, 18, 82)
+    x = rand_planes(130, 18, 9, 9, seed=5)  # spans two 128-row M tiles per board group
+    pol_all, val_all = gnet.infer(x)
+    pol_1, val_1 = gnet.infer(x[77:78])
+    np.testing.assert_array_equal(pol_all[77], pol_1[0])
+    np.testing.assert_array_equal(val_all[77], val_1[0])
+
+
+def test_asymmetric_weights_transpose_detect(ctx):
+    """one-hot filters with asymmetric taps: catches row/col or tap-order swaps exactly."""
+    K, H, W, F = 64, 5, 5, 2
+    gnet = A.Net(ctx, K, 0, 8, W, H, F, 26, bn_mode=2)
+    onet = O.Net(K, 0, 8, W, H, F, 26, bn_mode=2)
+    rng = np.random.default_rng(3)
+    for i in range(onet.num_params()):
+        p = onet.get_param(i)
+        name = onet.param_name(i)
+        if name == "FilterInit":
+            p = np.zeros((K, F, 3, 3), np.float32)
+            for o in range(K):
+                p[o, o % F, (o // F) % 3, (o // (3 * F)) % 3] = 1.0 + o  # asymmetric one-hot taps
+        elif name.endswith("_gamma"):
+            p = np.ones_like(p)
+        elif name.endswith("_beta"):
+            p = np.zeros_like(p)
+        else:
+            p = rng.normal(0, 0.1, p.size).astype(np.float32)
+        onet.set_param(i, p)
+        gnet.set_param(i, p)
+    gnet.commit()
+    x = rng.normal(0, 1, (3, F, H, W)).astype(np.float32)
+    pol_o, val_o = onet.infer(x)
+    pol_g, val_g = gnet.infer(x)
+    np.testing.assert_allclose(pol_g, pol_o, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(val_g, val_o, atol=VAL_ATOL)
+
+
+def test_init_random_matches_oracle_rng(ctx):
+    """agz_net_init_random and the oracle state the same SplitMix64/Glorot recipe independently."""
+    onet = O.Net(32, 1, 64, 5, 5, 2, 26)
+    onet.init_random(99)
+    gnet = A.Net(ctx, 32, 1, 64, 5, 5, 2, 26)
+    gnet.init_random(99)
+    for i in range(onet.num_params()):
+        np.testing.assert_array_equal(gnet.get_param(i), onet.get_param(i))
+
+
+def test_infer_before_commit_fails(ctx):
+    gnet = A.Net(ctx, 32, 1, 64, 5, 5, 2, 26)
+    with pytest.raises(A.AgzError):
+        gnet.infer(np.zeros((1, 2, 5, 5), np.float32))
