@@ -133,10 +133,20 @@ def _pi(a):
 class Ctx:
     def __init__(self, device=0):
         self.h = C.c_void_p()
+        self._children = []
         _check(lib().agz_ctx_create(device, C.byref(self.h)), "agz_ctx_create")
 
+    def _adopt(self, child):
+        import weakref
+        self._children.append(weakref.ref(child))
+
     def close(self):
+        """destroys dependants (arenas, nets) first: their handles hold a pointer to this ctx"""
         if self.h:
+            kids = [r() for r in self._children]
+            for k in sorted([k for k in kids if k is not None], key=lambda k: 0 if isinstance(k, Arena) else 1):
+                k.close()
+            self._children = []
             lib().agz_ctx_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -170,11 +180,12 @@ class Net:
         self.conf = NetConf(K, SharedLayers, FC, BatchSize, Width, Height, Features, ActionSpace, bn_mode, bn_eps)
         self.h = C.c_void_p()
         _check(lib().agz_net_create(ctx.h, C.byref(self.conf), C.byref(self.h)), "agz_net_create")
+        ctx._adopt(self)
 
     def close(self):
-        if self.h:
+        if self.h and self.ctx.h:
             lib().agz_net_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -247,11 +258,12 @@ class Arena:
         self._nets = []
         _check(lib().agz_arena_create(ctx.h, C.byref(self.gconf), C.byref(self.mconf), n_games, seed, max_nodes,
                                       C.byref(self.h)), "agz_arena_create")
+        ctx._adopt(self)
 
     def close(self):
-        if self.h:
+        if self.h and self.ctx.h:
             lib().agz_arena_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
     def __del__(self):
         try:

@@ -1,21 +1,1163 @@
-// placeholder until the device MCTS engine lands (next commit)
-#include "common.hpp"
-#define NYI(name) { agz::set_error(name ": not built yet"); return AGZ_E_UNSUPPORTED; }
-extern "C" {
-int agz_arena_create(agz_ctx*, const agz_game_conf*, const agz_mcts_conf*, int, uint64_t, int, agz_arena**) NYI("agz_arena_create")
-void agz_arena_destroy(agz_arena*) {}
-int agz_arena_set_inferencer(agz_arena*, int, int, agz_net*) NYI("x")
-int agz_arena_reset(agz_arena*, const uint8_t*) NYI("x")
-int agz_arena_play(agz_arena*, int, int) NYI("x")
-int agz_arena_begin_move(agz_arena*) NYI("x")
-int agz_arena_simulate(agz_arena*, int) NYI("x")
-int agz_arena_end_move(agz_arena*, int) NYI("x")
-int agz_arena_get_stats(agz_arena*, agz_arena_stats*) NYI("x")
-int agz_arena_get_game(agz_arena*, int, int32_t*, agz_game_state*) NYI("x")
-int agz_arena_get_history(agz_arena*, int, int32_t*, int, int*) NYI("x")
-int agz_arena_root_children(agz_arena*, int, int, int32_t*, uint32_t*, float*, float*, int, int*) NYI("x")
-int agz_arena_tree_nodes(agz_arena*, int, int, int*) NYI("x")
-int agz_arena_get_examples(agz_arena*, float*, float*, float*, int32_t*, int, int*) NYI("x")
-int agz_arena_clear_examples(agz_arena*) NYI("x")
-int agz_arena_examples_dev(agz_arena*, float**, float**, float**, int*) NYI("x")
+// Batched self-play engine: n_games x { agogo.Arena + 2 x mcts.MCTS + game.State } resident in HBM.
+//
+// Reference path replaced:
+//   Arena.Play loop           arena.go:96-138        -> agz_arena_play / begin_move / simulate / end_move
+//   MCTS.Search               mcts/search.go:92-164  -> k_begin_move (updateRoot) + prepare + Budget x step + k_end_move
+//   searchState.pipeline      mcts/search.go:209-257 -> k_select (descent+Apply) ; NN ; k_expand (expand+backup)
+//   Node.Select / Evaluate    mcts/node.go:147-237   -> select_child()
+//   expandAndSimulate         mcts/search.go:259-339 -> k_expand
+//   bestMove / fancySort      mcts/search.go:341-390, mcts/utils.go:18-47 -> k_end_move
+//   Policies / cachedPolicies mcts/tree.go:128-142   -> policy-cache list per tree
+//   game.State (mnk,c4,komi,wq) game/*                -> engine_dev.hpp
+//   encoders                  encoding_helper.go:29-68, cmd/tictactoe/main.go:26-47 -> encode_leaf()
+//
+// One simulation step = every unfinished game runs ONE pipeline() in its current agent's tree; the leaves of
+// all games are coalesced into one batched network evaluation (the reference evaluates one leaf per call in
+// row 0 of an ActionSpace-row batch, dualnet/meta.go:175-189).  Searches are sequential per tree, so the
+// statistics equal the sequential oracle bit for bit; parallelism comes from thousands of trees.
+//
+// Bound: these kernels are HBM/latency-bound integer + scalar-float work (select reads 12 B per child,
+// backup writes 8 B per path node); they are sized to stay off the critical path of the conv tower.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "engine_dev.hpp"
+#include "net.hpp"
+
+namespace agz {
+
+__device__ __forceinline__ size_t pool_base(const Dev& d, int t, int pool) { return ((size_t)t * 2 + pool) * d.cap; }
+
+// Evaluate(): mcts/node.go:147-159 (virtual loss is never observable in a sequential search)
+__device__ __forceinline__ float evaluate(float bs, uint32_t visits, int player) {
+  float score = __fdiv_rn(bs, (float)visits);
+  if (player == AGZ_WHITE) score = __fsub_rn(1.0f, score);
+  return score;
 }
+
+// Node.Select: mcts/node.go:170-237.  64 lanes over the contiguous child block; strict '>' keeps the first maximum.
+__device__ int select_child(const Dev& d, size_t base, int off, int n, int player, float PUCT, int lane) {
+  uint32_t pv = 0;
+  for (int i = lane; i < n; i += WAVE) pv += d.visits[base + off + i];
+  for (int o = 32; o > 0; o >>= 1) pv += __shfl_xor(pv, o, 64);
+  float numerator = __fsqrt_rn((float)pv);
+  float best = -INFINITY;
+  int idx = -1;
+  for (int i = lane; i < n; i += WAVE) {
+    uint32_t v = d.visits[base + off + i];
+    float bs = d.bsum[base + off + i];
+    float psa = d.prior[base + off + i];
+    float qsa = evaluate(bs, v, player);
+    float denominator = __fadd_rn(1.0f, (float)v);
+    float lastTerm = __fdiv_rn(numerator, denominator);
+    float puct = __fmul_rn(__fmul_rn(PUCT, psa), lastTerm);
+    float usa = __fadd_rn(qsa, puct);
+    if (usa > best) { best = usa; idx = i; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    float ob = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(idx, o, 64);
+    bool take = (ob > best) || (ob == best && oi >= 0 && (idx < 0 || oi < idx));
+    if (take) { best = ob; idx = oi; }
+  }
+  return idx;  // -1: the reference panics "Cannot return nil" (node.go:232-234)
+}
+
+// ---- state in LDS -----------------------------------------------------------------------------------
+struct St {
+  int to_move, ply, passes;
+  uint32_t hash;
+};
+
+// game.State.Apply for a move that is known to be legal; updates s.board / ring / st.  Returns captures taken.
+__device__ int apply_move(const GameCfg& c, const Dev& d, Sh& s, St& st, int mv, bool use_ring, int lane) {
+  int player = st.to_move;
+  int taken = 0;
+  if (c.kind == AGZ_GAME_MNK) {  // mnk.go:122-142
+    if (lane == 0) s.board[mv] = (int8_t)player;
+  } else if (c.kind == AGZ_GAME_C4) {  // c4/game.go:56-73, c4.go:47-70
+    if (mv != AGZ_PASS) {
+      int r = c4_drop_row(c, s.board, mv);
+      __syncthreads();
+      if (lane == 0 && r >= 0) s.board[r * c.n + mv] = (int8_t)player;
+    }
+  } else {  // komi/game.go:104-130,277-313 ; wq/game.go:81-92 (+pass completion)
+    if (mv != AGZ_PASS) {
+      analyse(c, s, d.ztable, lane);
+      taken = go_apply(c, s, d.ztable, mv, player, &st.hash, lane);
+      st.passes = 0;
+    } else {
+      st.passes++;
+    }
+  }
+  __syncthreads();
+  if (c.flip_in_tree) st.to_move = opp(player);
+  st.ply++;
+  if (use_ring) {
+    int slot = st.ply % RING;
+    for (int i = lane; i < c.cells; i += WAVE) s.ring[slot][i] = s.board[i];
+    __syncthreads();
+  }
+  return taken;
+}
+
+__device__ __forceinline__ int move_number(const GameCfg& c, int ply) { return c.kind == AGZ_GAME_C4 ? 1 : ply; }  // c4/game.go:52
+
+// legality of every action for `player` on the board in s (go-like boards must be analysed)
+__device__ void legal_mask(const GameCfg& c, const Sh& s, int player, uint8_t* out, int lane) {
+  for (int i = lane; i < c.A; i += WAVE) {
+    bool ok;
+    if (c.kind == AGZ_GAME_MNK) ok = s.board[i] == AGZ_NONE;                         // mnk.go:102-120
+    else if (c.kind == AGZ_GAME_C4) ok = s.board[i] == AGZ_NONE;                     // top cell of column i empty (c4.go:59-70)
+    else ok = go_legal(c, s, i, player);                                               // komi/game.go:78-102
+    out[i] = ok ? 1 : 0;
+  }
+  if (lane == 0) out[c.A] = c.pass_legal ? 1 : 0;
+}
+
+// Encoders.  Output is the network's input tile for this leaf: padded NHWC [Hp][Wp][32].
+__device__ void encode_nhwc(const GameCfg& c, const Sh& s, const St& st, float* out, int lane) {
+  const int Wp = c.n + 2;
+  for (int i = lane; i < c.cells; i += WAVE) {
+    int h = i / c.n, w = i - h * c.n;
+    float* o = out + ((size_t)(h + 1) * Wp + (w + 1)) * 32;
+    if (c.encoder == AGZ_ENC_TWOPLANE) {  // cmd/tictactoe/main.go:26-47
+      int v = s.board[i];
+      o[0] = v == AGZ_BLACK ? 1.f : (v == AGZ_WHITE ? -1.f : 0.001f);
+      o[1] = st.to_move == AGZ_BLACK ? 1.f : (st.to_move == AGZ_WHITE ? -1.f : 0.f);
+    } else {  // WQEncoder, encoding_helper.go:29-68
+      int mn = move_number(c, st.ply);
+      bool nb = st.to_move == AGZ_BLACK;
+      int blackStart = nb ? 0 : 8, whiteStart = nb ? 8 : 0;
+#pragma unroll
+      for (int k = 1; k < 8; k++) {
+        int j = mn - k;  // board after move j (Historical(h), h = mn-1-k, needs h > 0)
+        float e = 0.f;
+        if (j >= 2) { int v = s.ring[j % RING][i]; e = v == AGZ_BLACK ? 1.f : (v == AGZ_WHITE ? -1.f : 0.f); }
+        o[blackStart + k - 1] = e;
+        o[whiteStart + k - 1] = j >= 2 ? -e : 0.f;  // vecf32.Scale(retVal, -1): empty cells become -0.0
+      }
+      o[7] = 0.f; o[15] = 0.f;
+      o[16] = nb ? 1.f : 0.f;
+      o[17] = nb ? 0.f : -1.f;
+    }
+  }
+}
+// same encoders in the reference's flat NCHW [F][cells] layout (training examples, arena.go:106)
+__device__ void encode_nchw(const GameCfg& c, const Sh& s, const St& st, float* out, int lane) {
+  for (int i = lane; i < c.cells; i += WAVE) {
+    if (c.encoder == AGZ_ENC_TWOPLANE) {
+      int v = s.board[i];
+      out[i] = v == AGZ_BLACK ? 1.f : (v == AGZ_WHITE ? -1.f : 0.001f);
+      out[c.cells + i] = st.to_move == AGZ_BLACK ? 1.f : (st.to_move == AGZ_WHITE ? -1.f : 0.f);
+    } else {
+      int mn = move_number(c, st.ply);
+      bool nb = st.to_move == AGZ_BLACK;
+      int blackStart = nb ? 0 : 8, whiteStart = nb ? 8 : 0;
+      for (int k = 1; k < 8; k++) {
+        int j = mn - k;
+        float e = 0.f;
+        if (j >= 2) { int v = s.ring[j % RING][i]; e = v == AGZ_BLACK ? 1.f : (v == AGZ_WHITE ? -1.f : 0.f); }
+        out[(blackStart + k - 1) * c.cells + i] = e;
+        out[(whiteStart + k - 1) * c.cells + i] = j >= 2 ? -e : 0.f;  // -0.0 for empty cells, as vecf32.Scale gives
+      }
+      out[7 * c.cells + i] = 0.f; out[15 * c.cells + i] = 0.f;
+      out[16 * c.cells + i] = nb ? 1.f : 0.f;
+      out[17 * c.cells + i] = nb ? 0.f : -1.f;
+    }
+  }
+}
+
+__device__ void load_state(const GameCfg& c, const Dev& d, int g, Sh& s, St& st, bool use_ring, int lane) {
+  for (int i = lane; i < c.cells; i += WAVE) s.board[i] = d.board[(size_t)g * CELLS_PAD + i];
+  if (use_ring)
+    for (int r = 0; r < RING; r++)
+      for (int i = lane; i < c.cells; i += WAVE) s.ring[r][i] = d.ring[((size_t)g * RING + r) * CELLS_PAD + i];
+  st.to_move = d.to_move[g];
+  st.ply = d.ply[g];
+  st.passes = d.passes[g];
+  st.hash = d.zhash[g];
+  __syncthreads();
+}
+
+__device__ __forceinline__ int agent_of(const Dev& d, int g) {
+  // the Arena's currentPlayer (arena.go:81-89,226-233): A moves when its colour is to move
+  int tm = d.to_move[g];
+  bool a_black = d.a_is_black[g] != 0;
+  return ((tm == AGZ_BLACK) == a_black) ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_reset(Dev d, GameCfg c, const uint8_t* a_is_black, unsigned long long seed) {
+  int g = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < CELLS_PAD; i += WAVE) d.board[(size_t)g * CELLS_PAD + i] = 0;
+  for (int i = lane; i < RING * CELLS_PAD; i += WAVE) d.ring[(size_t)g * RING * CELLS_PAD + i] = 0;
+  if (lane == 0) {
+    int ab;
+    if (a_is_black) ab = a_is_black[g] ? 1 : 0;
+    else {  // a.r.Intn(2) == 0 -> A is Black (arena.go:81); the build's SplitMix64 stream
+      unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(g + 1);
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+      ab = (z >> 63) == 0 ? 1 : 0;
+    }
+    d.a_is_black[g] = ab;
+    d.to_move[g] = AGZ_BLACK;  // the agent holding Black starts: game.SetToMove(currentPlayer.Player), arena.go:91
+    d.ply[g] = 0; d.passes[g] = 0; d.pass_count[g] = 0; d.ended[g] = 0; d.winner[g] = AGZ_NONE;
+    d.last_move[g] = AGZ_PASS; d.cap_b[g] = 0.f; d.cap_w[g] = 0.f; d.zhash[g] = 0; d.ex_last[g] = -1;
+    d.leaf_kind[g] = LEAF_NONE;
+    for (int a = 0; a < 2; a++) {
+      int t = a * d.G + g;
+      d.n_nodes[t] = 0; d.cur_pool[t] = 0; d.has_root[t] = 0; d.has_prev[t] = 0; d.prev_ply[t] = 0; d.stalled[t] = 0;
+      d.overflow[t] = 0; d.pc_n[t] = 0;
+      d.rng[t] = seed * 2654435761ull + (unsigned long long)t * 0x9E3779B97F4A7C15ull + 1;
+    }
+  }
+}
+
+// updateRoot + newRootState: mcts/search.go:424-500.  Tree reuse re-roots by copying the kept subtree into
+// the tree's other pool in BFS block order (the reference frees the siblings into a freelist, tree.go:183-209;
+// node identities are not observable, statistics and child order are).
+__global__ __launch_bounds__(64) void k_begin_move(Dev d, GameCfg c, MctsCfg mc) {
+  __shared__ Sh s;
+  int g = blockIdx.x, lane = threadIdx.x;
+  if (d.ended[g]) return;
+  int agent = agent_of(d, g);
+  int t = agent * d.G + g;
+  int player = d.to_move[g];
+  St st;
+  load_state(c, d, g, s, st, false, lane);
+  if (lane == 0) d.stalled[t] = 0;
+  int pool = d.cur_pool[t];
+  size_t base = pool_base(d, t, pool);
+  bool ok = d.has_root[t] && d.has_prev[t] && c.kind != AGZ_GAME_C4;  // c4: Eq() can never hold (App. C c2)
+  int depth = 0, node = 0;
+  if (ok) {
+    int prev_ply = d.prev_ply[t];
+    depth = st.ply - prev_ply;
+    if (depth < 0) ok = false;
+    if (ok && c.kind != AGZ_GAME_WQ) {
+      // tmp := current.Clone(); UndoLastMove x depth (removes the stone only, mnk.go:184-189, komi/game.go:201-206);
+      // tmp.Eq(prev) compares boards.
+      int bad = 0;
+      for (int i = lane; i < c.cells; i += WAVE) {
+        int v = s.board[i];
+        for (int k = 0; k < depth; k++) { int mv = d.moves[(size_t)g * d.moves_stride + st.ply - 1 - k]; if (mv == i) v = AGZ_NONE; }
+        if (v != d.prev_board[(size_t)t * CELLS_PAD + i]) bad = 1;
+      }
+      if (__syncthreads_or(bad)) ok = false;
+    }
+    for (int k = 0; ok && k < depth; k++) {  // replay LastMove()s, findChild (node.go:285-296)
+      int mv = d.moves[(size_t)g * d.moves_stride + prev_ply + k];
+      int off = d.kids_off[base + node], n = off >= 0 ? d.kids_n[base + node] : 0;
+      int found = 0x7fffffff;
+      for (int i = lane; i < n; i += WAVE) if (d.nmove[base + off + i] == mv && i < found) found = i;
+      for (int o = 32; o > 0; o >>= 1) { int f2 = __shfl_xor(found, o, 64); found = f2 < found ? f2 : found; }
+      if (found == 0x7fffffff) ok = false; else node = off + found;
+    }
+  }
+  if (ok) {
+    if (node != 0) {
+      // compaction copy of the subtree rooted at `node` into the other pool
+      size_t nb = pool_base(d, t, pool ^ 1);
+      if (lane == 0) {
+        d.prior[nb] = d.prior[base + node]; d.visits[nb] = d.visits[base + node]; d.bsum[nb] = d.bsum[base + node];
+        d.kids_off[nb] = d.kids_off[base + node]; d.kids_n[nb] = d.kids_n[base + node]; d.nmove[nb] = d.nmove[base + node];
+      }
+      __syncthreads();
+      int new_n = 1, scan = 0;
+      while (scan < new_n) {
+        int hi = min(scan + WAVE, new_n);
+        int i = scan + lane;
+        int ooff = (i < hi) ? d.kids_off[nb + i] : -1;
+        unsigned long long m = __ballot(ooff >= 0);
+        while (m) {
+          int src_lane = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          int so = __shfl(ooff, src_lane, 64);
+          int ni = scan + src_lane;
+          int cnt = d.kids_n[nb + ni];
+          for (int k = lane; k < cnt; k += WAVE) {
+            d.prior[nb + new_n + k] = d.prior[base + so + k];
+            d.visits[nb + new_n + k] = d.visits[base + so + k];
+            d.bsum[nb + new_n + k] = d.bsum[base + so + k];
+            d.kids_off[nb + new_n + k] = d.kids_off[base + so + k];  // still an OLD-pool offset until scanned
+            d.kids_n[nb + new_n + k] = d.kids_n[base + so + k];
+            d.nmove[nb + new_n + k] = d.nmove[base + so + k];
+          }
+          if (lane == 0) d.kids_off[nb + ni] = new_n;
+          new_n += cnt;
+        }
+        __syncthreads();
+        scan = hi;
+      }
+      if (lane == 0) { d.cur_pool[t] = pool ^ 1; d.n_nodes[t] = new_n; }
+    }
+  } else {
+    // fresh root: Pass if legal, else the first legal move (search.go:476-487); pool restarts empty
+    int rootmv = AGZ_PASS;
+    if (!c.pass_legal) {
+      if (c.go_like) analyse(c, s, nullptr, lane);
+      int first = 0x7fffffff;
+      for (int i = lane; i < c.A; i += WAVE) {
+        bool legal = c.go_like ? go_legal(c, s, i, player) : (s.board[i] == AGZ_NONE);
+        if (legal && i < first) first = i;
+      }
+      for (int o = 32; o > 0; o >>= 1) { int f2 = __shfl_xor(first, o, 64); first = f2 < first ? f2 : first; }
+      rootmv = first == 0x7fffffff ? AGZ_PASS : first;
+    }
+    if (lane == 0) {
+      d.prior[base] = 0.f; d.visits[base] = 1; d.bsum[base] = 0.f; d.kids_off[base] = -1; d.kids_n[base] = 0;
+      d.nmove[base] = (int16_t)rootmv; d.n_nodes[t] = 1; d.has_root[t] = 1;
+    }
+  }
+  if (lane == 0) d.has_prev[t] = 0;  // t.searchState.prev = nil (search.go:490)
+}
+
+// pipeline() descent: mcts/search.go:209-257 up to (and excluding) the network call.
+// prep != 0 runs prepareRoot (search.go:392-408) instead: the root itself is the leaf if it is expandable.
+__global__ __launch_bounds__(64) void k_select(Dev d, GameCfg c, MctsCfg mc, float* act_in0, float* act_in1, int prep) {
+  __shared__ Sh s;
+  int g = blockIdx.x, lane = threadIdx.x;
+  if (d.ended[g]) { if (lane == 0) d.leaf_kind[g] = LEAF_NONE; return; }
+  int agent = agent_of(d, g);
+  int t = agent * d.G + g;
+  if (d.stalled[t]) { if (lane == 0) { d.leaf_kind[g] = LEAF_NULL; d.path_len[g] = 0; } return; }
+  const bool use_ring = c.encoder == AGZ_ENC_WQ;
+  St st;
+  load_state(c, d, g, s, st, use_ring, lane);
+  size_t base = pool_base(d, t, d.cur_pool[t]);
+  int32_t* path = d.path + (size_t)g * MAXPATH;
+  int node = 0, depth = 1, plen = 1, kind = LEAF_NONE;
+  float result = 0.f;
+  if (lane == 0) path[0] = 0;
+  while (true) {
+    if (depth > mc.maxDepth) { kind = LEAF_NULL; break; }  // search.go:211-215
+    int off = d.kids_off[base + node];
+    if (off < 0) {  // IsExpandable(0)
+      if (c.has_passes && st.passes >= 2) {
+        if (prep) { kind = LEAF_TERMINAL; result = 0.f; }  // expandAndSimulate returns (0,false); root.Update(0)
+        else {  // combinedScore, utils.go:62-67
+          analyse(c, s, nullptr, lane);
+          float b, w;
+          area_scores(c, s, lane, &b, &w);
+          result = __fsub_rn(__fsub_rn(b, w), c.komi);
+          kind = LEAF_TERMINAL;
+        }
+      } else {
+        kind = LEAF_EXPAND;
+      }
+      break;
+    }
+    if (prep) { kind = LEAF_NONE; break; }  // root already has children: prepareRoot does nothing
+    int n = d.kids_n[base + node];
+    int ci = select_child(d, base, off, n, st.to_move, mc.PUCT, lane);
+    if (ci < 0) { kind = LEAF_NULL; break; }
+    int child = off + ci;
+    int mv = d.nmove[base + child];
+    apply_move(c, d, s, st, mv, use_ring, lane);  // children were created from legal moves of this very state
+    if (lane == 0) path[plen] = child;
+    plen++;
+    node = child;
+    depth++;
+  }
+  if (kind == LEAF_EXPAND) {
+    if (c.go_like) analyse(c, s, nullptr, lane);
+    legal_mask(c, s, st.to_move, d.leaf_legal + (size_t)g * CELLS_PAD, lane);
+    for (int i = lane; i < c.cells; i += WAVE) d.leaf_board[(size_t)g * CELLS_PAD + i] = s.board[i];
+    float* act = agent == 0 ? act_in0 : act_in1;
+    if (act) encode_nhwc(c, s, st, act + (size_t)d.slot_of_game[g] * (c.m + 2) * (c.n + 2) * 32, lane);
+  }
+  if (lane == 0) {
+    d.leaf_kind[g] = kind;
+    d.leaf_player[g] = st.to_move;
+    d.leaf_ply[g] = move_number(c, st.ply);
+    d.leaf_result[g] = result;
+    d.path_len[g] = plen;
+  }
+}
+
+// expandAndSimulate (mcts/search.go:259-339) after the network call + the BACKPROPAGATE half of pipeline().
+__global__ __launch_bounds__(64) void k_expand(Dev d, GameCfg c, MctsCfg mc, InfDesc inf, int prep) {
+  __shared__ Sh s;
+  int g = blockIdx.x, lane = threadIdx.x;
+  if (d.ended[g]) return;
+  int kind = d.leaf_kind[g];
+  int agent = agent_of(d, g);
+  int t = agent * d.G + g;
+  if (kind == LEAF_NONE) return;
+  if (!prep && lane == 0) atomicAdd(&d.counters[CNT_SIMS], 1ull);
+  if (kind == LEAF_NULL) { if (lane == 0) d.stalled[t] = 1; return; }
+  size_t base = pool_base(d, t, d.cur_pool[t]);
+  const int32_t* path = d.path + (size_t)g * MAXPATH;
+  int plen = d.path_len[g];
+  int node = path[plen - 1];
+  float result = d.leaf_result[g];
+  bool have = true;
+  if (kind == LEAF_EXPAND) {
+    int player = d.leaf_player[g];
+    const uint8_t* legal = d.leaf_legal + (size_t)g * CELLS_PAD;
+    const int ik = inf.kind[agent];
+    const int plen_pol = inf.policy_len[agent];
+    const float* pol = nullptr;
+    float value = 0.f;
+    uint32_t ph = 0;
+    if (ik == AGZ_INF_NET) {
+      int slot = d.slot_of_game[g];
+      pol = inf.policy[agent] + (size_t)slot * plen_pol;
+      value = inf.value[agent][slot];
+    } else if (ik == AGZ_INF_DUMMY) {  // dummy.go:10-23
+      int dp = inf.dummy_player[agent];
+      value = dp == 1 ? 1.f : (dp == 2 ? -1.f : 0.f);
+    } else if (ik == AGZ_INF_SCRIPT) {  // mcts/example_test.go:40-72 (8 / 9 == 0)
+      int mn = d.leaf_ply[g];
+      value = (mn == 0 || mn == 1 || mn == 5) ? 0.5f : 0.f;
+    } else if (ik == AGZ_INF_HASH) {  // synthetic position hash (oracle/arena.hpp HashNN)
+      uint32_t h = 0;
+      for (int i = lane; i < c.cells; i += WAVE) h += mix32((uint32_t)i * 4u + (uint32_t)d.leaf_board[(size_t)g * CELLS_PAD + i] + 1u);
+      for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+      h += mix32(0xABCD0000u + (uint32_t)player);
+      ph = h;
+      value = (float)(mix32(h ^ 0xDEADBEEFu) >> 8) * (1.0f / 16777216.0f);
+    } else {  // AGZ_INF_UNIFORM, mcts/example_test.go:158-166
+      value = 1 / 25.0f;
+    }
+    auto policy_at = [&](int i) -> float {
+      switch (ik) {
+        case AGZ_INF_NET: return pol[i];
+        case AGZ_INF_DUMMY: return __fdiv_rn(1.f, (float)plen_pol);
+        case AGZ_INF_SCRIPT: {
+          int mn = d.leaf_ply[g];
+          const int8_t cell[9] = {4, 0, 2, 6, 3, 5, 1, 7, 8};
+          if (mn >= 0 && mn < 9 && i == cell[mn]) return (mn & 1) ? 0.1f : 0.9f;
+          return 0.f;
+        }
+        case AGZ_INF_HASH: return (float)((mix32(ph + (uint32_t)i * 0x9E3779B9u) >> 8) + 1u) * (1.0f / 16777216.0f);
+        default: return 1 / 25.0f;
+      }
+    };
+    if (player == AGZ_WHITE) value = __fsub_rn(1.f, value);  // search.go:278-280
+    // nodelist in move order, Pass last (search.go:285-296)
+    int n = 0;
+    for (int b0 = 0; b0 < c.A; b0 += WAVE) {
+      int i = b0 + lane;
+      bool ok = i < c.A && legal[i];
+      unsigned long long m = __ballot(ok);
+      if (ok) {
+        int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+        s.fscore[pos] = policy_at(i);
+        s.fmove[pos] = i;
+      }
+      n += __popcll(m);
+    }
+    if (legal[c.A]) {
+      if (lane == 0) { s.fscore[n] = policy_at(plen_pol - 1); s.fmove[n] = AGZ_PASS; }  // passProb = policy[len-1]
+      n++;
+    }
+    __syncthreads();
+    // legalSum: sequential float32 sum in list order, as the reference accumulates it
+    float legalSum = 0.f;
+    if (lane == 0) { for (int i = 0; i < n; i++) legalSum = __fadd_rn(legalSum, s.fscore[i]); }
+    legalSum = __shfl(legalSum, 0, 64);
+    if (legalSum > 1.401298464e-45f) {
+      for (int i = lane; i < n; i += WAVE) s.fscore[i] = __fdiv_rn(s.fscore[i], legalSum);
+    } else {
+      float prob = __fdiv_rn(1.f, (float)n);
+      for (int i = lane; i < n; i += WAVE) s.fscore[i] = prob;
+    }
+    __syncthreads();
+    result = value;
+    if (n > 0) {
+      int off = d.n_nodes[t];
+      if (off + n > d.cap) {  // pool exhausted: reported, the tree stops growing (AGZ_E_TREE_FULL)
+        if (lane == 0) { if (!d.overflow[t]) atomicAdd(&d.counters[CNT_FULL], 1ull); d.overflow[t] = 1; d.stalled[t] = 1; }
+        have = false;
+      } else {
+        // sort.Sort(byScore) as a STABLE descending sort: rank = #greater + #equal-before
+        for (int i = lane; i < n; i += WAVE) {
+          float si = s.fscore[i];
+          int rank = 0;
+          for (int j = 0; j < n; j++) { float sj = s.fscore[j]; rank += (sj > si) || (sj == si && j < i); }
+          size_t o = base + off + rank;
+          d.prior[o] = si; d.visits[o] = 1; d.bsum[o] = 0.f; d.kids_off[o] = -1; d.kids_n[o] = 0;  // tree.go:106-117
+          d.nmove[o] = (int16_t)s.fmove[i];
+        }
+        if (lane == 0) { d.kids_off[base + node] = off; d.kids_n[base + node] = (int16_t)n; d.n_nodes[t] = off + n; }
+      }
+    }
+    if (lane == 0) atomicAdd(&d.counters[CNT_EVALS], 1ull);
+  }
+  if (have) {  // Update along the path (search.go:251-253, node.go:70-76): same black-perspective value at every level
+    for (int j = lane; j < plen; j += WAVE) {
+      size_t o = base + path[j];
+      d.visits[o] = d.visits[o] + 1;
+      d.bsum[o] = __fadd_rn(d.bsum[o], result);
+    }
+    if (!prep && lane == 0) atomicAdd(&d.counters[CNT_NONNULL], 1ull);
+  }
+}
+
+// bestMove + Policies + Arena.Play's per-move bookkeeping (search.go:341-390,152-161; arena.go:98-138)
+__global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, int record) {
+  __shared__ Sh s;
+  __shared__ uint32_t cv[CELLS_PAD];   // child visits
+  __shared__ int16_t ckn[CELLS_PAD];   // child kids_n
+  __shared__ int32_t rankv[CELLS_PAD];
+  int g = blockIdx.x, lane = threadIdx.x;
+  if (d.ended[g]) return;
+  int agent = agent_of(d, g);
+  int t = agent * d.G + g;
+  int player = d.to_move[g];
+  const bool use_ring = true;
+  St st;
+  load_state(c, d, g, s, st, use_ring, lane);
+  size_t base = pool_base(d, t, d.cur_pool[t]);
+  int off = d.kids_off[base], n = off >= 0 ? d.kids_n[base] : 0;
+  int best = AGZ_PASS;
+  float bestScore = 0.f;
+  if (n > 0) {
+    // children -> LDS: fscore=prior, cv=visits, touch=bsum bits, fmove=move, gsize=kids_off, ckn=kids_n
+    for (int i = lane; i < n; i += WAVE) {
+      s.fscore[i] = d.prior[base + off + i]; cv[i] = d.visits[base + off + i];
+      s.touch[i] = __float_as_int(d.bsum[base + off + i]); s.fmove[i] = d.nmove[base + off + i];
+      s.gsize[i] = d.kids_off[base + off + i]; ckn[i] = d.kids_n[base + off + i];
+    }
+    __syncthreads();
+    // fancySort (utils.go:18-47), stable
+    for (int i = lane; i < n; i += WAVE) {
+      uint32_t vi = cv[i];
+      float ei = evaluate(__int_as_float(s.touch[i]), vi, player), pi = s.fscore[i];
+      int rank = 0;
+      for (int j = 0; j < n; j++) {
+        uint32_t vj = cv[j];
+        bool jl, il;  // less(j,i), less(i,j)
+        if (vj != vi) { jl = vj > vi; il = vi > vj; }
+        else if (vi == 0) { float pj = s.fscore[j]; jl = pj > pi; il = pi > pj; }
+        else { float ej = evaluate(__int_as_float(s.touch[j]), vj, player); jl = ej > ei; il = ei > ej; }
+        rank += jl || (!jl && !il && j < i);
+      }
+      rankv[i] = rank;
+    }
+    __syncthreads();
+    // label[] := order (sorted position -> original index)
+    for (int i = lane; i < n; i += WAVE) s.label[rankv[i]] = i;
+    __syncthreads();
+    // randomizeChildren (tree.go:212-247) when moveNum < RandomCount
+    if (move_number(c, st.ply) < mc.RandomCount) {
+      if (lane == 0) {
+        float accum = 0.f, norm = 0.f;
+        int nacc = 0, index = 0;
+        bool bail = false;
+        for (int q = 0; q < n && !bail; q++) {
+          uint32_t v = cv[s.label[q]];
+          if (norm == 0.f) { norm = (float)v; if (v <= mc.RandomMinVisits) bail = true; }
+          if (!bail && v > mc.RandomMinVisits) {
+            accum = __fadd_rn(accum, powf(__fdiv_rn((float)v, norm), __fdiv_rn(1.f, mc.RandomTemperature)));
+            s.libs[nacc++] = __float_as_int(accum);
+          }
+        }
+        if (!bail) {
+          unsigned long long z = (d.rng[t] += 0x9E3779B97F4A7C15ull);
+          z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+          float rnd = __fmul_rn((float)(z >> 40) * (1.0f / 16777216.0f), accum);
+          for (int q = 0; q < nacc; q++) if (rnd < __int_as_float(s.libs[q])) { index = q; break; }
+          if (index != 0)
+            for (int q = 0; q < n - index; q++) { int tmp = s.label[q]; s.label[q] = s.label[q + index]; s.label[q + index] = tmp; }
+        }
+      }
+      __syncthreads();
+    }
+    // write the block back in its new order (the reference sorts children[root] in place)
+    for (int q = lane; q < n; q += WAVE) {
+      int i = s.label[q];
+      size_t o = base + off + q;
+      d.prior[o] = s.fscore[i]; d.visits[o] = cv[i]; d.bsum[o] = __int_as_float(s.touch[i]);
+      d.nmove[o] = (int16_t)s.fmove[i]; d.kids_off[o] = s.gsize[i]; d.kids_n[o] = ckn[i];
+    }
+    int f = s.label[0];
+    best = s.fmove[f];
+    bestScore = evaluate(__int_as_float(s.touch[f]), cv[f], player);
+    // first non-pass child in sorted order (noPass, search.go:530-545; children are legal moves of this state)
+    int np = 0x7fffffff;
+    for (int q = lane; q < n; q += WAVE) if (s.fmove[s.label[q]] != AGZ_PASS && q < np) np = q;
+    for (int o = 32; o > 0; o >>= 1) { int f2 = __shfl_xor(np, o, 64); np = f2 < np ? f2 : np; }
+    bool do_nopass = false;
+    float rootScore = d.prior[base];
+    bool losing = (rootScore > 0 && player == AGZ_WHITE) || (rootScore < 0 && player == AGZ_BLACK);
+    int lastmv = d.last_move[g];
+    if (mc.PassPreference == AGZ_DONT_PREFER_PASS && best == AGZ_PASS) do_nopass = true;
+    else if (!mc.DumbPass && best == AGZ_PASS) { if (losing) do_nopass = true; }
+    else if (!mc.DumbPass && lastmv == AGZ_PASS) { if (!losing) best = AGZ_PASS; }  // LastMove() of an empty history IS Pass (-1)
+    if (do_nopass && np != 0x7fffffff) {
+      int i = s.label[np];
+      best = s.fmove[i];
+      bestScore = 1.f;
+      if (cv[i] != 0) bestScore = evaluate(__int_as_float(s.touch[i]), cv[i], player);
+    }
+    // shouldResign (search.go:502-528)
+    if (best == AGZ_PASS && mc.PassPreference != AGZ_DONT_RESIGN && mc.ResignPercentage != 0.f) {
+      int threshold = (mc.maxDepth) / 4;
+      if (move_number(c, st.ply) > threshold) {
+        float rt = mc.ResignPercentage < 0.f ? 0.1f : mc.ResignPercentage;
+        if (!(bestScore > rt)) best = AGZ_RESIGN;
+      }
+    }
+  }
+  __syncthreads();
+  // board hash of the searched state (search.go:96): zobrist for komi/wq, FNV for mnk/c4
+  uint32_t hash = c.go_like ? st.hash : fnv_board(c, s.board);
+  int pcn = d.pc_n[t];
+  if (n > 0 && lane == 0) {  // t.cachedPolicies[sa{boardHash, retVal}]++
+    d.pc_hash[(size_t)t * d.moves_stride + pcn] = hash; d.pc_move[(size_t)t * d.moves_stride + pcn] = (int16_t)best; d.pc_n[t] = pcn + 1;
+  }
+  if (n > 0) pcn++;
+  __syncthreads();
+  if (record) {  // arena.go:105-123
+    // Policies (tree.go:128-142): counts of (hash, a) for a in [0, A], normalised; NaN when the move was Pass/Resign
+    float tot = 0.f;
+    for (int q = 0; q < pcn; q++) {
+      int mv = d.pc_move[(size_t)t * d.moves_stride + q];
+      if (d.pc_hash[(size_t)t * d.moves_stride + q] == hash && mv >= 0 && mv <= c.A) tot += 1.f;
+    }
+    if (tot > 0.f) {  // validPolicies (arena.go:241-251): sum 0 -> NaN -> dropped
+      int e = -1;
+      if (lane == 0) e = atomicAdd(d.ex_count, 1);
+      e = __shfl(e, 0, 64);
+      if (e < d.ex_cap) {
+        float* P = d.ex_policy + (size_t)e * (c.A + 1);
+        for (int a = lane; a <= c.A; a += WAVE) {
+          float cnt = 0.f;
+          for (int q = 0; q < pcn; q++)
+            if (d.pc_hash[(size_t)t * d.moves_stride + q] == hash && d.pc_move[(size_t)t * d.moves_stride + q] == a) cnt += 1.f;
+          P[a] = __fdiv_rn(cnt, tot);
+        }
+        encode_nchw(c, s, st, d.ex_planes + (size_t)e * c.F * c.cells, lane);
+        if (lane == 0) {
+          d.ex_value[e] = (float)player;  // "THIS IS A HACK": mover colour until the game ends (arena.go:111-113)
+          d.ex_game[e] = g; d.ex_prev[e] = d.ex_last[g]; d.ex_last[g] = e;
+          atomicAdd(&d.counters[CNT_EXAMPLES], 1ull);
+        }
+      } else if (lane == 0) {
+        atomicSub(d.ex_count, 1);
+      }
+    }
+  }
+  // t.prev = t.current.Clone() (search.go:152)
+  for (int i = lane; i < c.cells; i += WAVE) d.prev_board[(size_t)t * CELLS_PAD + i] = s.board[i];
+  if (lane == 0 && n > 0) { d.prev_ply[t] = st.ply; d.has_prev[t] = 1; }
+  __syncthreads();
+  // a.game = a.game.Apply(PlayerMove{player, best}) (arena.go:127-130)
+  int ended = 0, winner = AGZ_NONE;
+  int pass_count = d.pass_count[g];
+  pass_count = (best == AGZ_PASS) ? pass_count + 1 : 0;
+  float capb = d.cap_b[g], capw = d.cap_w[g];
+  if (lane == 0) d.moves[(size_t)g * d.moves_stride + st.ply] = (int16_t)best;
+  bool resigned = best == AGZ_RESIGN;
+  if (!resigned) {
+    bool legal_pass = c.pass_legal;
+    if (best == AGZ_PASS && !legal_pass) {
+      // mnk/komi Apply of an illegal pass leaves the state unchanged (mnk.go:123-125, komi/game.go:107-110)
+    } else {
+      st.to_move = player;
+      int taken = apply_move(c, d, s, st, best, use_ring, lane);
+      if (!c.flip_in_tree) st.ply = st.ply;  // c4: history still grows (game.go:60-64); MoveNumber() stays 1
+      if (player == AGZ_BLACK) capb += (float)taken; else capw += (float)taken;
+    }
+  }
+  // switchPlayer + (next Search) SetToMove: the next agent's colour
+  int next_colour = opp(player);
+  // Ended(): per game
+  if (resigned) { ended = 1; winner = opp(player); }
+  else if (pass_count >= 2) {  // arena.go:135 breaks without re-evaluating Ended(); wq (completed) scores the board
+    ended = 1;
+    if (c.kind == AGZ_GAME_WQ) {
+      analyse(c, s, nullptr, lane);
+      float b, w; area_scores(c, s, lane, &b, &w);
+      w = __fadd_rn(w, c.komi);
+      winner = (w == b) ? AGZ_NONE : (w > b ? AGZ_WHITE : AGZ_BLACK);
+    }
+  } else if (c.max_moves > 0 && st.ply >= c.max_moves) {
+    ended = 1;
+    if (c.kind == AGZ_GAME_WQ) {
+      analyse(c, s, nullptr, lane);
+      float b, w; area_scores(c, s, lane, &b, &w);
+      w = __fadd_rn(w, c.komi);
+      winner = (b > w) ? AGZ_BLACK : (w > b ? AGZ_WHITE : AGZ_NONE);
+    }
+  } else if (c.kind == AGZ_GAME_MNK) {  // mnk.go:161-174
+    if (mnk_is_winner(c, s.board, AGZ_BLACK)) { ended = 1; winner = AGZ_BLACK; }
+    else if (mnk_is_winner(c, s.board, AGZ_WHITE)) { ended = 1; winner = AGZ_WHITE; }
+    else { int e = 0; for (int i = lane; i < c.cells; i += WAVE) e |= (s.board[i] == AGZ_NONE); ended = __syncthreads_or(e) ? 0 : 1; }
+  } else if (c.kind == AGZ_GAME_C4) {  // c4/game.go:164-183 (passCount of the GAME: consecutive passes > 2)
+    int w = c4_check_win(c, s.board);
+    if (w != AGZ_NONE) { ended = 1; winner = w; }
+    else { int e = 0; for (int i = lane; i < c.cells; i += WAVE) e |= (s.board[i] == AGZ_NONE); ended = __syncthreads_or(e) ? 0 : 1; }
+  } else if (c.kind == AGZ_GAME_KOMI) {  // komi/game.go:145-187
+    float kf = (float)c.k;
+    if (capw >= kf) { ended = 1; winner = AGZ_WHITE; }
+    else if (capb >= kf) { ended = 1; winner = AGZ_BLACK; }
+    else {
+      analyse(c, s, nullptr, lane);
+      int cur = 0, op = 0;
+      for (int i = lane; i < c.cells; i += WAVE) { cur |= go_legal(c, s, i, next_colour); op |= go_legal(c, s, i, opp(next_colour)); }
+      cur = __syncthreads_or(cur); op = __syncthreads_or(op);
+      if (!(cur && op)) { ended = 1; winner = capw > capb ? AGZ_WHITE : (capb > capw ? AGZ_BLACK : AGZ_NONE); }
+    }
+  } else {  // wq: passes >= 2 ends (game.go:94-115)
+    if (st.passes >= 2) {
+      ended = 1;
+      analyse(c, s, nullptr, lane);
+      float b, w; area_scores(c, s, lane, &b, &w);
+      w = __fadd_rn(w, c.komi);
+      winner = (w == b) ? AGZ_NONE : (w > b ? AGZ_WHITE : AGZ_BLACK);
+    }
+  }
+  __syncthreads();
+  // write the state back
+  for (int i = lane; i < c.cells; i += WAVE) d.board[(size_t)g * CELLS_PAD + i] = s.board[i];
+  {
+    int slot = st.ply % RING;
+    for (int i = lane; i < c.cells; i += WAVE) d.ring[((size_t)g * RING + slot) * CELLS_PAD + i] = s.ring[slot][i];
+  }
+  if (lane == 0) {
+    d.to_move[g] = next_colour; d.ply[g] = st.ply; d.passes[g] = st.passes; d.zhash[g] = st.hash;
+    d.pass_count[g] = pass_count; d.cap_b[g] = capb; d.cap_w[g] = capw; d.last_move[g] = best;
+    d.ended[g] = ended; d.winner[g] = winner;
+    atomicAdd(&d.counters[CNT_MOVES], 1ull);
+    if (ended) {
+      atomicAdd(&d.counters[CNT_GAMES], 1ull);
+      // label the game's examples (arena.go:146-155)
+      for (int e = d.ex_last[g]; e >= 0; e = d.ex_prev[e]) {
+        float mover = d.ex_value[e];
+        d.ex_value[e] = winner == AGZ_NONE ? 0.f : (mover == (float)winner ? 1.f : -1.f);
+      }
+      d.ex_last[g] = -1;
+    }
+  }
+}
+
+}  // namespace agz
+
+using namespace agz;
+
+// ---------------------------------------------------------------------------------------------------
+struct agz_arena {
+  agz_ctx* ctx = nullptr;
+  GameCfg gc{};
+  MctsCfg mc{};
+  Dev d{};
+  int G = 0;
+  uint64_t seed = 0;
+  std::vector<void*> allocs;
+  int inf_kind[2] = {AGZ_INF_DUMMY, AGZ_INF_DUMMY};
+  agz_net* net[2] = {nullptr, nullptr};
+  float* d_policy[2] = {nullptr, nullptr};
+  float* d_value[2] = {nullptr, nullptr};
+  std::vector<uint8_t> a_is_black;
+  std::vector<int32_t> slot_host;
+  int ply_parity = 0;       // all unfinished games are at the same ply
+  int nA_slots = 0, nB_slots = 0;
+  bool in_move = false;
+  int moves_done = 0;
+
+  template <typename T>
+  int alloc(T** p, size_t n) {
+    void* q = nullptr;
+    AGZ_HIP_TRY(hipMalloc(&q, n * sizeof(T)));
+    AGZ_HIP_TRY(hipMemsetAsync(q, 0, n * sizeof(T), ctx->stream));
+    allocs.push_back(q);
+    *p = (T*)q;
+    return AGZ_OK;
+  }
+  bool split_nets() const { return inf_kind[0] == AGZ_INF_NET && inf_kind[1] == AGZ_INF_NET && net[0] != net[1]; }
+  int update_slots();
+  int nn_step(int prep);
+};
+
+// NN batch slots.  One shared net (or synthetic inferencers): slot = game.  Two different nets: games whose
+// current agent is A take slots [0, nA), B's take [nA, G) so that each net runs one dense sub-batch.
+int agz_arena::update_slots() {
+  slot_host.resize(G);
+  if (!split_nets()) {
+    for (int g = 0; g < G; g++) slot_host[g] = g;
+    nA_slots = G; nB_slots = G;
+  } else {
+    int na = 0;
+    for (int g = 0; g < G; g++) { bool a_moves = (a_is_black[g] != 0) == (ply_parity == 0); if (a_moves) na++; }
+    int ia = 0, ib = na;
+    for (int g = 0; g < G; g++) { bool a_moves = (a_is_black[g] != 0) == (ply_parity == 0); slot_host[g] = a_moves ? ia++ : ib++; }
+    nA_slots = na; nB_slots = G - na;
+  }
+  AGZ_HIP_TRY(hipMemcpyAsync(d.slot_of_game, slot_host.data(), G * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return AGZ_OK;
+}
+
+int agz_arena::nn_step(int prep) {
+  // select -> network -> expand, all asynchronous on the ctx stream
+  float* act0 = nullptr; float* act1 = nullptr;
+  const size_t slot_elems = (size_t)(gc.m + 2) * (gc.n + 2) * 32;
+  if (inf_kind[0] == AGZ_INF_NET) act0 = net[0]->d_act_in;
+  if (inf_kind[1] == AGZ_INF_NET) act1 = split_nets() ? net[1]->d_act_in : (net[1]->d_act_in);
+  if (split_nets()) { /* both nets see global slot indices; net B's sub-batch starts at slot nA */ }
+  {
+    ProfScope ps(ctx, AGZ_PROF_SELECT);
+    hipLaunchKernelGGL(k_select, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, act0, act1, prep);
+  }
+  InfDesc inf{};
+  for (int a = 0; a < 2; a++) {
+    inf.kind[a] = inf_kind[a];
+    inf.policy[a] = d_policy[a]; inf.value[a] = d_value[a];
+    inf.dummy_player[a] = 0;  // useDummy captures Agent.Player before colours are drawn: None (agogo.go:83-87, agent.go:105-113)
+    switch (inf_kind[a]) {
+      case AGZ_INF_NET: inf.policy_len[a] = net[a]->conf.ActionSpace; break;
+      case AGZ_INF_DUMMY: inf.policy_len[a] = gc.A; break;
+      case AGZ_INF_SCRIPT: inf.policy_len[a] = 10; break;
+      case AGZ_INF_HASH: inf.policy_len[a] = gc.A + 1; break;
+      default: inf.policy_len[a] = 25; break;
+    }
+  }
+  if (!split_nets()) {
+    agz_net* n = inf_kind[0] == AGZ_INF_NET ? net[0] : (inf_kind[1] == AGZ_INF_NET ? net[1] : nullptr);
+    if (n) {
+      int a = inf_kind[0] == AGZ_INF_NET ? 0 : 1;
+      int r = n->forward_packed(G, d_policy[a], d_value[a]);
+      if (r != AGZ_OK) return r;
+      if (inf_kind[0] == AGZ_INF_NET && inf_kind[1] == AGZ_INF_NET) { inf.policy[1] = d_policy[0]; inf.value[1] = d_value[0]; }
+    }
+  } else {
+    // net A on slots [0,nA), net B on slots [nA,G): each net's input buffer is indexed by global slot
+    if (nA_slots > 0) { int r = net[0]->forward_packed(nA_slots, d_policy[0], d_value[0]); if (r != AGZ_OK) return r; }
+    if (nB_slots > 0) {
+      agz_net* nb = net[1];
+      float* save = nb->d_act_in;
+      nb->d_act_in = save + (size_t)nA_slots * slot_elems;
+      int r = nb->forward_packed(nB_slots, d_policy[1] + (size_t)nA_slots * nb->conf.ActionSpace, d_value[1] + nA_slots);
+      nb->d_act_in = save;
+      if (r != AGZ_OK) return r;
+    }
+  }
+  {
+    ProfScope ps(ctx, AGZ_PROF_EXPAND);
+    hipLaunchKernelGGL(k_expand, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, inf, prep);
+  }
+  AGZ_HIP_TRY(hipGetLastError());
+  return AGZ_OK;
+}
+
+extern "C" {
+
+int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_conf* mcts, int n_games, uint64_t seed,
+                     int max_nodes, agz_arena** out) {
+  AGZ_REQUIRE(ctx && game && mcts && out, AGZ_E_INVALID, "agz_arena_create: NULL argument");
+  AGZ_REQUIRE(n_games >= 1, AGZ_E_INVALID, "agz_arena_create: n_games must be >= 1");
+  AGZ_REQUIRE(mcts->PUCT > 0 && mcts->PUCT <= 1, AGZ_E_INVALID, "MCTSConf is not valid (PUCT must be in (0,1], tree.go:42-44)");
+  AGZ_REQUIRE(game->kind >= 0 && game->kind <= 3, AGZ_E_INVALID, "agz_arena_create: unknown game kind %d", game->kind);
+  AGZ_REQUIRE(game->m >= 1 && game->n >= 1 && game->m * game->n <= 361, AGZ_E_UNSUPPORTED, "board %dx%d unsupported (max 361 cells)", game->m, game->n);
+  if (game->kind == AGZ_GAME_KOMI || game->kind == AGZ_GAME_WQ)
+    AGZ_REQUIRE(game->m == game->n, AGZ_E_UNSUPPORTED, "komi/wq boards must be square on device (the reference's non-square geometry is degenerate, game/naughty.go:9-19)");
+  AGZ_REQUIRE(game->encoder == AGZ_ENC_TWOPLANE || game->encoder == AGZ_ENC_WQ, AGZ_E_INVALID, "unknown encoder");
+  AGZ_REQUIRE(mcts->Budget >= 0, AGZ_E_INVALID, "Budget must be >= 0");
+  AGZ_HIP_TRY(hipSetDevice(ctx->device));
+  agz_arena* a = new agz_arena();
+  a->ctx = ctx; a->G = n_games; a->seed = seed;
+  GameCfg& c = a->gc;
+  c.kind = game->kind; c.m = game->m; c.n = game->n; c.k = game->k; c.cells = c.m * c.n;
+  c.A = c.kind == AGZ_GAME_C4 ? c.n : c.cells;
+  c.max_moves = game->max_moves > 0 ? game->max_moves : 2 * c.cells;
+  c.encoder = game->encoder; c.F = c.encoder == AGZ_ENC_WQ ? 18 : 2;
+  c.komi = game->komi;
+  c.flip_in_tree = c.kind != AGZ_GAME_C4;
+  c.pass_legal = (c.kind == AGZ_GAME_WQ || c.kind == AGZ_GAME_C4);
+  c.go_like = (c.kind == AGZ_GAME_KOMI || c.kind == AGZ_GAME_WQ);
+  c.has_passes = c.kind == AGZ_GAME_WQ;
+  MctsCfg& m = a->mc;
+  m.PUCT = mcts->PUCT; m.maxDepth = mcts->M * mcts->N; m.RandomCount = mcts->RandomCount; m.Budget = mcts->Budget;
+  m.RandomMinVisits = mcts->RandomMinVisits; m.RandomTemperature = mcts->RandomTemperature; m.DumbPass = mcts->DumbPass;
+  m.ResignPercentage = mcts->ResignPercentage; m.PassPreference = mcts->PassPreference;
+  AGZ_REQUIRE(m.maxDepth + 2 <= MAXPATH, AGZ_E_UNSUPPORTED, "M*N too large");
+  Dev& d = a->d;
+  const int G = n_games, T = 2 * G;
+  d.G = G; d.T = T;
+  long long cap = max_nodes > 0 ? max_nodes : (long long)(2 * (mcts->Budget + 2)) * (c.A + 1) + 16;
+  if (cap > 8000000) cap = 8000000;
+  d.cap = (int)cap;
+  d.moves_stride = c.max_moves + 4;
+  int r = AGZ_OK;
+#define AL(p, n) if ((r = a->alloc(&d.p, (size_t)(n))) != AGZ_OK) { agz_arena_destroy(a); return r; }
+  AL(board, (size_t)G * CELLS_PAD) AL(ring, (size_t)G * RING * CELLS_PAD) AL(to_move, G) AL(ply, G) AL(passes, G)
+  AL(pass_count, G) AL(ended, G) AL(winner, G) AL(a_is_black, G) AL(last_move, G) AL(cap_b, G) AL(cap_w, G) AL(zhash, G)
+  AL(moves, (size_t)G * d.moves_stride)
+  size_t pool = (size_t)T * 2 * d.cap;
+  AL(prior, pool) AL(visits, pool) AL(bsum, pool) AL(kids_off, pool) AL(kids_n, pool) AL(nmove, pool)
+  AL(n_nodes, T) AL(cur_pool, T) AL(has_root, T) AL(has_prev, T) AL(prev_ply, T) AL(prev_board, (size_t)T * CELLS_PAD)
+  AL(stalled, T) AL(overflow, T) AL(pc_hash, (size_t)T * d.moves_stride) AL(pc_move, (size_t)T * d.moves_stride) AL(pc_n, T) AL(rng, T)
+  AL(slot_of_game, G) AL(leaf_kind, G) AL(leaf_player, G) AL(leaf_ply, G) AL(leaf_result, G) AL(leaf_board, (size_t)G * CELLS_PAD)
+  AL(leaf_legal, (size_t)G * CELLS_PAD) AL(path, (size_t)G * MAXPATH) AL(path_len, G) AL(counters, 8)
+  {
+    size_t per_ex = (size_t)c.F * c.cells + (c.A + 1) + 3;
+    size_t want = (size_t)G * c.max_moves;
+    size_t budget = (size_t)(2ull << 30) / (per_ex * 4);  // <= 2 GiB of examples per arena
+    d.ex_cap = (int)std::min(want, budget);
+  }
+  AL(ex_planes, (size_t)d.ex_cap * c.F * c.cells) AL(ex_policy, (size_t)d.ex_cap * (c.A + 1)) AL(ex_value, d.ex_cap)
+  AL(ex_game, d.ex_cap) AL(ex_prev, d.ex_cap) AL(ex_last, G) AL(ex_count, 1)
+  {  // zobrist keys: komi draws only the first size+1 table entries (komi/zobrist.go:38); wq draws all (wq/zobrist.go:31-42)
+    std::vector<int32_t> zt((size_t)2 * c.cells, 0);
+    SplitMix64 rr(1337);
+    int lim = c.kind == AGZ_GAME_KOMI ? std::min(c.cells + 1, 2 * c.cells) : 2 * c.cells;
+    for (int i = 0; i < lim; i++) zt[i] = rr.int31();
+    int32_t* zp = nullptr;
+    if ((r = a->alloc(&zp, zt.size())) != AGZ_OK) { agz_arena_destroy(a); return r; }
+    hipMemcpyAsync(zp, zt.data(), zt.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+    hipStreamSynchronize(ctx->stream);
+    d.ztable = zp;
+  }
+#undef AL
+  a->a_is_black.assign(G, 1);
+  *out = a;
+  return agz_arena_reset(a, nullptr);
+}
+
+void agz_arena_destroy(agz_arena* a) {
+  if (!a) return;
+  hipSetDevice(a->ctx->device);
+  hipStreamSynchronize(a->ctx->stream);
+  for (void* p : a->allocs) hipFree(p);
+  for (int i = 0; i < 2; i++) { if (a->d_policy[i]) hipFree(a->d_policy[i]); if (a->d_value[i]) hipFree(a->d_value[i]); }
+  delete a;
+}
+
+int agz_arena_set_inferencer(agz_arena* a, int agent, int kind, agz_net* net) {
+  AGZ_REQUIRE(a && (agent == 0 || agent == 1), AGZ_E_INVALID, "agz_arena_set_inferencer: bad agent");
+  AGZ_REQUIRE(kind >= AGZ_INF_NET && kind <= AGZ_INF_UNIFORM, AGZ_E_INVALID, "unknown inferencer kind %d", kind);
+  if (kind == AGZ_INF_NET) {
+    AGZ_REQUIRE(net && net->committed, AGZ_E_STATE, "AGZ_INF_NET needs a committed net");
+    AGZ_REQUIRE(net->ctx == a->ctx, AGZ_E_INVALID, "net belongs to another ctx");
+    AGZ_REQUIRE(net->conf.Height == a->gc.m && net->conf.Width == a->gc.n && net->conf.Features == a->gc.F, AGZ_E_INVALID,
+                "net geometry (%dx%dx%d) does not match the game/encoder (%dx%dx%d)", net->conf.Height, net->conf.Width,
+                net->conf.Features, a->gc.m, a->gc.n, a->gc.F);
+    AGZ_REQUIRE(net->conf.ActionSpace >= a->gc.A, AGZ_E_INVALID, "net ActionSpace %d < game ActionSpace %d", net->conf.ActionSpace, a->gc.A);
+    AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+    int r = net->ensure_batch(a->G);
+    if (r != AGZ_OK) return r;
+    if (a->d_policy[agent]) { hipFree(a->d_policy[agent]); a->d_policy[agent] = nullptr; }
+    if (a->d_value[agent]) { hipFree(a->d_value[agent]); a->d_value[agent] = nullptr; }
+    AGZ_HIP_TRY(hipMalloc(&a->d_policy[agent], (size_t)a->G * net->conf.ActionSpace * sizeof(float)));
+    AGZ_HIP_TRY(hipMalloc(&a->d_value[agent], (size_t)a->G * sizeof(float)));
+  }
+  a->inf_kind[agent] = kind;
+  a->net[agent] = kind == AGZ_INF_NET ? net : nullptr;
+  return a->update_slots();
+}
+
+int agz_arena_reset(agz_arena* a, const uint8_t* a_is_black) {
+  AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  hipStream_t s = a->ctx->stream;
+  uint8_t* dab = nullptr;
+  if (a_is_black) {
+    AGZ_HIP_TRY(hipMalloc(&dab, a->G));
+    AGZ_HIP_TRY(hipMemcpyAsync(dab, a_is_black, a->G, hipMemcpyHostToDevice, s));
+  }
+  AGZ_HIP_TRY(hipMemsetAsync(a->d.counters, 0, 8 * sizeof(unsigned long long), s));
+  AGZ_HIP_TRY(hipMemsetAsync(a->d.ex_count, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_reset, dim3(a->G), dim3(64), 0, s, a->d, a->gc, dab, (unsigned long long)a->seed);
+  std::vector<int32_t> ab(a->G);
+  AGZ_HIP_TRY(hipMemcpyAsync(ab.data(), a->d.a_is_black, a->G * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  if (dab) hipFree(dab);
+  for (int g = 0; g < a->G; g++) a->a_is_black[g] = (uint8_t)ab[g];
+  a->ply_parity = 0; a->in_move = false; a->moves_done = 0;
+  a->seed += 0x9E3779B97F4A7C15ull;  // next reset draws new colours
+  return a->update_slots();
+}
+
+int agz_arena_begin_move(agz_arena* a) {
+  AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
+  AGZ_REQUIRE(!a->in_move, AGZ_E_STATE, "agz_arena_begin_move: previous move not ended");
+  for (int i = 0; i < 2; i++) AGZ_REQUIRE(a->inf_kind[i] != AGZ_INF_NET || a->net[i], AGZ_E_STATE, "agent %d has no net", i);
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  if (a->split_nets()) { int r = a->update_slots(); if (r != AGZ_OK) return r; }
+  {
+    ProfScope ps(a->ctx, AGZ_PROF_MOVE);
+    hipLaunchKernelGGL(k_begin_move, dim3(a->G), dim3(64), 0, a->ctx->stream, a->d, a->gc, a->mc);
+  }
+  a->in_move = true;
+  return a->nn_step(1);  // prepareRoot
+}
+
+int agz_arena_simulate(agz_arena* a, int k) {
+  AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
+  AGZ_REQUIRE(a->in_move, AGZ_E_STATE, "agz_arena_simulate: call agz_arena_begin_move first");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  for (int i = 0; i < k; i++) { int r = a->nn_step(0); if (r != AGZ_OK) return r; }
+  return AGZ_OK;
+}
+
+int agz_arena_end_move(agz_arena* a, int record) {
+  AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
+  AGZ_REQUIRE(a->in_move, AGZ_E_STATE, "agz_arena_end_move: call agz_arena_begin_move first");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  {
+    ProfScope ps(a->ctx, AGZ_PROF_MOVE);
+    hipLaunchKernelGGL(k_end_move, dim3(a->G), dim3(64), 0, a->ctx->stream, a->d, a->gc, a->mc, record);
+  }
+  AGZ_HIP_TRY(hipGetLastError());
+  a->in_move = false;
+  a->ply_parity ^= 1;
+  a->moves_done++;
+  return AGZ_OK;
+}
+
+int agz_arena_get_stats(agz_arena* a, agz_arena_stats* out) {
+  AGZ_REQUIRE(a && out, AGZ_E_INVALID, "NULL argument");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  unsigned long long c[8];
+  std::vector<int32_t> ended(a->G);
+  AGZ_HIP_TRY(hipMemcpyAsync(c, a->d.counters, sizeof(c), hipMemcpyDeviceToHost, a->ctx->stream));
+  AGZ_HIP_TRY(hipMemcpyAsync(ended.data(), a->d.ended, a->G * sizeof(int32_t), hipMemcpyDeviceToHost, a->ctx->stream));
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  out->sims_total = (int64_t)c[CNT_SIMS]; out->sims_nonnull = (int64_t)c[CNT_NONNULL]; out->nn_evals = (int64_t)c[CNT_EVALS];
+  out->moves_played = (int64_t)c[CNT_MOVES]; out->games_finished = (int64_t)c[CNT_GAMES]; out->examples = (int64_t)c[CNT_EXAMPLES];
+  out->n_games = a->G; out->tree_full = (int32_t)c[CNT_FULL]; out->reserved = 0;
+  int act = 0;
+  for (int g = 0; g < a->G; g++) act += ended[g] ? 0 : 1;
+  out->n_active = act;
+  return AGZ_OK;
+}
+
+int agz_arena_play(agz_arena* a, int n_moves, int record) {
+  AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
+  int played = 0;
+  while (n_moves <= 0 || played < n_moves) {
+    if ((played % 4) == 0 || n_moves <= 0) {  // poll the device for "all games ended"
+      agz_arena_stats st;
+      int r = agz_arena_get_stats(a, &st);
+      if (r != AGZ_OK) return r;
+      if (st.tree_full) { agz::set_error("agz_arena_play: %d tree pool(s) overflowed (max_nodes too small)", st.tree_full); return AGZ_E_TREE_FULL; }
+      if (st.n_active == 0) break;
+    }
+    int r = agz_arena_begin_move(a);
+    if (r != AGZ_OK) return r;
+    r = agz_arena_simulate(a, a->mc.Budget);
+    if (r != AGZ_OK) return r;
+    r = agz_arena_end_move(a, record);
+    if (r != AGZ_OK) return r;
+    played++;
+  }
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  return AGZ_OK;
+}
+
+int agz_arena_get_game(agz_arena* a, int g, int32_t* board, agz_game_state* st) {
+  AGZ_REQUIRE(a && g >= 0 && g < a->G, AGZ_E_INVALID, "bad game index");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  hipStream_t s = a->ctx->stream;
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  if (board) {
+    std::vector<int8_t> b(CELLS_PAD);
+    AGZ_HIP_TRY(hipMemcpy(b.data(), a->d.board + (size_t)g * CELLS_PAD, CELLS_PAD, hipMemcpyDeviceToHost));
+    for (int i = 0; i < a->gc.cells; i++) board[i] = b[i];
+  }
+  if (st) {
+    int32_t v[7]; float f[2];
+    int32_t* src[7] = {a->d.to_move, a->d.ply, a->d.passes, a->d.ended, a->d.winner, a->d.a_is_black, a->d.last_move};
+    for (int i = 0; i < 7; i++) AGZ_HIP_TRY(hipMemcpy(&v[i], src[i] + g, sizeof(int32_t), hipMemcpyDeviceToHost));
+    AGZ_HIP_TRY(hipMemcpy(&f[0], a->d.cap_b + g, sizeof(float), hipMemcpyDeviceToHost));
+    AGZ_HIP_TRY(hipMemcpy(&f[1], a->d.cap_w + g, sizeof(float), hipMemcpyDeviceToHost));
+    st->to_move = v[0]; st->move_number = a->gc.kind == AGZ_GAME_C4 ? 1 : v[1]; st->passes = v[2]; st->ended = v[3]; st->winner = v[4];
+    st->a_is_black = v[5]; st->last_move = v[6]; st->reserved = v[1]; st->score_black = f[0]; st->score_white = f[1];
+  }
+  return AGZ_OK;
+}
+
+int agz_arena_get_history(agz_arena* a, int g, int32_t* moves, int cap, int* n) {
+  AGZ_REQUIRE(a && g >= 0 && g < a->G && n, AGZ_E_INVALID, "bad argument");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  int32_t ply = 0;
+  AGZ_HIP_TRY(hipMemcpy(&ply, a->d.ply + g, sizeof(int32_t), hipMemcpyDeviceToHost));
+  // plies recorded = number of end_move calls the game took part in: moves[] is indexed by ply-at-search time
+  std::vector<int16_t> mv(a->d.moves_stride);
+  AGZ_HIP_TRY(hipMemcpy(mv.data(), a->d.moves + (size_t)g * a->d.moves_stride, mv.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+  *n = ply;
+  for (int i = 0; i < ply && i < cap; i++) moves[i] = mv[i];
+  return AGZ_OK;
+}
+
+int agz_arena_root_children(agz_arena* a, int g, int agent, int32_t* moves, uint32_t* visits, float* bs, float* priors,
+                            int cap, int* n) {
+  AGZ_REQUIRE(a && g >= 0 && g < a->G && (agent == 0 || agent == 1) && n, AGZ_E_INVALID, "bad argument");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  int t = agent * a->G + g;
+  int32_t pool = 0, off = -1, hr = 0;
+  int16_t kn = 0;
+  AGZ_HIP_TRY(hipMemcpy(&hr, a->d.has_root + t, 4, hipMemcpyDeviceToHost));
+  *n = 0;
+  if (!hr) return AGZ_OK;
+  AGZ_HIP_TRY(hipMemcpy(&pool, a->d.cur_pool + t, 4, hipMemcpyDeviceToHost));
+  size_t base = ((size_t)t * 2 + pool) * a->d.cap;
+  AGZ_HIP_TRY(hipMemcpy(&off, a->d.kids_off + base, 4, hipMemcpyDeviceToHost));
+  AGZ_HIP_TRY(hipMemcpy(&kn, a->d.kids_n + base, 2, hipMemcpyDeviceToHost));
+  if (off < 0) return AGZ_OK;
+  int k = std::min<int>(kn, cap);
+  std::vector<int16_t> mv(k);
+  AGZ_HIP_TRY(hipMemcpy(mv.data(), a->d.nmove + base + off, k * sizeof(int16_t), hipMemcpyDeviceToHost));
+  for (int i = 0; i < k; i++) moves[i] = mv[i];
+  AGZ_HIP_TRY(hipMemcpy(visits, a->d.visits + base + off, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  AGZ_HIP_TRY(hipMemcpy(bs, a->d.bsum + base + off, k * sizeof(float), hipMemcpyDeviceToHost));
+  AGZ_HIP_TRY(hipMemcpy(priors, a->d.prior + base + off, k * sizeof(float), hipMemcpyDeviceToHost));
+  *n = kn;
+  return AGZ_OK;
+}
+
+int agz_arena_tree_nodes(agz_arena* a, int g, int agent, int* n_nodes) {
+  AGZ_REQUIRE(a && g >= 0 && g < a->G && (agent == 0 || agent == 1) && n_nodes, AGZ_E_INVALID, "bad argument");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  AGZ_HIP_TRY(hipMemcpy(n_nodes, a->d.n_nodes + agent * a->G + g, 4, hipMemcpyDeviceToHost));
+  return AGZ_OK;
+}
+
+int agz_arena_get_examples(agz_arena* a, float* planes, float* policy, float* value, int32_t* game_idx, int cap, int* n) {
+  AGZ_REQUIRE(a && n, AGZ_E_INVALID, "bad argument");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  int32_t cnt = 0;
+  AGZ_HIP_TRY(hipMemcpy(&cnt, a->d.ex_count, 4, hipMemcpyDeviceToHost));
+  cnt = std::min(cnt, a->d.ex_cap);
+  *n = cnt;
+  int k = std::min(cnt, cap);
+  if (k <= 0) return AGZ_OK;
+  const GameCfg& c = a->gc;
+  if (planes) AGZ_HIP_TRY(hipMemcpy(planes, a->d.ex_planes, (size_t)k * c.F * c.cells * 4, hipMemcpyDeviceToHost));
+  if (policy) AGZ_HIP_TRY(hipMemcpy(policy, a->d.ex_policy, (size_t)k * (c.A + 1) * 4, hipMemcpyDeviceToHost));
+  if (value) AGZ_HIP_TRY(hipMemcpy(value, a->d.ex_value, (size_t)k * 4, hipMemcpyDeviceToHost));
+  if (game_idx) AGZ_HIP_TRY(hipMemcpy(game_idx, a->d.ex_game, (size_t)k * 4, hipMemcpyDeviceToHost));
+  return AGZ_OK;
+}
+
+int agz_arena_clear_examples(agz_arena* a) {
+  AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  AGZ_HIP_TRY(hipMemsetAsync(a->d.ex_count, 0, 4, a->ctx->stream));
+  AGZ_HIP_TRY(hipMemsetAsync(a->d.ex_last, 0xff, a->G * 4, a->ctx->stream));
+  return AGZ_OK;
+}
+
+int agz_arena_examples_dev(agz_arena* a, float** planes, float** policy, float** value, int* n) {
+  AGZ_REQUIRE(a && n, AGZ_E_INVALID, "bad argument");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  int32_t cnt = 0;
+  AGZ_HIP_TRY(hipMemcpy(&cnt, a->d.ex_count, 4, hipMemcpyDeviceToHost));
+  *n = std::min(cnt, a->d.ex_cap);
+  if (planes) *planes = a->d.ex_planes;
+  if (policy) *policy = a->d.ex_policy;
+  if (value) *value = a->d.ex_value;
+  return AGZ_OK;
+}
+
+}  // extern "C"

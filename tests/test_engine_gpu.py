@@ -1,0 +1,201 @@
+"""GPU parity: the device self-play engine (libagz: game rules + MCTS + arena) vs the sequential CPU oracle.
+
+Bar: BIT-EXACT — chosen moves, root visit counts, blackScores (float32 bit patterns), priors, child order,
+recorded examples (planes, policy targets, value labels), winners.  Inferencers are deterministic
+(synthetic hash / scripted / uniform) so network rounding cannot perturb the comparison; the NET case feeds
+the oracle's MCTS with the GPU network's own outputs through a callback.
+"""
+import numpy as np
+import pytest
+
+import agogo_amd as A
+import oracle_lib as O
+from agogo_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def f32bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def run_pair(ctx, kind, m, n, k=0, komi=0.0, enc=capi.ENC_TWOPLANE, budget=50, inf=capi.INF_HASH, a_is_black=(1,),
+             max_moves=0, n_plies=0, policy_len=0, max_nodes=0, **mcts_kw):
+    """plays len(a_is_black) device games in one arena and one oracle arena per game, comparing every ply."""
+    G = len(a_is_black)
+    dev = A.Arena(ctx, kind, m, n, k, komi, encoder=enc, n_games=G, Budget=budget, max_moves=max_moves,
+                  max_nodes=max_nodes, **mcts_kw)
+    dev.set_inferencer(0, inf)
+    dev.set_inferencer(1, inf)
+    dev.reset(np.array(a_is_black, dtype=np.uint8))
+    orcs = []
+    for g in range(G):
+        o = O.Arena(kind, m, n, k, komi, enc=enc, Budget=budget, max_moves=max_moves, **mcts_kw)
+        o.set_inferencer(0, inf, policy_len=policy_len)
+        o.set_inferencer(1, inf, policy_len=policy_len)
+        o.begin(int(a_is_black[g]))
+        orcs.append(o)
+    ply = 0
+    alive = [True] * G
+    while any(alive) and (n_plies <= 0 or ply < n_plies):
+        dev.begin_move()
+        dev.simulate(budget)
+        dev.end_move(record=True)
+        for g in range(G):
+            if not alive[g]:
+                continue
+            o = orcs[g]
+            _, ost0 = o.state()
+            mover_is_a = (ost0["to_move"] == O.BLACK) == bool(a_is_black[g])
+            agent = 0 if mover_is_a else 1
+            cont = o.step(record=True)
+            omv, ovis, obs, opr = o.root_children(agent)
+            dmv, dvis, dbs, dpr = dev.root_children(g, agent)
+            ctxmsg = "game %d ply %d agent %d" % (g, ply, agent)
+            np.testing.assert_array_equal(dmv, omv, err_msg="child moves/order " + ctxmsg)
+            np.testing.assert_array_equal(dvis, ovis, err_msg="visits " + ctxmsg)
+            np.testing.assert_array_equal(f32bits(dbs), f32bits(obs), err_msg="blackScores " + ctxmsg)
+            np.testing.assert_array_equal(f32bits(dpr), f32bits(opr), err_msg="priors " + ctxmsg)
+            assert dev.history(g)[-1] == o.history()[-1], ctxmsg
+            oboard, ost = o.state()
+            dboard, dst = dev.game(g)
+            np.testing.assert_array_equal(dboard, oboard, err_msg="board " + ctxmsg)
+            assert dst["ended"] == ost["ended"], ctxmsg
+            if ost["ended"]:
+                assert dst["winner"] == ost["winner"], ctxmsg
+                alive[g] = False
+            assert cont == (not ost["ended"])
+        ply += 1
+    # histories and examples
+    dp, dpol, dval, dgi = dev.examples()
+    for g in range(G):
+        np.testing.assert_array_equal(dev.history(g), orcs[g].history())
+        ob, op, ov = orcs[g].examples()
+        sel = dgi == g
+        assert sel.sum() == ob.shape[0], "example count game %d" % g
+        if ob.shape[0]:
+            np.testing.assert_array_equal(f32bits(dp[sel]), f32bits(ob))
+            np.testing.assert_array_equal(f32bits(dpol[sel]), f32bits(op))
+            ended = orcs[g].state()[1]["ended"]
+            if ended:
+                np.testing.assert_array_equal(dval[sel], ov)
+    st = dev.stats()
+    assert st["tree_full"] == 0
+    return dev, orcs
+
+
+def test_tictactoe_script_example_nn(ctx):
+    """mcts/example_test.go dummyNN through Arena.Play (two trees): documented game 4,0,2,6,3,5,1,7,8."""
+    dev, orcs = run_pair(ctx, capi.GAME_MNK, 3, 3, 3, budget=200, inf=capi.INF_SCRIPT, a_is_black=(1, 0))
+    assert list(dev.history(0)) == [4, 0, 2, 6, 3, 5, 1, 7, 8]
+    assert dev.game(0)[1]["winner"] == capi.NONE
+
+
+@pytest.mark.parametrize("budget", [1, 7, 64, 333])
+def test_tictactoe_hash(ctx, budget):
+    run_pair(ctx, capi.GAME_MNK, 3, 3, 3, budget=budget, a_is_black=(1, 0, 1))
+
+
+def test_tictactoe_dummy_uniform(ctx):
+    run_pair(ctx, capi.GAME_MNK, 3, 3, 3, budget=100, inf=capi.INF_DUMMY, a_is_black=(1,))
+
+
+def test_mnk_5x5_k4(ctx):
+    run_pair(ctx, capi.GAME_MNK, 5, 5, 4, budget=80, a_is_black=(1, 0))
+
+
+def test_connect4(ctx):
+    run_pair(ctx, capi.GAME_C4, 6, 7, 4, budget=60, a_is_black=(1, 0))
+
+
+def test_komi_5x5(ctx):
+    run_pair(ctx, capi.GAME_KOMI, 5, 5, 3, budget=60, a_is_black=(1, 0))
+
+
+def test_komi_7x7_uniform_example(ctx):
+    """mcts/example_test.go Example_Komi's dummyNN2 (1/25 policy) generalised to the board's action space."""
+    run_pair(ctx, capi.GAME_KOMI, 5, 5, 3, budget=100, inf=capi.INF_UNIFORM, a_is_black=(0,), policy_len=25)
+
+
+def test_wq_5x5_full_game(ctx):
+    run_pair(ctx, capi.GAME_WQ, 5, 5, komi=0.5, enc=capi.ENC_WQ, budget=40, a_is_black=(1, 0), max_moves=60)
+
+
+def test_wq_9x9_prefix(ctx):
+    run_pair(ctx, capi.GAME_WQ, 9, 9, komi=7.5, enc=capi.ENC_WQ, budget=30, a_is_black=(1, 0), max_moves=200,
+             n_plies=40)
+
+
+def test_wq_19x19_prefix(ctx):
+    run_pair(ctx, capi.GAME_WQ, 19, 19, komi=7.5, enc=capi.ENC_WQ, budget=12, a_is_black=(1,), n_plies=10)
+
+
+def test_wq_prefer_pass_and_smart_pass(ctx):
+    run_pair(ctx, capi.GAME_WQ, 5, 5, komi=0.5, budget=25, a_is_black=(1,), max_moves=40, DumbPass=False,
+             PassPreference=capi.PREFER_PASS)
+
+
+def test_random_count_temperature_one(ctx):
+    run_pair(ctx, capi.GAME_MNK, 3, 3, 3, budget=40, a_is_black=(1,), RandomCount=0)
+
+
+def test_net_inferencer_end_to_end(ctx):
+    """NET inferencer: device trees driven by the GPU net vs oracle trees driven by the SAME GPU net outputs."""
+    H = W = 5
+    Aspace = H * W + 1
+    net = A.Net(ctx, 32, 2, 64, W, H, 2, Aspace, bn_mode=capi.BN_IDENTITY)
+    net.init_random(7)
+    for i in range(net.num_params()):
+        name, n = net.param_info(i)
+        if name.endswith("_gamma"):
+            net.set_param(i, np.ones(n, np.float32))
+        elif name.endswith("_beta"):
+            net.set_param(i, np.zeros(n, np.float32))
+    net.commit()
+    budget = 24
+    dev = A.Arena(ctx, capi.GAME_KOMI, H, W, 3, encoder=capi.ENC_TWOPLANE, n_games=2, Budget=budget)
+    dev.set_inferencer(0, capi.INF_NET, net)
+    dev.set_inferencer(1, capi.INF_NET, net)
+    ab = np.array([1, 0], dtype=np.uint8)
+    dev.reset(ab)
+
+    def cb(planes):
+        pol, val = net.infer(planes.reshape(1, 2, H, W))
+        return pol[0], float(val[0])
+
+    orcs = []
+    for g in range(2):
+        o = O.Arena(O.KOMI, H, W, 3, enc=O.ENC_TWOPLANE, Budget=budget)
+        o.set_callback(0, cb, Aspace)
+        o.set_callback(1, cb, Aspace)
+        o.begin(int(ab[g]))
+        orcs.append(o)
+    for ply in range(6):
+        dev.begin_move()
+        dev.simulate(budget)
+        dev.end_move(record=True)
+        for g in range(2):
+            o = orcs[g]
+            _, ost0 = o.state()
+            agent = 0 if ((ost0["to_move"] == O.BLACK) == bool(ab[g])) else 1
+            o.step(record=True)
+            omv, ovis, obs, opr = o.root_children(agent)
+            dmv, dvis, dbs, dpr = dev.root_children(g, agent)
+            np.testing.assert_array_equal(dmv, omv)
+            np.testing.assert_array_equal(dvis, ovis)
+            np.testing.assert_array_equal(f32bits(dbs), f32bits(obs))
+    st = dev.stats()
+    assert st["nn_evals"] > 0 and st["sims_nonnull"] > 0
+
+
+def test_counters_and_eval_count(ctx):
+    """NN evaluations = 8*N + 9 for the scripted tic-tac-toe game (SURVEY App. A validation note)."""
+    N = 50
+    dev = A.Arena(ctx, capi.GAME_MNK, 3, 3, 3, n_games=1, Budget=N)
+    dev.set_inferencer(0, capi.INF_SCRIPT)
+    dev.set_inferencer(1, capi.INF_SCRIPT)
+    dev.reset(np.array([1], dtype=np.uint8))
+    dev.play(0, record=True)
+    st = dev.stats()
+    assert st["games_finished"] == 1 and st["moves_played"] == 9
+    assert st["sims_total"] == 9 * N

@@ -15,9 +15,21 @@ pytestmark = pytest.mark.gpu
 POL_ATOL, POL_RTOL, VAL_ATOL = 2e-5, 1e-4, 1e-4
 
 
-def make_pair(ctx, K, L, FC, W, H, F, Aspace, bn_mode=0, seed=1337):
+def make_pair(ctx, K, L, FC, W, H, F, Aspace, bn_mode=0, seed=1337, tame=True):
+    """tame=True rescales BN gamma so the folded per-(c,h,w) scale is O(1): with the raw reference
+    initialiser kinds the degenerate-eps BN (x316 per layer) saturates softmax/tanh and every board
+    gives the same one-hot policy — a parity check on that alone would be vacuous."""
     onet = O.Net(K, L, FC, W, H, F, Aspace, bn_mode=bn_mode)
     onet.init_random(seed)
+    if tame:
+        rng = np.random.default_rng(seed + 1)
+        for i in range(onet.num_params()):
+            name = onet.param_name(i)
+            if name.endswith("_gamma"):
+                s = rng.uniform(0.5, 1.5, onet.get_param(i).size).astype(np.float32)
+                onet.set_param(i, s * np.float32(np.sqrt(1e-5) if bn_mode == 0 else 1.0))
+            elif name.endswith("_beta"):
+                onet.set_param(i, rng.normal(0, 0.1, onet.get_param(i).size).astype(np.float32))
     gnet = A.Net(ctx, K, L, FC, W, H, F, Aspace, bn_mode=bn_mode)
     assert gnet.num_params() == onet.num_params()
     for i in range(onet.num_params()):
@@ -54,6 +66,16 @@ CASES = [
 ]
 
 
+def test_infer_matches_oracle_reference_init(ctx):
+    """raw reference initialiser kinds + degenerate-eps BN (saturating, but parity must still hold)."""
+    onet, gnet = make_pair(ctx, 32, 2, 64, 5, 5, 2, 26, bn_mode=0, tame=False)
+    x = rand_planes(6, 2, 5, 5, seed=11)
+    pol_o, val_o = onet.infer(x)
+    pol_g, val_g = gnet.infer(x)
+    np.testing.assert_allclose(pol_g, pol_o, atol=1e-4, rtol=1e-3)
+    np.testing.assert_allclose(val_g, val_o, atol=1e-4)
+
+
 @pytest.mark.parametrize("K,L,FC,W,H,F,Aspace,B,bn_mode", CASES)
 def test_infer_matches_oracle(ctx, K, L, FC, W, H, F, Aspace, B, bn_mode):
     onet, gnet = make_pair(ctx, K, L, FC, W, H, F, Aspace, bn_mode)
@@ -64,8 +86,9 @@ def test_infer_matches_oracle(ctx, K, L, FC, W, H, F, Aspace, B, bn_mode):
     np.testing.assert_allclose(pol_g.sum(axis=1), 1.0, atol=1e-5)
     np.testing.assert_allclose(pol_g, pol_o, atol=POL_ATOL, rtol=POL_RTOL)
     np.testing.assert_allclose(val_g, val_o, atol=VAL_ATOL)
-    # not a degenerate comparison: outputs differ across boards
-    assert np.abs(pol_o[0] - pol_o[-1]).max() > 1e-6
+    # not a degenerate comparison: outputs differ across boards (a 3-filter net can legitimately be all-dead ReLUs)
+    if K >= 8:
+        assert np.abs(pol_o - pol_o[0]).max() > 1e-6
 
 
 def test_batch_independence(ctx):
