@@ -348,11 +348,12 @@ int agz_net::ensure_batch(int B) {
 
 template <int WM, int WN, int MT, bool DUAL>
 static void launch_conv(agz_ctx* ctx, ConvArgs& a) {
+  const int klass = DUAL ? AGZ_PROF_CONV : AGZ_PROF_CONV_INIT;
   constexpr int BM = WM * MT * 32, BNT = WN * 64;
   a.n_mtiles = ceil_div(a.M, BM);
   a.n_ntiles = ceil_div(a.Ntot, BNT);
   dim3 grid(a.n_mtiles * a.n_ntiles), block(256);
-  ProfScope ps(ctx, AGZ_PROF_CONV);
+  ProfScope ps(ctx, klass);
   hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, MT, DUAL>), grid, block, 0, ctx->stream, a);
 }
 

@@ -1,0 +1,69 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" on CPU).
+
+Self-play shards by independent games: zero data-path collectives.  The only exchange step is the
+gather of per-rank example buffers before dual.Train (agogo.go:118-133): variable-count all-gather below.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class _DevArray:
+    """zero-copy view of a libagz device buffer for torch.as_tensor (CUDA array interface v2)"""
+
+    def __init__(self, ptr, shape, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def device_tensor(ptr, shape, device):
+    return torch.as_tensor(_DevArray(ptr, shape), device=device)
+
+
+def all_gather_examples(planes, policy, value, group=None):
+    """Variable-count all-gather of example records {Board[F*HW], Policy[A+1], Value} (datatypes.go:41-46).
+
+    Inputs are this rank's [n_r, *] tensors (any device the backend supports).  Returns the concatenation
+    over ranks in rank order.  Direct all-gather of padded blocks: with RCCL every peer pair uses its own
+    xGMI link concurrently, so the exchange is bound by one link's bandwidth per peer, not by a ring.
+    """
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return planes, policy, value
+    world = dist.get_world_size(group)
+    n = torch.tensor([planes.shape[0]], dtype=torch.int64, device=planes.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    nmax = max(counts)
+    out = []
+    for t in (planes, policy, value.reshape(-1, 1)):
+        pad = torch.zeros((nmax, t.shape[1]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+        out.append(torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0))
+    return out[0], out[1], out[2].reshape(-1)
+
+
+def shard_games(total_games, rank, world):
+    """games [lo, hi) owned by `rank` (config #4: 4096 games sharded 512/GPU)"""
+    per = total_games // world
+    extra = total_games % world
+    lo = rank * per + min(rank, extra)
+    hi = lo + per + (1 if rank < extra else 0)
+    return lo, hi

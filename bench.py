@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py — MCTS simulations/sec of batched self-play on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+Workload (configs[3] per GPU, the configuration the metric is quoted on): 19x19 Go (game/wq), K=256,
+20 dual-branch blocks, FC=512, ActionSpace 362, WQEncoder (F=18), 512 concurrent self-play games per GPU,
+800 simulations per move, synthetic random-init weights (fixed seed), games started from the empty board.
+
+One STEP = one simulation for every game on the GPU: PUCT descent + Apply in each game's tree (k_select),
+ONE batched 512-leaf pass through the conv tower and heads, expansion + backup (k_expand).  Every
+`Budget` steps the move is finished (bestMove, Apply, tree re-root) and the next one prepared — inside the
+timed region.  value = non-null simulations (search.go:175-178) completed by all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import agogo_amd as A  # noqa: E402
+from agogo_amd import capi  # noqa: E402
+from agogo_amd import dist as adist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def standard_bn_init(net):
+    """gamma = 1, beta = 0 (identity statistics): keeps random-init activations O(1) so the synthetic search trees
+    branch like a trained net's instead of saturating softmax/tanh (DESIGN.md §synthetic inputs)."""
+    for i in range(net.num_params()):
+        name, n = net.param_info(i)
+        if name.endswith("_gamma"):
+            net.set_param(i, np.ones(n, np.float32))
+        elif name.endswith("_beta"):
+            net.set_param(i, np.zeros(n, np.float32))
+
+
+def cpu_baseline(size, K, L, budget_s=20.0):
+    """The oracle (CPU restatement of the reference algorithm: per-leaf inference, sequential pipeline) timed on
+    ONE host core, on a bounded sample of the same workload: one 19x19 game, one move, a few simulations."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    A_ = size * size + 1
+    net = O.Net(K, L, 2 * K, size, size, 18, A_, bn_mode=2)
+    net.init_random(1337)
+    for i in range(net.num_params()):
+        nm = net.param_name(i)
+        if nm.endswith("_gamma"):
+            net.set_param(i, np.ones_like(net.get_param(i)))
+        elif nm.endswith("_beta"):
+            net.set_param(i, np.zeros_like(net.get_param(i)))
+    x = np.zeros((1, 18, size, size), np.float32)
+    t0 = time.perf_counter()
+    net.infer(x)
+    t_eval = time.perf_counter() - t0
+    sims = int(max(2, min(64, budget_s / max(t_eval, 1e-3) - 1)))
+    ar = O.Arena(O.WQ, size, size, komi=7.5, enc=O.ENC_WQ, Budget=sims)
+    ar.set_inferencer(0, O.INF_NET, net)
+    ar.set_inferencer(1, O.INF_NET, net)
+    ar.begin(1)
+    t0 = time.perf_counter()
+    ar.step(record=True)
+    dt = time.perf_counter() - t0
+    st = ar.tree_stats(0)
+    return {"value": st["playouts"] / dt, "unit": "sims/s", "cores": 1, "kind": "port",
+            "sample": "oracle (C++ restatement, per-leaf inference): 1 game, 1 move, %d sims + root eval = %d evals "
+                      "in %.1f s on one host core of %d" % (sims, st["nn_evals"], dt, os.cpu_count() or 0),
+            "evals_per_s": st["nn_evals"] / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--games", type=int, default=512, help="concurrent self-play games per GPU")
+    ap.add_argument("--size", type=int, default=19)
+    ap.add_argument("--K", type=int, default=256)
+    ap.add_argument("--L", type=int, default=20)
+    ap.add_argument("--budget", type=int, default=800, help="simulations per move")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-nets", action="store_true", help="agents A and B hold different networks")
+    args = ap.parse_args()
+
+    rank, local, world = adist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libagz has no CPU fallback)")
+    torch.cuda.set_device(local)
+    ctx = A.Ctx(local)
+    S, K, L, G = args.size, args.K, args.L, args.games
+    Aspace = S * S + 1
+    nets = []
+    for i in range(2 if args.two_nets else 1):
+        net = A.Net(ctx, K, L, 2 * K, S, S, 18, Aspace, bn_mode=capi.BN_IDENTITY)
+        net.init_random(1337 + i)
+        standard_bn_init(net)
+        net.commit()
+        nets.append(net)
+    arena = A.Arena(ctx, capi.GAME_WQ, S, S, komi=7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337 + rank,
+                    Budget=args.budget, PUCT=1.0, RandomCount=0, DumbPass=True,
+                    PassPreference=capi.DONT_PREFER_PASS)
+    arena.set_inferencer(0, capi.INF_NET, nets[0])
+    arena.set_inferencer(1, capi.INF_NET, nets[-1])
+    arena.reset()
+
+    sims_in_move = [0]
+
+    def step():
+        if sims_in_move[0] == 0:
+            arena.begin_move()
+        arena.simulate(1)
+        sims_in_move[0] += 1
+        if sims_in_move[0] == args.budget:
+            arena.end_move(True)
+            sims_in_move[0] = 0
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    st0 = arena.stats()
+    ctx.prof_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    st1 = arena.stats()
+
+    sims = st1["sims_nonnull"] - st0["sims_nonnull"]
+    sims_all = st1["sims_total"] - st0["sims_total"]
+    evals = st1["nn_evals"] - st0["nn_evals"]
+    t_max, sims_sum, evals_sum, iters_sum = dt, sims, evals, sims_all
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        cc = torch.tensor([sims, evals, sims_all], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        t_max, sims_sum, evals_sum, iters_sum = float(tt.item()), float(cc[0].item()), float(cc[1].item()), float(cc[2].item())
+
+    prof = {}
+    for name, k in (("conv_dual", capi.PROF_CONV), ("conv_init", capi.PROF_CONV_INIT), ("heads", capi.PROF_HEADS),
+                    ("select", capi.PROF_SELECT), ("expand", capi.PROF_EXPAND), ("move", capi.PROF_MOVE)):
+        n, ms = ctx.prof_read(k)
+        prof[name] = {"launches": n, "avg_ms": (ms / n) if n else None, "total_ms": ms}
+
+    # optional: the one exchange step of the path — gather recorded examples across ranks (untimed leg)
+    gather_ms = None
+    if world > 1:
+        import ctypes as C
+        pp, po, pv, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int32(0)
+        capi._check(capi.lib().agz_arena_examples_dev(arena.h, C.byref(pp), C.byref(po), C.byref(pv), C.byref(n)), "examples_dev")
+        k = max(n.value, 1)
+        dev = torch.device("cuda", local)
+        tp = adist.device_tensor(pp.value, (k, 18 * S * S), dev)[: n.value]
+        tpo = adist.device_tensor(po.value, (k, Aspace), dev)[: n.value]
+        tv = adist.device_tensor(pv.value, (k,), dev)[: n.value]
+        fence()
+        g0 = time.perf_counter()
+        gp, _, _ = adist.all_gather_examples(tp, tpo, tv)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        n_gathered = int(gp.shape[0])
+
+    if rank == 0:
+        flops_eval = nets[0].flops_per_eval()
+        hw = S * S
+        conv_flops_launch = 2.0 * (G * hw) * (2 * K) * (9 * K)  # algorithmic FLOPs of one dual-block launch
+        conv_ms = prof["conv_dual"]["avg_ms"]
+        achieved = conv_flops_launch / (conv_ms * 1e-3) / 1e12 if conv_ms else None
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_conv_dual.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "mcts_sims_per_sec", "value": sims_sum / t_max, "unit": "sims/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "19x19 Go (wq) self-play: K=%d, %d dual-branch blocks, FC=%d, A=%d, WQEncoder F=18, "
+                                   "%d concurrent games/GPU, %d sims/move, leaf batch=%d, one net for both agents=%s"
+                                   % (K, L, 2 * K, Aspace, G, args.budget, G, str(not args.two_nets)),
+                       "board": S, "K": K, "blocks": L, "games_per_gpu": G, "sims_per_move": args.budget,
+                       "weights": "random-init seed 1337 (GlorotU conv, GlorotN FC; BN gamma=1 beta=0, identity stats)",
+                       "parallelism": "games sharded %d/GPU, no data-path collective" % G},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved / FP32_MFMA_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
+                         "kernel": "conv3x3_mfma_kernel<2,2,2,DUAL> (fused dual-branch block)",
+                         "flops_per_launch": conv_flops_launch, "avg_launch_ms": conv_ms,
+                         "launches": prof["conv_dual"]["launches"]},
+            "extra": {"nn_evals_per_s": evals_sum / t_max, "iterations_per_s": iters_sum / t_max,
+                      "moves_per_s": sims_sum / t_max / args.budget,
+                      "games_per_s_est": sims_sum / t_max / args.budget / (2 * hw),
+                      "games_per_s_note": "moves/s divided by the 2*M*N move cap (random-init nets almost never pass twice)",
+                      "end_to_end_tflops": evals_sum * flops_eval / t_max / 1e12,
+                      "end_to_end_frac_of_fp32_peak": evals_sum * flops_eval / t_max / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
+                      "kernel_classes": prof, "examples_allgather_ms": gather_ms,
+                      "tree_full": st1["tree_full"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(S, K, L)
+            except Exception as e:  # the oracle is only the baseline leg; never the measured path
+                out["cpu_baseline"] = {"value": None, "unit": "sims/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    arena.close()
+    for n_ in nets:
+        n_.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

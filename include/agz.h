@@ -60,12 +60,13 @@ void* agz_ctx_stream(agz_ctx* ctx);
 /* kernel-class timers: HIP events recorded on the ctx stream around every launch of a class.
  * enable=1 starts collecting (and clears), enable=0 stops.  agz_ctx_prof_read syncs and returns
  * the launch count and summed milliseconds of one class. */
-#define AGZ_PROF_CONV 0    /* 3x3 conv tower kernels (dominant) */
+#define AGZ_PROF_CONV 0    /* fused dual-branch 3x3 conv block launches (the dominant kernel) */
 #define AGZ_PROF_HEADS 1   /* policy/value head kernel */
 #define AGZ_PROF_SELECT 2  /* MCTS select/apply/encode */
 #define AGZ_PROF_EXPAND 3  /* MCTS expand/backup */
 #define AGZ_PROF_MOVE 4    /* root update / best move / apply */
-#define AGZ_PROF_NCLASS 5
+#define AGZ_PROF_CONV_INIT 5 /* the single F->K input conv */
+#define AGZ_PROF_NCLASS 6
 int agz_ctx_prof_enable(agz_ctx* ctx, int enable);
 int agz_ctx_prof_read(agz_ctx* ctx, int klass, int64_t* launches, double* total_ms);
 

@@ -12,6 +12,7 @@
 //   SoftMax     = exp(x-max)/sum over the last axis;  Tanh, ReLU elementwise.
 // The only reference-pinned piece is round() (dualnet/config_test.go:5-17).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <string>
@@ -126,24 +127,41 @@ struct Dual {
     for (int o = 0; o < Cout; o++)
       for (int c = 0; c < Cin; c++)
         for (int t = 0; t < k * k; t++) wt[((size_t)t * Cin + c) * Cout + o] = w[((size_t)o * Cin + c) * k * k + t];
-    for (int h = 0; h < H; h++)
-      for (int x0 = 0; x0 < W; x0++) {
-        float* a = &acc[(size_t)(h * W + x0) * Cout];
-        for (int ky = 0; ky < k; ky++) {
-          int ih = h + ky - pad;
-          if (ih < 0 || ih >= H) continue;
-          for (int kx = 0; kx < k; kx++) {
-            int iw = x0 + kx - pad;
-            if (iw < 0 || iw >= W) continue;
-            const float* wp = &wt[(size_t)(ky * k + kx) * Cin * Cout];
-            for (int c = 0; c < Cin; c++) {
-              float xv = x[(size_t)c * hw + ih * W + iw];
-              const float* wr = wp + (size_t)c * Cout;
-              for (int o = 0; o < Cout; o++) a[o] += xv * wr[o];
+    // blocks of PB pixels share each weight row (the sum order per output stays (ky,kx,cin))
+    constexpr int PB = 8;
+    std::vector<float> blk((size_t)Cout * PB);
+    for (int p0 = 0; p0 < hw; p0 += PB) {
+      int np = hw - p0 < PB ? hw - p0 : PB;
+      std::fill(blk.begin(), blk.end(), 0.f);
+      for (int ky = 0; ky < k; ky++)
+        for (int kx = 0; kx < k; kx++) {
+          const float* wp = &wt[(size_t)(ky * k + kx) * Cin * Cout];
+          int off[PB];
+          bool any = false;
+          for (int q = 0; q < PB; q++) {
+            off[q] = -1;
+            if (q >= np) continue;
+            int p = p0 + q, h = p / W, x0 = p % W;
+            int ih = h + ky - pad, iw = x0 + kx - pad;
+            if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+            off[q] = ih * W + iw;
+            any = true;
+          }
+          if (!any) continue;
+          for (int c = 0; c < Cin; c++) {
+            float xv[PB];
+            for (int q = 0; q < PB; q++) xv[q] = off[q] >= 0 ? x[(size_t)c * hw + off[q]] : 0.f;
+            const float* wr = wp + (size_t)c * Cout;
+            for (int o = 0; o < Cout; o++) {
+              float wv = wr[o];
+              float* bo = &blk[(size_t)o * PB];
+              for (int q = 0; q < PB; q++) bo[q] += xv[q] * wv;
             }
           }
         }
-      }
+      for (int q = 0; q < np; q++)
+        for (int o = 0; o < Cout; o++) acc[(size_t)(p0 + q) * Cout + o] = blk[(size_t)o * PB + q];
+    }
     y->assign((size_t)Cout * hw, 0.f);
     for (int p = 0; p < hw; p++)
       for (int o = 0; o < Cout; o++) (*y)[(size_t)o * hw + p] = acc[(size_t)p * Cout + o];

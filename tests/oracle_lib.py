@@ -85,6 +85,11 @@ def lib():
     sig("orc_arena_num_examples", i32, vp)
     sig("orc_arena_get_example", None, vp, i32, pf, pf, pf)
     sig("orc_arena_example_sizes", i32, vp, pi, pi)
+    sig("orc_example_new", vp, i32, i32, i32, i32, f64, f32, i32, i32, i32, i32, u64)
+    sig("orc_example_free", None, vp)
+    sig("orc_example_turn", i32, vp, pi, pi)
+    sig("orc_example_root_children", i32, vp, pi, C.POINTER(C.c_uint32), pf, i32)
+    sig("orc_example_nn_evals", i64, vp)
     _LIB = L
     return L
 
@@ -327,3 +332,34 @@ class Arena:
             lib().orc_arena_get_example(self.h, i, _pf(B[i]), _pf(P[i]), C.byref(v))
             V[i] = v.value
         return B, P, V
+
+
+class ExampleSearch:
+    """mcts/example_test.go:74-103 pattern: ONE mcts.MCTS searched alternately for both players."""
+
+    def __init__(self, kind, m, n, k=0, komi=0.0, PUCT=1.0, Budget=200, inf=INF_SCRIPT, policy_len=0, first_player=BLACK,
+                 seed=1):
+        self.h = lib().orc_example_new(kind, m, n, k, komi, PUCT, Budget, inf, policy_len, first_player, seed)
+        self.cells = m * n
+
+    def __del__(self):
+        try:
+            lib().orc_example_free(self.h)
+        except Exception:
+            pass
+
+    def turn(self):
+        e, w = C.c_int32(0), C.c_int32(0)
+        best = lib().orc_example_turn(self.h, C.byref(e), C.byref(w))
+        return best, bool(e.value), w.value
+
+    def root_children(self):
+        cap = self.cells + 2
+        mv = np.zeros(cap, np.int32)
+        vis = np.zeros(cap, np.uint32)
+        bs = np.zeros(cap, np.float32)
+        n = lib().orc_example_root_children(self.h, _pi(mv), vis.ctypes.data_as(C.POINTER(C.c_uint32)), _pf(bs), cap)
+        return [(int(mv[i]), int(vis[i]), float(bs[i])) for i in range(n)]
+
+    def nn_evals(self):
+        return lib().orc_example_nn_evals(self.h)
