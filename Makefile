@@ -3,7 +3,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CS := agogo_amd/csrc
 OUT := agogo_amd/lib
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Iinclude
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-uninitialized -Iinclude
 # engine.hip holds the bit-exact MCTS arithmetic: no fused multiply-add contraction (Go/amd64 never fuses)
 ENGINE_FLAGS := -ffp-contract=off
 

@@ -55,7 +55,7 @@ class GameState(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libagz.so")
+    return os.environ.get("AGZ_LIB_PATH") or os.path.join(_HERE, "lib", "libagz.so")
 
 
 def lib():

@@ -94,25 +94,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   const int NK = 9 * NC;
   const int w_tap_stride = a.Ntot * a.Cin_p;
 
-  float4 ra[A_PER_T], rb[B_PER_T];
-  // (macros, not lambdas: by-reference captures of ra/rb make LLVM promote them to LDS instead of VGPRs)
+  // staging registers as NAMED scalars (arrays here get demoted to scratch/LDS by hipcc once sched_barriers or
+  // conditionals sit between their definition and use — rule 20 of the CDNA guide)
+  static_assert(A_PER_T == 4 && (B_PER_T == 4 || B_PER_T == 2), "staging layout");
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define AGZ_GLOAD(IT)                                                                                     \
   {                                                                                                       \
     int tap_ = (IT) / NC, cc_ = (IT) - tap_ * NC;                                                         \
     int ky_ = tap_ / 3, kx_ = tap_ - ky_ * 3;                                                             \
     int xo_ = ((ky_ - 1) * a.Wp + (kx_ - 1)) * a.Cin_p + cc_ * 32;                                        \
     int wo_ = tap_ * w_tap_stride + cc_ * 32;                                                             \
-    _Pragma("unroll") for (int i = 0; i < A_PER_T; i++) ra[i] =                                           \
-        *reinterpret_cast<const float4*>(a.x + a_goff[i] + xo_);                                          \
-    _Pragma("unroll") for (int i = 0; i < B_PER_T; i++) rb[i] =                                           \
-        *reinterpret_cast<const float4*>(a.w + b_goff[i] + wo_);                                          \
+    ra0 = *reinterpret_cast<const float4*>(a.x + a_goff[0] + xo_);                                        \
+    ra1 = *reinterpret_cast<const float4*>(a.x + a_goff[1] + xo_);                                        \
+    ra2 = *reinterpret_cast<const float4*>(a.x + a_goff[2] + xo_);                                        \
+    ra3 = *reinterpret_cast<const float4*>(a.x + a_goff[3] + xo_);                                        \
+    rb0 = *reinterpret_cast<const float4*>(a.w + b_goff[0] + wo_);                                        \
+    rb1 = *reinterpret_cast<const float4*>(a.w + b_goff[1] + wo_);                                        \
+    if constexpr (B_PER_T > 2) {                                                                          \
+      rb2 = *reinterpret_cast<const float4*>(a.w + b_goff[2] + wo_);                                      \
+      rb3 = *reinterpret_cast<const float4*>(a.w + b_goff[3] + wo_);                                      \
+    }                                                                                                     \
   }
 #define AGZ_LSTORE(BUF)                                                                                   \
   {                                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < A_PER_T; i++)                                                   \
-        *reinterpret_cast<float4*>(lds + (BUF) * STAGE + a_loff[i]) = ra[i];                              \
-    _Pragma("unroll") for (int i = 0; i < B_PER_T; i++)                                                   \
-        *reinterpret_cast<float4*>(lds + (BUF) * STAGE + BM * 32 + b_loff[i]) = rb[i];                    \
+    float* la_ = lds + (BUF) * STAGE;                                                                     \
+    float* lb_ = la_ + BM * 32;                                                                           \
+    *reinterpret_cast<float4*>(la_ + a_loff[0]) = ra0;                                                    \
+    *reinterpret_cast<float4*>(la_ + a_loff[1]) = ra1;                                                    \
+    *reinterpret_cast<float4*>(la_ + a_loff[2]) = ra2;                                                    \
+    *reinterpret_cast<float4*>(la_ + a_loff[3]) = ra3;                                                    \
+    *reinterpret_cast<float4*>(lb_ + b_loff[0]) = rb0;                                                    \
+    *reinterpret_cast<float4*>(lb_ + b_loff[1]) = rb1;                                                    \
+    if constexpr (B_PER_T > 2) {                                                                          \
+      *reinterpret_cast<float4*>(lb_ + b_loff[2]) = rb2;                                                  \
+      *reinterpret_cast<float4*>(lb_ + b_loff[3]) = rb3;                                                  \
+    }                                                                                                     \
   }
 
   f32x16 acc[MT][2];
@@ -139,32 +155,67 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   AGZ_GLOAD(0);
   AGZ_LSTORE(0);
   __syncthreads();
+  // Fragment double-buffering: the ds_read_b128s of k-step ks+1 are issued BEFORE the 16 MFMAs of k-step ks
+  // and sched_barrier pins that order (hipcc otherwise sinks loads next to their first use, exposing the LDS
+  // and — for the staging loads — the full L2/HBM latency once per K-iteration).
+#define AGZ_FRAG_READ(AV, BV, KS)                                                                                 \
+  {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < MT; i++) AV[i] =                                                        \
+        *reinterpret_cast<const float4*>(Ab + swz_off(a_row[i], 2 * (KS) + khalf));                               \
+    _Pragma("unroll") for (int j = 0; j < 2; j++) BV[j] =                                                         \
+        *reinterpret_cast<const float4*>(Bb + swz_off(b_row[j], 2 * (KS) + khalf));                               \
+  }
+#define AGZ_MFMA16(AV, BV)                                                                                        \
+  {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < 2; j++)                  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].x, BV[j].x, acc[i][j], 0, 0, 0);                   \
+    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < 2; j++)                  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].y, BV[j].y, acc[i][j], 0, 0, 0);                   \
+    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < 2; j++)                  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].z, BV[j].z, acc[i][j], 0, 0, 0);                   \
+    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < 2; j++)                  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].w, BV[j].w, acc[i][j], 0, 0, 0);                   \
+  }
 #define AGZ_COMPUTE(BUF)                                                                                          \
   {                                                                                                               \
     const float* Ab = lds + (BUF) * STAGE;                                                                        \
     const float* Bb = Ab + BM * 32;                                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ks++) {                                                            \
-      float4 av[MT], bv[2];                                                                                       \
-      _Pragma("unroll") for (int i = 0; i < MT; i++) av[i] =                                                      \
-          *reinterpret_cast<const float4*>(Ab + swz_off(a_row[i], 2 * ks + khalf));                               \
-      _Pragma("unroll") for (int j = 0; j < 2; j++) bv[j] =                                                       \
-          *reinterpret_cast<const float4*>(Bb + swz_off(b_row[j], 2 * ks + khalf));                               \
-      _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < 2; j++) {              \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);                   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);                   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);                   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);                   \
-      }                                                                                                           \
-    }                                                                                                             \
+    float4 av0[MT], bv0[2], av1[MT], bv1[2];                                                                      \
+    AGZ_FRAG_READ(av0, bv0, 0)                                                                                    \
+    AGZ_FRAG_READ(av1, bv1, 1)                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    AGZ_MFMA16(av0, bv0)                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    AGZ_FRAG_READ(av0, bv0, 2)                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    AGZ_MFMA16(av1, bv1)                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    AGZ_FRAG_READ(av1, bv1, 3)                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    AGZ_MFMA16(av0, bv0)                                                                                          \
+    AGZ_MFMA16(av1, bv1)                                                                                          \
   }
+#ifndef AGZ_PROBE
+#define AGZ_PROBE 0  // timing experiments only (scripts/probe_conv.sh): 1 = no LDS store/barrier, 2 = + no global loads
+#endif
   for (int it = 0; it < NK - 1; it++) {
     const int buf = it & 1;
+#if AGZ_PROBE < 2
     AGZ_GLOAD(it + 1);
+#endif
+    __builtin_amdgcn_sched_barrier(0);  // keep the staging loads in flight across the whole MFMA section
     AGZ_COMPUTE(buf);
+    __builtin_amdgcn_sched_barrier(0);
+#if AGZ_PROBE == 0
     AGZ_LSTORE(buf ^ 1);
     __syncthreads();
+#elif AGZ_PROBE == 1
+    asm volatile("" ::"v"(ra0.x), "v"(ra1.x), "v"(ra2.x), "v"(ra3.x), "v"(rb0.x), "v"(rb1.x), "v"(rb2.x), "v"(rb3.x));
+#endif
   }
   AGZ_COMPUTE((NK - 1) & 1);
+#undef AGZ_FRAG_READ
+#undef AGZ_MFMA16
 #undef AGZ_COMPUTE
 #undef AGZ_GLOAD
 #undef AGZ_LSTORE

@@ -1,0 +1,129 @@
+// Header-only C++ mirror of the reference's operator interface for the hot path, over the C ABI (include/agz.h).
+// Same names, argument meaning and error behaviour as the Go types, so host code and tests read like the
+// reference's: dual::Config / dual::Dual / dual::Inferencer (dualnet/config.go, dual.go, meta.go),
+// mcts::Config (mcts/tree.go:15-29), agogo::Arena (arena.go) for a batch of games.
+// Errors: the reference returns `error` or panics; here agz::Error is thrown with agz_last_error().
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/agz.h"
+
+namespace agz {
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+inline void check(int rc, const char* what) {
+  if (rc != AGZ_OK) throw Error(std::string(what) + ": " + agz_last_error());
+}
+struct Ctx {
+  agz_ctx* h = nullptr;
+  explicit Ctx(int device = 0) { check(agz_ctx_create(device, &h), "agz_ctx_create"); }
+  ~Ctx() { agz_ctx_destroy(h); }
+  Ctx(const Ctx&) = delete;
+  Ctx& operator=(const Ctx&) = delete;
+};
+}  // namespace agz
+
+namespace dual {
+// dualnet/config.go:4-16
+struct Config {
+  int K = 0, SharedLayers = 0, FC = 0;
+  double L2 = 0;
+  int BatchSize = 0, Width = 0, Height = 0, Features = 0, ActionSpace = 0;
+  bool FwdOnly = false;
+  bool IsValid() const { return K >= 1 && ActionSpace >= 3 && SharedLayers >= 0 && FC > 1 && BatchSize >= 1 && Features > 0; }
+};
+inline int round(int a) {  // config.go:44-58
+  int n = a - 1;
+  n |= n >> 1; n |= n >> 2; n |= n >> 4; n |= n >> 8; n |= n >> 16; n++;
+  int lt = n / 2;
+  return (a - lt) < (n - a) ? lt : n;
+}
+inline Config DefaultConf(int m, int n, int actionSpace) {  // config.go:18-31
+  Config c; int k = round((m * n) / 3);
+  c.K = k; c.SharedLayers = m; c.FC = 2 * k; c.BatchSize = 256; c.Width = n; c.Height = m; c.Features = 18; c.ActionSpace = actionSpace;
+  return c;
+}
+// dual.Dual (dualnet/dual.go:16-47): parameters live on the device
+struct Dual {
+  Config conf;
+  agz_net* h = nullptr;
+  Dual(agz::Ctx& ctx, const Config& c, int bn_mode = AGZ_BN_DEGENERATE_EPS) : conf(c) {
+    if (!c.IsValid()) throw agz::Error("NNConf is not valid. Unable to proceed");  // agogo.go:42-44 panics
+    agz_net_conf nc{c.K, c.SharedLayers, c.FC, c.BatchSize, c.Width, c.Height, c.Features, c.ActionSpace, bn_mode, 1e-5f};
+    agz::check(agz_net_create(ctx.h, &nc, &h), "dual.New");
+  }
+  ~Dual() { agz_net_destroy(h); }
+  void Init(uint64_t seed) { agz::check(agz_net_init_random(h, seed), "Dual.Init"); agz::check(agz_net_commit(h), "Dual.Init"); }
+  int NumLearnables() const { return agz_net_num_params(h); }  // len(Model())
+  void Let(int i, const std::vector<float>& v) { agz::check(agz_net_set_param(h, i, v.data(), v.size()), "G.Let"); }
+  void Commit() { agz::check(agz_net_commit(h), "commit"); }
+};
+// dual.Inferencer (dualnet/meta.go:106-194), batched
+struct Inferencer {
+  Dual& d;
+  explicit Inferencer(Dual& dd) : d(dd) {}
+  // Infer: planes [B,F,H,W] -> policy [B,ActionSpace], value [B]
+  void Infer(const std::vector<float>& planes, int B, std::vector<float>* policy, std::vector<float>* value) {
+    policy->resize((size_t)B * d.conf.ActionSpace);
+    value->resize(B);
+    agz::check(agz_net_infer(d.h, planes.data(), B, policy->data(), value->data()), "Inferencer.Infer");
+  }
+};
+}  // namespace dual
+
+namespace mcts {
+enum PassPreference { DontPreferPass = AGZ_DONT_PREFER_PASS, PreferPass = AGZ_PREFER_PASS, DontResign = AGZ_DONT_RESIGN };
+// mcts/tree.go:15-29 (Timeout -> exactly Budget simulations)
+struct Config {
+  float PUCT = 1.0f;
+  int M = 0, N = 0, RandomCount = 0;
+  int32_t Budget = 10000;
+  uint32_t RandomMinVisits = 0;
+  float RandomTemperature = 0;
+  bool DumbPass = true;
+  float ResignPercentage = 0;
+  int PassPreference = DontPreferPass;
+  bool IsValid() const { return PUCT > 0 && PUCT <= 1; }
+};
+inline Config DefaultConfig(int boardSize) { Config c; c.M = c.N = boardSize; return c; }  // tree.go:31-41
+}  // namespace mcts
+
+namespace agogo {
+struct Example { std::vector<float> Board, Policy; float Value; };  // datatypes.go:41-46
+// n_games x Arena (arena.go:20-179)
+struct Arena {
+  agz_arena* h = nullptr;
+  int cells, F, A;
+  Arena(agz::Ctx& ctx, int kind, int m, int n, int k, float komi, int encoder, const mcts::Config& mc, int n_games, uint64_t seed)
+      : cells(m * n), F(encoder == AGZ_ENC_WQ ? 18 : 2), A(kind == AGZ_GAME_C4 ? n : m * n) {
+    if (!mc.IsValid()) throw agz::Error("MCTSConf is not valid. Unable to proceed");  // agogo.go:45-47
+    agz_game_conf g{kind, m, n, k, komi, 0, encoder};
+    agz_mcts_conf c{mc.PUCT, mc.M, mc.N, mc.RandomCount, mc.Budget, mc.RandomMinVisits, mc.RandomTemperature, mc.DumbPass ? 1 : 0,
+                    mc.ResignPercentage, mc.PassPreference};
+    agz::check(agz_arena_create(ctx.h, &g, &c, n_games, seed, 0, &h), "MakeArena");
+  }
+  ~Arena() { agz_arena_destroy(h); }
+  void SetAgents(dual::Dual* a, dual::Dual* b) {  // nil -> dummyInferer (agogo.go:83-87)
+    agz::check(agz_arena_set_inferencer(h, 0, a ? AGZ_INF_NET : AGZ_INF_DUMMY, a ? a->h : nullptr), "Agent A");
+    agz::check(agz_arena_set_inferencer(h, 1, b ? AGZ_INF_NET : AGZ_INF_DUMMY, b ? b->h : nullptr), "Agent B");
+  }
+  // Play every game to the end (Arena.Play, arena.go:80-179), recording examples
+  std::vector<Example> Play(bool record) {
+    agz::check(agz_arena_reset(h, nullptr), "Arena.Play");
+    agz::check(agz_arena_play(h, 0, record ? 1 : 0), "Arena.Play");
+    int n = 0;
+    agz::check(agz_arena_get_examples(h, nullptr, nullptr, nullptr, nullptr, 0, &n), "examples");
+    std::vector<float> P((size_t)n * F * cells), Q((size_t)n * (A + 1)), V(n);
+    if (n) agz::check(agz_arena_get_examples(h, P.data(), Q.data(), V.data(), nullptr, n, &n), "examples");
+    std::vector<Example> ex(n);
+    for (int i = 0; i < n; i++) {
+      ex[i].Board.assign(P.begin() + (size_t)i * F * cells, P.begin() + (size_t)(i + 1) * F * cells);
+      ex[i].Policy.assign(Q.begin() + (size_t)i * (A + 1), Q.begin() + (size_t)(i + 1) * (A + 1));
+      ex[i].Value = V[i];
+    }
+    return ex;
+  }
+};
+}  // namespace agogo

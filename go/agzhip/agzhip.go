@@ -1,0 +1,212 @@
+// Package agzhip binds libagz.so (MI355X self-play hot path) into gorgonia/agogo through cgo.
+//
+// NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no Go toolchain.  This is the binding a
+// maintainer adds on the reference side (see INTEGRATION.md).  Every exported Go type implements the
+// reference interface it replaces:
+//
+//	Inferencer    -> agogo.Inferer            (datatypes.go:56-59)   batch-1 path for Agent.Infer
+//	BatchedArena  -> the role of Arena.Play / AZ.SelfPlay (arena.go:80-179, agogo.go:93-97) for N games
+//
+// Threading: an agz_ctx is not thread-safe; every method locks the OS thread for the duration of the call
+// and serialises on the Ctx mutex (under `-tags cuda` agogo itself runs a single VM, const_cuda.go:5).
+package agzhip
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../agogo_amd/lib -lagz
+#include <stdlib.h>
+#include "agz.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"runtime"
+	"sync"
+	"unsafe"
+
+	"github.com/gorgonia/agogo"
+	dual "github.com/gorgonia/agogo/dualnet"
+	"github.com/gorgonia/agogo/game"
+	"github.com/gorgonia/agogo/mcts"
+)
+
+func lastErr(code C.int) error {
+	if code == 0 {
+		return nil
+	}
+	return errors.New(C.GoString(C.agz_last_error()))
+}
+
+// Ctx owns one HIP device + stream.
+type Ctx struct {
+	mu sync.Mutex
+	h  *C.agz_ctx
+}
+
+func NewCtx(device int) (*Ctx, error) {
+	c := &Ctx{}
+	if err := lastErr(C.agz_ctx_create(C.int(device), &c.h)); err != nil {
+		return nil, err
+	}
+	return c, nil
+}
+
+func (c *Ctx) Close() error { c.mu.Lock(); defer c.mu.Unlock(); C.agz_ctx_destroy(c.h); c.h = nil; return nil }
+
+func (c *Ctx) enter() func() {
+	runtime.LockOSThread()
+	c.mu.Lock()
+	return func() { c.mu.Unlock(); runtime.UnlockOSThread() }
+}
+
+// Net is a device-resident dual network.
+type Net struct {
+	ctx  *Ctx
+	h    *C.agz_net
+	conf dual.Config
+}
+
+// NewNet mirrors dual.New + Init (dualnet/dual.go:33-47) and copies the learnables of d in Model() order
+// exactly like dual.Infer's copy loop (dualnet/meta.go:141-146).  bnMode selects the BatchNorm inference
+// reading (C.AGZ_BN_*).
+func NewNet(ctx *Ctx, d *dual.Dual, bnMode int) (*Net, error) {
+	defer ctx.enter()()
+	cc := C.agz_net_conf{
+		K: C.int32_t(d.K), SharedLayers: C.int32_t(d.SharedLayers), FC: C.int32_t(d.FC), BatchSize: C.int32_t(d.BatchSize),
+		Width: C.int32_t(d.Width), Height: C.int32_t(d.Height), Features: C.int32_t(d.Features),
+		ActionSpace: C.int32_t(d.ActionSpace), bn_mode: C.int32_t(bnMode), bn_eps: 1e-5,
+	}
+	n := &Net{ctx: ctx, conf: d.Config}
+	if err := lastErr(C.agz_net_create(ctx.h, &cc, &n.h)); err != nil {
+		return nil, err
+	}
+	for i, node := range d.Model() {
+		data := node.Value().Data().([]float32)
+		if err := lastErr(C.agz_net_set_param(n.h, C.int(i), (*C.float)(unsafe.Pointer(&data[0])), C.size_t(len(data)))); err != nil {
+			return nil, err
+		}
+	}
+	if err := lastErr(C.agz_net_commit(n.h)); err != nil {
+		return nil, err
+	}
+	return n, nil
+}
+
+func (n *Net) Close() error { defer n.ctx.enter()(); C.agz_net_destroy(n.h); n.h = nil; return nil }
+
+// Inferencer implements agogo.Inferer over a Net (the batch-1 path; the batched path is BatchedArena).
+type Inferencer struct{ *Net }
+
+var _ agogo.Inferer = Inferencer{}
+
+// Infer evaluates one encoded board (dualnet/meta.go:168-190).  The returned slice is freshly allocated —
+// the reference returns a slice aliasing the VM output (meta.go:186-189), a latent race not reproduced here.
+func (m Inferencer) Infer(board []float32) (policy []float32, value float32, err error) {
+	defer m.ctx.enter()()
+	policy = make([]float32, m.conf.ActionSpace)
+	var v C.float
+	err = lastErr(C.agz_net_infer(m.h, (*C.float)(unsafe.Pointer(&board[0])), 1, (*C.float)(unsafe.Pointer(&policy[0])), &v))
+	return policy, float32(v), err // Agent.Infer panics on err (agent.go:66-71): behaviour preserved by the caller
+}
+
+// GameKind maps an in-tree game.State to its device implementation; arbitrary user games are not supported.
+type GameKind int
+
+const (
+	MNK  GameKind = C.AGZ_GAME_MNK
+	C4   GameKind = C.AGZ_GAME_C4
+	Komi GameKind = C.AGZ_GAME_KOMI
+	WQ   GameKind = C.AGZ_GAME_WQ
+)
+
+// BatchedArena plays nGames self-play games concurrently on one GPU.
+type BatchedArena struct {
+	ctx    *Ctx
+	h      *C.agz_arena
+	m, n   int
+	feats  int
+	action int
+}
+
+// NewBatchedArena mirrors MakeArena (arena.go:42-70) for nGames games: conf is the reference mcts.Config with
+// Timeout replaced by exactly conf.Budget simulations per move.
+func NewBatchedArena(ctx *Ctx, kind GameKind, m, n, k int, komi float32, encoder int, conf mcts.Config, nGames int, seed uint64) (*BatchedArena, error) {
+	defer ctx.enter()()
+	gc := C.agz_game_conf{kind: C.int32_t(kind), m: C.int32_t(m), n: C.int32_t(n), k: C.int32_t(k), komi: C.float(komi), encoder: C.int32_t(encoder)}
+	dumb := 0
+	if conf.DumbPass {
+		dumb = 1
+	}
+	mc := C.agz_mcts_conf{PUCT: C.float(conf.PUCT), M: C.int32_t(conf.M), N: C.int32_t(conf.N), RandomCount: C.int32_t(conf.RandomCount),
+		Budget: C.int32_t(conf.Budget), RandomMinVisits: C.uint32_t(conf.RandomMinVisits), RandomTemperature: C.float(conf.RandomTemperature),
+		DumbPass: C.int32_t(dumb), ResignPercentage: C.float(conf.ResignPercentage), PassPreference: C.int32_t(conf.PassPreference)}
+	a := &BatchedArena{ctx: ctx, m: m, n: n}
+	a.feats = 2
+	if encoder == C.AGZ_ENC_WQ {
+		a.feats = 18
+	}
+	a.action = m * n
+	if kind == C4 {
+		a.action = n
+	}
+	if err := lastErr(C.agz_arena_create(ctx.h, &gc, &mc, C.int(nGames), C.uint64_t(seed), 0, &a.h)); err != nil {
+		return nil, err
+	}
+	return a, nil
+}
+
+// SetAgents installs the two agents' networks (Agent.NN + SwitchToInference, agent.go:42-57); nil selects the
+// reference's dummyInferer (agogo.go:83-87).
+func (a *BatchedArena) SetAgents(na, nb *Net) error {
+	defer a.ctx.enter()()
+	for i, n := range []*Net{na, nb} {
+		kind, h := C.int(C.AGZ_INF_DUMMY), (*C.agz_net)(nil)
+		if n != nil {
+			kind, h = C.int(C.AGZ_INF_NET), n.h
+		}
+		if err := lastErr(C.agz_arena_set_inferencer(a.h, C.int(i), kind, h)); err != nil {
+			return err
+		}
+	}
+	return nil
+}
+
+// SelfPlay plays every game to its end and returns the recorded examples (AZ.SelfPlay × nGames, agogo.go:93-97).
+func (a *BatchedArena) SelfPlay() ([]agogo.Example, error) {
+	defer a.ctx.enter()()
+	if err := lastErr(C.agz_arena_reset(a.h, nil)); err != nil {
+		return nil, err
+	}
+	if err := lastErr(C.agz_arena_play(a.h, 0, 1)); err != nil {
+		return nil, err
+	}
+	var n C.int
+	if err := lastErr(C.agz_arena_get_examples(a.h, nil, nil, nil, nil, 0, &n)); err != nil || n == 0 {
+		return nil, err
+	}
+	bl, pl := a.feats*a.m*a.n, a.action+1
+	planes, policy, value := make([]float32, int(n)*bl), make([]float32, int(n)*pl), make([]float32, int(n))
+	if err := lastErr(C.agz_arena_get_examples(a.h, (*C.float)(unsafe.Pointer(&planes[0])), (*C.float)(unsafe.Pointer(&policy[0])),
+		(*C.float)(unsafe.Pointer(&value[0])), nil, n, &n)); err != nil {
+		return nil, err
+	}
+	ex := make([]agogo.Example, int(n))
+	for i := range ex {
+		ex[i] = agogo.Example{Board: planes[i*bl : (i+1)*bl], Policy: policy[i*pl : (i+1)*pl], Value: value[i]}
+	}
+	return ex, nil
+}
+
+func (a *BatchedArena) Close() error { defer a.ctx.enter()(); C.agz_arena_destroy(a.h); a.h = nil; return nil }
+
+var _ = game.Pass // keep the import: game.Single values cross the ABI as int32 (-1 pass, -2 resign)
+
+// Constants mirrored for callers (include/agz.h).
+const (
+	BNDegenerateEps = int(C.AGZ_BN_DEGENERATE_EPS)
+	BNRunning       = int(C.AGZ_BN_RUNNING)
+	BNIdentity      = int(C.AGZ_BN_IDENTITY)
+	EncTwoPlane     = int(C.AGZ_ENC_TWOPLANE)
+	EncWQ           = int(C.AGZ_ENC_WQ)
+)
