@@ -25,6 +25,7 @@
 #include <cstring>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace agz {
 
@@ -34,41 +35,34 @@ struct ConvArgs {
   const void* ep;
   float* y;
   int M, HW, W, Wp, HpWp;
+  int n_full_blocks;  // blocks [0, n_full_blocks) are full-height tiles, the rest half-height tiles from row m_split
+  int m_split;
   int Cin_p, Cout_p, Ntot;
   int n_mtiles, n_ntiles;
 };
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
-// WM x WN waves, each wave MT x 2 MFMA tiles.  BM = WM*MT*32 rows (pixels), BNT = WN*64 GEMM columns.
+// One block tile: WM x WN waves, each wave MT x 2 MFMA tiles.  BM = WM*MT*32 rows (pixels), BNT = WN*64 GEMM columns.
 template <int WM, int WN, int MT, bool DUAL>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, const int m0, const int n_tile) {
   constexpr int BM = WM * MT * 32;
   constexpr int BNT = WN * 64;
-  constexpr int A_PER_T = BM * 8 / 256;   // 16-byte chunks per thread per tile
-  constexpr int B_PER_T = BNT * 8 / 256;
   static_assert(WM * WN == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BNT) * 32];
   constexpr int STAGE = (BM + BNT) * 32;  // floats per pipeline stage: A tile then B tile
-
-  // XCD-aware tile mapping (bijective): consecutive block ids land on different XCDs; give each XCD a
-  // contiguous run of tiles so the n-tiles of one m-tile (same A rows) share an L2.
-  const int nblk = a.n_mtiles * a.n_ntiles;
-  int tile;
-  {
-    int id = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = id & 7, slot = id >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
-  const int m_tile = tile / a.n_ntiles, n_tile = tile - m_tile * a.n_ntiles;
-  const int m0 = m_tile * BM, n0 = n_tile * BNT;
+  const int n0 = n_tile * BNT;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
 
-  // --- per-thread staging assignments
+  // ---- staging: global -> VGPR -> LDS, 16-byte chunks, XOR-swizzled LDS image -------------------------------------
+  // (direct global->LDS DMA was measured slower here: its per-CU fill rate is too close to the 18 GB/s/CU this
+  //  kernel streams)
+  constexpr int A_PER_T = BM * 8 / 256;   // 16-byte chunks per thread per tile
+  constexpr int B_PER_T = BNT * 8 / 256;
+  static_assert((A_PER_T == 4 || A_PER_T == 2) && (B_PER_T == 4 || B_PER_T == 2), "staging layout");
   const int chunk = tid & 7;
-  int a_goff[A_PER_T];  // float offset of (row pixel, chunk) in x for tap (0,0) centre
-  int a_loff[A_PER_T];
+  int a_goff[A_PER_T], a_loff[A_PER_T];
 #pragma unroll
   for (int i = 0; i < A_PER_T; i++) {
     int row = (tid >> 3) + 32 * i;
@@ -79,8 +73,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
     a_goff[i] = ((b * a.HpWp) + (h + 1) * a.Wp + (w + 1)) * a.Cin_p + chunk * 4;
     a_loff[i] = swz_off(row, chunk);
   }
-  int b_goff[B_PER_T];
-  int b_loff[B_PER_T];
+  int b_goff[B_PER_T], b_loff[B_PER_T];
 #pragma unroll
   for (int i = 0; i < B_PER_T; i++) {
     int row = (tid >> 3) + 32 * i;
@@ -89,47 +82,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
     b_goff[i] = n * a.Cin_p + chunk * 4;
     b_loff[i] = swz_off(row, chunk);
   }
-
   const int NC = a.Cin_p >> 5;
   const int NK = 9 * NC;
   const int w_tap_stride = a.Ntot * a.Cin_p;
 
-  // staging registers as NAMED scalars (arrays here get demoted to scratch/LDS by hipcc once sched_barriers or
-  // conditionals sit between their definition and use — rule 20 of the CDNA guide)
-  static_assert(A_PER_T == 4 && (B_PER_T == 4 || B_PER_T == 2), "staging layout");
-  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define AGZ_GLOAD(IT)                                                                                     \
-  {                                                                                                       \
-    int tap_ = (IT) / NC, cc_ = (IT) - tap_ * NC;                                                         \
-    int ky_ = tap_ / 3, kx_ = tap_ - ky_ * 3;                                                             \
-    int xo_ = ((ky_ - 1) * a.Wp + (kx_ - 1)) * a.Cin_p + cc_ * 32;                                        \
-    int wo_ = tap_ * w_tap_stride + cc_ * 32;                                                             \
-    ra0 = *reinterpret_cast<const float4*>(a.x + a_goff[0] + xo_);                                        \
-    ra1 = *reinterpret_cast<const float4*>(a.x + a_goff[1] + xo_);                                        \
-    ra2 = *reinterpret_cast<const float4*>(a.x + a_goff[2] + xo_);                                        \
-    ra3 = *reinterpret_cast<const float4*>(a.x + a_goff[3] + xo_);                                        \
-    rb0 = *reinterpret_cast<const float4*>(a.w + b_goff[0] + wo_);                                        \
-    rb1 = *reinterpret_cast<const float4*>(a.w + b_goff[1] + wo_);                                        \
-    if constexpr (B_PER_T > 2) {                                                                          \
-      rb2 = *reinterpret_cast<const float4*>(a.w + b_goff[2] + wo_);                                      \
-      rb3 = *reinterpret_cast<const float4*>(a.w + b_goff[3] + wo_);                                      \
-    }                                                                                                     \
+  // Staging registers are NAMED scalars: arrays get demoted to scratch/LDS by hipcc here (CDNA guide rule 20).
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // set 0
+  float4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;  // set 1
+  int xo_, wo_;
+#define AGZ_TILE_OFFS(IT)                                                                   \
+  {                                                                                         \
+    int t_ = (IT) < NK ? (IT) : NK - 1;                                                     \
+    int tap_ = t_ / NC, cc_ = t_ - tap_ * NC;                                               \
+    int ky_ = tap_ / 3, kx_ = tap_ - ky_ * 3;                                               \
+    xo_ = ((ky_ - 1) * a.Wp + (kx_ - 1)) * a.Cin_p + cc_ * 32;                              \
+    wo_ = tap_ * w_tap_stride + cc_ * 32;                                                   \
   }
-#define AGZ_LSTORE(BUF)                                                                                   \
-  {                                                                                                       \
-    float* la_ = lds + (BUF) * STAGE;                                                                     \
-    float* lb_ = la_ + BM * 32;                                                                           \
-    *reinterpret_cast<float4*>(la_ + a_loff[0]) = ra0;                                                    \
-    *reinterpret_cast<float4*>(la_ + a_loff[1]) = ra1;                                                    \
-    *reinterpret_cast<float4*>(la_ + a_loff[2]) = ra2;                                                    \
-    *reinterpret_cast<float4*>(la_ + a_loff[3]) = ra3;                                                    \
-    *reinterpret_cast<float4*>(lb_ + b_loff[0]) = rb0;                                                    \
-    *reinterpret_cast<float4*>(lb_ + b_loff[1]) = rb1;                                                    \
-    if constexpr (B_PER_T > 2) {                                                                          \
-      *reinterpret_cast<float4*>(lb_ + b_loff[2]) = rb2;                                                  \
-      *reinterpret_cast<float4*>(lb_ + b_loff[3]) = rb3;                                                  \
-    }                                                                                                     \
-  }
+#define AGZ_GLA(R, I) if constexpr ((I) < A_PER_T) R = *reinterpret_cast<const float4*>(a.x + a_goff[(I) < A_PER_T ? (I) : 0] + xo_);
+#define AGZ_GLB(R, I) if constexpr ((I) < B_PER_T) R = *reinterpret_cast<const float4*>(a.w + b_goff[(I) < B_PER_T ? (I) : 0] + wo_);
+#define AGZ_LSA(R, I, BUF) if constexpr ((I) < A_PER_T) *reinterpret_cast<float4*>(lds + (BUF) * STAGE + a_loff[(I) < A_PER_T ? (I) : 0]) = R;
+#define AGZ_LSB(R, I, BUF) if constexpr ((I) < B_PER_T) *reinterpret_cast<float4*>(lds + (BUF) * STAGE + BM * 32 + b_loff[(I) < B_PER_T ? (I) : 0]) = R;
+#define AGZ_SB __builtin_amdgcn_sched_barrier(0);
 
   f32x16 acc[MT][2];
 #pragma unroll
@@ -152,73 +125,95 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   }
   const int khalf = lane >> 5;
 
-  AGZ_GLOAD(0);
-  AGZ_LSTORE(0);
+  // Operand (fragment) reads: inline-asm ds_read_b128 into registers that stay live across the whole loop ("+v").
+  // Letting hipcc allocate short-lived fragment registers makes it alias them onto staging registers whose global
+  // loads are still in flight, and it then protects the overwrite with s_waitcnt vmcnt(0) at the top of every
+  // iteration — the whole L2 latency exposed 72 times per tile (measured: -7%).  The asm reads carry hand-counted
+  // lgkmcnt waits (LDS ops retire in order; the interleaved ds_writes are counted too), each followed by a
+  // sched_barrier because hipcc may hoist register-only MFMAs above an asm wait (guide §5.4 rule 18).
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds);
+  unsigned a_addr[MT], b_addr[2], a_sw[MT], b_sw[2];
+#pragma unroll
+  for (int i = 0; i < MT; i++) { a_addr[i] = lds_base + a_row[i] * 128; a_sw[i] = (a_row[i] >> 1) & 7; }
+#pragma unroll
+  for (int j = 0; j < 2; j++) { b_addr[j] = lds_base + BM * 128 + b_row[j] * 128; b_sw[j] = (b_row[j] >> 1) & 7; }
+  f32x4 f0a[MT], f0b[2], f1a[MT], f1b[2];  // native vectors: "+v" asm operands must not be HIP's struct float4
+#pragma unroll
+  for (int i = 0; i < MT; i++) { f0a[i] = f32x4{0.f, 0.f, 0.f, 0.f}; f1a[i] = f0a[i]; }
+#pragma unroll
+  for (int j = 0; j < 2; j++) { f0b[j] = f32x4{0.f, 0.f, 0.f, 0.f}; f1b[j] = f0b[j]; }
+#define AGZ_LDSR(DST, ADDR) asm volatile("ds_read_b128 %0, %1" : "+v"(DST) : "v"(ADDR));
+#define AGZ_FRAG_READ(AV, BV, KS, BUF)                                                                            \
+  {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                              \
+      unsigned ad_ = a_addr[i] + (BUF) * (STAGE * 4) + (((2 * (KS) + khalf) ^ a_sw[i]) << 4);                     \
+      AGZ_LDSR(AV[i], ad_)                                                                                        \
+    }                                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; j++) {                                                               \
+      unsigned ad_ = b_addr[j] + (BUF) * (STAGE * 4) + (((2 * (KS) + khalf) ^ b_sw[j]) << 4);                     \
+      AGZ_LDSR(BV[j], ad_)                                                                                        \
+    }                                                                                                             \
+  }
+#define AGZ_WAIT_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); __builtin_amdgcn_sched_barrier(0);
+#define AGZ_MQ(AV, BV, C)                                                                                         \
+  _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < 2; j++)                    \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].C, BV[j].C, acc[i][j], 0, 0, 0);
+  constexpr int NRD = MT + 2;               // ds_reads per fragment set
+  constexpr int NWA = A_PER_T, NWB = B_PER_T;  // ds_writes in the two store phases
+
+  // ---- main loop: 3-deep software pipeline ---------------------------------------------------------------------
+  //   tile it   : multiplied out of LDS stage it&1
+  //   tile it+1 : sits in staging set X (loaded during the previous iteration), written to stage (it+1)&1 now
+  //   tile it+2 : global loads issued now into staging set Y
+  // Every global_load / ds_write / ds_read is slotted BETWEEN MFMA quads and pinned with sched_barrier: a wave
+  // issues in order, so a memory instruction placed behind an MFMA costs nothing while the 64-cycle MFMA occupies
+  // the matrix pipe; clumped at the top/bottom of the iteration they idle it.
+#define AGZ_ITER(IT, BUF, XA0, XA1, XA2, XA3, XB0, XB1, XB2, XB3, YA0, YA1, YA2, YA3, YB0, YB1, YB2, YB3)         \
+  {                                                                                                               \
+    AGZ_TILE_OFFS((IT) + 2)                                                                                       \
+    AGZ_FRAG_READ(f0a, f0b, 0, BUF)                                                                               \
+    AGZ_FRAG_READ(f1a, f1b, 1, BUF)                                                                               \
+    AGZ_WAIT_LGKM(NRD) /* k-step 0 operands landed */                                                             \
+    AGZ_MQ(f0a, f0b, x) AGZ_SB AGZ_GLA(YA0, 0) AGZ_SB AGZ_MQ(f0a, f0b, y) AGZ_SB AGZ_GLA(YA1, 1)                  \
+    AGZ_SB AGZ_MQ(f0a, f0b, z) AGZ_SB AGZ_GLA(YA2, 2) AGZ_SB AGZ_MQ(f0a, f0b, w) AGZ_SB AGZ_GLA(YA3, 3)           \
+    AGZ_SB AGZ_FRAG_READ(f0a, f0b, 2, BUF)                                                                        \
+    AGZ_WAIT_LGKM(NRD) /* k-step 1 */                                                                             \
+    AGZ_MQ(f1a, f1b, x) AGZ_SB AGZ_GLB(YB0, 0) AGZ_SB AGZ_MQ(f1a, f1b, y) AGZ_SB AGZ_GLB(YB1, 1)                  \
+    AGZ_SB AGZ_MQ(f1a, f1b, z) AGZ_SB AGZ_GLB(YB2, 2) AGZ_SB AGZ_MQ(f1a, f1b, w) AGZ_SB AGZ_GLB(YB3, 3)           \
+    AGZ_SB AGZ_FRAG_READ(f1a, f1b, 3, BUF)                                                                        \
+    AGZ_WAIT_LGKM(NRD) /* k-step 2 */                                                                             \
+    AGZ_MQ(f0a, f0b, x) AGZ_SB AGZ_LSA(XA0, 0, (BUF) ^ 1) AGZ_SB AGZ_MQ(f0a, f0b, y) AGZ_SB AGZ_LSA(XA1, 1, (BUF) ^ 1) \
+    AGZ_SB AGZ_MQ(f0a, f0b, z) AGZ_SB AGZ_LSA(XA2, 2, (BUF) ^ 1) AGZ_SB AGZ_MQ(f0a, f0b, w) AGZ_SB AGZ_LSA(XA3, 3, (BUF) ^ 1) \
+    AGZ_SB                                                                                                        \
+    AGZ_WAIT_LGKM(NWA) /* k-step 3 operands: only the A-part ds_writes may still be outstanding */                \
+    AGZ_MQ(f1a, f1b, x) AGZ_SB AGZ_LSB(XB0, 0, (BUF) ^ 1) AGZ_SB AGZ_MQ(f1a, f1b, y) AGZ_SB AGZ_LSB(XB1, 1, (BUF) ^ 1) \
+    AGZ_SB AGZ_MQ(f1a, f1b, z) AGZ_SB AGZ_LSB(XB2, 2, (BUF) ^ 1) AGZ_SB AGZ_MQ(f1a, f1b, w) AGZ_SB AGZ_LSB(XB3, 3, (BUF) ^ 1) \
+    AGZ_SB                                                                                                        \
+    __syncthreads();                                                                                              \
+  }
+  (void)NWB;
+  // prologue: tile 0 -> LDS stage 0 (through set 1), tile 1 -> set 0
+  AGZ_TILE_OFFS(0)
+  AGZ_GLA(sa0, 0) AGZ_GLA(sa1, 1) AGZ_GLA(sa2, 2) AGZ_GLA(sa3, 3) AGZ_GLB(sb0, 0) AGZ_GLB(sb1, 1) AGZ_GLB(sb2, 2) AGZ_GLB(sb3, 3)
+  AGZ_TILE_OFFS(1)
+  AGZ_GLA(ra0, 0) AGZ_GLA(ra1, 1) AGZ_GLA(ra2, 2) AGZ_GLA(ra3, 3) AGZ_GLB(rb0, 0) AGZ_GLB(rb1, 1) AGZ_GLB(rb2, 2) AGZ_GLB(rb3, 3)
+  AGZ_LSA(sa0, 0, 0) AGZ_LSA(sa1, 1, 0) AGZ_LSA(sa2, 2, 0) AGZ_LSA(sa3, 3, 0) AGZ_LSB(sb0, 0, 0) AGZ_LSB(sb1, 1, 0) AGZ_LSB(sb2, 2, 0) AGZ_LSB(sb3, 3, 0)
   __syncthreads();
-  // Fragment double-buffering: the ds_read_b128s of k-step ks+1 are issued BEFORE the 16 MFMAs of k-step ks
-  // and sched_barrier pins that order (hipcc otherwise sinks loads next to their first use, exposing the LDS
-  // and — for the staging loads — the full L2/HBM latency once per K-iteration).
-#define AGZ_FRAG_READ(AV, BV, KS)                                                                                 \
-  {                                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < MT; i++) AV[i] =                                                        \
-        *reinterpret_cast<const float4*>(Ab + swz_off(a_row[i], 2 * (KS) + khalf));                               \
-    _Pragma("unroll") for (int j = 0; j < 2; j++) BV[j] =                                                         \
-        *reinterpret_cast<const float4*>(Bb + swz_off(b_row[j], 2 * (KS) + khalf));                               \
+  for (int it = 0; it < NK; it += 2) {
+    AGZ_ITER(it, 0, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3)
+    if (it + 1 < NK) AGZ_ITER(it + 1, 1, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)
   }
-#define AGZ_MFMA16(AV, BV)                                                                                        \
-  {                                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < 2; j++)                  \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].x, BV[j].x, acc[i][j], 0, 0, 0);                   \
-    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < 2; j++)                  \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].y, BV[j].y, acc[i][j], 0, 0, 0);                   \
-    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < 2; j++)                  \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].z, BV[j].z, acc[i][j], 0, 0, 0);                   \
-    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < 2; j++)                  \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].w, BV[j].w, acc[i][j], 0, 0, 0);                   \
-  }
-#define AGZ_COMPUTE(BUF)                                                                                          \
-  {                                                                                                               \
-    const float* Ab = lds + (BUF) * STAGE;                                                                        \
-    const float* Bb = Ab + BM * 32;                                                                               \
-    float4 av0[MT], bv0[2], av1[MT], bv1[2];                                                                      \
-    AGZ_FRAG_READ(av0, bv0, 0)                                                                                    \
-    AGZ_FRAG_READ(av1, bv1, 1)                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    AGZ_MFMA16(av0, bv0)                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    AGZ_FRAG_READ(av0, bv0, 2)                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    AGZ_MFMA16(av1, bv1)                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    AGZ_FRAG_READ(av1, bv1, 3)                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    AGZ_MFMA16(av0, bv0)                                                                                          \
-    AGZ_MFMA16(av1, bv1)                                                                                          \
-  }
-#ifndef AGZ_PROBE
-#define AGZ_PROBE 0  // timing experiments only (scripts/probe_conv.sh): 1 = no LDS store/barrier, 2 = + no global loads
-#endif
-  for (int it = 0; it < NK - 1; it++) {
-    const int buf = it & 1;
-#if AGZ_PROBE < 2
-    AGZ_GLOAD(it + 1);
-#endif
-    __builtin_amdgcn_sched_barrier(0);  // keep the staging loads in flight across the whole MFMA section
-    AGZ_COMPUTE(buf);
-    __builtin_amdgcn_sched_barrier(0);
-#if AGZ_PROBE == 0
-    AGZ_LSTORE(buf ^ 1);
-    __syncthreads();
-#elif AGZ_PROBE == 1
-    asm volatile("" ::"v"(ra0.x), "v"(ra1.x), "v"(ra2.x), "v"(ra3.x), "v"(rb0.x), "v"(rb1.x), "v"(rb2.x), "v"(rb3.x));
-#endif
-  }
-  AGZ_COMPUTE((NK - 1) & 1);
+#undef AGZ_ITER
+#undef AGZ_WAIT_LGKM
+#undef AGZ_LDSR
+#undef AGZ_MQ
 #undef AGZ_FRAG_READ
-#undef AGZ_MFMA16
-#undef AGZ_COMPUTE
-#undef AGZ_GLOAD
-#undef AGZ_LSTORE
+#undef AGZ_SB
+#undef AGZ_LSB
+#undef AGZ_LSA
+#undef AGZ_GLB
+#undef AGZ_GLA
+#undef AGZ_TILE_OFFS
   // --- epilogue: BN(scale,shift) + ReLU (+ dual add + ReLU), store interior of padded NHWC
   // C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -254,6 +249,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
           }
         }
       }
+    }
+  }
+}
+
+// Grid = [full tiles (MT x 2 per wave) | remainder tiles with MT = 1 (half the rows)].  All full tiles cost the same,
+// so the dispatcher runs them in lockstep rounds of 2 workgroups per CU; when the tile count is not a multiple of
+// that, the half-height tiles (dispatched last, in block-id order) fill the final partial round twice as finely.
+template <int WM, int WN, int MT, bool DUAL>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * (WM * MT * 32 + WN * 64) * 32];
+  const int id = blockIdx.x;
+  if (id < a.n_full_blocks) {
+    // XCD-aware tile mapping (bijective): consecutive block ids land on different XCDs; give each XCD a contiguous
+    // run of tiles so the n-tiles of one m-tile (same A rows) share an L2.
+    const int nblk = a.n_full_blocks;
+    int q = nblk >> 3, r = nblk & 7, xcd = id & 7, slot = id >> 3;
+    int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int m_tile = tile / a.n_ntiles, n_tile = tile - m_tile * a.n_ntiles;
+    conv_tile<WM, WN, MT, DUAL>(a, lds, m_tile * (WM * MT * 32), n_tile);
+  } else {
+    if constexpr (MT > 1) {
+      const int t = id - a.n_full_blocks;
+      const int m_tile = t / a.n_ntiles, n_tile = t - m_tile * a.n_ntiles;
+      conv_tile<WM, WN, 1, DUAL>(a, lds, a.m_split + m_tile * (WM * 32), n_tile);
     }
   }
 }
@@ -401,9 +420,20 @@ template <int WM, int WN, int MT, bool DUAL>
 static void launch_conv(agz_ctx* ctx, ConvArgs& a) {
   const int klass = DUAL ? AGZ_PROF_CONV : AGZ_PROF_CONV_INIT;
   constexpr int BM = WM * MT * 32, BNT = WN * 64;
-  a.n_mtiles = ceil_div(a.M, BM);
   a.n_ntiles = ceil_div(a.Ntot, BNT);
-  dim3 grid(a.n_mtiles * a.n_ntiles), block(256);
+  a.n_mtiles = ceil_div(a.M, BM);
+  const int slots = 2 * ctx->num_cus;
+  int tiles = a.n_mtiles * a.n_ntiles;
+  a.n_full_blocks = tiles;
+  a.m_split = a.M;
+  int extra = 0;
+  if (MT == 2 && tiles > slots && tiles % slots != 0 && slots % a.n_ntiles == 0) {
+    int full_m = (tiles / slots) * (slots / a.n_ntiles);  // m-tiles covered by whole rounds
+    a.n_full_blocks = full_m * a.n_ntiles;
+    a.m_split = full_m * BM;
+    extra = ceil_div(a.M - a.m_split, BM / 2) * a.n_ntiles;
+  }
+  dim3 grid(a.n_full_blocks + extra), block(256);
   ProfScope ps(ctx, klass);
   hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, MT, DUAL>), grid, block, 0, ctx->stream, a);
 }

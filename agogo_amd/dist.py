@@ -50,6 +50,8 @@ def all_gather_examples(planes, policy, value, group=None):
     dist.all_gather(counts, n, group=group)
     counts = [int(c.item()) for c in counts]
     nmax = max(counts)
+    if nmax == 0:
+        return planes, policy, value
     out = []
     for t in (planes, policy, value.reshape(-1, 1)):
         pad = torch.zeros((nmax, t.shape[1]), dtype=t.dtype, device=t.device)
