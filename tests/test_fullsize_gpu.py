@@ -1,0 +1,170 @@
+"""GPU: parity at BASELINE.json's sizes.
+
+Where the oracle finishes in seconds it is compared directly; at the full 19x19 / K=256 / 20-block / 512-game
+size the checks are size-independent properties: batch independence, determinism across identical games
+(a checksum of checksums), MCTS conservation laws (search.go:392-408, tree.go:110, node.go:70-76), plus a
+two-board spot check of the full-size network against the oracle.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+import agogo_amd as A
+import oracle_lib as O
+from agogo_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def std_bn(net):
+    for i in range(net.num_params()):
+        name, n = net.param_info(i)
+        if name.endswith("_gamma"):
+            net.set_param(i, np.ones(n, np.float32))
+        elif name.endswith("_beta"):
+            net.set_param(i, np.zeros(n, np.float32))
+
+
+def make_net(ctx, K, L, S, F, seed=1337):
+    net = A.Net(ctx, K, L, 2 * K, S[1], S[0], F, (S[1] if F == 2 and S == (6, 7) else S[0] * S[1]) + 1,
+                bn_mode=capi.BN_IDENTITY)
+    net.init_random(seed)
+    std_bn(net)
+    net.commit()
+    return net
+
+
+def oracle_twin(net, K, L, S, F, Aspace):
+    o = O.Net(K, L, 2 * K, S[1], S[0], F, Aspace, bn_mode=2)
+    for i in range(net.num_params()):
+        o.set_param(i, net.get_param(i))
+    return o
+
+
+def test_g19_network_full_size_spot_check_and_batch_independence(ctx):
+    """config #4 network (K=256, 20 blocks, 19x19, B=512): 2 boards vs the oracle, and every board of the batch
+    equals its own batch-1 evaluation bit for bit."""
+    S, K, L, F = (19, 19), 256, 20, 18
+    net = make_net(ctx, K, L, S, F)
+    rng = np.random.default_rng(1)
+    x = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), size=(512, F, 19, 19), p=[0.2, 0.6, 0.2]).astype(np.float32)
+    pol, val = net.infer(x)
+    assert np.all(np.isfinite(pol)) and np.all(np.isfinite(val))
+    np.testing.assert_allclose(pol.sum(axis=1), 1.0, atol=2e-5)
+    for b in (0, 511, 257):
+        p1, v1 = net.infer(x[b:b + 1])
+        np.testing.assert_array_equal(p1[0], pol[b])
+        np.testing.assert_array_equal(v1[0], val[b])
+    onet = oracle_twin(net, K, L, S, F, 362)
+    po, vo = onet.infer(x[[0, 511]])
+    np.testing.assert_allclose(pol[[0, 511]], po, atol=2e-5, rtol=2e-4)
+    np.testing.assert_allclose(val[[0, 511]], vo, atol=2e-4)
+    assert np.abs(pol[0] - pol[511]).max() > 1e-6
+
+
+def _tree_digest(arena, g, agent):
+    mv, vis, bs, pr = arena.root_children(g, agent)
+    return zlib.crc32(mv.tobytes() + vis.tobytes() + bs.tobytes() + pr.tobytes())
+
+
+def test_g19_512_games_conservation_and_determinism(ctx):
+    """config #4 engine shape: 512 concurrent 19x19 games; synthetic hash inferencer; 3 plies x 24 sims."""
+    G, budget = 512, 24
+    ab = np.array([1, 0] * (G // 2), dtype=np.uint8)
+    arena = A.Arena(ctx, capi.GAME_WQ, 19, 19, komi=7.5, encoder=capi.ENC_WQ, n_games=G, Budget=budget, max_nodes=40000)
+    arena.set_inferencer(0, capi.INF_HASH)
+    arena.set_inferencer(1, capi.INF_HASH)
+    arena.reset(ab)
+    orc = {}
+    for ab_v in (1, 0):
+        o = O.Arena(O.WQ, 19, 19, komi=7.5, enc=O.ENC_WQ, Budget=budget)
+        o.set_inferencer(0, O.INF_HASH)
+        o.set_inferencer(1, O.INF_HASH)
+        o.begin(ab_v)
+        orc[ab_v] = o
+    for ply in range(3):
+        s0 = arena.stats()
+        arena.begin_move()
+        arena.simulate(budget)
+        arena.end_move(True)
+        s1 = arena.stats()
+        assert s1["sims_total"] - s0["sims_total"] == G * budget
+        d_evals, d_sims = s1["nn_evals"] - s0["nn_evals"], s1["sims_nonnull"] - s0["sims_nonnull"]
+        if ply < 2:   # fresh trees: prepareRoot evaluates every root once (search.go:392-408)
+            assert d_evals == G + d_sims
+        else:         # re-rooted trees (search.go:424-469): only roots that were still unexpanded are evaluated
+            assert d_sims <= d_evals <= G + d_sims
+        digests = {}
+        for ab_v in (1, 0):
+            o = orc[ab_v]
+            _, st0 = o.state()
+            agent = 0 if ((st0["to_move"] == O.BLACK) == bool(ab_v)) else 1
+            o.step(True)
+            omv, ovis, obs, opr = o.root_children(agent)
+            g0 = 0 if ab_v == 1 else 1
+            dmv, dvis, dbs, dpr = arena.root_children(g0, agent)
+            np.testing.assert_array_equal(dmv, omv)
+            np.testing.assert_array_equal(dvis, ovis)
+            np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+            # conservation: every child starts at 1 visit; each non-null sim adds one visit to exactly one child
+            assert int(dvis.sum()) - len(dvis) == budget
+            assert abs(float(dpr.sum()) - 1.0) < 1e-4
+            digests[ab_v] = (agent, _tree_digest(arena, g0, agent))
+        # checksum of checksums: all 256 games with the same colour assignment are identical
+        for g in range(0, G, 37):
+            agent, want = digests[int(ab[g])]
+            assert _tree_digest(arena, g, agent) == want, "game %d diverged at ply %d" % (g, ply)
+            assert arena.history(g)[-1] == orc[int(ab[g])].history()[-1]
+    assert arena.stats()["tree_full"] == 0
+
+
+def _drive_with_gpu_net(ctx, kind, S, komi, enc, F, K, L, budget, plies, a_is_black, k=0):
+    net = make_net(ctx, K, L, S, F)
+    Aspace = net.conf.ActionSpace
+    arena = A.Arena(ctx, kind, S[0], S[1], k, komi, encoder=enc, n_games=2, Budget=budget)
+    arena.set_inferencer(0, capi.INF_NET, net)
+    arena.set_inferencer(1, capi.INF_NET, net)
+    ab = np.array(a_is_black, dtype=np.uint8)
+    arena.reset(ab)
+
+    def cb(planes):
+        p, v = net.infer(planes.reshape(1, F, S[0], S[1]))
+        return p[0], float(v[0])
+
+    okind = {capi.GAME_C4: O.C4, capi.GAME_WQ: O.WQ}[kind]
+    orcs = []
+    for g in range(2):
+        o = O.Arena(okind, S[0], S[1], k, komi, enc=enc, Budget=budget)
+        o.set_callback(0, cb, Aspace)
+        o.set_callback(1, cb, Aspace)
+        o.begin(int(ab[g]))
+        orcs.append(o)
+    for ply in range(plies):
+        arena.begin_move()
+        arena.simulate(budget)
+        arena.end_move(True)
+        for g in range(2):
+            o = orcs[g]
+            _, st0 = o.state()
+            if st0["ended"]:
+                continue
+            agent = 0 if ((st0["to_move"] == O.BLACK) == bool(ab[g])) else 1
+            o.step(True)
+            omv, ovis, obs, _ = o.root_children(agent)
+            dmv, dvis, dbs, _ = arena.root_children(g, agent)
+            np.testing.assert_array_equal(dmv, omv, err_msg="game %d ply %d" % (g, ply))
+            np.testing.assert_array_equal(dvis, ovis, err_msg="game %d ply %d" % (g, ply))
+            np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+            assert arena.history(g)[-1] == o.history()[-1]
+
+
+def test_config2_connect4_k64_l6_400sims(ctx):
+    """BASELINE config #2 (Connect-4, K=64, 6 blocks, 400 sims/move): first plies, device trees vs oracle trees fed
+    with the same GPU network outputs."""
+    _drive_with_gpu_net(ctx, capi.GAME_C4, (6, 7), 0.0, capi.ENC_TWOPLANE, 2, 64, 6, 400, 4, (1, 0), k=4)
+
+
+def test_config3_go9_k128_l10_400sims(ctx):
+    """BASELINE config #3 (9x9 Go, K=128, 10 blocks, 400 sims/move): first plies."""
+    _drive_with_gpu_net(ctx, capi.GAME_WQ, (9, 9), 7.5, capi.ENC_WQ, 18, 128, 10, 400, 3, (1, 0))
