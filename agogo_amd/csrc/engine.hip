@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64) void k_expand(Dev d, GameCfg c, MctsCfg mc, Inf
 }
 
 // bestMove + Policies + Arena.Play's per-move bookkeeping (search.go:341-390,152-161; arena.go:98-138)
-__global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, int record) {
+__global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, int record, int restart) {
   __shared__ Sh s;
   __shared__ uint32_t cv[CELLS_PAD];   // child visits
   __shared__ int16_t ckn[CELLS_PAD];   // child kids_n
@@ -734,6 +734,25 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
       d.ex_last[g] = -1;
     }
   }
+  // continuous self-play (AZ.SelfPlay in a loop, agogo.go:110-114): a finished game is replaced at once by a new
+  // one — fresh board, fresh trees (arena.go:175-176 builds new mcts.New trees per game), colours drawn again
+  if (ended && restart) {
+    __syncthreads();
+    for (int i = lane; i < CELLS_PAD; i += WAVE) d.board[(size_t)g * CELLS_PAD + i] = 0;
+    for (int i = lane; i < RING * CELLS_PAD; i += WAVE) d.ring[(size_t)g * RING * CELLS_PAD + i] = 0;
+    if (lane == 0) {
+      unsigned long long z = (d.rng[g] += 0x9E3779B97F4A7C15ull);
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+      d.a_is_black[g] = (z >> 63) == 0 ? 1 : 0;
+      d.to_move[g] = AGZ_BLACK; d.ply[g] = 0; d.passes[g] = 0; d.pass_count[g] = 0; d.ended[g] = 0; d.winner[g] = AGZ_NONE;
+      d.last_move[g] = AGZ_PASS; d.cap_b[g] = 0.f; d.cap_w[g] = 0.f; d.zhash[g] = 0;
+      for (int ag = 0; ag < 2; ag++) {
+        int tt = ag * d.G + g;
+        d.n_nodes[tt] = 0; d.cur_pool[tt] = 0; d.has_root[tt] = 0; d.has_prev[tt] = 0; d.prev_ply[tt] = 0; d.stalled[tt] = 0;
+        d.pc_n[tt] = 0;
+      }
+    }
+  }
 }
 
 }  // namespace agz
@@ -758,6 +777,7 @@ struct agz_arena {
   int ply_parity = 0;       // all unfinished games are at the same ply
   int nA_slots = 0, nB_slots = 0;
   bool in_move = false;
+  bool restart = false;  // continuous self-play: finished games restart immediately
   int moves_done = 0;
 
   template <typename T>
@@ -896,7 +916,7 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
   AL(leaf_legal, (size_t)G * CELLS_PAD) AL(path, (size_t)G * MAXPATH) AL(path_len, G) AL(counters, 8)
   {
     size_t per_ex = (size_t)c.F * c.cells + (c.A + 1) + 3;
-    size_t want = (size_t)G * c.max_moves;
+    size_t want = std::max<size_t>((size_t)G * c.max_moves * 2, 16384);  // room for restarted games (agz_arena_selfplay)
     size_t budget = (size_t)(2ull << 30) / (per_ex * 4);  // <= 2 GiB of examples per arena
     d.ex_cap = (int)std::min(want, budget);
   }
@@ -1001,7 +1021,7 @@ int agz_arena_end_move(agz_arena* a, int record) {
   AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
   {
     ProfScope ps(a->ctx, AGZ_PROF_MOVE);
-    hipLaunchKernelGGL(k_end_move, dim3(a->G), dim3(64), 0, a->ctx->stream, a->d, a->gc, a->mc, record);
+    hipLaunchKernelGGL(k_end_move, dim3(a->G), dim3(64), 0, a->ctx->stream, a->d, a->gc, a->mc, record, a->restart ? 1 : 0);
   }
   AGZ_HIP_TRY(hipGetLastError());
   a->in_move = false;
@@ -1048,6 +1068,28 @@ int agz_arena_play(agz_arena* a, int n_moves, int record) {
   }
   AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
   return AGZ_OK;
+}
+
+int agz_arena_selfplay(agz_arena* a, int64_t n_games_target, int record) {
+  AGZ_REQUIRE(a && n_games_target >= 1, AGZ_E_INVALID, "agz_arena_selfplay: bad argument");
+  AGZ_REQUIRE(!a->split_nets(), AGZ_E_UNSUPPORTED, "agz_arena_selfplay: agents with two different nets must use agz_arena_play (lockstep plies)");
+  AGZ_REQUIRE(!a->in_move, AGZ_E_STATE, "agz_arena_selfplay: a move is in progress");
+  a->restart = true;
+  int rc = AGZ_OK;
+  for (int64_t moves = 0;; moves++) {
+    if ((moves & 3) == 0) {
+      agz_arena_stats st;
+      if ((rc = agz_arena_get_stats(a, &st)) != AGZ_OK) break;
+      if (st.tree_full) { agz::set_error("agz_arena_selfplay: %d tree pool(s) overflowed", st.tree_full); rc = AGZ_E_TREE_FULL; break; }
+      if (st.games_finished >= n_games_target) break;
+    }
+    if ((rc = agz_arena_begin_move(a)) != AGZ_OK) break;
+    if ((rc = agz_arena_simulate(a, a->mc.Budget)) != AGZ_OK) break;
+    if ((rc = agz_arena_end_move(a, record)) != AGZ_OK) break;
+  }
+  a->restart = false;
+  if (rc == AGZ_OK) AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  return rc;
 }
 
 int agz_arena_get_game(agz_arena* a, int g, int32_t* board, agz_game_state* st) {

@@ -78,6 +78,31 @@ def cpu_baseline(size, K, L, budget_s=20.0):
             "evals_per_s": st["nn_evals"] / dt}
 
 
+def games_leg(ctx, seconds_cap=60.0):
+    """Measured games/s (not an estimate) on BASELINE config #2: Connect-4, K=64, 6 blocks, 256 concurrent games,
+    400 sims/move, continuous self-play until 256 games have finished."""
+    net = A.Net(ctx, 64, 6, 128, 7, 6, 2, 8, bn_mode=capi.BN_IDENTITY)
+    net.init_random(1337)
+    standard_bn_init(net)
+    net.commit()
+    arena = A.Arena(ctx, capi.GAME_C4, 6, 7, 4, encoder=capi.ENC_TWOPLANE, n_games=256, seed=1337, Budget=400)
+    arena.set_inferencer(0, capi.INF_NET, net)
+    arena.set_inferencer(1, capi.INF_NET, net)
+    arena.reset()
+    ctx.sync()
+    t0 = time.perf_counter()
+    arena.selfplay(256, record=True)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    st = arena.stats()
+    out = {"workload": "config #2: Connect-4 6x7, K=64, 6 blocks, 256 concurrent games, 400 sims/move, continuous self-play",
+           "games_finished": st["games_finished"], "seconds": dt, "games_per_s": st["games_finished"] / dt,
+           "sims_per_s": st["sims_nonnull"] / dt, "moves_per_s": st["moves_played"] / dt, "examples": st["examples"]}
+    arena.close()
+    net.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +114,7 @@ def main():
     ap.add_argument("--L", type=int, default=20)
     ap.add_argument("--budget", type=int, default=800, help="simulations per move")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-games-leg", action="store_true", help="skip the measured games/s leg (config #2)")
     ap.add_argument("--two-nets", action="store_true", help="agents A and B hold different networks")
     args = ap.parse_args()
 
@@ -218,6 +244,11 @@ def main():
                       "kernel_classes": prof, "examples_allgather_ms": gather_ms,
                       "tree_full": st1["tree_full"]},
         }
+        if world == 1 and not args.no_games_leg:
+            try:
+                out["extra"]["games_leg"] = games_leg(ctx)
+            except Exception as e:
+                out["extra"]["games_leg"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(S, K, L)

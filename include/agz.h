@@ -175,6 +175,11 @@ int agz_arena_reset(agz_arena* arena, const uint8_t* a_is_black);
  * (mcts/search.go:92-164) -> record example -> Apply -> switch player -> Ended / two passes.
  * n_moves = how many plies to advance (<=0: until all games ended). */
 int agz_arena_play(agz_arena* arena, int n_moves, int record);
+/* Continuous self-play: like agz_arena_play, but a finished game is replaced at once by a fresh one (new trees,
+ * colours drawn again) so all n_games slots stay busy; returns once n_games_target games have finished since the
+ * last reset.  This is the `for e < episodes { ex = append(ex, a.SelfPlay()...) }` loop of AZ.Learn
+ * (agogo.go:110-114) with the episodes running concurrently.  Needs both agents on one net (or synthetic). */
+int agz_arena_selfplay(agz_arena* arena, int64_t n_games_target, int record);
 /* Finer steps of one ply, for benchmarks and parity tests:
  *   begin_move   = updateRoot + prepareRoot (search.go:94-109)
  *   simulate(k)  = k x { pipeline (search.go:209-257) for every game, leaves coalesced into one

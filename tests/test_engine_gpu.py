@@ -199,3 +199,25 @@ def test_counters_and_eval_count(ctx):
     st = dev.stats()
     assert st["games_finished"] == 1 and st["moves_played"] == 9
     assert st["sims_total"] == 9 * N
+
+
+def test_continuous_selfplay_restarts_games(ctx):
+    """agz_arena_selfplay: finished games are replaced immediately; every recorded example is a labelled one-hot."""
+    G, target = 8, 30
+    dev = A.Arena(ctx, capi.GAME_MNK, 3, 3, 3, n_games=G, Budget=20, seed=5)
+    dev.set_inferencer(0, capi.INF_HASH)
+    dev.set_inferencer(1, capi.INF_HASH)
+    dev.reset()
+    dev.selfplay(target, record=True)
+    st = dev.stats()
+    assert st["games_finished"] >= target
+    assert st["n_active"] == G  # every slot already hosts a new game
+    planes, policy, value, gidx = dev.examples()
+    assert len(value) == st["examples"] > 5 * target
+    assert np.all(policy.sum(axis=1) == 1.0) and np.all(policy.max(axis=1) == 1.0)
+    # examples of finished games carry +-1/0 labels; at most G*9 examples belong to unfinished games (raw colour 1/2)
+    finished = np.isin(value, (-1.0, 0.0, 1.0))
+    assert (~finished).sum() <= G * 9
+    # both colour assignments occurred after restarts
+    ab = [dev.game(g)[1]["a_is_black"] for g in range(G)]
+    assert st["moves_played"] >= 5 * target and set(ab) <= {0, 1}
