@@ -189,7 +189,8 @@ __device__ __forceinline__ int agent_of(const Dev& d, int g) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_reset(Dev d, GameCfg c, const uint8_t* a_is_black, unsigned long long seed) {
+__global__ __launch_bounds__(64) void k_reset(Dev d, GameCfg c, const uint8_t* a_is_black, unsigned long long seed,
+                                               unsigned long long tree_seed) {
   int g = blockIdx.x, lane = threadIdx.x;
   for (int i = lane; i < CELLS_PAD; i += WAVE) d.board[(size_t)g * CELLS_PAD + i] = 0;
   for (int i = lane; i < RING * CELLS_PAD; i += WAVE) d.ring[(size_t)g * RING * CELLS_PAD + i] = 0;
@@ -206,11 +207,12 @@ __global__ __launch_bounds__(64) void k_reset(Dev d, GameCfg c, const uint8_t* a
     d.ply[g] = 0; d.passes[g] = 0; d.pass_count[g] = 0; d.ended[g] = 0; d.winner[g] = AGZ_NONE;
     d.last_move[g] = AGZ_PASS; d.cap_b[g] = 0.f; d.cap_w[g] = 0.f; d.zhash[g] = 0; d.ex_last[g] = -1;
     d.leaf_kind[g] = LEAF_NONE;
+    d.rng_game[g] = seed * 0x9E3779B97F4A7C15ull + (unsigned long long)g * 0xD1B54A32D192ED03ull + 7ull;
     for (int a = 0; a < 2; a++) {
       int t = a * d.G + g;
       d.n_nodes[t] = 0; d.cur_pool[t] = 0; d.has_root[t] = 0; d.has_prev[t] = 0; d.prev_ply[t] = 0; d.stalled[t] = 0;
       d.overflow[t] = 0; d.pc_n[t] = 0;
-      d.rng[t] = seed * 2654435761ull + (unsigned long long)t * 0x9E3779B97F4A7C15ull + 1;
+      d.rng[t] = (tree_seed + (unsigned long long)g) * 2ull + 1ull + (unsigned long long)a;  // mcts.New's rand (tree.go:84): stream of the oracle's Arena(seed+g)
     }
   }
 }
@@ -552,7 +554,8 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
           uint32_t v = cv[s.label[q]];
           if (norm == 0.f) { norm = (float)v; if (v <= mc.RandomMinVisits) bail = true; }
           if (!bail && v > mc.RandomMinVisits) {
-            accum = __fadd_rn(accum, powf(__fdiv_rn((float)v, norm), __fdiv_rn(1.f, mc.RandomTemperature)));
+            float ex = __fdiv_rn(1.f, mc.RandomTemperature), rt = __fdiv_rn((float)v, norm);
+            accum = __fadd_rn(accum, ex == 1.f ? rt : powf(rt, ex));  // pow(x, 1) == x exactly
             s.libs[nacc++] = __float_as_int(accum);
           }
         }
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
     for (int i = lane; i < CELLS_PAD; i += WAVE) d.board[(size_t)g * CELLS_PAD + i] = 0;
     for (int i = lane; i < RING * CELLS_PAD; i += WAVE) d.ring[(size_t)g * RING * CELLS_PAD + i] = 0;
     if (lane == 0) {
-      unsigned long long z = (d.rng[g] += 0x9E3779B97F4A7C15ull);
+      unsigned long long z = (d.rng_game[g] += 0x9E3779B97F4A7C15ull);
       z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
       d.a_is_black[g] = (z >> 63) == 0 ? 1 : 0;
       d.to_move[g] = AGZ_BLACK; d.ply[g] = 0; d.passes[g] = 0; d.pass_count[g] = 0; d.ended[g] = 0; d.winner[g] = AGZ_NONE;
@@ -750,6 +753,7 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
         int tt = ag * d.G + g;
         d.n_nodes[tt] = 0; d.cur_pool[tt] = 0; d.has_root[tt] = 0; d.has_prev[tt] = 0; d.prev_ply[tt] = 0; d.stalled[tt] = 0;
         d.pc_n[tt] = 0;
+        d.rng[tt] = d.rng_game[g] * 2ull + 1ull + (unsigned long long)ag;
       }
     }
   }
@@ -766,7 +770,7 @@ struct agz_arena {
   MctsCfg mc{};
   Dev d{};
   int G = 0;
-  uint64_t seed = 0;
+  uint64_t seed = 0, seed0 = 0;  // seed advances per reset (colour draws); seed0 fixes the per-tree RNG streams
   std::vector<void*> allocs;
   int inf_kind[2] = {AGZ_INF_DUMMY, AGZ_INF_DUMMY};
   agz_net* net[2] = {nullptr, nullptr};
@@ -880,7 +884,7 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
   AGZ_REQUIRE(mcts->Budget >= 0, AGZ_E_INVALID, "Budget must be >= 0");
   AGZ_HIP_TRY(hipSetDevice(ctx->device));
   agz_arena* a = new agz_arena();
-  a->ctx = ctx; a->G = n_games; a->seed = seed;
+  a->ctx = ctx; a->G = n_games; a->seed = seed; a->seed0 = seed;
   GameCfg& c = a->gc;
   c.kind = game->kind; c.m = game->m; c.n = game->n; c.k = game->k; c.cells = c.m * c.n;
   c.A = c.kind == AGZ_GAME_C4 ? c.n : c.cells;
@@ -911,7 +915,7 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
   size_t pool = (size_t)T * 2 * d.cap;
   AL(prior, pool) AL(visits, pool) AL(bsum, pool) AL(kids_off, pool) AL(kids_n, pool) AL(nmove, pool)
   AL(n_nodes, T) AL(cur_pool, T) AL(has_root, T) AL(has_prev, T) AL(prev_ply, T) AL(prev_board, (size_t)T * CELLS_PAD)
-  AL(stalled, T) AL(overflow, T) AL(pc_hash, (size_t)T * d.moves_stride) AL(pc_move, (size_t)T * d.moves_stride) AL(pc_n, T) AL(rng, T)
+  AL(stalled, T) AL(overflow, T) AL(pc_hash, (size_t)T * d.moves_stride) AL(pc_move, (size_t)T * d.moves_stride) AL(pc_n, T) AL(rng, T) AL(rng_game, G)
   AL(slot_of_game, G) AL(leaf_kind, G) AL(leaf_player, G) AL(leaf_ply, G) AL(leaf_result, G) AL(leaf_board, (size_t)G * CELLS_PAD)
   AL(leaf_legal, (size_t)G * CELLS_PAD) AL(path, (size_t)G * MAXPATH) AL(path_len, G) AL(counters, 8)
   {
@@ -982,7 +986,7 @@ int agz_arena_reset(agz_arena* a, const uint8_t* a_is_black) {
   }
   AGZ_HIP_TRY(hipMemsetAsync(a->d.counters, 0, 8 * sizeof(unsigned long long), s));
   AGZ_HIP_TRY(hipMemsetAsync(a->d.ex_count, 0, sizeof(int32_t), s));
-  hipLaunchKernelGGL(k_reset, dim3(a->G), dim3(64), 0, s, a->d, a->gc, dab, (unsigned long long)a->seed);
+  hipLaunchKernelGGL(k_reset, dim3(a->G), dim3(64), 0, s, a->d, a->gc, dab, (unsigned long long)a->seed, (unsigned long long)a->seed0);
   std::vector<int32_t> ab(a->G);
   AGZ_HIP_TRY(hipMemcpyAsync(ab.data(), a->d.a_is_black, a->G * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   AGZ_HIP_TRY(hipStreamSynchronize(s));

@@ -85,7 +85,8 @@ struct Dev {
   uint32_t* pc_hash;      // [T][max_moves+4] cachedPolicies keys (tree.go:75): (hash, move) per Search
   int16_t* pc_move;
   int32_t* pc_n;          // [T]
-  uint64_t* rng;          // [T] SplitMix64 state
+  uint64_t* rng;          // [T] SplitMix64 state of mcts.MCTS.rand (randomizeChildren)
+  uint64_t* rng_game;     // [G] SplitMix64 state of Arena.r (colour draws on restart)
   // ---- per-simulation scratch
   int32_t* slot_of_game;  // [G] NN batch slot
   int32_t* leaf_kind;     // [G]

@@ -116,9 +116,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-games-leg", action="store_true", help="skip the measured games/s leg (config #2)")
     ap.add_argument("--two-nets", action="store_true", help="agents A and B hold different networks")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="debug: all ranks use GPU 0 and gloo collectives (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
-    rank, local, world = adist.init_from_env()
+    rank, local, world = adist.init_from_env(backend="gloo" if args.shared_gpu else None)
+    if args.shared_gpu:
+        local = 0
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():

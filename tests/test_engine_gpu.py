@@ -136,7 +136,31 @@ def test_wq_prefer_pass_and_smart_pass(ctx):
 
 
 def test_random_count_temperature_one(ctx):
-    run_pair(ctx, capi.GAME_MNK, 3, 3, 3, budget=40, a_is_black=(1,), RandomCount=0)
+    """randomizeChildren (mcts/tree.go:212-247) on the first plies: per-tree SplitMix64 streams seeded like the
+    oracle's mcts.New(seed*2+1 / seed*2+2); device arena seed S, game g <-> oracle Arena(seed=S+g)."""
+    S, G, budget = 4242, 3, 60
+    dev = A.Arena(ctx, capi.GAME_MNK, 3, 3, 3, n_games=G, Budget=budget, seed=S, RandomCount=4, RandomTemperature=1.0,
+                  RandomMinVisits=0)
+    dev.set_inferencer(0, capi.INF_HASH)
+    dev.set_inferencer(1, capi.INF_HASH)
+    ab = np.array([1, 0, 1], dtype=np.uint8)
+    dev.reset(ab)
+    dev.play(0, record=True)
+    differs = False
+    for g in range(G):
+        o = O.Arena(O.MNK, 3, 3, 3, Budget=budget, seed=S + g, RandomCount=4, RandomTemperature=1.0, RandomMinVisits=0)
+        o.set_inferencer(0, O.INF_HASH)
+        o.set_inferencer(1, O.INF_HASH)
+        o.begin(int(ab[g]))
+        o.play(0, True)
+        np.testing.assert_array_equal(dev.history(g), o.history())
+        o2 = O.Arena(O.MNK, 3, 3, 3, Budget=budget, seed=S + g)  # RandomCount = 0
+        o2.set_inferencer(0, O.INF_HASH)
+        o2.set_inferencer(1, O.INF_HASH)
+        o2.begin(int(ab[g]))
+        o2.play(0, True)
+        differs |= list(o2.history()) != list(o.history())
+    assert differs, "randomisation never changed a move: the test would be vacuous"
 
 
 def test_net_inferencer_end_to_end(ctx):
