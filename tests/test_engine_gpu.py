@@ -245,3 +245,64 @@ def test_continuous_selfplay_restarts_games(ctx):
     # both colour assignments occurred after restarts
     ab = [dev.game(g)[1]["a_is_black"] for g in range(G)]
     assert st["moves_played"] >= 5 * target and set(ab) <= {0, 1}
+
+
+def test_two_different_nets_a_vs_b(ctx):
+    """Arena.Play between two DIFFERENT networks (AZ.Learn's evaluation games, agogo.go:144-148): the batch is split
+    into an A sub-batch and a B sub-batch per ply; trees must equal the oracle's fed with the respective net."""
+    H = W = 5
+    Aspace = H * W + 1
+    nets = []
+    for seed in (11, 12):
+        net = A.Net(ctx, 32, 1, 64, W, H, 2, Aspace, bn_mode=capi.BN_IDENTITY)
+        net.init_random(seed)
+        for i in range(net.num_params()):
+            name, n = net.param_info(i)
+            if name.endswith("_gamma"):
+                net.set_param(i, np.ones(n, np.float32))
+            elif name.endswith("_beta"):
+                net.set_param(i, np.zeros(n, np.float32))
+        net.commit()
+        nets.append(net)
+    budget, G = 20, 5
+    dev = A.Arena(ctx, capi.GAME_KOMI, H, W, 3, encoder=capi.ENC_TWOPLANE, n_games=G, Budget=budget)
+    dev.set_inferencer(0, capi.INF_NET, nets[0])
+    dev.set_inferencer(1, capi.INF_NET, nets[1])
+    ab = np.array([1, 0, 0, 1, 0], dtype=np.uint8)
+    dev.reset(ab)
+
+    def mk_cb(net):
+        def cb(planes):
+            p, v = net.infer(planes.reshape(1, 2, H, W))
+            return p[0], float(v[0])
+        return cb
+
+    orcs = []
+    for g in range(G):
+        o = O.Arena(O.KOMI, H, W, 3, enc=O.ENC_TWOPLANE, Budget=budget)
+        o.set_callback(0, mk_cb(nets[0]), Aspace)
+        o.set_callback(1, mk_cb(nets[1]), Aspace)
+        o.begin(int(ab[g]))
+        orcs.append(o)
+    for ply in range(8):
+        dev.begin_move()
+        dev.simulate(budget)
+        dev.end_move(record=False)
+        for g in range(G):
+            o = orcs[g]
+            _, st0 = o.state()
+            if st0["ended"]:
+                continue
+            agent = 0 if ((st0["to_move"] == O.BLACK) == bool(ab[g])) else 1
+            o.step(record=False)
+            omv, ovis, obs, _ = o.root_children(agent)
+            dmv, dvis, dbs, _ = dev.root_children(g, agent)
+            np.testing.assert_array_equal(dmv, omv, err_msg="game %d ply %d" % (g, ply))
+            np.testing.assert_array_equal(dvis, ovis, err_msg="game %d ply %d" % (g, ply))
+            np.testing.assert_array_equal(f32bits(dbs), f32bits(obs))
+            assert dev.history(g)[-1] == o.history()[-1]
+    # the two nets really disagree somewhere (otherwise the split would be untested)
+    x = np.full((1, 2, H, W), 0.001, np.float32)
+    x[0, 1] = 1.0
+    x[0, 0, 2, 2] = 1.0
+    assert np.abs(nets[0].infer(x)[0] - nets[1].infer(x)[0]).max() > 1e-6
