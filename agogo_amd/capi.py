@@ -97,6 +97,9 @@ def lib():
     sig("agz_net_infer", i32, vp, pf, i32, pf, pf)
     sig("agz_net_infer_dev", i32, vp, vp, i32, vp, vp)
     sig("agz_net_flops_per_eval", f64, vp)
+    sig("agz_net_save", i32, vp, C.c_char_p)
+    sig("agz_net_load", i32, vp, C.c_char_p)
+    sig("agz_arena_get_results", i32, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64))
     sig("agz_arena_create", i32, vp, C.POINTER(GameConf), C.POINTER(MctsConf), i32, u64, i32, pvp)
     sig("agz_arena_destroy", None, vp)
     sig("agz_arena_set_inferencer", i32, vp, i32, i32, vp)
@@ -241,6 +244,12 @@ class Net:
     def flops_per_eval(self):
         return lib().agz_net_flops_per_eval(self.h)
 
+    def save(self, path):
+        _check(lib().agz_net_save(self.h, os.fsencode(path)), "agz_net_save")
+
+    def load(self, path):
+        _check(lib().agz_net_load(self.h, os.fsencode(path)), "agz_net_load")
+
 
 class Arena:
     """n_games x agogo.Arena (arena.go:20-179): batched self-play with per-agent mcts.MCTS trees on device."""
@@ -305,6 +314,11 @@ class Arena:
         s = ArenaStats()
         _check(lib().agz_arena_get_stats(self.h, C.byref(s)), "agz_arena_get_stats")
         return {f: getattr(s, f) for f, _ in ArenaStats._fields_ if f != "reserved"}
+
+    def results(self):
+        a, b, d = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _check(lib().agz_arena_get_results(self.h, C.byref(a), C.byref(b), C.byref(d)), "agz_arena_get_results")
+        return {"a_wins": a.value, "b_wins": b.value, "draws": d.value}
 
     def game(self, g):
         board = np.zeros(self.m * self.n, dtype=np.int32)

@@ -729,6 +729,10 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
     atomicAdd(&d.counters[CNT_MOVES], 1ull);
     if (ended) {
       atomicAdd(&d.counters[CNT_GAMES], 1ull);
+      {  // Agent.Wins / Loss / Draw (arena.go:156-171)
+        int a_colour = d.a_is_black[g] ? AGZ_BLACK : AGZ_WHITE;
+        atomicAdd(&d.counters[winner == AGZ_NONE ? CNT_DRAWS : (winner == a_colour ? CNT_A_WINS : CNT_B_WINS)], 1ull);
+      }
       // label the game's examples (arena.go:146-155)
       for (int e = d.ex_last[g]; e >= 0; e = d.ex_prev[e]) {
         float mover = d.ex_value[e];
@@ -917,7 +921,7 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
   AL(n_nodes, T) AL(cur_pool, T) AL(has_root, T) AL(has_prev, T) AL(prev_ply, T) AL(prev_board, (size_t)T * CELLS_PAD)
   AL(stalled, T) AL(overflow, T) AL(pc_hash, (size_t)T * d.moves_stride) AL(pc_move, (size_t)T * d.moves_stride) AL(pc_n, T) AL(rng, T) AL(rng_game, G)
   AL(slot_of_game, G) AL(leaf_kind, G) AL(leaf_player, G) AL(leaf_ply, G) AL(leaf_result, G) AL(leaf_board, (size_t)G * CELLS_PAD)
-  AL(leaf_legal, (size_t)G * CELLS_PAD) AL(path, (size_t)G * MAXPATH) AL(path_len, G) AL(counters, 8)
+  AL(leaf_legal, (size_t)G * CELLS_PAD) AL(path, (size_t)G * MAXPATH) AL(path_len, G) AL(counters, CNT_N)
   {
     size_t per_ex = (size_t)c.F * c.cells + (c.A + 1) + 3;
     size_t want = std::max<size_t>((size_t)G * c.max_moves * 2, 16384);  // room for restarted games (agz_arena_selfplay)
@@ -984,7 +988,7 @@ int agz_arena_reset(agz_arena* a, const uint8_t* a_is_black) {
     AGZ_HIP_TRY(hipMalloc(&dab, a->G));
     AGZ_HIP_TRY(hipMemcpyAsync(dab, a_is_black, a->G, hipMemcpyHostToDevice, s));
   }
-  AGZ_HIP_TRY(hipMemsetAsync(a->d.counters, 0, 8 * sizeof(unsigned long long), s));
+  AGZ_HIP_TRY(hipMemsetAsync(a->d.counters, 0, CNT_N * sizeof(unsigned long long), s));
   AGZ_HIP_TRY(hipMemsetAsync(a->d.ex_count, 0, sizeof(int32_t), s));
   hipLaunchKernelGGL(k_reset, dim3(a->G), dim3(64), 0, s, a->d, a->gc, dab, (unsigned long long)a->seed, (unsigned long long)a->seed0);
   std::vector<int32_t> ab(a->G);
@@ -1037,7 +1041,7 @@ int agz_arena_end_move(agz_arena* a, int record) {
 int agz_arena_get_stats(agz_arena* a, agz_arena_stats* out) {
   AGZ_REQUIRE(a && out, AGZ_E_INVALID, "NULL argument");
   AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
-  unsigned long long c[8];
+  unsigned long long c[CNT_N];
   std::vector<int32_t> ended(a->G);
   AGZ_HIP_TRY(hipMemcpyAsync(c, a->d.counters, sizeof(c), hipMemcpyDeviceToHost, a->ctx->stream));
   AGZ_HIP_TRY(hipMemcpyAsync(ended.data(), a->d.ended, a->G * sizeof(int32_t), hipMemcpyDeviceToHost, a->ctx->stream));
@@ -1048,6 +1052,18 @@ int agz_arena_get_stats(agz_arena* a, agz_arena_stats* out) {
   int act = 0;
   for (int g = 0; g < a->G; g++) act += ended[g] ? 0 : 1;
   out->n_active = act;
+  return AGZ_OK;
+}
+
+int agz_arena_get_results(agz_arena* a, int64_t* a_wins, int64_t* b_wins, int64_t* draws) {
+  AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  unsigned long long c[CNT_N];
+  AGZ_HIP_TRY(hipMemcpyAsync(c, a->d.counters, sizeof(c), hipMemcpyDeviceToHost, a->ctx->stream));
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  if (a_wins) *a_wins = (int64_t)c[CNT_A_WINS];
+  if (b_wins) *b_wins = (int64_t)c[CNT_B_WINS];
+  if (draws) *draws = (int64_t)c[CNT_DRAWS];
   return AGZ_OK;
 }
 

@@ -22,6 +22,7 @@
 #include "net.hpp"
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -706,6 +707,50 @@ int agz_net_infer(agz_net* n, const float* planes, int B, float* policy, float* 
   AGZ_HIP_TRY(hipMemcpyAsync(value, n->d_value, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
   AGZ_HIP_TRY(hipStreamSynchronize(s));
   return AGZ_OK;
+}
+
+int agz_net_save(const agz_net* n, const char* path) {
+  AGZ_REQUIRE(n && path, AGZ_E_INVALID, "agz_net_save: NULL argument");
+  FILE* f = fopen(path, "wb");
+  AGZ_REQUIRE(f, AGZ_E_INVALID, "agz_net_save: cannot open %s", path);
+  bool ok = fwrite("AGZNET01", 1, 8, f) == 8 && fwrite(&n->conf, sizeof(agz_net_conf), 1, f) == 1;
+  uint64_t np = n->params.size();
+  ok = ok && fwrite(&np, 8, 1, f) == 1;
+  for (const Param& p : n->params) {
+    uint64_t cnt = p.v.size();
+    ok = ok && fwrite(&cnt, 8, 1, f) == 1 && fwrite(p.v.data(), 4, cnt, f) == cnt;
+  }
+  for (const BNStats& b : n->bn) {
+    uint64_t C = b.mean.size();
+    ok = ok && fwrite(&C, 8, 1, f) == 1 && fwrite(b.mean.data(), 4, C, f) == C && fwrite(b.var.data(), 4, C, f) == C;
+  }
+  ok = (fclose(f) == 0) && ok;
+  AGZ_REQUIRE(ok, AGZ_E_INVALID, "agz_net_save: write to %s failed", path);
+  return AGZ_OK;
+}
+
+int agz_net_load(agz_net* n, const char* path) {
+  AGZ_REQUIRE(n && path, AGZ_E_INVALID, "agz_net_load: NULL argument");
+  FILE* f = fopen(path, "rb");
+  AGZ_REQUIRE(f, AGZ_E_INVALID, "agz_net_load: cannot open %s", path);
+  char magic[8];
+  agz_net_conf c;
+  uint64_t np = 0;
+  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "AGZNET01", 8) == 0 && fread(&c, sizeof(c), 1, f) == 1 && fread(&np, 8, 1, f) == 1;
+  if (ok) ok = memcmp(&c, &n->conf, sizeof(c)) == 0 && np == n->params.size();
+  if (!ok) { fclose(f); agz::set_error("agz_net_load: %s is not a checkpoint of this network configuration", path); return AGZ_E_INVALID; }
+  for (Param& p : n->params) {
+    uint64_t cnt = 0;
+    ok = ok && fread(&cnt, 8, 1, f) == 1 && cnt == p.v.size() && fread(p.v.data(), 4, cnt, f) == cnt;
+  }
+  for (BNStats& b : n->bn) {
+    uint64_t C = 0;
+    ok = ok && fread(&C, 8, 1, f) == 1 && C == b.mean.size() && fread(b.mean.data(), 4, C, f) == C && fread(b.var.data(), 4, C, f) == C;
+  }
+  fclose(f);
+  AGZ_REQUIRE(ok, AGZ_E_INVALID, "agz_net_load: %s is truncated or mismatched", path);
+  n->committed = false;
+  return agz_net_commit(n);
 }
 
 double agz_net_flops_per_eval(const agz_net* n) {

@@ -118,6 +118,12 @@ int agz_net_commit(agz_net* net);
 int agz_net_infer(agz_net* net, const float* planes, int B, float* policy, float* value);
 /* same with device pointers, asynchronous on the ctx stream */
 int agz_net_infer_dev(agz_net* net, const float* planes_dev, int B, float* policy_dev, float* value_dev);
+/* Checkpoint of the learnables in Model() order (+ BN statistics).  The reference gob-encodes G.Values
+ * (AZ.Save / Dual.GobEncode, agogo.go:175-209, dualnet/dual.go:180-206); gob is Go-only, so this is a documented
+ * flat format: "AGZNET01", agz_net_conf, n_params, then per parameter {uint64 n, float32[n]}, then per BN op
+ * {uint64 C, mean[C], var[C]}.  agz_net_load requires an identical conf and leaves the net committed. */
+int agz_net_save(const agz_net* net, const char* path);
+int agz_net_load(agz_net* net, const char* path);
 /* FLOPs of one evaluation (SURVEY App. D formula) */
 double agz_net_flops_per_eval(const agz_net* net);
 
@@ -203,6 +209,10 @@ typedef struct agz_arena_stats {
   int32_t reserved;
 } agz_arena_stats;
 int agz_arena_get_stats(agz_arena* arena, agz_arena_stats* out);
+/* Agent statistics since the last reset (Agent.Wins / Loss / Draw, arena.go:156-171; Statistics, statistics.go):
+ * A's wins = B's losses and vice versa.  AZ.Learn's gating rule is b_wins / (b_wins + a_wins) > UpdateThreshold
+ * (agogo.go:155). */
+int agz_arena_get_results(agz_arena* arena, int64_t* a_wins, int64_t* b_wins, int64_t* draws);
 /* game state of game g: board [m*n] colours, to_move, move number, passes, ended, winner, a_is_black,
  * last best move */
 typedef struct agz_game_state {

@@ -306,3 +306,26 @@ def test_two_different_nets_a_vs_b(ctx):
     x[0, 1] = 1.0
     x[0, 0, 2, 2] = 1.0
     assert np.abs(nets[0].infer(x)[0] - nets[1].infer(x)[0]).max() > 1e-6
+
+
+def test_results_counters_match_winners(ctx):
+    """Agent.Wins/Loss/Draw bookkeeping (arena.go:156-171) equals a recount from the per-game winners."""
+    G = 16
+    dev = A.Arena(ctx, capi.GAME_MNK, 3, 3, 3, n_games=G, Budget=15, seed=99)
+    dev.set_inferencer(0, capi.INF_HASH)
+    dev.set_inferencer(1, capi.INF_HASH)
+    dev.reset()
+    dev.play(0, record=False)
+    res = dev.results()
+    a = b = d = 0
+    for g in range(G):
+        st = dev.game(g)[1]
+        assert st["ended"] == 1
+        if st["winner"] == capi.NONE:
+            d += 1
+        elif (st["winner"] == capi.BLACK) == bool(st["a_is_black"]):
+            a += 1
+        else:
+            b += 1
+    assert res == {"a_wins": a, "b_wins": b, "draws": d}
+    assert a + b + d == G == dev.stats()["games_finished"]

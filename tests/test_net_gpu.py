@@ -144,3 +144,23 @@ def test_infer_before_commit_fails(ctx):
     gnet = A.Net(ctx, 32, 1, 64, 5, 5, 2, 26)
     with pytest.raises(A.AgzError):
         gnet.infer(np.zeros((1, 2, 5, 5), np.float32))
+
+
+def test_checkpoint_roundtrip(ctx, tmp_path):
+    """AZ.Save / Load analogue (agogo.go:175-209; dualnet TestEncodeDecode dual_test.go:111-141): learnables equal
+    after decode, outputs identical, mismatched configuration rejected."""
+    onet, gnet = make_pair(ctx, 32, 2, 64, 5, 5, 2, 26, bn_mode=1)
+    path = str(tmp_path / "example.model")
+    gnet.save(path)
+    other = A.Net(ctx, 32, 2, 64, 5, 5, 2, 26, bn_mode=1)
+    other.load(path)
+    for i in range(gnet.num_params()):
+        np.testing.assert_array_equal(other.get_param(i), gnet.get_param(i))
+    x = rand_planes(3, 2, 5, 5, seed=4)
+    p0, v0 = gnet.infer(x)
+    p1, v1 = other.infer(x)
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(v0, v1)
+    wrong = A.Net(ctx, 32, 1, 64, 5, 5, 2, 26, bn_mode=1)
+    with pytest.raises(A.AgzError):
+        wrong.load(path)
