@@ -219,7 +219,7 @@ def main():
         achieved = conv_flops_launch / (conv_ms * 1e-3) / 1e12 if conv_ms else None
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_conv_dual.json")
-        if os.path.exists(pmc_path):
+        if os.path.exists(pmc_path) and (S, K, L, G) == (19, 256, 20, 512):  # the PMC pass was taken on this exact shape
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
             except Exception:

@@ -6,6 +6,7 @@
 #include <memory>
 
 #include "arena.hpp"
+#include "train.hpp"
 
 using namespace oracle;
 
@@ -294,5 +295,61 @@ int orc_example_root_children(void* h, int32_t* moves, uint32_t* visits, float* 
   return n;
 }
 int64_t orc_example_nn_evals(void* h) { return ((ExampleBox*)h)->t->nnEvals; }
+
+
+// ---- dual.Train restatement (oracle/train.hpp) ----
+static DualConfig mkconf(int K, int L, int FC, int BatchSize, int W, int H, int F, int A, float eps) {
+  DualConfig c; c.K = K; c.SharedLayers = L; c.FC = FC; c.BatchSize = BatchSize; c.Width = W; c.Height = H; c.Features = F;
+  c.ActionSpace = A; c.bn_mode = 0; c.bn_eps = eps; return c;
+}
+void* orc_train_new(int K, int L, int FC, int BatchSize, int W, int H, int F, int A, float eps) {
+  DualConfig c = mkconf(K, L, FC, BatchSize, W, H, F, A, eps);
+  if (!c.IsValid()) return nullptr;
+  return new TrainNet<float>(c);
+}
+void orc_train_free(void* h) { delete (TrainNet<float>*)h; }
+int orc_train_num_params(void* h) { return (int)((TrainNet<float>*)h)->P.size(); }
+int64_t orc_train_param_size(void* h, int i) { return (int64_t)((TrainNet<float>*)h)->P.at(i).size(); }
+const char* orc_train_param_name(void* h, int i) { return ((TrainNet<float>*)h)->names.at(i).c_str(); }
+void orc_train_init_random(void* h, uint64_t seed) { ((TrainNet<float>*)h)->InitRandom(seed); }
+void orc_train_get_param(void* h, int i, float* out) { auto& v = ((TrainNet<float>*)h)->P.at(i); memcpy(out, v.data(), v.size() * 4); }
+void orc_train_set_param(void* h, int i, const float* in) { auto& v = ((TrainNet<float>*)h)->P.at(i); memcpy(v.data(), in, v.size() * 4); }
+void orc_train_get_grad(void* h, int i, float* out) { auto& v = ((TrainNet<float>*)h)->G.at(i); memcpy(out, v.data(), v.size() * 4); }
+// one batch: forward (training-mode BN) + backward; lr > 0 also applies the vanilla SGD step. returns the cost
+float orc_train_batch(void* h, const float* planes, const float* Pi, const float* V, float lr) {
+  TrainNet<float>* t = (TrainNet<float>*)h;
+  float c = t->ForwardBackward(planes, Pi, V, true);
+  if (lr > 0) t->Step(lr);
+  return c;
+}
+// analytic gradients vs central finite differences, both in double. returns the max relative error over n_checks
+// randomly chosen parameter entries (spread over all parameter tensors).
+double orc_train_gradcheck(int K, int L, int FC, int BatchSize, int W, int H, int F, int A, uint64_t seed, int n_checks) {
+  DualConfig c = mkconf(K, L, FC, BatchSize, W, H, F, A, 1e-5f);
+  TrainNet<double> t(c);
+  t.InitRandom(seed);
+  SplitMix64 r(seed ^ 0x1234);
+  for (auto& p : t.P) for (double& x : p) x *= 3.0;  // move away from the tiny Glorot scale so ReLUs are mixed
+  for (size_t i = 0; i < t.P.size(); i++) if (t.kinds[i] == 1) for (double& x : t.P[i]) x = 0.5 + r.float64();
+  size_t nx = (size_t)BatchSize * F * H * W;
+  std::vector<double> X(nx), Pi((size_t)BatchSize * A), V(BatchSize);
+  for (double& x : X) x = r.float64() * 2 - 1;
+  for (int b = 0; b < BatchSize; b++) { Pi[(size_t)b * A + (r.next() % A)] = 1.0; V[b] = (double)((int)(r.next() % 3) - 1); }
+  t.ForwardBackward(X.data(), Pi.data(), V.data(), true);
+  auto G = t.G;
+  double worst = 0;
+  for (int k = 0; k < n_checks; k++) {
+    size_t pi = (size_t)(k % t.P.size());
+    size_t idx = (size_t)(r.next() % t.P[pi].size());
+    double keep = t.P[pi][idx], eps = 1e-5;
+    t.P[pi][idx] = keep + eps; double cp = t.ForwardBackward(X.data(), Pi.data(), V.data(), false);
+    t.P[pi][idx] = keep - eps; double cm = t.ForwardBackward(X.data(), Pi.data(), V.data(), false);
+    t.P[pi][idx] = keep;
+    double num = (cp - cm) / (2 * eps), ana = G[pi][idx];
+    double err = std::fabs(num - ana) / std::max(1e-7, std::fabs(num) + std::fabs(ana));
+    if (std::fabs(num) + std::fabs(ana) > 1e-9 && err > worst) worst = err;
+  }
+  return worst;
+}
 
 }  // extern "C"

@@ -85,6 +85,17 @@ def lib():
     sig("orc_arena_num_examples", i32, vp)
     sig("orc_arena_get_example", None, vp, i32, pf, pf, pf)
     sig("orc_arena_example_sizes", i32, vp, pi, pi)
+    sig("orc_train_new", vp, i32, i32, i32, i32, i32, i32, i32, i32, f32)
+    sig("orc_train_free", None, vp)
+    sig("orc_train_num_params", i32, vp)
+    sig("orc_train_param_size", i64, vp, i32)
+    sig("orc_train_param_name", C.c_char_p, vp, i32)
+    sig("orc_train_init_random", None, vp, u64)
+    sig("orc_train_get_param", None, vp, i32, pf)
+    sig("orc_train_set_param", None, vp, i32, pf)
+    sig("orc_train_get_grad", None, vp, i32, pf)
+    sig("orc_train_batch", f32, vp, pf, pf, pf, f32)
+    sig("orc_train_gradcheck", f64, i32, i32, i32, i32, i32, i32, i32, i32, u64, i32)
     sig("orc_example_new", vp, i32, i32, i32, i32, f64, f32, i32, i32, i32, i32, u64)
     sig("orc_example_free", None, vp)
     sig("orc_example_turn", i32, vp, pi, pi)
@@ -363,3 +374,48 @@ class ExampleSearch:
 
     def nn_evals(self):
         return lib().orc_example_nn_evals(self.h)
+
+
+class TrainNet:
+    """dual.Train restatement (dualnet/meta.go:16-54): full-shape learnables, training-mode BN, backward, SGD."""
+
+    def __init__(self, K, L, FC, W, H, F, A, BatchSize, bn_eps=1e-5):
+        self.conf = dict(K=K, SharedLayers=L, FC=FC, BatchSize=BatchSize, Width=W, Height=H, Features=F, ActionSpace=A)
+        self.h = lib().orc_train_new(K, L, FC, BatchSize, W, H, F, A, bn_eps)
+        assert self.h
+
+    def __del__(self):
+        try:
+            lib().orc_train_free(self.h)
+        except Exception:
+            pass
+
+    def num_params(self):
+        return lib().orc_train_num_params(self.h)
+
+    def param_name(self, i):
+        return lib().orc_train_param_name(self.h, i).decode()
+
+    def init_random(self, seed):
+        lib().orc_train_init_random(self.h, seed)
+
+    def get_param(self, i):
+        a = np.zeros(lib().orc_train_param_size(self.h, i), np.float32)
+        lib().orc_train_get_param(self.h, i, _pf(a))
+        return a
+
+    def set_param(self, i, v):
+        a = np.ascontiguousarray(v, np.float32)
+        assert a.size == lib().orc_train_param_size(self.h, i)
+        lib().orc_train_set_param(self.h, i, _pf(a))
+
+    def get_grad(self, i):
+        a = np.zeros(lib().orc_train_param_size(self.h, i), np.float32)
+        lib().orc_train_get_grad(self.h, i, _pf(a))
+        return a
+
+    def batch(self, planes, Pi, V, lr=0.0):
+        x = np.ascontiguousarray(planes, np.float32)
+        p = np.ascontiguousarray(Pi, np.float32)
+        v = np.ascontiguousarray(V, np.float32)
+        return float(lib().orc_train_batch(self.h, _pf(x), _pf(p), _pf(v), lr))
