@@ -100,6 +100,20 @@ def lib():
     sig("agz_net_save", i32, vp, C.c_char_p)
     sig("agz_net_load", i32, vp, C.c_char_p)
     sig("agz_arena_get_results", i32, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+    sig("agz_trainer_create", i32, vp, C.POINTER(NetConf), pvp)
+    sig("agz_trainer_destroy", None, vp)
+    sig("agz_trainer_num_params", i32, vp)
+    sig("agz_trainer_param_info", i32, vp, i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t))
+    sig("agz_trainer_set_param", i32, vp, i32, pf, C.c_size_t)
+    sig("agz_trainer_get_param", i32, vp, i32, pf, C.c_size_t)
+    sig("agz_trainer_get_grad", i32, vp, i32, pf, C.c_size_t)
+    sig("agz_trainer_init_random", i32, vp, u64)
+    sig("agz_trainer_batch", i32, vp, pf, pf, pf, C.c_float, pf)
+    sig("agz_trainer_forward_backward", i32, vp, pf, pf, pf, pf)
+    sig("agz_trainer_apply", i32, vp, C.c_float, C.c_float)
+    sig("agz_trainer_grads_dev", i32, vp, pvp, C.POINTER(C.c_size_t))
+    sig("agz_train", i32, vp, pf, pf, pf, i32, i32, u64, pf)
+    sig("agz_trainer_export", i32, vp, vp)
     sig("agz_arena_create", i32, vp, C.POINTER(GameConf), C.POINTER(MctsConf), i32, u64, i32, pvp)
     sig("agz_arena_destroy", None, vp)
     sig("agz_arena_set_inferencer", i32, vp, i32, i32, vp)
@@ -148,7 +162,7 @@ class Ctx:
         """destroys dependants (arenas, nets) first: their handles hold a pointer to this ctx"""
         if self.h:
             kids = [r() for r in self._children]
-            for k in sorted([k for k in kids if k is not None], key=lambda k: 0 if isinstance(k, Arena) else 1):
+            for k in sorted([k for k in kids if k is not None], key=lambda k: 0 if isinstance(k, Arena) else 1):  # arenas first
                 k.close()
             self._children = []
             lib().agz_ctx_destroy(self.h)
@@ -249,6 +263,88 @@ class Net:
 
     def load(self, path):
         _check(lib().agz_net_load(self.h, os.fsencode(path)), "agz_net_load")
+
+
+class Trainer:
+    """dual.Train on device (dualnet/meta.go:16-54): full-shape learnables, training-mode BN, backward, vanilla SGD."""
+
+    def __init__(self, ctx, K, SharedLayers, FC, Width, Height, Features, ActionSpace, BatchSize, bn_eps=1e-5):
+        self.ctx = ctx
+        self.conf = NetConf(K, SharedLayers, FC, BatchSize, Width, Height, Features, ActionSpace, 0, bn_eps)
+        self.h = C.c_void_p()
+        _check(lib().agz_trainer_create(ctx.h, C.byref(self.conf), C.byref(self.h)), "agz_trainer_create")
+        ctx._adopt(self)
+
+    def close(self):
+        if self.h and self.ctx.h:
+            lib().agz_trainer_destroy(self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_params(self):
+        return lib().agz_trainer_num_params(self.h)
+
+    def param_info(self, i):
+        name = C.create_string_buffer(128)
+        n = C.c_size_t(0)
+        _check(lib().agz_trainer_param_info(self.h, i, name, 128, C.byref(n)), "agz_trainer_param_info")
+        return name.value.decode(), n.value
+
+    def set_param(self, i, v):
+        a = np.ascontiguousarray(v, dtype=np.float32).ravel()
+        _check(lib().agz_trainer_set_param(self.h, i, _pf(a), a.size), "agz_trainer_set_param")
+
+    def get_param(self, i):
+        a = np.zeros(self.param_info(i)[1], np.float32)
+        _check(lib().agz_trainer_get_param(self.h, i, _pf(a), a.size), "agz_trainer_get_param")
+        return a
+
+    def get_grad(self, i):
+        a = np.zeros(self.param_info(i)[1], np.float32)
+        _check(lib().agz_trainer_get_grad(self.h, i, _pf(a), a.size), "agz_trainer_get_grad")
+        return a
+
+    def init_random(self, seed):
+        _check(lib().agz_trainer_init_random(self.h, seed), "agz_trainer_init_random")
+
+    def batch(self, planes, pi, v, lr=0.1):
+        x = np.ascontiguousarray(planes, np.float32)
+        p = np.ascontiguousarray(pi, np.float32)
+        vv = np.ascontiguousarray(v, np.float32)
+        c = C.c_float(0)
+        _check(lib().agz_trainer_batch(self.h, _pf(x), _pf(p), _pf(vv), lr, C.byref(c)), "agz_trainer_batch")
+        return c.value
+
+    def forward_backward(self, planes, pi, v):
+        x = np.ascontiguousarray(planes, np.float32)
+        p = np.ascontiguousarray(pi, np.float32)
+        vv = np.ascontiguousarray(v, np.float32)
+        c = C.c_float(0)
+        _check(lib().agz_trainer_forward_backward(self.h, _pf(x), _pf(p), _pf(vv), C.byref(c)), "agz_trainer_forward_backward")
+        return c.value
+
+    def apply(self, lr=0.1, grad_scale=1.0):
+        _check(lib().agz_trainer_apply(self.h, lr, grad_scale), "agz_trainer_apply")
+
+    def grads_dev(self):
+        ptr, n = C.c_void_p(), C.c_size_t(0)
+        _check(lib().agz_trainer_grads_dev(self.h, C.byref(ptr), C.byref(n)), "agz_trainer_grads_dev")
+        return ptr.value, n.value
+
+    def train(self, Xs, policies, values, batches, iterations, seed=1337):
+        """dual.Train; arrays are shuffled in place"""
+        assert Xs.dtype == np.float32 and policies.dtype == np.float32 and values.dtype == np.float32
+        c = C.c_float(0)
+        _check(lib().agz_train(self.h, _pf(Xs), _pf(policies), _pf(values), batches, iterations, seed, C.byref(c)), "agz_train")
+        return c.value
+
+    def export(self, net):
+        _check(lib().agz_trainer_export(self.h, net.h), "agz_trainer_export")
 
 
 class Arena:

@@ -38,6 +38,7 @@ struct ConvArgs {
   int M, HW, W, Wp, HpWp;
   int Cin_p, Cout_p, Ntot;
   int n_mtiles, n_ntiles;
+  int raw;  // 1: store the GEMM result as is (training forward / data-gradient passes), no BN/ReLU epilogue
 };
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -242,9 +243,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, const i
         for (int j = 0; j < 2; j++) {
           int c = n0 + (wn * 2 + j) * 32 + (lane & 31);
           if (mvalid && c < a.Cout_p) {
-            float2 e = reinterpret_cast<const float2*>(a.ep)[(size_t)p * a.Cout_p + c];
-            float v = acc[i][j][r] * e.x + e.y;
-            a.y[obase + c] = v > 0.f ? v : 0.f;
+            if (a.raw) {
+              a.y[obase + c] = acc[i][j][r];
+            } else {
+              float2 e = reinterpret_cast<const float2*>(a.ep)[(size_t)p * a.Cout_p + c];
+              float v = acc[i][j][r] * e.x + e.y;
+              a.y[obase + c] = v > 0.f ? v : 0.f;
+            }
           }
         }
       }
@@ -413,6 +418,17 @@ static void launch_conv(agz_ctx* ctx, ConvArgs& a) {
   dim3 grid(a.n_mtiles * a.n_ntiles), block(256);
   ProfScope ps(ctx, klass);
   hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, MT, DUAL>), grid, block, 0, ctx->stream, a);
+}
+
+// Raw 3x3 convolution (no epilogue) on padded-NHWC tensors: y[pix][n] = sum_{tap,c} x[pix+off(tap)][c] * w[tap][n][c].
+// Used by the trainer for the training-mode forward, and — with tap-flipped, transposed weights — for the data gradient.
+int agz::conv3x3_raw(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p) {
+  ConvArgs a{};
+  a.M = B * H * W; a.HW = H * W; a.W = W; a.Wp = W + 2; a.HpWp = (H + 2) * (W + 2);
+  a.x = x; a.w = w; a.ep = nullptr; a.y = y; a.Cin_p = Cin_p; a.Cout_p = Cout_p; a.Ntot = Cout_p; a.raw = 1;
+  if (Cout_p % 128 == 0) launch_conv<2, 2, 2, false>(ctx, a); else launch_conv<4, 1, 1, false>(ctx, a);
+  AGZ_HIP_TRY(hipGetLastError());
+  return AGZ_OK;
 }
 
 int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {

@@ -13,6 +13,7 @@ struct Param {
   int kind;                    // 0 conv filter, 1 BN gamma/beta, 2 FC weight, 3 FC bias
 };
 struct BNStats { std::vector<float> mean, var; };
+int conv3x3_raw(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p);
 }  // namespace agz
 
 struct agz_net {

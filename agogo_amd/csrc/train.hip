@@ -1,0 +1,781 @@
+// dual.Train on device: training-mode forward, backward, vanilla SGD.
+//
+// Reference: dualnet/meta.go:16-54 (Train), dualnet/dual.go:50-132 (fwd + bwd graph),
+// dualnet/ermahagerdmonards.go:106-147 (the "xent" on logits), G.NewVanillaSolver(lr 0.1) meta.go:17-20.
+// Learnables keep the reference's FULL shapes: BN gamma/beta [B,C,H,W] and FC biases [B,units] are batch-shaped
+// (SURVEY App. B b3/b5); inference uses row 0 (agz_trainer_export == the copy loop of dual.Infer, meta.go:141-146).
+//
+// Device layout: activations / conv outputs padded NHWC (zero halo) like the inference tower; the two convs of a
+// block run as ONE GEMM with 2K output channels [a | b]; gamma/beta stored [B][HW][C] so they line up with the
+// GEMM rows.  All learnables live in one flat buffer P and all gradients in one flat buffer G (same offsets):
+// the SGD step is a single axpy and a data-parallel run needs ONE all-reduce over G (agz_trainer_grads_dev).
+//
+// Kernels: forward conv and data-gradient conv reuse conv3x3_mfma_kernel (raw epilogue; the data gradient is the
+// same GEMM with tap-flipped, transposed weights); the weight gradient is its own fp32 MFMA kernel (k_wgrad);
+// BatchNorm statistics / apply / backward and the heads are bandwidth-bound elementwise + reduction kernels.
+// Status: correct (parity vs oracle/train.hpp within fp32 tolerance); k_wgrad is not tuned yet.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "net.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace agz {
+
+struct TGeo { int B, H, W, HW, Hp, Wp, M; };  // M = B*HW rows
+
+__device__ __forceinline__ size_t pix_off(const TGeo& g, int r) {  // padded pixel index of GEMM row r
+  int b = r / g.HW, p = r - b * g.HW;
+  int h = p / g.W, w = p - h * g.W;
+  return ((size_t)b * g.Hp + h + 1) * g.Wp + w + 1;
+}
+
+// ---- BatchNorm statistics: per-channel sums over the M interior rows of z [pix][C] -----------------------------
+// pass 0: sum(z)                    -> acc[c]
+// pass 1: sum((z - mean)^2)         -> acc[c]      (two-pass variance like the oracle)
+__global__ void k_bn_sum(TGeo g, const float* __restrict__ z, int C, const float* __restrict__ mean, double* __restrict__ acc,
+                         int rows_per_block) {
+  int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, g.M);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float mu = mean ? mean[c] : 0.f;
+    double s = 0;
+    for (int r = r0; r < r1; r++) {
+      float v = z[pix_off(g, r) * C + c];
+      if (mean) { float d = v - mu; s += (double)d * d; } else s += v;
+    }
+    atomicAdd(&acc[c], s);
+  }
+}
+// finalize: pass 0 -> mean = acc/m ; pass 1 -> inv = 1/sqrt(acc/m + eps).  Clears acc.
+__global__ void k_bn_fin(double* acc, int C, double m, float eps, float* mean, float* inv, int pass) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (pass == 0) mean[c] = (float)(acc[c] / m); else inv[c] = 1.0f / sqrtf((float)(acc[c] / m) + eps);
+  acc[c] = 0;
+}
+
+// ---- tower BN apply (+ReLU, + dual add + ReLU).  z [pix][nbr*Kp]; gamma/beta [M][nbr*Kp]; out [pix][Kp] --------
+__global__ void k_bn_apply(TGeo g, const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
+                           const float* __restrict__ mean, const float* __restrict__ inv, float* __restrict__ out, int Kp, int nbr) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)g.M * Kp) return;
+  int r = (int)(idx / Kp), c = (int)(idx - (size_t)r * Kp);
+  size_t po = pix_off(g, r);
+  int C = nbr * Kp;
+  float acc = 0.f;
+  for (int br = 0; br < nbr; br++) {
+    int cc = br * Kp + c;
+    float xh = (z[po * C + cc] - mean[cc]) * inv[cc];
+    float y = gamma[(size_t)r * C + cc] * xh + beta[(size_t)r * C + cc];
+    acc += y > 0.f ? y : 0.f;
+  }
+  out[po * Kp + c] = (nbr == 2) ? (acc > 0.f ? acc : 0.f) : acc;
+}
+
+// ---- tower BN backward, step 1: d(out) -> dgamma, dbeta, d(xhat) (stored in dz) and the two channel sums -------
+__global__ void k_bn_bwd1(TGeo g, const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
+                          const float* __restrict__ mean, const float* __restrict__ inv, const float* __restrict__ out,
+                          const float* __restrict__ dout, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                          float* __restrict__ dz, double* __restrict__ s1, double* __restrict__ s2, int Kp, int nbr,
+                          int rows_per_block) {
+  int C = nbr * Kp;
+  int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, g.M);
+  for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
+    int c = cc % Kp;
+    double a1 = 0, a2 = 0;
+    for (int r = r0; r < r1; r++) {
+      size_t po = pix_off(g, r);
+      float g0 = dout[po * Kp + c];
+      if (nbr == 2 && !(out[po * Kp + c] > 0.f)) g0 = 0.f;
+      float xh = (z[po * C + cc] - mean[cc]) * inv[cc];
+      float gm = gamma[(size_t)r * C + cc];
+      float y = gm * xh + beta[(size_t)r * C + cc];
+      float gg = y > 0.f ? g0 : 0.f;
+      dgamma[(size_t)r * C + cc] = gg * xh;
+      dbeta[(size_t)r * C + cc] = gg;
+      float dxh = gg * gm;
+      dz[po * C + cc] = dxh;
+      a1 += dxh; a2 += (double)dxh * xh;
+    }
+    atomicAdd(&s1[cc], a1);
+    atomicAdd(&s2[cc], a2);
+  }
+}
+// step 2: dz = inv * (dxhat - s1/m - xhat*s2/m)
+__global__ void k_bn_bwd2(TGeo g, const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ inv,
+                          float* __restrict__ dz, const double* __restrict__ s1, const double* __restrict__ s2, int C) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)g.M * C) return;
+  int r = (int)(idx / C), cc = (int)(idx - (size_t)r * C);
+  size_t po = pix_off(g, r);
+  float xh = (z[po * C + cc] - mean[cc]) * inv[cc];
+  float m = (float)g.M;
+  dz[po * C + cc] = inv[cc] * (dz[po * C + cc] - (float)s1[cc] / m - xh * ((float)s2[cc] / m));
+}
+
+// ---- weight gradient: dW[tap][n][c] += sum_r dz[pix(r)][n] * x[pix(r)+off(tap)][c]  (fp32 MFMA, split over rows) ----
+// block tile 128 (n) x 128 (c), 4 waves x (2x2 MFMA 32x32x2), K-loop over `rows` GEMM rows in steps of 32; partial
+// results are added with float atomics (one wgrad launch per layer; order-dependent rounding is within tolerance).
+struct WgArgs {
+  const float* dz; const float* x; float* dw;
+  TGeo g; int N, Cin, rows_per_block, n_tiles, c_tiles;
+};
+__global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
+  __shared__ float As[32][132];  // [k row][n]   (+4 pad: conflict-free ds_read_b32 across the two lane halves)
+  __shared__ float Bs[32][132];  // [k row][c]
+  int bid = blockIdx.x;
+  int ct = bid % a.c_tiles; bid /= a.c_tiles;
+  int nt = bid % a.n_tiles; bid /= a.n_tiles;
+  int tap = bid % 9; int chunk = bid / 9;
+  int n0 = nt * 128, c0 = ct * 128;
+  int ky = tap / 3, kx = tap - ky * 3;
+  long tapoff = (long)(ky - 1) * a.g.Wp + (kx - 1);
+  int r_begin = chunk * a.rows_per_block, r_end = min(r_begin + a.rows_per_block, a.g.M);
+  int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  // staging: 32 rows x 128 cols = 1024 float4 / 256 threads = 4 each
+  for (int rb = r_begin; rb < r_end; rb += 32) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int e = tid + 256 * q;        // float4 index
+      int row = e >> 5, col = (e & 31) * 4;
+      int r = rb + row;
+      float4 va = make_float4(0, 0, 0, 0), vb = va;
+      if (r < r_end) {
+        size_t po = pix_off(a.g, r);
+        if (n0 + col < a.N) va = *reinterpret_cast<const float4*>(a.dz + po * a.N + n0 + col);
+        if (c0 + col < a.Cin) vb = *reinterpret_cast<const float4*>(a.x + (size_t)((long)po + tapoff) * a.Cin + c0 + col);
+      }
+      *reinterpret_cast<float4*>(&As[row][col]) = va;
+      *reinterpret_cast<float4*>(&Bs[row][col]) = vb;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 32; k += 2) {
+      int kr = k + (lane >> 5);
+      float a0 = As[kr][wm * 64 + (lane & 31)], a1 = As[kr][wm * 64 + 32 + (lane & 31)];
+      float b0 = Bs[kr][wn * 64 + (lane & 31)], b1 = Bs[kr][wn * 64 + 32 + (lane & 31)];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int c = c0 + wn * 64 + j * 32 + (lane & 31);
+        if (n < a.N && c < a.Cin) atomicAdd(&a.dw[((size_t)tap * a.N + n) * a.Cin + c], acc[i][j][r]);
+      }
+}
+
+// wt[8-tap][c][n] = wf[tap][n][c]   (data-gradient weights: flipped taps, transposed)
+__global__ void k_make_wt(const float* __restrict__ wf, float* __restrict__ wt, int N, int Cin) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t tot = (size_t)9 * N * Cin;
+  if (idx >= tot) return;
+  int c = (int)(idx % Cin); size_t t = idx / Cin; int n = (int)(t % N); int tap = (int)(t / N);
+  wt[((size_t)(8 - tap) * Cin + c) * N + n] = wf[idx];
+}
+
+__global__ void k_pack_planes_t(const float* __restrict__ planes, float* __restrict__ out, TGeo g, int F, int Fp) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)g.M * Fp) return;
+  int r = (int)(idx / Fp), c = (int)(idx - (size_t)r * Fp);
+  int b = r / g.HW, p = r - b * g.HW;
+  out[pix_off(g, r) * Fp + c] = c < F ? planes[((size_t)b * F + c) * g.HW + p] : 0.f;
+}
+
+__global__ void k_axpy(float* __restrict__ p, const float* __restrict__ g, float alpha, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] += alpha * g[i];
+}
+
+// ---- heads (small; one thread per output element, plain loops) --------------------------------------------------
+// zh[r][j] = sum_c x[pix(r)][c] * hc[j][c], j = 0,1 policy, 2 value
+__global__ void k_head_conv(TGeo g, const float* __restrict__ x, const float* __restrict__ hc, float* __restrict__ zh, int Kp) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= g.M * 3) return;
+  int r = idx / 3, j = idx - r * 3;
+  const float* xp = x + pix_off(g, r) * Kp;
+  float s = 0.f;
+  for (int c = 0; c < Kp; c++) s += xp[c] * hc[j * Kp + c];
+  zh[idx] = s;
+}
+// per-channel stats of zh [M][3]: single block
+__global__ void k_head_stats(TGeo g, const float* __restrict__ zh, float eps, float* __restrict__ mean, float* __restrict__ inv) {
+  __shared__ double red[256];
+  for (int j = 0; j < 3; j++) {
+    double s = 0;
+    for (int r = threadIdx.x; r < g.M; r += 256) s += zh[r * 3 + j];
+    red[threadIdx.x] = s; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    float mu = (float)(red[0] / g.M); __syncthreads();
+    s = 0;
+    for (int r = threadIdx.x; r < g.M; r += 256) { float d = zh[r * 3 + j] - mu; s += (double)d * d; }
+    red[threadIdx.x] = s; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) { mean[j] = mu; inv[j] = 1.0f / sqrtf((float)(red[0] / g.M) + eps); }
+    __syncthreads();
+  }
+}
+// yh[b][j][p] = relu(gamma*xhat+beta); head gamma/beta layout [B][3][HW]
+__global__ void k_head_apply(TGeo g, const float* __restrict__ zh, const float* __restrict__ hg, const float* __restrict__ hb,
+                             const float* __restrict__ mean, const float* __restrict__ inv, float* __restrict__ yh) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= g.M * 3) return;
+  int r = idx / 3, j = idx - r * 3;
+  int b = r / g.HW, p = r - b * g.HW;
+  float xh = (zh[idx] - mean[j]) * inv[j];
+  size_t o = ((size_t)b * 3 + j) * g.HW + p;
+  float y = hg[o] * xh + hb[o];
+  yh[o] = y > 0.f ? y : 0.f;
+}
+struct HeadT {
+  int B, HW, A, FC;
+  const float* yh;  // [B][3][HW]
+  const float *Wp, *bp, *W1, *b1, *W2, *b2;
+  const float *Pi, *V;
+  float *logits, *hpre, *o;
+  float *dWp, *dbp, *dW1, *db1, *dW2, *db2, *dyh;  // dyh [B][3][HW]
+  float* cost;  // [2]: pcost, vcost sums
+};
+__global__ void k_fc_fwd(HeadT h) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int nl = h.B * h.A, nh = h.B * h.FC;
+  if (idx < nl) {
+    int b = idx / h.A, j = idx - b * h.A;
+    const float* yp = h.yh + (size_t)b * 3 * h.HW;  // policy features: channels 0,1 contiguous = flatten c-major
+    float s = 0.f;
+    for (int i = 0; i < 2 * h.HW; i++) s += yp[i] * h.Wp[(size_t)i * h.A + j];
+    h.logits[idx] = s + h.bp[idx];
+  } else if (idx < nl + nh) {
+    int k = idx - nl;
+    int b = k / h.FC, j = k - b * h.FC;
+    const float* yv = h.yh + ((size_t)b * 3 + 2) * h.HW;
+    float s = 0.f;
+    for (int i = 0; i < h.HW; i++) s += yv[i] * h.W1[(size_t)i * h.FC + j];
+    h.hpre[k] = s + h.b1[k];
+  }
+}
+__global__ void k_value_out(HeadT h) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= h.B) return;
+  float s = 0.f;
+  for (int j = 0; j < h.FC; j++) { float hv = h.hpre[(size_t)b * h.FC + j]; s += (hv > 0.f ? hv : 0.f) * h.W2[j]; }
+  h.o[b] = s + h.b2[b];
+}
+__global__ void k_cost(HeadT h) {  // single block
+  __shared__ double red[256];
+  double s = 0;
+  for (int i = threadIdx.x; i < h.B * h.A; i += 256) s += -(double)(h.Pi[i] * h.logits[i] + (1.f - h.Pi[i]) * (1.f - h.logits[i]));
+  red[threadIdx.x] = s; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) h.cost[0] = (float)(red[0] / ((double)h.B * h.A));
+  __syncthreads();
+  s = 0;
+  for (int b = threadIdx.x; b < h.B; b += 256) { double d = h.o[b] - h.V[b]; s += d * d; }
+  red[threadIdx.x] = s; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) h.cost[1] = (float)(red[0] / h.B);
+}
+// backward of the FC parts.  One thread per gradient element (sums over the batch inside).
+__global__ void k_fc_bwd(HeadT h) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const float sc = 1.0f / ((float)h.B * (float)h.A);
+  int n_wp = 2 * h.HW * h.A, n_bp = h.B * h.A, n_w1 = h.HW * h.FC, n_b1 = h.B * h.FC, n_w2 = h.FC, n_b2 = h.B;
+  int n_dy = h.B * 3 * h.HW;
+  if (idx < n_wp) {  // dWp[i][j] = sum_b yp[b][i] * dl[b][j]
+    int i = idx / h.A, j = idx - i * h.A;
+    float s = 0.f;
+    for (int b = 0; b < h.B; b++) s += h.yh[(size_t)b * 3 * h.HW + i] * ((1.f - 2.f * h.Pi[(size_t)b * h.A + j]) * sc);
+    h.dWp[idx] = s;
+    return;
+  }
+  idx -= n_wp;
+  if (idx < n_bp) { h.dbp[idx] = (1.f - 2.f * h.Pi[idx]) * sc; return; }
+  idx -= n_bp;
+  if (idx < n_w1) {  // dW1[i][j] = sum_b yv[b][i] * dh[b][j]
+    int i = idx / h.FC, j = idx - i * h.FC;
+    float s = 0.f;
+    for (int b = 0; b < h.B; b++) {
+      float dob = 2.f * (h.o[b] - h.V[b]) / (float)h.B;
+      float dh = h.hpre[(size_t)b * h.FC + j] > 0.f ? dob * h.W2[j] : 0.f;
+      s += h.yh[((size_t)b * 3 + 2) * h.HW + i] * dh;
+    }
+    h.dW1[idx] = s;
+    return;
+  }
+  idx -= n_w1;
+  if (idx < n_b1) {
+    int b = idx / h.FC, j = idx - b * h.FC;
+    float dob = 2.f * (h.o[b] - h.V[b]) / (float)h.B;
+    h.db1[idx] = h.hpre[idx] > 0.f ? dob * h.W2[j] : 0.f;
+    return;
+  }
+  idx -= n_b1;
+  if (idx < n_w2) {
+    float s = 0.f;
+    for (int b = 0; b < h.B; b++) { float hv = h.hpre[(size_t)b * h.FC + idx]; s += (2.f * (h.o[b] - h.V[b]) / (float)h.B) * (hv > 0.f ? hv : 0.f); }
+    h.dW2[idx] = s;
+    return;
+  }
+  idx -= n_w2;
+  if (idx < n_b2) { h.db2[idx] = 2.f * (h.o[idx] - h.V[idx]) / (float)h.B; return; }
+  idx -= n_b2;
+  if (idx < n_dy) {  // d(yh)[b][j][p]
+    int b = idx / (3 * h.HW), q = idx - b * 3 * h.HW;
+    float s = 0.f;
+    if (q < 2 * h.HW) {
+      for (int j = 0; j < h.A; j++) s += ((1.f - 2.f * h.Pi[(size_t)b * h.A + j]) * sc) * h.Wp[(size_t)q * h.A + j];
+    } else {
+      int i = q - 2 * h.HW;
+      float dob = 2.f * (h.o[b] - h.V[b]) / (float)h.B;
+      for (int j = 0; j < h.FC; j++) if (h.hpre[(size_t)b * h.FC + j] > 0.f) s += dob * h.W2[j] * h.W1[(size_t)i * h.FC + j];
+    }
+    h.dyh[idx] = s;
+  }
+}
+// head BN backward (3 channels, single block): dzh[r][j], dgamma/dbeta [B][3][HW]
+__global__ void k_head_bn_bwd(TGeo g, const float* __restrict__ zh, const float* __restrict__ yh, const float* __restrict__ dyh,
+                              const float* __restrict__ hg, const float* __restrict__ mean, const float* __restrict__ inv,
+                              float* __restrict__ dhg, float* __restrict__ dhb, float* __restrict__ dzh) {
+  __shared__ double r1[256], r2[256];
+  for (int j = 0; j < 3; j++) {
+    double a1 = 0, a2 = 0;
+    for (int r = threadIdx.x; r < g.M; r += 256) {
+      int b = r / g.HW, p = r - b * g.HW;
+      size_t o = ((size_t)b * 3 + j) * g.HW + p;
+      float gg = yh[o] > 0.f ? dyh[o] : 0.f;
+      float xh = (zh[r * 3 + j] - mean[j]) * inv[j];
+      dhg[o] = gg * xh; dhb[o] = gg;
+      float dxh = gg * hg[o];
+      dzh[r * 3 + j] = dxh;
+      a1 += dxh; a2 += (double)dxh * xh;
+    }
+    r1[threadIdx.x] = a1; r2[threadIdx.x] = a2; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; } __syncthreads(); }
+    float s1 = (float)r1[0], s2 = (float)r2[0], m = (float)g.M; __syncthreads();
+    for (int r = threadIdx.x; r < g.M; r += 256) {
+      float xh = (zh[r * 3 + j] - mean[j]) * inv[j];
+      dzh[r * 3 + j] = inv[j] * (dzh[r * 3 + j] - s1 / m - xh * (s2 / m));
+    }
+    __syncthreads();
+  }
+}
+// head conv backward: dhc[j][c] = sum_r dzh[r][j]*x[pix(r)][c] ; dx[pix(r)][c] = sum_j dzh[r][j]*hc[j][c]
+__global__ void k_head_conv_bwd_w(TGeo g, const float* __restrict__ x, const float* __restrict__ dzh, float* __restrict__ dhc, int Kp,
+                                  int rows_per_block) {
+  int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, g.M);
+  for (int e = threadIdx.x; e < 3 * Kp; e += blockDim.x) {
+    int j = e / Kp, c = e - j * Kp;
+    float s = 0.f;
+    for (int r = r0; r < r1; r++) s += dzh[r * 3 + j] * x[pix_off(g, r) * Kp + c];
+    atomicAdd(&dhc[e], s);
+  }
+}
+__global__ void k_head_conv_bwd_x(TGeo g, const float* __restrict__ dzh, const float* __restrict__ hc, float* __restrict__ dx, int Kp) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)g.M * Kp) return;
+  int r = (int)(idx / Kp), c = (int)(idx - (size_t)r * Kp);
+  dx[pix_off(g, r) * Kp + c] = dzh[r * 3] * hc[c] + dzh[r * 3 + 1] * hc[Kp + c] + dzh[r * 3 + 2] * hc[2 * Kp + c];
+}
+
+}  // namespace agz
+
+using namespace agz;
+
+struct TLayer {
+  int Cin_p, Cout_p, nbr;
+  size_t o_wf, o_gamma, o_beta;   // offsets in the flat P / G buffers
+  float *wt = nullptr, *z = nullptr, *out = nullptr, *mean = nullptr, *inv = nullptr;
+};
+struct TParamRef { std::string name; int kind; std::vector<int> shape; int layer; int sub; };  // sub: 0 filter(a) 1 gamma 2 beta, for dual +10 = branch b
+
+struct agz_trainer {
+  agz_ctx* ctx = nullptr;
+  agz_net_conf conf{};
+  TGeo g{};
+  int K, Kp, Fp = 32, L, A, FC, B, F;
+  std::vector<TLayer> layers;          // 0 = init, 1..L = blocks
+  std::vector<TParamRef> prefs;        // reference Model() order
+  size_t n_flat = 0;
+  float *P = nullptr, *G = nullptr;    // flat learnables / gradients
+  // head offsets in flat
+  size_t o_hc, o_hg, o_hb, o_Wp, o_bp, o_W1, o_b1, o_W2, o_b2;
+  // work buffers
+  float *x0 = nullptr, *dA = nullptr, *dB = nullptr, *dz = nullptr, *dz0 = nullptr;
+  double* acc = nullptr;               // [2][1024] channel sums
+  float *zh = nullptr, *yh = nullptr, *dyh = nullptr, *dzh = nullptr, *hmean = nullptr, *hinv = nullptr;
+  float *logits = nullptr, *hpre = nullptr, *o = nullptr, *cost = nullptr;
+  float *d_planes = nullptr, *d_pi = nullptr, *d_v = nullptr;
+  std::vector<void*> allocs;
+  template <typename T> int alloc(T** p, size_t n) {
+    void* q = nullptr;
+    AGZ_HIP_TRY(hipMalloc(&q, n * sizeof(T)));
+    AGZ_HIP_TRY(hipMemsetAsync(q, 0, n * sizeof(T), ctx->stream));
+    allocs.push_back(q); *p = (T*)q; return AGZ_OK;
+  }
+  int forward_backward_dev(const float* planes_dev, const float* pi_dev, const float* v_dev);
+};
+
+static inline int nblk(size_t n, int bs = 256) { return (int)((n + bs - 1) / bs); }
+
+int agz_trainer::forward_backward_dev(const float* planes, const float* pi, const float* v) {
+  hipStream_t s = ctx->stream;
+  const int RPB = 64;
+  hipLaunchKernelGGL(k_pack_planes_t, dim3(nblk((size_t)g.M * Fp)), dim3(256), 0, s, planes, x0, g, F, Fp);
+  AGZ_HIP_TRY(hipMemsetAsync(G, 0, n_flat * sizeof(float), s));
+  // ---- forward, training-mode BN
+  const float* cur = x0;
+  for (int l = 0; l <= L; l++) {
+    TLayer& ly = layers[l];
+    int r = conv3x3_raw(ctx, cur, P + ly.o_wf, ly.z, B, g.H, g.W, ly.Cin_p, ly.Cout_p);
+    if (r != AGZ_OK) return r;
+    int C = ly.Cout_p;
+    hipLaunchKernelGGL(k_bn_sum, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, C, (const float*)nullptr, acc, RPB);
+    hipLaunchKernelGGL(k_bn_fin, dim3(nblk(C)), dim3(256), 0, s, acc, C, (double)g.M, conf.bn_eps, ly.mean, ly.inv, 0);
+    hipLaunchKernelGGL(k_bn_sum, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, C, (const float*)ly.mean, acc, RPB);
+    hipLaunchKernelGGL(k_bn_fin, dim3(nblk(C)), dim3(256), 0, s, acc, C, (double)g.M, conf.bn_eps, ly.mean, ly.inv, 1);
+    hipLaunchKernelGGL(k_bn_apply, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean,
+                       ly.inv, ly.out, Kp, ly.nbr);
+    cur = ly.out;
+  }
+  // ---- heads forward
+  HeadT h{};
+  h.B = B; h.HW = g.HW; h.A = A; h.FC = FC; h.yh = yh; h.Wp = P + o_Wp; h.bp = P + o_bp; h.W1 = P + o_W1; h.b1 = P + o_b1;
+  h.W2 = P + o_W2; h.b2 = P + o_b2; h.Pi = pi; h.V = v; h.logits = logits; h.hpre = hpre; h.o = o;
+  h.dWp = G + o_Wp; h.dbp = G + o_bp; h.dW1 = G + o_W1; h.db1 = G + o_b1; h.dW2 = G + o_W2; h.db2 = G + o_b2; h.dyh = dyh; h.cost = cost;
+  hipLaunchKernelGGL(k_head_conv, dim3(nblk((size_t)g.M * 3)), dim3(256), 0, s, g, cur, P + o_hc, zh, Kp);
+  hipLaunchKernelGGL(k_head_stats, dim3(1), dim3(256), 0, s, g, zh, conf.bn_eps, hmean, hinv);
+  hipLaunchKernelGGL(k_head_apply, dim3(nblk((size_t)g.M * 3)), dim3(256), 0, s, g, zh, P + o_hg, P + o_hb, hmean, hinv, yh);
+  hipLaunchKernelGGL(k_fc_fwd, dim3(nblk((size_t)B * A + (size_t)B * FC)), dim3(256), 0, s, h);
+  hipLaunchKernelGGL(k_value_out, dim3(nblk(B)), dim3(256), 0, s, h);
+  hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, s, h);
+  // ---- heads backward
+  size_t n_fc = (size_t)2 * g.HW * A + (size_t)B * A + (size_t)g.HW * FC + (size_t)B * FC + FC + B + (size_t)B * 3 * g.HW;
+  hipLaunchKernelGGL(k_fc_bwd, dim3(nblk(n_fc)), dim3(256), 0, s, h);
+  hipLaunchKernelGGL(k_head_bn_bwd, dim3(1), dim3(256), 0, s, g, zh, yh, dyh, P + o_hg, hmean, hinv, G + o_hg, G + o_hb, dzh);
+  hipLaunchKernelGGL(k_head_conv_bwd_w, dim3(nblk(g.M, RPB)), dim3(256), 0, s, g, cur, dzh, G + o_hc, Kp, RPB);
+  float* dcur = dA;
+  float* dnext = dB;
+  hipLaunchKernelGGL(k_head_conv_bwd_x, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, dzh, P + o_hc, dcur, Kp);
+  // ---- tower backward
+  for (int l = L; l >= 0; l--) {
+    TLayer& ly = layers[l];
+    int C = ly.Cout_p;
+    const float* xin = l == 0 ? x0 : layers[l - 1].out;
+    double* s1 = acc; double* s2 = acc + 1024;
+    float* dz = l == 0 ? this->dz0 : this->dz;  // (different pixel strides: keep the [pix][2Kp] buffer's zero halo intact)
+    hipLaunchKernelGGL(k_bn_bwd1, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean, ly.inv,
+                       ly.out, dcur, G + ly.o_gamma, G + ly.o_beta, dz, s1, s2, Kp, ly.nbr, RPB);
+    hipLaunchKernelGGL(k_bn_bwd2, dim3(nblk((size_t)g.M * C)), dim3(256), 0, s, g, ly.z, ly.mean, ly.inv, dz, s1, s2, C);
+    AGZ_HIP_TRY(hipMemsetAsync(acc, 0, 2048 * sizeof(double), s));
+    // weight gradient
+    WgArgs wa{};
+    wa.dz = dz; wa.x = xin; wa.dw = G + ly.o_wf; wa.g = g; wa.N = C; wa.Cin = ly.Cin_p; wa.rows_per_block = 2048;
+    wa.n_tiles = ceil_div(C, 128); wa.c_tiles = ceil_div(ly.Cin_p, 128);
+    int chunks = ceil_div(g.M, wa.rows_per_block);
+    hipLaunchKernelGGL(k_wgrad, dim3(wa.n_tiles * wa.c_tiles * 9 * chunks), dim3(256), 0, s, wa);
+    if (l > 0) {  // data gradient: the forward GEMM with flipped/transposed weights over the [a|b] channels of dz
+      hipLaunchKernelGGL(k_make_wt, dim3(nblk((size_t)9 * C * ly.Cin_p)), dim3(256), 0, s, P + ly.o_wf, ly.wt, C, ly.Cin_p);
+      int r = conv3x3_raw(ctx, dz, ly.wt, dnext, B, g.H, g.W, C, ly.Cin_p);
+      if (r != AGZ_OK) return r;
+      std::swap(dcur, dnext);
+    }
+  }
+  AGZ_HIP_TRY(hipGetLastError());
+  return AGZ_OK;
+}
+
+extern "C" {
+
+int agz_trainer_create(agz_ctx* ctx, const agz_net_conf* c, agz_trainer** out) {
+  AGZ_REQUIRE(ctx && c && out, AGZ_E_INVALID, "agz_trainer_create: NULL argument");
+  AGZ_REQUIRE(c->K >= 1 && c->ActionSpace >= 3 && c->SharedLayers >= 0 && c->FC > 1 && c->BatchSize >= 1 && c->Features > 0,
+              AGZ_E_INVALID, "agz_trainer_create: NNConf is not valid");
+  AGZ_REQUIRE(c->Features <= 32, AGZ_E_UNSUPPORTED, "Features > 32 unsupported");
+  AGZ_HIP_TRY(hipSetDevice(ctx->device));
+  agz_trainer* t = new agz_trainer();
+  t->ctx = ctx; t->conf = *c;
+  t->K = c->K; t->Kp = round_up(c->K, 32); t->L = c->SharedLayers; t->A = c->ActionSpace; t->FC = c->FC; t->B = c->BatchSize; t->F = c->Features;
+  AGZ_REQUIRE(2 * t->Kp <= 1024, AGZ_E_UNSUPPORTED, "K > 512 unsupported by the trainer");
+  TGeo& g = t->g;
+  g.B = t->B; g.H = c->Height; g.W = c->Width; g.HW = g.H * g.W; g.Hp = g.H + 2; g.Wp = g.W + 2; g.M = g.B * g.HW;
+  const int K = t->K, Kp = t->Kp, HW = g.HW, B = t->B, H = g.H, W = g.W, A = t->A, FCn = t->FC, F = t->F;
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += (n + 3) & ~(size_t)3; return o; };
+  t->layers.resize(t->L + 1);
+  for (int l = 0; l <= t->L; l++) {
+    TLayer& ly = t->layers[l];
+    ly.nbr = l == 0 ? 1 : 2; ly.Cin_p = l == 0 ? t->Fp : Kp; ly.Cout_p = ly.nbr * Kp;
+    ly.o_wf = take((size_t)9 * ly.Cout_p * ly.Cin_p);
+    ly.o_gamma = take((size_t)g.M * ly.Cout_p);
+    ly.o_beta = take((size_t)g.M * ly.Cout_p);
+  }
+  t->o_hc = take((size_t)3 * Kp); t->o_hg = take((size_t)B * 3 * HW); t->o_hb = take((size_t)B * 3 * HW);
+  t->o_Wp = take((size_t)2 * HW * A); t->o_bp = take((size_t)B * A); t->o_W1 = take((size_t)HW * FCn); t->o_b1 = take((size_t)B * FCn);
+  t->o_W2 = take(FCn); t->o_b2 = take(B);
+  t->n_flat = off;
+  // reference Model() order (include/agz.h)
+  auto pr = [&](const std::string& nm, int kind, std::vector<int> shp, int layer, int sub) { t->prefs.push_back(TParamRef{nm, kind, shp, layer, sub}); };
+  pr("FilterInit", 0, {K, F, 3, 3}, 0, 0); pr("Init_gamma", 1, {B, K, H, W}, 0, 1); pr("Init_beta", 1, {B, K, H, W}, 0, 2);
+  for (int i = 0; i < t->L; i++) {
+    std::string s = std::to_string(i);
+    pr("FilterLayer1 of Shared Layer " + s, 0, {K, K, 3, 3}, i + 1, 0); pr("L1_" + s + "_gamma", 1, {B, K, H, W}, i + 1, 1); pr("L1_" + s + "_beta", 1, {B, K, H, W}, i + 1, 2);
+    pr("FilterLayer2 of Shared Layer " + s, 0, {K, K, 3, 3}, i + 1, 10); pr("L2_" + s + "_gamma", 1, {B, K, H, W}, i + 1, 11); pr("L2_" + s + "_beta", 1, {B, K, H, W}, i + 1, 12);
+  }
+  pr("FilterPolicyHead", 0, {2, K, 1, 1}, -1, 0); pr("PolicyHead_gamma", 1, {B, 2, H, W}, -1, 1); pr("PolicyHead_beta", 1, {B, 2, H, W}, -1, 2);
+  pr("Policy_w", 2, {2 * HW, A}, -1, 3); pr("Policy_b", 3, {B, A}, -1, 4);
+  pr("FilterValueHead", 0, {1, K, 1, 1}, -2, 0); pr("ValueHead_gamma", 1, {B, 1, H, W}, -2, 1); pr("ValueHead_beta", 1, {B, 1, H, W}, -2, 2);
+  pr("Value_w", 2, {HW, FCn}, -2, 3); pr("Value_b", 3, {B, FCn}, -2, 4);
+  pr("ValueOutput_w", 2, {FCn, 1}, -2, 5); pr("ValueOutput_b", 3, {B, 1}, -2, 6);
+  int r = AGZ_OK;
+#define TAL(p, n) if ((r = t->alloc(&t->p, (size_t)(n))) != AGZ_OK) { agz_trainer_destroy(t); return r; }
+  TAL(P, t->n_flat) TAL(G, t->n_flat)
+  size_t px = (size_t)B * g.Hp * g.Wp;
+  TAL(x0, px * t->Fp) TAL(dA, px * Kp) TAL(dB, px * Kp) TAL(dz, px * 2 * Kp) TAL(dz0, px * Kp) TAL(acc, 2048)
+  for (int l = 0; l <= t->L; l++) {
+    TLayer& ly = t->layers[l];
+    if ((r = t->alloc(&ly.z, px * ly.Cout_p)) != AGZ_OK || (r = t->alloc(&ly.out, px * Kp)) != AGZ_OK ||
+        (r = t->alloc(&ly.mean, (size_t)ly.Cout_p)) != AGZ_OK || (r = t->alloc(&ly.inv, (size_t)ly.Cout_p)) != AGZ_OK ||
+        (r = t->alloc(&ly.wt, (size_t)9 * ly.Cout_p * ly.Cin_p)) != AGZ_OK) { agz_trainer_destroy(t); return r; }
+  }
+  TAL(zh, (size_t)g.M * 3) TAL(yh, (size_t)g.M * 3) TAL(dyh, (size_t)g.M * 3) TAL(dzh, (size_t)g.M * 3) TAL(hmean, 4) TAL(hinv, 4)
+  TAL(logits, (size_t)B * A) TAL(hpre, (size_t)B * FCn) TAL(o, B) TAL(cost, 2)
+  TAL(d_planes, (size_t)B * F * HW) TAL(d_pi, (size_t)B * A) TAL(d_v, B)
+#undef TAL
+  AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *out = t;
+  return AGZ_OK;
+}
+
+void agz_trainer_destroy(agz_trainer* t) {
+  if (!t) return;
+  hipSetDevice(t->ctx->device);
+  hipStreamSynchronize(t->ctx->stream);
+  for (void* p : t->allocs) hipFree(p);
+  delete t;
+}
+
+int agz_trainer_num_params(const agz_trainer* t) { return t ? (int)t->prefs.size() : 0; }
+
+static size_t pref_size(const TParamRef& p) { size_t n = 1; for (int d : p.shape) n *= (size_t)d; return n; }
+
+int agz_trainer_param_info(const agz_trainer* t, int i, char* name, size_t cap, size_t* n) {
+  AGZ_REQUIRE(t && i >= 0 && i < (int)t->prefs.size(), AGZ_E_INVALID, "agz_trainer_param_info: bad index");
+  if (name && cap) { strncpy(name, t->prefs[i].name.c_str(), cap - 1); name[cap - 1] = 0; }
+  if (n) *n = pref_size(t->prefs[i]);
+  return AGZ_OK;
+}
+
+// reference layout <-> device layout for parameter i of flat buffer `buf` (P or G). dir 0: host -> device, 1: device -> host
+static int xfer_param(const agz_trainer* t, float* buf, int i, float* host, int dir) {
+  const TParamRef& p = t->prefs[i];
+  const int K = t->K, Kp = t->Kp, HW = t->g.HW, B = t->B, A = t->A, FCn = t->FC, F = t->F, Fp = t->Fp;
+  hipStream_t s = t->ctx->stream;
+  auto dev_rw = [&](size_t off, std::vector<float>& tmp) -> int {
+    if (dir == 0) AGZ_HIP_TRY(hipMemcpyAsync(buf + off, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, s));
+    else AGZ_HIP_TRY(hipMemcpyAsync(tmp.data(), buf + off, tmp.size() * 4, hipMemcpyDeviceToHost, s));
+    AGZ_HIP_TRY(hipStreamSynchronize(s));
+    return AGZ_OK;
+  };
+  if (p.layer >= 0) {
+    const TLayer& ly = t->layers[p.layer];
+    int br = p.sub >= 10 ? 1 : 0, sub = p.sub % 10;
+    int Cin = p.layer == 0 ? F : K, Cin_p = ly.Cin_p, C = ly.Cout_p;
+    if (sub == 0) {  // filter [K][Cin][3][3] <-> wf[tap][br*Kp + o][ci]
+      std::vector<float> tmp((size_t)9 * C * Cin_p);
+      if (hipMemcpy(tmp.data(), buf + ly.o_wf, tmp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { agz::set_error("xfer: D2H failed"); return AGZ_E_HIP; }
+      for (int o = 0; o < K; o++) for (int ci = 0; ci < Cin; ci++) for (int tp = 0; tp < 9; tp++) {
+        size_t di = ((size_t)tp * C + br * Kp + o) * Cin_p + ci, hi = ((size_t)o * Cin + ci) * 9 + tp;
+        if (dir == 0) tmp[di] = host[hi]; else host[hi] = tmp[di];
+      }
+      if (dir == 0) return dev_rw(ly.o_wf, tmp);
+      return AGZ_OK;
+    }
+    // gamma/beta [B][K][H][W] <-> [r = b*HW+p][br*Kp + c]
+    size_t off = sub == 1 ? ly.o_gamma : ly.o_beta;
+    std::vector<float> tmp((size_t)t->g.M * C);
+    if (hipMemcpy(tmp.data(), buf + off, tmp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { agz::set_error("xfer: D2H failed"); return AGZ_E_HIP; }
+    for (int b = 0; b < B; b++) for (int c = 0; c < K; c++) for (int q = 0; q < HW; q++) {
+      size_t di = ((size_t)b * HW + q) * C + br * Kp + c, hi = ((size_t)b * K + c) * HW + q;
+      if (dir == 0) tmp[di] = host[hi]; else host[hi] = tmp[di];
+    }
+    if (dir == 0) return dev_rw(off, tmp);
+    return AGZ_OK;
+  }
+  // heads
+  const bool pol = p.layer == -1;
+  auto plain = [&](size_t off, size_t n) -> int {
+    if (dir == 0) AGZ_HIP_TRY(hipMemcpy(buf + off, host, n * 4, hipMemcpyHostToDevice));
+    else AGZ_HIP_TRY(hipMemcpy(host, buf + off, n * 4, hipMemcpyDeviceToHost));
+    return AGZ_OK;
+  };
+  if (p.sub == 0) {  // 1x1 filter [nc][K] <-> hc[j][Kp]
+    int nc = pol ? 2 : 1, j0 = pol ? 0 : 2;
+    std::vector<float> tmp((size_t)3 * Kp);
+    AGZ_HIP_TRY(hipMemcpy(tmp.data(), buf + t->o_hc, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (int j = 0; j < nc; j++) for (int c = 0; c < K; c++) { if (dir == 0) tmp[(size_t)(j0 + j) * Kp + c] = host[(size_t)j * K + c]; else host[(size_t)j * K + c] = tmp[(size_t)(j0 + j) * Kp + c]; }
+    if (dir == 0) AGZ_HIP_TRY(hipMemcpy(buf + t->o_hc, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+    return AGZ_OK;
+  }
+  if (p.sub == 1 || p.sub == 2) {  // head gamma/beta [B][nc][HW] <-> [B][3][HW]
+    int nc = pol ? 2 : 1, j0 = pol ? 0 : 2;
+    size_t off = p.sub == 1 ? t->o_hg : t->o_hb;
+    std::vector<float> tmp((size_t)B * 3 * HW);
+    AGZ_HIP_TRY(hipMemcpy(tmp.data(), buf + off, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; b++) for (int j = 0; j < nc; j++) for (int q = 0; q < HW; q++) {
+      size_t di = ((size_t)b * 3 + j0 + j) * HW + q, hi = ((size_t)b * nc + j) * HW + q;
+      if (dir == 0) tmp[di] = host[hi]; else host[hi] = tmp[di];
+    }
+    if (dir == 0) AGZ_HIP_TRY(hipMemcpy(buf + off, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+    return AGZ_OK;
+  }
+  if (pol) return p.sub == 3 ? plain(t->o_Wp, (size_t)2 * HW * A) : plain(t->o_bp, (size_t)B * A);
+  switch (p.sub) {
+    case 3: return plain(t->o_W1, (size_t)HW * FCn);
+    case 4: return plain(t->o_b1, (size_t)B * FCn);
+    case 5: return plain(t->o_W2, FCn);
+    default: return plain(t->o_b2, B);
+  }
+  (void)Fp;
+}
+
+int agz_trainer_set_param(agz_trainer* t, int i, const float* host, size_t n) {
+  AGZ_REQUIRE(t && host && i >= 0 && i < (int)t->prefs.size(), AGZ_E_INVALID, "agz_trainer_set_param: bad argument");
+  AGZ_REQUIRE(n == pref_size(t->prefs[i]), AGZ_E_INVALID, "agz_trainer_set_param(%s): need %zu floats, got %zu", t->prefs[i].name.c_str(), pref_size(t->prefs[i]), n);
+  AGZ_HIP_TRY(hipSetDevice(t->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+  return xfer_param(t, t->P, i, const_cast<float*>(host), 0);
+}
+int agz_trainer_get_param(const agz_trainer* t, int i, float* host, size_t n) {
+  AGZ_REQUIRE(t && host && i >= 0 && i < (int)t->prefs.size() && n >= pref_size(t->prefs[i]), AGZ_E_INVALID, "agz_trainer_get_param: bad argument");
+  AGZ_HIP_TRY(hipSetDevice(t->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+  return xfer_param(t, t->P, i, host, 1);
+}
+int agz_trainer_get_grad(const agz_trainer* t, int i, float* host, size_t n) {
+  AGZ_REQUIRE(t && host && i >= 0 && i < (int)t->prefs.size() && n >= pref_size(t->prefs[i]), AGZ_E_INVALID, "agz_trainer_get_grad: bad argument");
+  AGZ_HIP_TRY(hipSetDevice(t->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+  return xfer_param(t, t->G, i, host, 1);
+}
+
+int agz_trainer_init_random(agz_trainer* t, uint64_t seed) {  // same recipe as agz_net_init_random over the FULL shapes
+  AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
+  SplitMix64 r(seed);
+  for (int i = 0; i < (int)t->prefs.size(); i++) {
+    const TParamRef& p = t->prefs[i];
+    std::vector<float> v(pref_size(p));
+    double field = 1; for (size_t k = 2; k < p.shape.size(); k++) field *= p.shape[k];
+    double stdev = std::sqrt(2.0 / ((double)(p.shape[0] + p.shape[1]) * field));
+    if (p.kind == 0) { double lim = stdev * std::sqrt(3.0); for (float& x : v) x = (float)((r.float64() * 2.0 - 1.0) * lim); }
+    else if (p.kind == 1 || p.kind == 2) {
+      for (size_t k = 0; k < v.size(); k += 2) {
+        double u1 = 1.0 - r.float64(), u2 = r.float64();
+        double rad = std::sqrt(-2.0 * std::log(u1)), th = 6.283185307179586476925 * u2;
+        v[k] = (float)(rad * std::cos(th) * stdev);
+        if (k + 1 < v.size()) v[k + 1] = (float)(rad * std::sin(th) * stdev);
+      }
+    }
+    int rc = agz_trainer_set_param(t, i, v.data(), v.size());
+    if (rc != AGZ_OK) return rc;
+  }
+  return AGZ_OK;
+}
+
+int agz_trainer_forward_backward(agz_trainer* t, const float* planes, const float* pi, const float* v, float* cost) {
+  AGZ_REQUIRE(t && planes && pi && v, AGZ_E_INVALID, "agz_trainer_forward_backward: NULL argument");
+  AGZ_HIP_TRY(hipSetDevice(t->ctx->device));
+  hipStream_t s = t->ctx->stream;
+  AGZ_HIP_TRY(hipMemcpyAsync(t->d_planes, planes, (size_t)t->B * t->F * t->g.HW * 4, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(t->d_pi, pi, (size_t)t->B * t->A * 4, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(t->d_v, v, (size_t)t->B * 4, hipMemcpyHostToDevice, s));
+  int r = t->forward_backward_dev(t->d_planes, t->d_pi, t->d_v);
+  if (r != AGZ_OK) return r;
+  float c[2] = {0, 0};
+  AGZ_HIP_TRY(hipMemcpyAsync(c, t->cost, 8, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  if (cost) *cost = c[0] + c[1];
+  return AGZ_OK;
+}
+
+int agz_trainer_apply(agz_trainer* t, float lr, float grad_scale) {  // solver.Step (meta.go:40): w -= lr * grad
+  AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
+  AGZ_HIP_TRY(hipSetDevice(t->ctx->device));
+  hipLaunchKernelGGL(k_axpy, dim3(nblk(t->n_flat)), dim3(256), 0, t->ctx->stream, t->P, t->G, -lr * grad_scale, t->n_flat);
+  AGZ_HIP_TRY(hipGetLastError());
+  return AGZ_OK;
+}
+
+int agz_trainer_batch(agz_trainer* t, const float* planes, const float* pi, const float* v, float lr, float* cost) {
+  int r = agz_trainer_forward_backward(t, planes, pi, v, cost);
+  if (r != AGZ_OK) return r;
+  r = agz_trainer_apply(t, lr, 1.0f);
+  if (r != AGZ_OK) return r;
+  AGZ_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+  return AGZ_OK;
+}
+
+int agz_trainer_grads_dev(agz_trainer* t, float** dev_ptr, size_t* n_floats) {
+  AGZ_REQUIRE(t && dev_ptr && n_floats, AGZ_E_INVALID, "NULL argument");
+  *dev_ptr = t->G; *n_floats = t->n_flat;
+  return AGZ_OK;
+}
+
+// dual.Train (dualnet/meta.go:16-54): iterations x batches of BatchSize rows; shuffleBatch (meta.go:57-102) after every
+// iteration with the build's SplitMix64 (Fisher-Yates j = r.Intn(i+1) pattern).  Xs/policies/values are shuffled IN PLACE
+// like the reference does.
+int agz_train(agz_trainer* t, float* Xs, float* policies, float* values, int batches, int iterations, uint64_t seed, float* last_cost) {
+  AGZ_REQUIRE(t && Xs && policies && values && batches >= 1 && iterations >= 0, AGZ_E_INVALID, "agz_train: bad argument");
+  const size_t xs = (size_t)t->F * t->g.HW, ps = (size_t)t->A;
+  const size_t n = (size_t)batches * t->B;
+  SplitMix64 rng(seed);
+  std::vector<float> tmp(std::max(xs, ps));
+  float c = 0;
+  for (int it = 0; it < iterations; it++) {
+    for (int b = 0; b < batches; b++) {
+      size_t s0 = (size_t)b * t->B;
+      int r = agz_trainer_batch(t, Xs + s0 * xs, policies + s0 * ps, values + s0, 0.1f, &c);
+      if (r != AGZ_OK) return r;
+    }
+    for (size_t i = 0; i < n; i++) {
+      size_t j = (size_t)(rng.next() % (uint64_t)(i + 1));
+      if (j == i) continue;
+      memcpy(tmp.data(), Xs + i * xs, xs * 4); memcpy(Xs + i * xs, Xs + j * xs, xs * 4); memcpy(Xs + j * xs, tmp.data(), xs * 4);
+      memcpy(tmp.data(), policies + i * ps, ps * 4); memcpy(policies + i * ps, policies + j * ps, ps * 4); memcpy(policies + j * ps, tmp.data(), ps * 4);
+      std::swap(values[i], values[j]);
+    }
+  }
+  if (last_cost) *last_cost = c;
+  return AGZ_OK;
+}
+
+// the copy loop of dual.Infer (meta.go:141-146): row 0 of every learnable -> the inference net, then commit
+int agz_trainer_export(const agz_trainer* t, agz_net* net) {
+  AGZ_REQUIRE(t && net, AGZ_E_INVALID, "NULL argument");
+  AGZ_REQUIRE((int)t->prefs.size() == agz_net_num_params(net), AGZ_E_INVALID, "agz_trainer_export: network shapes differ");
+  for (int i = 0; i < (int)t->prefs.size(); i++) {
+    std::vector<float> v(pref_size(t->prefs[i]));
+    int r = agz_trainer_get_param(t, i, v.data(), v.size());
+    if (r != AGZ_OK) return r;
+    size_t want = 0;
+    r = agz_net_param_info(net, i, nullptr, 0, &want);
+    if (r != AGZ_OK) return r;
+    AGZ_REQUIRE(v.size() >= want, AGZ_E_INVALID, "agz_trainer_export: parameter %d too small", i);
+    r = agz_net_set_param(net, i, v.data(), v.size());  // takes row 0 of batch-shaped tensors
+    if (r != AGZ_OK) return r;
+  }
+  return agz_net_commit(net);
+}
+
+}  // extern "C"

@@ -127,6 +127,34 @@ int agz_net_load(agz_net* net, const char* path);
 /* FLOPs of one evaluation (SURVEY App. D formula) */
 double agz_net_flops_per_eval(const agz_net* net);
 
+/* ---- dual.Train ---------------------------------------------------------------------- */
+typedef struct agz_trainer agz_trainer;
+/* The training graph of Dual.fwd + Dual.bwd (dualnet/dual.go:50-132) for conf->BatchSize rows.  Learnables keep the
+ * reference's FULL shapes in Model() order: conv filter [out,in,k,k]; BN gamma/beta [B,C,H,W]; FC w [in,units];
+ * FC b [B,units]  (batch-shaped).  BatchNorm runs in training mode (batch statistics). */
+int agz_trainer_create(agz_ctx* ctx, const agz_net_conf* conf, agz_trainer** out);
+void agz_trainer_destroy(agz_trainer* t);
+int agz_trainer_num_params(const agz_trainer* t);
+int agz_trainer_param_info(const agz_trainer* t, int index, char* name, size_t name_cap, size_t* n_elems);
+int agz_trainer_set_param(agz_trainer* t, int index, const float* host, size_t n);
+int agz_trainer_get_param(const agz_trainer* t, int index, float* host, size_t n);
+int agz_trainer_get_grad(const agz_trainer* t, int index, float* host, size_t n);
+int agz_trainer_init_random(agz_trainer* t, uint64_t seed);
+/* One batch of dual.Train's inner loop (dualnet/meta.go:33-40): Let planes/Pi/V, RunAll, solver.Step(lr).
+ * planes [B,F,H,W], pi [B,ActionSpace], v [B] host buffers; *cost = xent(logits,Pi) + mean((o-V)^2) (dual.go:113-121). */
+int agz_trainer_batch(agz_trainer* t, const float* planes, const float* pi, const float* v, float lr, float* cost);
+/* Split form for data-parallel training: forward_backward fills the flat gradient buffer; all-reduce it over RCCL
+ * (agz_trainer_grads_dev gives the device pointer: ONE collective per step); apply does w -= lr*grad_scale*grad. */
+int agz_trainer_forward_backward(agz_trainer* t, const float* planes, const float* pi, const float* v, float* cost);
+int agz_trainer_apply(agz_trainer* t, float lr, float grad_scale);
+int agz_trainer_grads_dev(agz_trainer* t, float** dev_ptr, size_t* n_floats);
+/* dual.Train(d, Xs, policies, values, batches, iterations) (dualnet/meta.go:16-54): lr 0.1 vanilla SGD, shuffleBatch
+ * after every iteration (build RNG; Xs/policies/values are shuffled in place like the reference). */
+int agz_train(agz_trainer* t, float* Xs, float* policies, float* values, int batches, int iterations, uint64_t seed,
+              float* last_cost);
+/* dual.Infer's copy loop (dualnet/meta.go:141-146): row 0 of every learnable -> the inference net; commits it. */
+int agz_trainer_export(const agz_trainer* t, agz_net* net);
+
 /* ---- batched self-play arenas: game.State + mcts.MCTS + agogo.Arena on device ---------------- */
 #define AGZ_GAME_MNK 0  /* game/mnk  (m,n,k) */
 #define AGZ_GAME_C4 1   /* game/c4   (rows=m, cols=n, k in a row) */

@@ -1,0 +1,115 @@
+"""GPU parity: dual.Train on device (agz_trainer_*) vs the oracle restatement (oracle/train.hpp).
+
+Tolerance (fp32 both sides, different summation orders, float atomics in the weight gradient): gradients
+|d - o| <= 2e-5 * max|o| + 1e-7 per tensor; cost 1e-5 relative; parameters after three SGD steps |d - o| <= 1e-4 * max|o| per tensor.
+The oracle's backward itself is pinned by a finite-difference check in double (tests/test_oracle_train.py)."""
+import numpy as np
+import pytest
+
+import agogo_amd as A
+import oracle_lib as O
+from agogo_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(ctx, K, L, FC, W, H, F, Aspace, B, seed=5):
+    ot = O.TrainNet(K, L, FC, W, H, F, Aspace, B)
+    ot.init_random(seed)
+    rng = np.random.default_rng(seed)
+    for i in range(ot.num_params()):
+        nm = ot.param_name(i)
+        p = ot.get_param(i)
+        if nm.endswith("_gamma"):
+            p = rng.uniform(0.5, 1.5, p.size).astype(np.float32)
+        elif nm.endswith("_beta") or nm.endswith("_b"):
+            p = rng.normal(0, 0.1, p.size).astype(np.float32)
+        else:
+            p = (p * 3.0).astype(np.float32)
+        ot.set_param(i, p)
+    dt = A.Trainer(ctx, K, L, FC, W, H, F, Aspace, B)
+    assert dt.num_params() == ot.num_params()
+    for i in range(ot.num_params()):
+        name, n = dt.param_info(i)
+        assert n == ot.get_param(i).size, (name, ot.param_name(i))
+        dt.set_param(i, ot.get_param(i))
+        np.testing.assert_array_equal(dt.get_param(i), ot.get_param(i))  # layout round trip
+    return ot, dt
+
+
+def batch_data(B, F, H, W, Aspace, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.choice(np.array([-1.0, 0.0, 1.0, 0.001], np.float32), size=(B, F, H, W)).astype(np.float32)
+    pi = np.zeros((B, Aspace), np.float32)
+    pi[np.arange(B), rng.integers(0, Aspace, B)] = 1.0
+    v = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), size=B).astype(np.float32)
+    return x, pi, v
+
+
+CASES = [
+    # K, L, FC, W, H, F, A, B
+    (32, 1, 16, 3, 3, 2, 10, 4),      # tic-tac-toe shaped
+    (32, 2, 64, 5, 5, 2, 26, 6),
+    (64, 2, 64, 7, 6, 2, 8, 5),       # connect-4 shaped, K=64 (cfg0 conv kernels), non-square
+    (128, 1, 64, 9, 9, 18, 82, 3),    # 9x9 go shaped
+]
+
+
+@pytest.mark.parametrize("K,L,FC,W,H,F,Aspace,B", CASES)
+def test_forward_backward_matches_oracle(ctx, K, L, FC, W, H, F, Aspace, B):
+    ot, dt = make_pair(ctx, K, L, FC, W, H, F, Aspace, B)
+    x, pi, v = batch_data(B, F, H, W, Aspace, seed=K + B)
+    co = ot.batch(x, pi, v, lr=0.0)
+    cd = dt.forward_backward(x, pi, v)
+    assert abs(cd - co) <= 1e-5 * max(1.0, abs(co)), (cd, co)
+    for i in range(ot.num_params()):
+        go, gd = ot.get_grad(i), dt.get_grad(i)
+        scale = float(np.abs(go).max())
+        err = float(np.abs(gd - go).max())
+        assert err <= 2e-5 * scale + 1e-7, (ot.param_name(i), err, scale)
+    # the gradient is not trivially zero
+    assert any(np.abs(ot.get_grad(i)).max() > 1e-6 for i in range(ot.num_params()))
+
+
+def test_sgd_steps_and_export(ctx):
+    """three dual.Train inner-loop steps (meta.go:33-40, lr 0.1), then dual.Infer's row-0 copy into an inference net."""
+    K, L, FC, W, H, F, Aspace, B = 32, 2, 32, 5, 5, 2, 26, 4
+    ot, dt = make_pair(ctx, K, L, FC, W, H, F, Aspace, B, seed=9)
+    costs = []
+    for step in range(3):
+        x, pi, v = batch_data(B, F, H, W, Aspace, seed=100 + step)
+        co = ot.batch(x, pi, v, lr=0.1)
+        cd = dt.batch(x, pi, v, lr=0.1)
+        assert abs(cd - co) <= 2e-5 * max(1.0, abs(co))
+        costs.append(cd)
+    for i in range(ot.num_params()):
+        po, pd = ot.get_param(i), dt.get_param(i)
+        scale = float(np.abs(po).max())
+        assert float(np.abs(pd - po).max()) <= 1e-4 * scale + 1e-7, ot.param_name(i)
+    # export: inference on row-0 parameters equals the oracle inference net built from row 0
+    net = A.Net(ctx, K, L, FC, W, H, F, Aspace, bn_mode=capi.BN_DEGENERATE_EPS)
+    dt.export(net)
+    onet = O.Net(K, L, FC, W, H, F, Aspace, bn_mode=0)
+    for i in range(onet.num_params()):
+        full = ot.get_param(i)
+        onet.set_param(i, full[: onet.get_param(i).size])
+        scale = float(np.abs(onet.get_param(i)).max())
+        assert float(np.abs(net.get_param(i) - onet.get_param(i)).max()) <= 1e-4 * scale + 1e-7
+    x = batch_data(3, F, H, W, Aspace, seed=7)[0]
+    pg, vg = net.infer(x)
+    assert np.all(np.isfinite(pg)) and np.all(np.isfinite(vg))
+
+
+def test_agz_train_loop_runs_and_shuffles(ctx):
+    """dual.Train(d, Xs, policies, values, batches, iterations): iterations x batches steps + shuffleBatch."""
+    K, L, FC, W, H, F, Aspace, B = 32, 1, 16, 3, 3, 2, 10, 8
+    dt = A.Trainer(ctx, K, L, FC, W, H, F, Aspace, B)
+    dt.init_random(3)
+    batches = 3
+    x, pi, v = batch_data(B * batches, F, H, W, Aspace, seed=1)
+    x0 = x.copy()
+    p_before = dt.get_param(0).copy()
+    cost = dt.train(x.reshape(B * batches, -1), pi, v, batches, 2, seed=11)
+    assert np.isfinite(cost)
+    assert not np.array_equal(dt.get_param(0), p_before)
+    assert not np.array_equal(x, x0) and np.array_equal(np.sort(x.reshape(B * batches, -1), axis=0), np.sort(x0.reshape(B * batches, -1), axis=0))
