@@ -69,3 +69,23 @@ def shard_games(total_games, rank, world):
     lo = rank * per + min(rank, extra)
     hi = lo + per + (1 if rank < extra else 0)
     return lo, hi
+
+
+def allreduce_gradients(trainer, local_device, group=None):
+    """Data-parallel dual.Train: ONE all-reduce over the trainer's flat gradient buffer (all learnables of
+    the network in one contiguous device buffer), in place.  With RCCL (backend nccl) the device buffer is reduced
+    directly over xGMI; with gloo (CPU test rigs) it is staged through host memory.  Returns the world size; follow with
+    trainer.apply(lr, grad_scale=1/world) for gradient averaging."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 1
+    world = dist.get_world_size(group)
+    ptr, n = trainer.grads_dev()
+    g = device_tensor(ptr, (n,), torch.device("cuda", local_device))
+    if dist.get_backend(group) == "gloo":
+        h = g.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        g.copy_(h)
+    else:
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    torch.cuda.synchronize()
+    return world

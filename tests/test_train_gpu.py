@@ -113,3 +113,17 @@ def test_agz_train_loop_runs_and_shuffles(ctx):
     assert np.isfinite(cost)
     assert not np.array_equal(dt.get_param(0), p_before)
     assert not np.array_equal(x, x0) and np.array_equal(np.sort(x.reshape(B * batches, -1), axis=0), np.sort(x0.reshape(B * batches, -1), axis=0))
+
+
+def test_data_parallel_step_two_ranks(ctx):
+    """C2: two ranks, rank-specific batches, ONE all-reduce over the flat gradient buffer, averaged SGD step
+    == single-process average.  Both ranks share GPU 0 here (gloo); on a multi-GPU node the same code runs over RCCL."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29577", os.path.join(root, "scripts", "dp_train_check.py"), "--shared-gpu"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert "DP_TRAIN_CHECK OK world 2" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
