@@ -5,6 +5,7 @@
 // Errors: the reference returns `error` or panics; here agz::Error is thrown with agz_last_error().
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -71,6 +72,29 @@ struct Inferencer {
     agz::check(agz_net_infer(d.h, planes.data(), B, policy->data(), value->data()), "Inferencer.Infer");
   }
 };
+// The trainable side of dual.Dual: learnables in their FULL (batch-shaped) form + dual.Train (dualnet/meta.go:16-54)
+struct Trainable {
+  Config conf;
+  agz_trainer* h = nullptr;
+  Trainable(agz::Ctx& ctx, const Config& c) : conf(c) {
+    if (!c.IsValid()) throw agz::Error("NNConf is not valid. Unable to proceed");
+    agz_net_conf nc{c.K, c.SharedLayers, c.FC, c.BatchSize, c.Width, c.Height, c.Features, c.ActionSpace, AGZ_BN_DEGENERATE_EPS, 1e-5f};
+    agz::check(agz_trainer_create(ctx.h, &nc, &h), "dual.New");
+  }
+  ~Trainable() { agz_trainer_destroy(h); }
+  Trainable(const Trainable&) = delete;
+  Trainable& operator=(const Trainable&) = delete;
+  void Init(uint64_t seed) { agz::check(agz_trainer_init_random(h, seed), "Dual.Init"); }
+  // dual.Infer (meta.go:125-162): copy row 0 of every learnable into an inference net
+  void SwitchToInference(Dual& inf) const { agz::check(agz_trainer_export(h, inf.h), "SwitchToInference"); }
+};
+// dual.Train(d, Xs, policies, values, batches, iterations) — shuffles the three arrays in place like the reference
+inline float Train(Trainable& d, std::vector<float>& Xs, std::vector<float>& policies, std::vector<float>& values, int batches,
+                   int iterations, uint64_t seed) {
+  float cost = 0;
+  agz::check(agz_train(d.h, Xs.data(), policies.data(), values.data(), batches, iterations, seed, &cost), "dual.Train");
+  return cost;
+}
 }  // namespace dual
 
 namespace mcts {
@@ -124,6 +148,85 @@ struct Arena {
       ex[i].Value = V[i];
     }
     return ex;
+  }
+};
+// agogo.Config (datatypes.go:14-25)
+struct Config {
+  std::string Name;
+  dual::Config NNConf;
+  mcts::Config MCTSConf;
+  double UpdateThreshold = 0.52;
+  int MaxExamples = 0;
+  int Encoder = AGZ_ENC_TWOPLANE;
+};
+struct GameSpec { int kind, m, n, k; float komi; };
+
+// AZ (agogo.go:21-172): the trainer loop around the device hot path.  Self-play episodes and arena games of an epoch
+// run concurrently as one batched arena each; everything else follows AZ.Learn line by line.
+struct AZ {
+  agz::Ctx& ctx;
+  GameSpec game;
+  Config conf;
+  std::unique_ptr<dual::Trainable> A, B;      // Agent.NN (trainable, full shapes)
+  std::unique_ptr<dual::Dual> infA, infB;     // SwitchToInference products (agent.go:42-57)
+  bool useDummy = true;
+  uint64_t seed;
+  struct EpochStats { int epoch; size_t examples; int batches; float cost; long a_wins, b_wins, draws; bool killedA; };
+  std::vector<EpochStats> log;
+
+  AZ(agz::Ctx& c, GameSpec g, const Config& cf, uint64_t seed_ = 1337) : ctx(c), game(g), conf(cf), seed(seed_) {  // agogo.go:41-72
+    if (!cf.NNConf.IsValid()) throw agz::Error("NNConf is not valid. Unable to proceed");
+    if (!cf.MCTSConf.IsValid()) throw agz::Error("MCTSConf is not valid. Unable to proceed");
+    A.reset(new dual::Trainable(ctx, cf.NNConf)); A->Init(seed * 3 + 1);
+    B.reset(new dual::Trainable(ctx, cf.NNConf)); B->Init(seed * 3 + 2);
+    infA.reset(new dual::Dual(ctx, cf.NNConf)); infB.reset(new dual::Dual(ctx, cf.NNConf));
+  }
+  static void shuffle_rows(std::vector<Example>& ex, uint64_t s) {  // shuffleExamples, agogo.go:251-257
+    uint64_t st = s;
+    auto next = [&] { uint64_t z = (st += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    for (size_t i = 0; i < ex.size(); i++) { size_t j = (size_t)(next() % (uint64_t)(i + 1)); std::swap(ex[i], ex[j]); }
+  }
+  // AZ.Learn (agogo.go:100-172)
+  void Learn(int iters, int episodes, int nniters, int arenaGames) {
+    for (int epoch = 0; epoch < iters; epoch++) {
+      EpochStats st{}; st.epoch = epoch;
+      A->SwitchToInference(*infA); B->SwitchToInference(*infB);           // setupSelfPlay, agogo.go:75-90
+      std::vector<Example> ex;
+      {
+        Arena sp(ctx, game.kind, game.m, game.n, game.k, game.komi, conf.Encoder, conf.MCTSConf, episodes, seed + 1000 * epoch);
+        if (epoch == 0 && useDummy) sp.SetAgents(nullptr, nullptr); else sp.SetAgents(infA.get(), infB.get());
+        ex = sp.Play(true);                                                // episodes x SelfPlay(), agogo.go:110-114
+      }
+      if (conf.MaxExamples > 0 && (int)ex.size() > conf.MaxExamples) { shuffle_rows(ex, seed + 7 * epoch); ex.resize(conf.MaxExamples); }
+      // prepareExamples (agogo.go:211-249)
+      shuffle_rows(ex, seed + 13 * epoch + 1);
+      const int BS = conf.NNConf.BatchSize;
+      int batches = (int)ex.size() / BS;
+      if (batches == 0) throw agz::Error("batches is nil, probably too few examples regarding the batchsize");  // agogo.go:123-125
+      size_t total = (size_t)batches * BS;
+      std::vector<float> Xs, Pi, V;
+      for (size_t i = 0; i < total; i++) { Xs.insert(Xs.end(), ex[i].Board.begin(), ex[i].Board.end()); Pi.insert(Pi.end(), ex[i].Policy.begin(), ex[i].Policy.end()); V.push_back(ex[i].Value); }
+      st.examples = ex.size(); st.batches = batches;
+      st.cost = dual::Train(*B, Xs, Pi, V, batches, nniters, seed + 17 * epoch);  // agogo.go:133
+      B->SwitchToInference(*infB);                                         // agogo.go:137
+      {
+        Arena ev(ctx, game.kind, game.m, game.n, game.k, game.komi, conf.Encoder, conf.MCTSConf, arenaGames, seed + 1000 * epoch + 500);
+        ev.SetAgents(infA.get(), infB.get());
+        ev.Play(false);                                                    // agogo.go:144-148
+        int64_t aw = 0, bw = 0, dr = 0;
+        agz::check(agz_arena_get_results(ev.h, &aw, &bw, &dr), "results");
+        st.a_wins = aw; st.b_wins = bw; st.draws = dr;
+      }
+      st.killedA = false;
+      if (st.b_wins + st.a_wins > 0 && (float)st.b_wins / (float)(st.b_wins + st.a_wins) > (float)conf.UpdateThreshold) {  // agogo.go:155
+        A = std::move(B);                                                  // a.A.NN = a.B.NN
+        st.killedA = true;
+      }
+      B.reset(new dual::Trainable(ctx, conf.NNConf));                      // newB: a fresh random net (arena.go:205-224)
+      B->Init(seed * 3 + 100 + epoch);
+      useDummy = useDummy && false;                                        // the dummy is only used in epoch 0 (agogo.go:83-87)
+      log.push_back(st);
+    }
   }
 };
 }  // namespace agogo
