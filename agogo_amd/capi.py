@@ -96,6 +96,7 @@ def lib():
     sig("agz_net_commit", i32, vp)
     sig("agz_net_infer", i32, vp, pf, i32, pf, pf)
     sig("agz_net_infer_dev", i32, vp, vp, i32, vp, vp)
+    sig("agz_net_set_latency_mode", i32, vp, i32)
     sig("agz_net_flops_per_eval", f64, vp)
     sig("agz_net_save", i32, vp, C.c_char_p)
     sig("agz_net_load", i32, vp, C.c_char_p)
@@ -249,6 +250,9 @@ class Net:
         val = np.zeros(B, dtype=np.float32)
         _check(lib().agz_net_infer(self.h, _pf(x), B, _pf(pol), _pf(val)), "agz_net_infer")
         return pol, val
+
+    def set_latency_mode(self, on=True):
+        _check(lib().agz_net_set_latency_mode(self.h, int(on)), "agz_net_set_latency_mode")
 
     def infer_dev(self, planes_ptr, B, policy_ptr, value_ptr):
         """device pointers (ints); asynchronous on the ctx stream"""

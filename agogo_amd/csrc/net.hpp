@@ -52,6 +52,11 @@ struct agz_net {
   float* d_planes = nullptr;  // [B][F][H][W]
   float* d_policy = nullptr;  // [B][A]
   float* d_value = nullptr;   // [B]
+  float* d_ws = nullptr;      // split-K workspace (small batches)
+  size_t ws_cap = 0;
+  float* d_hs = nullptr;      // latency-regime head scratch: [B][3][HW] features + [B][A+FC] columns
+  size_t hs_cap = 0;
+  bool latency_mode = true;   // allow the small-batch regime (split-K tower + spread heads), agz_net_set_latency_mode
 
   int ensure_batch(int B);
   void free_device();

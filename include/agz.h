@@ -118,6 +118,12 @@ int agz_net_commit(agz_net* net);
 int agz_net_infer(agz_net* net, const float* planes, int B, float* policy, float* value);
 /* same with device pointers, asynchronous on the ctx stream */
 int agz_net_infer_dev(agz_net* net, const float* planes_dev, int B, float* policy_dev, float* value_dev);
+/* Small-batch ("latency") regime for tournament-style single-tree Agent.Search (agent.go:76-81: one board per
+ * Infer call): when a forward's tower would occupy <= 1/4 of the CUs, the convolutions run split-K and the heads are
+ * spread over the chip.  On by default.  Within a regime results are bit-identical for every batch size; ACROSS the
+ * two regimes the fp32 summation order differs (same tolerance vs the reference).  Turn it off for strict bitwise
+ * batch-size independence at every batch size. */
+int agz_net_set_latency_mode(agz_net* net, int on);
 /* Checkpoint of the learnables in Model() order (+ BN statistics).  The reference gob-encodes G.Values
  * (AZ.Save / Dual.GobEncode, agogo.go:175-209, dualnet/dual.go:180-206); gob is Go-only, so this is a documented
  * flat format: "AGZNET01", agz_net_conf, n_params, then per parameter {uint64 n, float32[n]}, then per BN op

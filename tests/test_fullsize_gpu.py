@@ -44,7 +44,7 @@ def oracle_twin(net, K, L, S, F, Aspace):
 
 def test_g19_network_full_size_spot_check_and_batch_independence(ctx):
     """config #4 network (K=256, 20 blocks, 19x19, B=512): 2 boards vs the oracle, and every board of the batch
-    equals its own batch-1 evaluation bit for bit."""
+    equals its own batch-1 evaluation (bit for bit with the latency regime off)."""
     S, K, L, F = (19, 19), 256, 20, 18
     net = make_net(ctx, K, L, S, F)
     rng = np.random.default_rng(1)
@@ -53,9 +53,16 @@ def test_g19_network_full_size_spot_check_and_batch_independence(ctx):
     assert np.all(np.isfinite(pol)) and np.all(np.isfinite(val))
     np.testing.assert_allclose(pol.sum(axis=1), 1.0, atol=2e-5)
     for b in (0, 511, 257):
+        # batch 1 takes the split-K latency regime: same maths, different fp32 summation order
+        p1, v1 = net.infer(x[b:b + 1])
+        np.testing.assert_allclose(p1[0], pol[b], atol=2e-5, rtol=2e-4)
+        np.testing.assert_allclose(v1[0], val[b], atol=2e-4)
+    net.set_latency_mode(False)  # regime off: bit for bit
+    for b in (0, 511, 257):
         p1, v1 = net.infer(x[b:b + 1])
         np.testing.assert_array_equal(p1[0], pol[b])
         np.testing.assert_array_equal(v1[0], val[b])
+    net.set_latency_mode(True)
     onet = oracle_twin(net, K, L, S, F, 362)
     po, vo = onet.infer(x[[0, 511]])
     np.testing.assert_allclose(pol[[0, 511]], po, atol=2e-5, rtol=2e-4)
