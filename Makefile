@@ -7,8 +7,8 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-functi
 # engine.hip holds the bit-exact MCTS arithmetic: no fused multiply-add contraction (Go/amd64 never fuses)
 ENGINE_FLAGS := -ffp-contract=off
 
-SRCS := $(CS)/ctx.hip $(CS)/net.hip $(CS)/engine.hip $(CS)/train.hip
-OBJS := $(OUT)/ctx.o $(OUT)/net.o $(OUT)/engine.o $(OUT)/train.o
+SRCS := $(CS)/ctx.hip $(CS)/net.hip $(CS)/engine.hip $(CS)/train.hip $(CS)/examples.hip
+OBJS := $(OUT)/ctx.o $(OUT)/net.o $(OUT)/engine.o $(OUT)/train.o $(OUT)/examples.o
 HDRS := $(wildcard $(CS)/*.hpp) include/agz.h
 
 all: $(OUT)/libagz.so oracle tests/cpp/az_learn_ttt
@@ -24,6 +24,9 @@ $(OUT)/net.o: $(CS)/net.hip $(HDRS)
 	@mkdir -p $(OUT)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(OUT)/train.o: $(CS)/train.hip $(HDRS)
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(OUT)/examples.o: $(CS)/examples.hip $(HDRS)
 	@mkdir -p $(OUT)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(OUT)/engine.o: $(CS)/engine.hip $(HDRS)

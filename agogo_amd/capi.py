@@ -132,6 +132,22 @@ def lib():
     sig("agz_arena_get_examples", i32, vp, pf, pf, pf, pi, i32, pi)
     sig("agz_arena_clear_examples", i32, vp)
     sig("agz_arena_examples_dev", i32, vp, pvp, pvp, pvp, pi)
+    i64, pi64 = C.c_int64, C.POINTER(C.c_int64)
+    sig("agz_train_dev", i32, vp, vp, vp, vp, i32, i32, u64, pf)
+    sig("agz_examples_create", i32, vp, i32, i32, i32, i32, pvp)
+    sig("agz_examples_destroy", None, vp)
+    sig("agz_examples_count", i32, vp, pi64)
+    sig("agz_examples_clear", i32, vp)
+    sig("agz_examples_append_arena", i32, vp, vp)
+    sig("agz_examples_append_dev", i32, vp, vp, vp, vp, i64)
+    sig("agz_examples_append_host", i32, vp, pf, pf, pf, i64)
+    sig("agz_examples_get", i32, vp, pf, pf, pf, i64, pi64)
+    sig("agz_examples_augment_rotate", i32, vp)
+    sig("agz_examples_prepare", i32, vp, i32, i32, u64, pi)
+    sig("agz_examples_tensors_dev", i32, vp, pvp, pvp, pvp, pi64, pi)
+    sig("agz_examples_get_tensors", i32, vp, pf, pf, pf)
+    sig("agz_examples_raw_dev", i32, vp, pvp, pvp, pvp)
+    sig("agz_rotate_boards", i32, vp, pf, i32, i32, i32, pf)
     _LIB = L
     return L
 
@@ -347,6 +363,13 @@ class Trainer:
         _check(lib().agz_train(self.h, _pf(Xs), _pf(policies), _pf(values), batches, iterations, seed, C.byref(c)), "agz_train")
         return c.value
 
+    def train_dev(self, Xs_ptr, policies_ptr, values_ptr, batches, iterations, seed=1337):
+        """dual.Train over device tensors (see Examples.tensors_dev); nothing is copied to the host"""
+        c = C.c_float(0)
+        _check(lib().agz_train_dev(self.h, C.c_void_p(Xs_ptr), C.c_void_p(policies_ptr), C.c_void_p(values_ptr), batches,
+                                   iterations, seed, C.byref(c)), "agz_train_dev")
+        return c.value
+
     def export(self, net):
         _check(lib().agz_trainer_export(self.h, net.h), "agz_trainer_export")
 
@@ -465,3 +488,95 @@ class Arena:
 
     def clear_examples(self):
         _check(lib().agz_arena_clear_examples(self.h), "agz_arena_clear_examples")
+
+
+class Examples:
+    """[]agogo.Example on device + Augmenter / shuffleExamples / prepareExamples (agogo.go:110-133, 211-257)."""
+
+    def __init__(self, ctx, Features, Height, Width, PolicyLen):
+        self.ctx = ctx
+        self.F, self.H, self.W, self.A1 = Features, Height, Width, PolicyLen
+        self.h = C.c_void_p()
+        _check(lib().agz_examples_create(ctx.h, Features, Height, Width, PolicyLen, C.byref(self.h)), "agz_examples_create")
+        ctx._adopt(self)
+
+    def close(self):
+        if self.h and self.ctx.h:
+            lib().agz_examples_destroy(self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        n = C.c_int64(0)
+        _check(lib().agz_examples_count(self.h, C.byref(n)), "agz_examples_count")
+        return n.value
+
+    def clear(self):
+        _check(lib().agz_examples_clear(self.h), "agz_examples_clear")
+
+    def append_arena(self, arena):
+        _check(lib().agz_examples_append_arena(self.h, arena.h), "agz_examples_append_arena")
+
+    def append_dev(self, planes_ptr, policy_ptr, value_ptr, n):
+        _check(lib().agz_examples_append_dev(self.h, C.c_void_p(planes_ptr), C.c_void_p(policy_ptr), C.c_void_p(value_ptr), n),
+               "agz_examples_append_dev")
+
+    def append_host(self, planes, policy, value):
+        p = np.ascontiguousarray(planes, np.float32)
+        q = np.ascontiguousarray(policy, np.float32)
+        v = np.ascontiguousarray(value, np.float32)
+        n = v.size
+        assert p.size == n * self.F * self.H * self.W and q.size == n * self.A1
+        _check(lib().agz_examples_append_host(self.h, _pf(p), _pf(q), _pf(v), n), "agz_examples_append_host")
+
+    def get(self):
+        n = len(self)
+        p = np.zeros((n, self.F * self.H * self.W), np.float32)
+        q = np.zeros((n, self.A1), np.float32)
+        v = np.zeros(n, np.float32)
+        k = C.c_int64(0)
+        _check(lib().agz_examples_get(self.h, _pf(p), _pf(q), _pf(v), n, C.byref(k)), "agz_examples_get")
+        return p, q, v
+
+    def raw_dev(self):
+        """device pointers of the raw store (Board, Policy, Value rows in append order)"""
+        x, p, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().agz_examples_raw_dev(self.h, C.byref(x), C.byref(p), C.byref(v)), "agz_examples_raw_dev")
+        return x.value, p.value, v.value
+
+    def augment_rotate(self):
+        _check(lib().agz_examples_augment_rotate(self.h), "agz_examples_augment_rotate")
+
+    def prepare(self, BatchSize, maxExamples=0, seed=1337):
+        b = C.c_int32(0)
+        _check(lib().agz_examples_prepare(self.h, BatchSize, maxExamples, seed, C.byref(b)), "agz_examples_prepare")
+        return b.value
+
+    def tensors_dev(self):
+        x, p, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rows, b = C.c_int64(0), C.c_int32(0)
+        _check(lib().agz_examples_tensors_dev(self.h, C.byref(x), C.byref(p), C.byref(v), C.byref(rows), C.byref(b)),
+               "agz_examples_tensors_dev")
+        return x.value, p.value, v.value, rows.value, b.value
+
+    def tensors(self):
+        _, _, _, rows, _ = self.tensors_dev()
+        x = np.zeros((rows, self.F, self.H, self.W), np.float32)
+        p = np.zeros((rows, self.A1), np.float32)
+        v = np.zeros(rows, np.float32)
+        _check(lib().agz_examples_get_tensors(self.h, _pf(x), _pf(p), _pf(v)), "agz_examples_get_tensors")
+        return x, p, v
+
+
+def rotate_boards(ctx, boards, m, n):
+    """RotateBoard (encoding_helper.go:80-107) on a stack of m x n boards"""
+    b = np.ascontiguousarray(boards, np.float32)
+    count = b.size // (m * n)
+    out = np.zeros_like(b)
+    _check(lib().agz_rotate_boards(ctx.h, _pf(b), count, m, n, _pf(out)), "agz_rotate_boards")
+    return out

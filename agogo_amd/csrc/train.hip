@@ -194,6 +194,15 @@ __global__ void k_pack_planes_t(const float* __restrict__ planes, float* __restr
   out[pix_off(g, r) * Fp + c] = c < F ? planes[((size_t)b * F + c) * g.HW + p] : 0.f;
 }
 
+// dst[r][:] = src[idx[r]][:] — batch assembly for agz_train_dev (rows stay where they are; the shuffle moves indices)
+__global__ void k_gather_rows_t(const float* __restrict__ src, const int32_t* __restrict__ idx, float* __restrict__ dst, int row_len,
+                                size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  size_t r = i / row_len;
+  dst[i] = src[(size_t)idx[r] * row_len + (i - r * row_len)];
+}
+
 __global__ void k_axpy(float* __restrict__ p, const float* __restrict__ g, float alpha, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] += alpha * g[i];
@@ -757,6 +766,50 @@ int agz_train(agz_trainer* t, float* Xs, float* policies, float* values, int bat
     }
   }
   if (last_cost) *last_cost = c;
+  return AGZ_OK;
+}
+
+// dual.Train over DEVICE tensors (Xs [rows,F,H,W], policies [rows,A], values [rows], rows = batches*BatchSize — e.g.
+// agz_examples_tensors_dev).  Same loop and the same shuffleBatch stream as agz_train, but the shuffle permutes a row
+// index (4 B/row) instead of swapping rows, each batch is gathered device to device, and the cost is read back once at
+// the end — no host round trip of the examples and no per-batch synchronisation.  The device tensors are left unchanged.
+int agz_train_dev(agz_trainer* t, const float* Xs_dev, const float* policies_dev, const float* values_dev, int batches, int iterations,
+                  uint64_t seed, float* last_cost) {
+  AGZ_REQUIRE(t && Xs_dev && policies_dev && values_dev && batches >= 1 && iterations >= 0, AGZ_E_INVALID, "agz_train_dev: bad argument");
+  AGZ_HIP_TRY(hipSetDevice(t->ctx->device));
+  hipStream_t s = t->ctx->stream;
+  const size_t xs = (size_t)t->F * t->g.HW, ps = (size_t)t->A;
+  const size_t n = (size_t)batches * t->B;
+  std::vector<int32_t> perm(n);
+  for (size_t i = 0; i < n; i++) perm[i] = (int32_t)i;
+  int32_t* d_perm = nullptr;
+  AGZ_HIP_TRY(hipMalloc(&d_perm, n * 4));
+  SplitMix64 rng(seed);
+  int rc = AGZ_OK;
+  for (int it = 0; it < iterations && rc == AGZ_OK; it++) {
+    hipError_t e = hipMemcpyAsync(d_perm, perm.data(), n * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);   // perm is reshuffled on the host below
+    if (e != hipSuccess) { agz::set_error("agz_train_dev: %s", hipGetErrorString(e)); rc = AGZ_E_HIP; break; }
+    for (int b = 0; b < batches && rc == AGZ_OK; b++) {
+      const int32_t* ib = d_perm + (size_t)b * t->B;
+      hipLaunchKernelGGL(k_gather_rows_t, dim3(nblk((size_t)t->B * xs)), dim3(256), 0, s, Xs_dev, ib, t->d_planes, (int)xs, (size_t)t->B * xs);
+      hipLaunchKernelGGL(k_gather_rows_t, dim3(nblk((size_t)t->B * ps)), dim3(256), 0, s, policies_dev, ib, t->d_pi, (int)ps, (size_t)t->B * ps);
+      hipLaunchKernelGGL(k_gather_rows_t, dim3(nblk((size_t)t->B)), dim3(256), 0, s, values_dev, ib, t->d_v, 1, (size_t)t->B);
+      rc = t->forward_backward_dev(t->d_planes, t->d_pi, t->d_v);
+      if (rc == AGZ_OK) rc = agz_trainer_apply(t, 0.1f, 1.0f);
+    }
+    for (size_t i = 0; i < n; i++) {  // shuffleBatch (meta.go:57-102) on the row index
+      size_t j = (size_t)(rng.next() % (uint64_t)(i + 1));
+      std::swap(perm[i], perm[j]);
+    }
+  }
+  float c[2] = {0, 0};
+  hipError_t e = hipMemcpyAsync(c, t->cost, 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(d_perm);
+  if (rc != AGZ_OK) return rc;
+  AGZ_HIP_TRY(e);
+  if (last_cost) *last_cost = iterations > 0 ? c[0] + c[1] : 0.f;
   return AGZ_OK;
 }
 

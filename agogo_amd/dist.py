@@ -62,6 +62,32 @@ def all_gather_examples(planes, policy, value, group=None):
     return out[0], out[1], out[2].reshape(-1)
 
 
+def gather_into_examples(arena, examples, local_device, group=None):
+    """The per-epoch exchange of SURVEY 8(e) end to end on the device: this rank's recorded examples (arena buffers)
+    -> RCCL all-gather over xGMI -> appended to an `Examples` set (agz_examples_append_dev), ready for
+    Examples.prepare + Trainer.train_dev.  Single process: a device-to-device append.  Every rank ends up with the
+    same set in rank order (within a rank: the reference's episode order)."""
+    from . import capi
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        examples.append_arena(arena)
+        return len(examples)
+    local = capi.Examples(examples.ctx, examples.F, examples.H, examples.W, examples.A1)
+    local.append_arena(arena)           # canonical (episode) order first, then exchange
+    n = len(local)
+    dev = torch.device("cuda", local_device)
+    p, q, v = local.raw_dev()
+    planes = device_tensor(p, (n, examples.F * examples.H * examples.W), dev) if n else torch.zeros((0, examples.F * examples.H * examples.W), device=dev)
+    policy = device_tensor(q, (n, examples.A1), dev) if n else torch.zeros((0, examples.A1), device=dev)
+    value = device_tensor(v, (n,), dev) if n else torch.zeros((0,), device=dev)
+    P, Q, V = all_gather_examples(planes, policy, value, group=group)
+    P, Q, V = P.contiguous(), Q.contiguous(), V.contiguous()
+    torch.cuda.synchronize(dev)
+    examples.append_dev(P.data_ptr(), Q.data_ptr(), V.data_ptr(), int(V.shape[0]))
+    examples.ctx.sync()
+    local.close()
+    return len(examples)
+
+
 def shard_games(total_games, rank, world):
     """games [lo, hi) owned by `rank` (config #4: 4096 games sharded 512/GPU)"""
     per = total_games // world

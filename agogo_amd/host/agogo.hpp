@@ -95,6 +95,13 @@ inline float Train(Trainable& d, std::vector<float>& Xs, std::vector<float>& pol
   agz::check(agz_train(d.h, Xs.data(), policies.data(), values.data(), batches, iterations, seed, &cost), "dual.Train");
   return cost;
 }
+// the same over device tensors (agz_examples_tensors_dev): nothing leaves HBM
+inline float TrainDev(Trainable& d, const float* Xs_dev, const float* policies_dev, const float* values_dev, int batches, int iterations,
+                      uint64_t seed) {
+  float cost = 0;
+  agz::check(agz_train_dev(d.h, Xs_dev, policies_dev, values_dev, batches, iterations, seed, &cost), "dual.Train");
+  return cost;
+}
 }  // namespace dual
 
 namespace mcts {
@@ -133,6 +140,11 @@ struct Arena {
     agz::check(agz_arena_set_inferencer(h, 0, a ? AGZ_INF_NET : AGZ_INF_DUMMY, a ? a->h : nullptr), "Agent A");
     agz::check(agz_arena_set_inferencer(h, 1, b ? AGZ_INF_NET : AGZ_INF_DUMMY, b ? b->h : nullptr), "Agent B");
   }
+  // Play every game to the end, leaving the recorded examples on the device (see Examples::Append)
+  void PlayOnDevice(bool record) {
+    agz::check(agz_arena_reset(h, nullptr), "Arena.Play");
+    agz::check(agz_arena_play(h, 0, record ? 1 : 0), "Arena.Play");
+  }
   // Play every game to the end (Arena.Play, arena.go:80-179), recording examples
   std::vector<Example> Play(bool record) {
     agz::check(agz_arena_reset(h, nullptr), "Arena.Play");
@@ -150,6 +162,22 @@ struct Arena {
     return ex;
   }
 };
+// []Example kept on the device (include/agz.h "example sets"): Augmenter, shuffleExamples, prepareExamples
+struct Examples {
+  agz_examples* h = nullptr;
+  Examples(agz::Ctx& ctx, int F, int H, int W, int policyLen) { agz::check(agz_examples_create(ctx.h, F, H, W, policyLen, &h), "Examples"); }
+  ~Examples() { agz_examples_destroy(h); }
+  Examples(const Examples&) = delete;
+  Examples& operator=(const Examples&) = delete;
+  size_t size() const { int64_t n = 0; agz::check(agz_examples_count(h, &n), "len(ex)"); return (size_t)n; }
+  void Append(Arena& a) { agz::check(agz_examples_append_arena(h, a.h), "append(ex, SelfPlay()...)"); }
+  void AugmentRotate() { agz::check(agz_examples_augment_rotate(h), "RotateBoard"); }
+  int Prepare(int BatchSize, int maxExamples, uint64_t seed) {  // agogo.go:118-121 + prepareExamples
+    int b = 0;
+    agz::check(agz_examples_prepare(h, BatchSize, maxExamples, seed, &b), "prepareExamples");
+    return b;
+  }
+};
 // agogo.Config (datatypes.go:14-25)
 struct Config {
   std::string Name;
@@ -158,6 +186,7 @@ struct Config {
   double UpdateThreshold = 0.52;
   int MaxExamples = 0;
   int Encoder = AGZ_ENC_TWOPLANE;
+  bool AugmentRotate = false;  // Augmenter (datatypes.go:24): the RotateBoard-based rotation augmenter, or none
 };
 struct GameSpec { int kind, m, n, k; float komi; };
 
@@ -181,33 +210,27 @@ struct AZ {
     B.reset(new dual::Trainable(ctx, cf.NNConf)); B->Init(seed * 3 + 2);
     infA.reset(new dual::Dual(ctx, cf.NNConf)); infB.reset(new dual::Dual(ctx, cf.NNConf));
   }
-  static void shuffle_rows(std::vector<Example>& ex, uint64_t s) {  // shuffleExamples, agogo.go:251-257
-    uint64_t st = s;
-    auto next = [&] { uint64_t z = (st += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
-    for (size_t i = 0; i < ex.size(); i++) { size_t j = (size_t)(next() % (uint64_t)(i + 1)); std::swap(ex[i], ex[j]); }
-  }
   // AZ.Learn (agogo.go:100-172)
   void Learn(int iters, int episodes, int nniters, int arenaGames) {
     for (int epoch = 0; epoch < iters; epoch++) {
       EpochStats st{}; st.epoch = epoch;
       A->SwitchToInference(*infA); B->SwitchToInference(*infB);           // setupSelfPlay, agogo.go:75-90
-      std::vector<Example> ex;
+      Examples ex(ctx, conf.NNConf.Features, conf.NNConf.Height, conf.NNConf.Width, conf.NNConf.ActionSpace);
       {
         Arena sp(ctx, game.kind, game.m, game.n, game.k, game.komi, conf.Encoder, conf.MCTSConf, episodes, seed + 1000 * epoch);
         if (epoch == 0 && useDummy) sp.SetAgents(nullptr, nullptr); else sp.SetAgents(infA.get(), infB.get());
-        ex = sp.Play(true);                                                // episodes x SelfPlay(), agogo.go:110-114
+        sp.PlayOnDevice(true);                                             // episodes x SelfPlay(), agogo.go:110-114
+        ex.Append(sp);                                                     // device to device, episode after episode
       }
-      if (conf.MaxExamples > 0 && (int)ex.size() > conf.MaxExamples) { shuffle_rows(ex, seed + 7 * epoch); ex.resize(conf.MaxExamples); }
-      // prepareExamples (agogo.go:211-249)
-      shuffle_rows(ex, seed + 13 * epoch + 1);
-      const int BS = conf.NNConf.BatchSize;
-      int batches = (int)ex.size() / BS;
+      if (conf.AugmentRotate) ex.AugmentRotate();                          // Arena.Play's aug(ex), arena.go:115-120
+      st.examples = ex.size();
+      // maxExamples cut (agogo.go:118-121) + prepareExamples (agogo.go:211-249), tensors stay in HBM
+      int batches = ex.Prepare(conf.NNConf.BatchSize, conf.MaxExamples, seed + 13 * epoch + 1);
       if (batches == 0) throw agz::Error("batches is nil, probably too few examples regarding the batchsize");  // agogo.go:123-125
-      size_t total = (size_t)batches * BS;
-      std::vector<float> Xs, Pi, V;
-      for (size_t i = 0; i < total; i++) { Xs.insert(Xs.end(), ex[i].Board.begin(), ex[i].Board.end()); Pi.insert(Pi.end(), ex[i].Policy.begin(), ex[i].Policy.end()); V.push_back(ex[i].Value); }
-      st.examples = ex.size(); st.batches = batches;
-      st.cost = dual::Train(*B, Xs, Pi, V, batches, nniters, seed + 17 * epoch);  // agogo.go:133
+      st.batches = batches;
+      float *Xs = nullptr, *Pi = nullptr, *V = nullptr;
+      agz::check(agz_examples_tensors_dev(ex.h, &Xs, &Pi, &V, nullptr, nullptr), "prepareExamples");
+      st.cost = dual::TrainDev(*B, Xs, Pi, V, batches, nniters, seed + 17 * epoch);  // agogo.go:133
       B->SwitchToInference(*infB);                                         // agogo.go:137
       {
         Arena ev(ctx, game.kind, game.m, game.n, game.k, game.komi, conf.Encoder, conf.MCTSConf, arenaGames, seed + 1000 * epoch + 500);

@@ -200,6 +200,47 @@ func (a *BatchedArena) SelfPlay() ([]agogo.Example, error) {
 
 func (a *BatchedArena) Close() error { defer a.ctx.enter()(); C.agz_arena_destroy(a.h); a.h = nil; return nil }
 
+// Examples is []agogo.Example kept in HBM: the rotation Augmenter (RotateBoard, encoding_helper.go:80-107), the
+// maxExamples cut (agogo.go:118-121) and prepareExamples (agogo.go:211-249) run on the device; only 4-byte row indices
+// ever touch the host.  Feed the prepared tensors to a trainer with agz_train_dev (dual.Train, dualnet/meta.go:16-54).
+type Examples struct {
+	ctx *Ctx
+	h   *C.agz_examples
+}
+
+func NewExamples(ctx *Ctx, features, height, width, policyLen int) (*Examples, error) {
+	defer ctx.enter()()
+	e := &Examples{ctx: ctx}
+	if err := lastErr(C.agz_examples_create(ctx.h, C.int(features), C.int(height), C.int(width), C.int(policyLen), &e.h)); err != nil {
+		return nil, err
+	}
+	return e, nil
+}
+
+// SelfPlayInto = `ex = append(ex, a.SelfPlay()...)` for all games of the batch, device to device (agogo.go:110-114).
+func (a *BatchedArena) SelfPlayInto(ex *Examples) error {
+	defer a.ctx.enter()()
+	if err := lastErr(C.agz_arena_reset(a.h, nil)); err != nil {
+		return err
+	}
+	if err := lastErr(C.agz_arena_play(a.h, 0, 1)); err != nil {
+		return err
+	}
+	return lastErr(C.agz_examples_append_arena(ex.h, a.h))
+}
+
+func (e *Examples) AugmentRotate() error { defer e.ctx.enter()(); return lastErr(C.agz_examples_augment_rotate(e.h)) }
+
+// Prepare returns the number of batches (0: "batches is nil", agogo.go:123-125).
+func (e *Examples) Prepare(batchSize, maxExamples int, seed uint64) (int, error) {
+	defer e.ctx.enter()()
+	var b C.int
+	err := lastErr(C.agz_examples_prepare(e.h, C.int(batchSize), C.int(maxExamples), C.uint64_t(seed), &b))
+	return int(b), err
+}
+
+func (e *Examples) Close() error { defer e.ctx.enter()(); C.agz_examples_destroy(e.h); e.h = nil; return nil }
+
 var _ = game.Pass // keep the import: game.Single values cross the ABI as int32 (-1 pass, -2 resign)
 
 // Constants mirrored for callers (include/agz.h).

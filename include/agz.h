@@ -158,6 +158,12 @@ int agz_trainer_grads_dev(agz_trainer* t, float** dev_ptr, size_t* n_floats);
  * after every iteration (build RNG; Xs/policies/values are shuffled in place like the reference). */
 int agz_train(agz_trainer* t, float* Xs, float* policies, float* values, int batches, int iterations, uint64_t seed,
               float* last_cost);
+/* dual.Train over DEVICE tensors (e.g. agz_examples_tensors_dev): same loop and shuffleBatch stream as agz_train; the
+ * shuffle permutes 4-byte row indices, batches are gathered device to device, the cost is read back once at the end.
+ * The tensors themselves are left in place (the reference shuffles rows in place, meta.go:57-102; AZ.Learn discards
+ * them right after, agogo.go:133). */
+int agz_train_dev(agz_trainer* t, const float* Xs_dev, const float* policies_dev, const float* values_dev, int batches,
+                  int iterations, uint64_t seed, float* last_cost);
 /* dual.Infer's copy loop (dualnet/meta.go:141-146): row 0 of every learnable -> the inference net; commits it. */
 int agz_trainer_export(const agz_trainer* t, agz_net* net);
 
@@ -270,6 +276,40 @@ int agz_arena_get_examples(agz_arena* arena, float* planes, float* policy, float
 int agz_arena_clear_examples(agz_arena* arena);
 /* device pointers of the example buffers (for an RCCL all-gather before dual.Train) */
 int agz_arena_examples_dev(agz_arena* arena, float** planes, float** policy, float** value, int* n);
+
+/* ---- example sets on device: what sits between AZ.SelfPlay and dual.Train ----------------------
+ * []agogo.Example (datatypes.go:41-46) as three device arrays: Board [n, F*H*W], Policy [n, PolicyLen], Value [n].
+ * The payload (27.4 KB per 19x19 example) never leaves HBM; the host handles 4-byte row indices only. */
+typedef struct agz_examples agz_examples;
+int agz_examples_create(agz_ctx* ctx, int Features, int Height, int Width, int PolicyLen, agz_examples** out);
+void agz_examples_destroy(agz_examples* ex);
+int agz_examples_count(const agz_examples* ex, int64_t* n);
+int agz_examples_clear(agz_examples* ex);
+/* `ex = append(ex, a.SelfPlay()...)` (agogo.go:110-114) for all games of a batched arena, in the reference's order:
+ * game after game, each in ply order. Device-to-device. */
+int agz_examples_append_arena(agz_examples* ex, agz_arena* arena);
+/* append n rows from device buffers (e.g. the RCCL all-gathered examples of the other ranks) / host buffers */
+int agz_examples_append_dev(agz_examples* ex, const float* planes_dev, const float* policy_dev, const float* value_dev, int64_t n);
+int agz_examples_append_host(agz_examples* ex, const float* planes, const float* policy, const float* value, int64_t n);
+/* device pointers of the raw store (rows in append order) — the send buffers of the RCCL all-gather */
+int agz_examples_raw_dev(agz_examples* ex, float** planes, float** policy, float** value);
+/* read back (tests / host-side consumers). *n = rows held; copies min(cap, *n) rows. */
+int agz_examples_get(agz_examples* ex, float* planes, float* policy, float* value, int64_t cap, int64_t* n);
+/* An Augmenter (datatypes.go:38-39; applied per recorded example, arena.go:115-120) built on RotateBoard
+ * (encoding_helper.go:80-107): every example e is replaced by [e, rot e, rot^2 e, rot^3 e] — every plane of Board
+ * and the m*n board part of Policy rotated, the pass entry and Value kept.  Non-square boards: AGZ_E_INVALID with
+ * RotateBoard's message. */
+int agz_examples_augment_rotate(agz_examples* ex);
+/* `if maxExamples > 0 && len(ex) > maxExamples { shuffleExamples(ex); ex = ex[:maxExamples] }` (agogo.go:118-121;
+ * maxExamples <= 0: skipped) followed by prepareExamples (agogo.go:211-249): shuffleExamples (agogo.go:251-257, build
+ * RNG), batches = len/BatchSize, the first batches*BatchSize rows tensorised.  *batches may be 0 ("batches is nil",
+ * agogo.go:123-125 — the caller's error). */
+int agz_examples_prepare(agz_examples* ex, int BatchSize, int maxExamples, uint64_t seed, int* batches);
+/* the prepared tensors: device pointers for agz_train_dev / host copies */
+int agz_examples_tensors_dev(agz_examples* ex, float** Xs, float** Policies, float** Values, int64_t* rows, int* batches);
+int agz_examples_get_tensors(agz_examples* ex, float* Xs, float* Policies, float* Values);
+/* RotateBoard (encoding_helper.go:80-107) on `count` boards of m x n floats (host buffers; runs on the device). */
+int agz_rotate_boards(agz_ctx* ctx, const float* boards, int count, int m, int n, float* out);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 
 #include "arena.hpp"
 #include "train.hpp"
+#include "examples.hpp"
 
 using namespace oracle;
 
@@ -350,6 +351,34 @@ double orc_train_gradcheck(int K, int L, int FC, int BatchSize, int W, int H, in
     if (std::fabs(num) + std::fabs(ana) > 1e-9 && err > worst) worst = err;
   }
   return worst;
+}
+
+// ---- example plumbing (oracle/examples.hpp) ----
+int orc_rotate_board(const float* board, int m, int n, float* out) { return RotateBoard(board, m, n, out) ? 0 : -1; }
+void* orc_exset_new(int F, int m, int n, int A1) { return new ExampleSet{F, m, n, A1, {}, {}, {}}; }
+void orc_exset_free(void* h) { delete (ExampleSet*)h; }
+void orc_exset_push(void* h, const float* boards, const float* policies, const float* values, int count) {
+  ExampleSet* s = (ExampleSet*)h;
+  for (int i = 0; i < count; i++) s->push(boards + (size_t)i * s->F * s->m * s->n, policies + (size_t)i * s->A1, values[i]);
+}
+int orc_exset_size(void* h) { return (int)((ExampleSet*)h)->size(); }
+int orc_exset_augment_rotate(void* h) { return ((ExampleSet*)h)->AugmentRotate() ? 0 : -1; }
+void orc_exset_get(void* h, float* boards, float* policies, float* values) {
+  ExampleSet* s = (ExampleSet*)h;
+  size_t xs = (size_t)s->F * s->m * s->n;
+  for (size_t i = 0; i < s->size(); i++) {
+    memcpy(boards + i * xs, s->board[i].data(), xs * 4);
+    memcpy(policies + i * s->A1, s->policy[i].data(), (size_t)s->A1 * 4);
+    values[i] = s->value[i];
+  }
+}
+// prepareExamples; outputs must hold (size/BatchSize)*BatchSize rows (after the maxExamples cut). returns batches
+int orc_exset_prepare(void* h, int BatchSize, int maxExamples, uint64_t seed, float* Xs, float* Pi, float* V) {
+  ExampleSet* s = (ExampleSet*)h;
+  std::vector<float> x, p, v;
+  int batches = s->Prepare(BatchSize, maxExamples, seed, &x, &p, &v);
+  memcpy(Xs, x.data(), x.size() * 4); memcpy(Pi, p.data(), p.size() * 4); memcpy(V, v.data(), v.size() * 4);
+  return batches;
 }
 
 }  // extern "C"

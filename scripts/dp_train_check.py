@@ -52,8 +52,51 @@ if rank == 0:
             ok = False
             print("MISMATCH", ref.param_info(i)[0], np.abs(got - want).max(), scale)
     print("DP_TRAIN_CHECK", "OK" if ok else "FAIL", "world", world)
+
+# ---- phase 2: the per-epoch example exchange on the device: arena buffers -> all-gather -> Examples ----
+from agogo_amd import capi
+
+
+def play(seed):
+    a = A.Arena(ctx, capi.GAME_MNK, 3, 3, 3, encoder=capi.ENC_TWOPLANE, n_games=6, seed=seed, Budget=20)
+    a.set_inferencer(0, capi.INF_HASH)
+    a.set_inferencer(1, capi.INF_HASH)
+    a.reset()
+    a.play(0, True)
+    return a
+
+
+mine = play(500 + rank)
+ex = A.Examples(ctx, 2, 3, 3, 10)
+n_all = adist.gather_into_examples(mine, ex, local)
+got = ex.get()
+batches = ex.prepare(8, 0, seed=31)       # same seed on every rank -> identical training tensors everywhere
+X, P, V = ex.tensors()
+digest = torch.tensor([float(np.abs(X).sum() + 3 * np.abs(P).sum() + 7 * V.sum()), float(n_all), float(batches)], dtype=torch.float64)
+if world > 1:
+    ds = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(ds, digest)
+    same = all(torch.equal(d, ds[0]) for d in ds)
+else:
+    same = True
+ok2 = same
+if rank == 0:
+    want = [[], [], []]
+    for r in range(world):                 # every rank's games are reproducible from its seed
+        a = play(500 + r)
+        pl, po, va, gi = a.examples()
+        o = np.argsort(gi, kind="stable")
+        for k, arr in enumerate((pl[o], po[o], va[o])):
+            want[k].append(arr)
+    for k in range(3):
+        w_ = np.concatenate(want[k], axis=0)
+        if w_.shape != got[k].shape or not np.array_equal(w_, got[k]):
+            ok2 = False
+            print("GATHER MISMATCH", k, w_.shape, got[k].shape)
+    print("EXAMPLE_GATHER_CHECK", "OK" if ok2 else "FAIL", "world", world, "examples", n_all, "batches", batches)
+ok = ok and ok2
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()
-t.close(); ctx.close()
+ex.close(); mine.close(); t.close(); ctx.close()
 sys.exit(0 if ok else 1)

@@ -85,6 +85,14 @@ def lib():
     sig("orc_arena_num_examples", i32, vp)
     sig("orc_arena_get_example", None, vp, i32, pf, pf, pf)
     sig("orc_arena_example_sizes", i32, vp, pi, pi)
+    sig("orc_rotate_board", i32, pf, i32, i32, pf)
+    sig("orc_exset_new", vp, i32, i32, i32, i32)
+    sig("orc_exset_free", None, vp)
+    sig("orc_exset_push", None, vp, pf, pf, pf, i32)
+    sig("orc_exset_size", i32, vp)
+    sig("orc_exset_augment_rotate", i32, vp)
+    sig("orc_exset_get", None, vp, pf, pf, pf)
+    sig("orc_exset_prepare", i32, vp, i32, i32, u64, pf, pf, pf)
     sig("orc_train_new", vp, i32, i32, i32, i32, i32, i32, i32, i32, f32)
     sig("orc_train_free", None, vp)
     sig("orc_train_num_params", i32, vp)
@@ -419,3 +427,55 @@ class TrainNet:
         p = np.ascontiguousarray(Pi, np.float32)
         v = np.ascontiguousarray(V, np.float32)
         return float(lib().orc_train_batch(self.h, _pf(x), _pf(p), _pf(v), lr))
+
+
+def rotate_board(board, m, n):
+    """RotateBoard restatement (encoding_helper.go:80-107); returns None where the reference returns an error."""
+    b = np.ascontiguousarray(board, np.float32)
+    out = np.zeros_like(b)
+    return out if lib().orc_rotate_board(_pf(b), m, n, _pf(out)) == 0 else None
+
+
+class ExampleSet:
+    """[]agogo.Example + rotation Augmenter + shuffleExamples/prepareExamples restatement (oracle/examples.hpp)."""
+
+    def __init__(self, F, m, n, A1):
+        self.F, self.m, self.n, self.A1 = F, m, n, A1
+        self.h = lib().orc_exset_new(F, m, n, A1)
+
+    def __del__(self):
+        try:
+            lib().orc_exset_free(self.h)
+        except Exception:
+            pass
+
+    def __len__(self):
+        return lib().orc_exset_size(self.h)
+
+    def push(self, boards, policies, values):
+        b = np.ascontiguousarray(boards, np.float32)
+        p = np.ascontiguousarray(policies, np.float32)
+        v = np.ascontiguousarray(values, np.float32)
+        lib().orc_exset_push(self.h, _pf(b), _pf(p), _pf(v), v.size)
+
+    def augment_rotate(self):
+        return lib().orc_exset_augment_rotate(self.h) == 0
+
+    def get(self):
+        n = len(self)
+        b = np.zeros((n, self.F * self.m * self.n), np.float32)
+        p = np.zeros((n, self.A1), np.float32)
+        v = np.zeros(n, np.float32)
+        lib().orc_exset_get(self.h, _pf(b), _pf(p), _pf(v))
+        return b, p, v
+
+    def prepare(self, BatchSize, maxExamples=0, seed=1337):
+        n = len(self)
+        if maxExamples > 0 and n > maxExamples:
+            n = maxExamples
+        rows = (n // BatchSize) * BatchSize
+        x = np.zeros((max(rows, 1), self.F, self.m, self.n), np.float32)
+        p = np.zeros((max(rows, 1), self.A1), np.float32)
+        v = np.zeros(max(rows, 1), np.float32)
+        batches = lib().orc_exset_prepare(self.h, BatchSize, maxExamples, seed, _pf(x), _pf(p), _pf(v))
+        return batches, x[:rows], p[:rows], v[:rows]

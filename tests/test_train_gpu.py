@@ -127,3 +127,5 @@ def test_data_parallel_step_two_ranks(ctx):
                           "127.0.0.1", "--master-port", "29577", os.path.join(root, "scripts", "dp_train_check.py"), "--shared-gpu"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert "DP_TRAIN_CHECK OK world 2" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    # phase 2 of the script: arena example buffers -> all-gather -> device Examples set, identical on both ranks
+    assert "EXAMPLE_GATHER_CHECK OK world 2" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
