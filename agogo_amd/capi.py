@@ -15,6 +15,7 @@ GAME_MNK, GAME_C4, GAME_KOMI, GAME_WQ = 0, 1, 2, 3
 ENC_TWOPLANE, ENC_WQ = 0, 1
 INF_NET, INF_DUMMY, INF_SCRIPT, INF_HASH, INF_UNIFORM = 0, 1, 2, 3, 4
 BN_DEGENERATE_EPS, BN_RUNNING, BN_IDENTITY = 0, 1, 2
+COMPUTE_F32_MFMA, COMPUTE_BF16X3 = 0, 1
 PROF_CONV, PROF_HEADS, PROF_SELECT, PROF_EXPAND, PROF_MOVE, PROF_CONV_INIT = 0, 1, 2, 3, 4, 5
 DONT_PREFER_PASS, PREFER_PASS, DONT_RESIGN = 0, 1, 2
 
@@ -97,6 +98,7 @@ def lib():
     sig("agz_net_infer", i32, vp, pf, i32, pf, pf)
     sig("agz_net_infer_dev", i32, vp, vp, i32, vp, vp)
     sig("agz_net_set_latency_mode", i32, vp, i32)
+    sig("agz_net_set_compute_mode", i32, vp, i32)
     sig("agz_net_flops_per_eval", f64, vp)
     sig("agz_net_save", i32, vp, C.c_char_p)
     sig("agz_net_load", i32, vp, C.c_char_p)
@@ -266,6 +268,9 @@ class Net:
         val = np.zeros(B, dtype=np.float32)
         _check(lib().agz_net_infer(self.h, _pf(x), B, _pf(pol), _pf(val)), "agz_net_infer")
         return pol, val
+
+    def set_compute_mode(self, mode):
+        _check(lib().agz_net_set_compute_mode(self.h, int(mode)), "agz_net_set_compute_mode")
 
     def set_latency_mode(self, on=True):
         _check(lib().agz_net_set_latency_mode(self.h, int(on)), "agz_net_set_latency_mode")

@@ -290,6 +290,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   conv_tile<WM, WN, MT, DUAL>(a, lds, m_tile * (WM * MT * 32), n_tile, blockIdx.y);
 }
 
+#include "conv_x3.hpp"
+
 // split-K finish: sum the partials (in split order) and apply the conv epilogue.  One thread per (pixel row m, 4 channels).
 template <bool DUAL>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvArgs a, int half) {
@@ -547,7 +549,8 @@ void agz_net::free_device() {
   f(d_w_init); f(d_ep_init);
   for (auto& p : d_w_dual) f(p);
   for (auto& p : d_ep_dual) f(p);
-  d_w_dual.clear(); d_ep_dual.clear();
+  for (auto& p : d_w3_dual) if (p) { hipFree(p); p = nullptr; }
+  d_w_dual.clear(); d_ep_dual.clear(); d_w3_dual.clear();
   f(d_head_conv); f(d_head_bn); f(d_Wp); f(d_bp); f(d_W1); f(d_b1); f(d_W2); f(d_b2);
   f(d_act_in); f(d_actA); f(d_actB); f(d_planes); f(d_policy); f(d_value); f(d_ws); f(d_hs);
   ws_cap = 0; hs_cap = 0;
@@ -654,7 +657,14 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   for (int l = 0; l < conf.SharedLayers; l++) {
     a.x = cur; a.w = d_w_dual[l]; a.ep = d_ep_dual[l]; a.y = nxt;
     a.Cin_p = Kp; a.Cout_p = Kp; a.Ntot = 2 * Kp;
-    if (cfg != 0) rc = launch_conv<4, 1, 1, true>(ctx, a, wsp, &ws_cap);
+    if (cfg == 0 && !latency && x3_mode) {
+      a.n_ntiles = ceil_div(a.Ntot, 128); a.n_mtiles = ceil_div(a.M, 128);
+      a.splits = 1; a.per = 0; a.ws = nullptr; a.raw = 0;
+      ProfScope ps(ctx, AGZ_PROF_CONV);
+      hipLaunchKernelGGL((conv3x3_x3_kernel<true>), dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, a, d_w3_dual[l]);
+      rc = AGZ_OK;
+    }
+    else if (cfg != 0) rc = launch_conv<4, 1, 1, true>(ctx, a, wsp, &ws_cap);
     else if (half_dual) rc = launch_conv<2, 2, 1, true>(ctx, a, wsp, &ws_cap);
     else rc = launch_conv<2, 2, 2, true>(ctx, a, wsp, &ws_cap);
     if (rc != AGZ_OK) return rc;
@@ -865,6 +875,8 @@ int agz_net_commit(agz_net* n) {
   for (auto& p : n->d_ep_dual) if (p) hipFree(p);
   n->d_w_dual.assign(c.SharedLayers, nullptr);
   n->d_ep_dual.assign(c.SharedLayers, nullptr);
+  for (auto& p : n->d_w3_dual) if (p) hipFree(p);
+  n->d_w3_dual.assign(c.SharedLayers, nullptr);
   const int half = (n->cfg == 0) ? 64 : 32;  // channels per block tile (BNT/2)
   for (int l = 0; l < c.SharedLayers; l++) {
     const Param& wa = n->params[pi];
@@ -888,6 +900,27 @@ int agz_net_commit(agz_net* n) {
     int r;
     if ((r = upload(&n->d_w_dual[l], wt, s)) != AGZ_OK) return r;
     if ((r = upload(&n->d_ep_dual[l], ep, s)) != AGZ_OK) return r;
+    if (n->cfg == 0) {
+      // bf16x3 image of the same (tile-interleaved) filter: w3[tap][cc16][piece][n][16], exact truncation split
+      const int NC16 = Kp / 16, Ntot = 2 * Kp;
+      std::vector<unsigned short> w3((size_t)9 * NC16 * 3 * Ntot * 16);
+      for (int t = 0; t < 9; t++) for (int nn = 0; nn < Ntot; nn++) for (int ci = 0; ci < Kp; ci++) {
+        float v = wt[((size_t)t * Ntot + nn) * Kp + ci];
+        uint32_t u, hu, mu, lu; memcpy(&u, &v, 4);
+        hu = u & 0xffff0000u; float hf; memcpy(&hf, &hu, 4);
+        float r1 = v - hf; uint32_t ru; memcpy(&ru, &r1, 4);
+        mu = ru & 0xffff0000u; float mf; memcpy(&mf, &mu, 4);
+        float r2 = r1 - mf; memcpy(&lu, &r2, 4);
+        size_t base = (((size_t)(t * NC16 + ci / 16) * 3) * Ntot + nn) * 16 + (ci % 16);
+        w3[base] = (unsigned short)(hu >> 16);
+        w3[base + (size_t)Ntot * 16] = (unsigned short)(mu >> 16);
+        w3[base + (size_t)2 * Ntot * 16] = (unsigned short)(lu >> 16);
+      }
+      if (n->d_w3_dual[l]) { hipFree(n->d_w3_dual[l]); n->d_w3_dual[l] = nullptr; }
+      AGZ_HIP_TRY(hipMalloc(&n->d_w3_dual[l], w3.size() * 2));
+      AGZ_HIP_TRY(hipMemcpyAsync(n->d_w3_dual[l], w3.data(), w3.size() * 2, hipMemcpyHostToDevice, s));
+      AGZ_HIP_TRY(hipStreamSynchronize(s));
+    }
     pi += 6; bi += 2;
   }
   // --- heads
@@ -918,6 +951,13 @@ int agz_net_commit(agz_net* n) {
     (void)A; (void)FCn;
   }
   n->committed = true;
+  return AGZ_OK;
+}
+
+int agz_net_set_compute_mode(agz_net* n, int mode) {
+  AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_compute_mode: NULL net");
+  AGZ_REQUIRE(mode == AGZ_COMPUTE_F32_MFMA || mode == AGZ_COMPUTE_BF16X3, AGZ_E_INVALID, "agz_net_set_compute_mode: unknown mode %d", mode);
+  n->x3_mode = mode == AGZ_COMPUTE_BF16X3;
   return AGZ_OK;
 }
 

@@ -124,6 +124,14 @@ int agz_net_infer_dev(agz_net* net, const float* planes_dev, int B, float* polic
  * two regimes the fp32 summation order differs (same tolerance vs the reference).  Turn it off for strict bitwise
  * batch-size independence at every batch size. */
 int agz_net_set_latency_mode(agz_net* net, int on);
+/* Arithmetic of the dual-block convolutions (both are fp32-grade and meet the same parity tolerance):
+ *   AGZ_COMPUTE_F32_MFMA  v_mfma_f32_32x32x2_f32, exact fp32 products (default)
+ *   AGZ_COMPUTE_BF16X3    every fp32 operand split exactly into three bf16 pieces, six bf16 MFMAs per product
+ *                         (dropped cross terms <= 2^-23 relative), fp32 accumulation — 2.67x the fp32 matrix rate.
+ *                         Used for K a multiple of 64 and batches that fill the chip; other shapes keep F32_MFMA. */
+#define AGZ_COMPUTE_F32_MFMA 0
+#define AGZ_COMPUTE_BF16X3 1
+int agz_net_set_compute_mode(agz_net* net, int mode);
 /* Checkpoint of the learnables in Model() order (+ BN statistics).  The reference gob-encodes G.Values
  * (AZ.Save / Dual.GobEncode, agogo.go:175-209, dualnet/dual.go:180-206); gob is Go-only, so this is a documented
  * flat format: "AGZNET01", agz_net_conf, n_params, then per parameter {uint64 n, float32[n]}, then per BN op

@@ -17,12 +17,15 @@ ap.add_argument("--L", type=int, default=20)
 ap.add_argument("--B", type=int, default=512)
 ap.add_argument("--size", type=int, default=19)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--x3", action="store_true")
 args = ap.parse_args()
 ctx = A.Ctx(0)
 S = args.size
 net = A.Net(ctx, args.K, args.L, 2 * args.K, S, S, 18, S * S + 1)
 net.init_random(1337)
 net.commit()
+if args.x3:
+    net.set_compute_mode(A.capi.COMPUTE_BF16X3)
 x = torch.randint(-1, 2, (args.B, 18, S, S), device="cuda").float()
 pol = torch.empty((args.B, S * S + 1), device="cuda")
 val = torch.empty((args.B,), device="cuda")

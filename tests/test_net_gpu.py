@@ -181,3 +181,28 @@ def test_checkpoint_roundtrip(ctx, tmp_path):
     wrong = A.Net(ctx, 32, 1, 64, 5, 5, 2, 26, bn_mode=1)
     with pytest.raises(A.AgzError):
         wrong.load(path)
+
+
+@pytest.mark.parametrize("K,L,FC,W,H,F,Aspace,B,bn_mode", [
+    (64, 2, 128, 9, 9, 18, 82, 70, 0),      # 5670 rows, partial last M tile
+    (128, 2, 64, 9, 9, 18, 82, 33, 2),      # two column tiles
+    (256, 2, 128, 19, 19, 18, 362, 8, 2),   # BASELINE width
+])
+def test_bf16x3_compute_mode_matches_oracle_and_f32(ctx, K, L, FC, W, H, F, Aspace, B, bn_mode):
+    """AGZ_COMPUTE_BF16X3 (conv_x3.hpp): exact 3-way bf16 split of both operands, 6 of the 9 piece products — the same
+    fp32 tolerance against the oracle as the fp32-MFMA path, and agreement with that path far inside it."""
+    onet, gnet = make_pair(ctx, K, L, FC, W, H, F, Aspace, bn_mode)
+    x = rand_planes(B, F, H, W, seed=K + B)
+    pol_f, val_f = gnet.infer(x)
+    gnet.set_compute_mode(A.capi.COMPUTE_BF16X3)
+    pol_g, val_g = gnet.infer(x)
+    gnet.set_compute_mode(A.capi.COMPUTE_F32_MFMA)
+    assert not np.array_equal(pol_g, pol_f)          # really a different arithmetic path
+    idx = [0, B // 2, B - 1]
+    pol_o, val_o = onet.infer(x[idx])
+    np.testing.assert_allclose(pol_g[idx], pol_o, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(val_g[idx], val_o, atol=VAL_ATOL)
+    np.testing.assert_allclose(pol_g, pol_f, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(val_g, val_f, atol=VAL_ATOL)
+    print("max |dpol| x3 vs f32:", np.abs(pol_g - pol_f).max(), " vs oracle:", np.abs(pol_g[idx] - pol_o).max(),
+          " f32 vs oracle:", np.abs(pol_f[idx] - pol_o).max())
