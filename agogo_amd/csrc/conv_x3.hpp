@@ -15,6 +15,12 @@
 // fused BN/ReLU/add epilogue is shared), 4 waves (2x2) of 64x64, K step 16 channels of one filter tap per iteration.
 // LDS per stage: A 3 pieces x 128 rows x 32 B + B the same = 24 KB; two stages.
 //   w3[tap][cc][piece][n][16] bf16: the 128 x 16 B-tile of one (tap, cc, piece) is one contiguous 4 KB run.
+//
+// Measured (MI355X, 19x19, K=256, 512 boards): 2.0-2.1 ms per dual block vs 3.23 ms for the fp32-MFMA kernel.  The
+// kernel is POWER-bound, not issue-bound: with all-zero weights the identical instruction stream runs in 1.70 ms, a
+// bare bf16 MFMA loop reaches 2130 TFLOP/s on non-zero data (2464 on zeros), and making the global loads cache-hot,
+// dropping the split, dropping the barrier, bypassing LDS for the weights or pinning the schedule all land within
+// +-4 % of each other.  What would move it is less data motion per MFMA (larger register tiles).
 #pragma once
 // (included by net.hip INSIDE namespace agz, after ConvArgs / f32x16)
 
@@ -29,14 +35,56 @@ __device__ __forceinline__ void x3_split(float v, unsigned& h, unsigned& m, unsi
   h = hu; m = mu; l = __float_as_uint(r2);
 }
 // two fp32 bit patterns whose low halves are dead -> packed bf16 pair (e0 in the low half)
-__device__ __forceinline__ unsigned x3_pack(unsigned e0, unsigned e1) { return (e0 >> 16) | (e1 & 0xffff0000u); }
+__device__ __forceinline__ unsigned x3_pack(unsigned e0, unsigned e1) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
 
 // 16-byte chunk position of (row, half) inside a piece image of 32-byte rows: XOR with bit 3 of the row makes both the
 // ds_write_b128 (rows t/2, halves t%2) and the fragment ds_read_b128 (32 rows x fixed half) conflict-free
 __device__ __forceinline__ unsigned x3_lds_off(int row, int half) { return (unsigned)(row * 32 + ((half ^ ((row >> 3) & 1)) << 4)); }
 
+// shared epilogue (same as conv_tile): BN(scale,shift) + ReLU (+ dual add + ReLU), interior of padded NHWC
+#define X3_EPILOGUE \
+  _Pragma("unroll") \
+  for (int i = 0; i < 2; i++) { \
+  _Pragma("unroll") \
+    for (int r = 0; r < 16; r++) { \
+      int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); \
+      int m = m0 + row; \
+      const bool mvalid = m < a.M; \
+      if (!mvalid) m = a.M - 1; \
+      int b = m / a.HW, p = m - b * a.HW; \
+      int h = p / a.W, w = p - h * a.W; \
+      size_t obase = ((size_t)b * a.HpWp + (h + 1) * a.Wp + (w + 1)) * a.Cout_p; \
+      if (DUAL) { \
+        int c = n_tile * (BNT / 2) + wn * 32 + (lane & 31); \
+        if (mvalid && c < a.Cout_p) { \
+          float4 e = reinterpret_cast<const float4*>(a.ep)[(size_t)p * a.Cout_p + c]; \
+          float va = acc[i][0][r] * e.x + e.y; \
+          float vb = acc[i][1][r] * e.z + e.w; \
+          va = va > 0.f ? va : 0.f; \
+          vb = vb > 0.f ? vb : 0.f; \
+          float s = va + vb; \
+          a.y[obase + c] = s > 0.f ? s : 0.f; \
+        } \
+      } else { \
+  _Pragma("unroll") \
+        for (int j = 0; j < 2; j++) { \
+          int c = n0 + (wn * 2 + j) * 32 + (lane & 31); \
+          if (mvalid && c < a.Cout_p) { \
+            if (a.raw) { \
+              a.y[obase + c] = acc[i][j][r]; \
+            } else { \
+              float2 e = reinterpret_cast<const float2*>(a.ep)[(size_t)p * a.Cout_p + c]; \
+              float v = acc[i][j][r] * e.x + e.y; \
+              a.y[obase + c] = v > 0.f ? v : 0.f; \
+            } \
+          } \
+        } \
+      } \
+    } \
+  }
+
 template <bool DUAL>
-__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(ConvArgs a, const unsigned short* __restrict__ w3) {
+__global__ __launch_bounds__(256, 3) void conv3x3_x3_kernel(ConvArgs a, const unsigned short* __restrict__ w3) {
   constexpr int BM = 128, BNT = 128;
   constexpr int PIECE = 128 * 32;            // bytes of one piece image
   constexpr int STAGE = 6 * PIECE;           // A hi,mid,lo then B hi,mid,lo
@@ -90,110 +138,105 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(ConvArgs a, const un
     fb[1] = x3_lds_off((wn * 2 + 1) * 32 + (lane & 31), lane >> 5);
   }
 
-  float4 ga0, ga1;       // A: 8 fp32
-  u32x4_t gb0, gb1, gb2;  // B: 3 pieces x 8 bf16
+  // staging registers: two named sets (tile it+1 waits in one while tile it+2 is being fetched into the other)
+  float4 xa0, xa1, ya0, ya1;           // A: 8 fp32
+  u32x4_t xb0, xb1, xb2, yb0, yb1, yb2;  // B: 3 pieces x 8 bf16
+  // fetch cursor: (tap, 16-channel chunk) of the NEXT tile to load, advanced incrementally (no per-iteration division);
+  // 32-bit byte offsets from the two uniform base pointers keep the address arithmetic off the VALU
+  const char* xbase = reinterpret_cast<const char*>(a.x);
+  const char* wbase = reinterpret_cast<const char*>(w3);
+  const unsigned a_gbyte = (unsigned)a_goff * 4u, b_gbyte = (unsigned)b_goff * 2u;
+  const unsigned piece_bytes = (unsigned)(piece_stride * 2);
+  int f_tap = 0, f_cc = 0;
+  unsigned xo_ = a_gbyte + (unsigned)(((-1) * a.Wp + (-1)) * a.Cin_p * 4), wo_ = b_gbyte;
+#define X3_ADVANCE()                                                                          \
+  {                                                                                           \
+    f_cc++;                                                                                   \
+    xo_ += 64u; wo_ += 3u * piece_bytes;                                                      \
+    if (f_cc == NC) {                                                                         \
+      f_cc = 0;                                                                               \
+      if (f_tap < 8) {                                                                        \
+        f_tap++;                                                                              \
+        int ky_ = f_tap / 3, kx_ = f_tap - ky_ * 3;                                           \
+        xo_ = a_gbyte + (unsigned)(((ky_ - 1) * a.Wp + (kx_ - 1)) * a.Cin_p * 4);             \
+      } else { /* past the end: keep re-reading the last tile (never consumed) */             \
+        f_cc = NC - 1; xo_ -= 64u; wo_ -= 3u * piece_bytes;                                   \
+      }                                                                                       \
+    }                                                                                         \
+  }
+#define X3_GLOAD(A0, A1, B0, B1, B2)                                                          \
+  A0 = *reinterpret_cast<const float4*>(xbase + xo_);                                         \
+  A1 = *reinterpret_cast<const float4*>(xbase + xo_ + 16u);                                   \
+  B0 = *reinterpret_cast<const u32x4_t*>(wbase + wo_);                                        \
+  B1 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + piece_bytes);                          \
+  B2 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + 2u * piece_bytes);                     \
+  X3_ADVANCE()
+#define X3_STORE_A(A0, A1, BUF)                                                              \
+  {                                                                                          \
+    unsigned char* st_ = lds + (BUF) * STAGE;                                                \
+    const float v_[8] = {A0.x, A0.y, A0.z, A0.w, A1.x, A1.y, A1.z, A1.w};                    \
+    unsigned h_[8], m_[8], l_[8];                                                            \
+    _Pragma("unroll") for (int e = 0; e < 8; e++) x3_split(v_[e], h_[e], m_[e], l_[e]);      \
+    u32x4_t ph_ = {x3_pack(h_[0], h_[1]), x3_pack(h_[2], h_[3]), x3_pack(h_[4], h_[5]), x3_pack(h_[6], h_[7])}; \
+    u32x4_t pm_ = {x3_pack(m_[0], m_[1]), x3_pack(m_[2], m_[3]), x3_pack(m_[4], m_[5]), x3_pack(m_[6], m_[7])}; \
+    u32x4_t pl_ = {x3_pack(l_[0], l_[1]), x3_pack(l_[2], l_[3]), x3_pack(l_[4], l_[5]), x3_pack(l_[6], l_[7])}; \
+    *reinterpret_cast<u32x4_t*>(st_ + 0 * PIECE + s_off) = ph_;                              \
+    *reinterpret_cast<u32x4_t*>(st_ + 1 * PIECE + s_off) = pm_;                              \
+    *reinterpret_cast<u32x4_t*>(st_ + 2 * PIECE + s_off) = pl_;                              \
+  }
+#define X3_STORE_B(B0, B1, B2, BUF)                                                          \
+  {                                                                                          \
+    unsigned char* st_ = lds + (BUF) * STAGE;                                                \
+    *reinterpret_cast<u32x4_t*>(st_ + 3 * PIECE + s_off) = B0;                               \
+    *reinterpret_cast<u32x4_t*>(st_ + 4 * PIECE + s_off) = B1;                               \
+    *reinterpret_cast<u32x4_t*>(st_ + 5 * PIECE + s_off) = B2;                               \
+  }
+#define X3_SB   /* no sched_barrier pins: measured 1.99 ms with hipcc's own schedule vs 2.05-2.10 pinned */
+#define X3_MF(I, J, PA, PB) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[I][PA], B_[J][PB], acc[I][J], 0, 0, 0);
+  // one piece product on all four 32x32 sub-tiles: consecutive MFMAs hit different accumulators
+#define X3_QUAD(PA, PB) X3_MF(0, 0, PA, PB) X3_MF(0, 1, PA, PB) X3_MF(1, 0, PA, PB) X3_MF(1, 1, PA, PB)
+  // One K step.  X* = tile it+1 (already in registers) -> split + ds_write into the other stage;  Y* = tile it+2, fetched now.
+  // Memory instructions are slotted between MFMA groups and pinned there: a wave issues in order, so whatever sits
+  // behind an MFMA is free while the matrix pipe works; left to itself hipcc sinks the global loads to the end of the
+  // iteration and exposes their whole latency at the top of the next one.  Products: smallest terms first.
+#define X3_ITER(BUF, XA0, XA1, XB0, XB1, XB2, YA0, YA1, YB0, YB1, YB2)                       \
+  {                                                                                          \
+    const unsigned char* st = lds + (BUF) * STAGE;                                           \
+    bf16x8_t A_[2][3], B_[2][3];                                                             \
+    _Pragma("unroll") for (int p = 0; p < 3; p++) {                                          \
+      _Pragma("unroll") for (int i = 0; i < 2; i++) A_[i][p] = *reinterpret_cast<const bf16x8_t*>(st + p * PIECE + fa[i]);       \
+      _Pragma("unroll") for (int j = 0; j < 2; j++) B_[j][p] = *reinterpret_cast<const bf16x8_t*>(st + (3 + p) * PIECE + fb[j]); \
+    }                                                                                        \
+    X3_SB                                                                                    \
+    X3_QUAD(2, 0) X3_SB                                                                      \
+    X3_GLOAD(YA0, YA1, YB0, YB1, YB2) X3_SB                                                  \
+    X3_QUAD(0, 2) X3_SB                                                                      \
+    X3_STORE_A(XA0, XA1, (BUF) ^ 1) X3_SB                                                    \
+    X3_QUAD(1, 1) X3_QUAD(1, 0) X3_SB                                                        \
+    X3_STORE_B(XB0, XB1, XB2, (BUF) ^ 1) X3_SB                                               \
+    X3_QUAD(0, 1) X3_QUAD(0, 0) X3_SB                                                        \
+    __syncthreads();                                                                         \
+  }
 
-  auto gload = [&](int it) {
-    int t = it < NK ? it : NK - 1;
-    int tap = t / NC, cc = t - tap * NC;
-    int ky = tap / 3, kx = tap - ky * 3;
-    const float* xp = a.x + a_goff + ((ky - 1) * a.Wp + (kx - 1)) * a.Cin_p + cc * 16;
-    ga0 = *reinterpret_cast<const float4*>(xp);
-    ga1 = *reinterpret_cast<const float4*>(xp + 4);
-    const unsigned short* wp = w3 + (size_t)(tap * NC + cc) * 3 * piece_stride + b_goff;
-    gb0 = *reinterpret_cast<const u32x4_t*>(wp);
-    gb1 = *reinterpret_cast<const u32x4_t*>(wp + piece_stride);
-    gb2 = *reinterpret_cast<const u32x4_t*>(wp + 2 * piece_stride);
-  };
-  auto lstore = [&](int buf) {
-    unsigned char* st = lds + buf * STAGE;
-    const float v[8] = {ga0.x, ga0.y, ga0.z, ga0.w, ga1.x, ga1.y, ga1.z, ga1.w};
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) x3_split(v[e], h[e], m[e], l[e]);
-    u32x4_t ph = {x3_pack(h[0], h[1]), x3_pack(h[2], h[3]), x3_pack(h[4], h[5]), x3_pack(h[6], h[7])};
-    u32x4_t pm = {x3_pack(m[0], m[1]), x3_pack(m[2], m[3]), x3_pack(m[4], m[5]), x3_pack(m[6], m[7])};
-    u32x4_t pl = {x3_pack(l[0], l[1]), x3_pack(l[2], l[3]), x3_pack(l[4], l[5]), x3_pack(l[6], l[7])};
-    *reinterpret_cast<u32x4_t*>(st + 0 * PIECE + s_off) = ph;
-    *reinterpret_cast<u32x4_t*>(st + 1 * PIECE + s_off) = pm;
-    *reinterpret_cast<u32x4_t*>(st + 2 * PIECE + s_off) = pl;
-    *reinterpret_cast<u32x4_t*>(st + 3 * PIECE + s_off) = gb0;
-    *reinterpret_cast<u32x4_t*>(st + 4 * PIECE + s_off) = gb1;
-    *reinterpret_cast<u32x4_t*>(st + 5 * PIECE + s_off) = gb2;
-  };
-
-  gload(0);
-  lstore(0);
-  gload(1);
+  // prologue: tile 0 -> stage 0 (through set Y), tile 1 -> set X
+  X3_GLOAD(ya0, ya1, yb0, yb1, yb2)
+  X3_GLOAD(xa0, xa1, xb0, xb1, xb2)
+  X3_STORE_A(ya0, ya1, 0)
+  X3_STORE_B(yb0, yb1, yb2, 0)
   __syncthreads();
-  for (int it = 0; it < NK; it++) {
-    const int buf = it & 1;
-    // tile it+1 (in registers since the previous iteration) -> the other stage; then fetch tile it+2
-    if (it + 1 < NK) lstore(buf ^ 1);
-    gload(it + 2);
-    const unsigned char* st = lds + buf * STAGE;
-    bf16x8_t A[2][3], B[2][3];
-#pragma unroll
-    for (int p = 0; p < 3; p++) {
-#pragma unroll
-      for (int i = 0; i < 2; i++) A[i][p] = *reinterpret_cast<const bf16x8_t*>(st + p * PIECE + fa[i]);
-#pragma unroll
-      for (int j = 0; j < 2; j++) B[j][p] = *reinterpret_cast<const bf16x8_t*>(st + (3 + p) * PIECE + fb[j]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        // smallest terms first
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][2], B[j][0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][2], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][0], acc[i][j], 0, 0, 0);
-      }
-    __syncthreads();
+  for (int it = 0; it < NK; it += 2) {
+    X3_ITER(0, xa0, xa1, xb0, xb1, xb2, ya0, ya1, yb0, yb1, yb2)
+    if (it + 1 < NK) X3_ITER(1, ya0, ya1, yb0, yb1, yb2, xa0, xa1, xb0, xb1, xb2)
   }
+#undef X3_ITER
+#undef X3_QUAD
+#undef X3_MF
+#undef X3_SB
+#undef X3_STORE_B
+#undef X3_STORE_A
+#undef X3_GLOAD
+#undef X3_ADVANCE
 
-  // --- epilogue (same as conv_tile): BN(scale,shift) + ReLU (+ dual add + ReLU), interior of padded NHWC
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      int m = m0 + row;
-      const bool mvalid = m < a.M;
-      if (!mvalid) m = a.M - 1;
-      int b = m / a.HW, p = m - b * a.HW;
-      int h = p / a.W, w = p - h * a.W;
-      size_t obase = ((size_t)b * a.HpWp + (h + 1) * a.Wp + (w + 1)) * a.Cout_p;
-      if (DUAL) {
-        int c = n_tile * (BNT / 2) + wn * 32 + (lane & 31);
-        if (mvalid && c < a.Cout_p) {
-          float4 e = reinterpret_cast<const float4*>(a.ep)[(size_t)p * a.Cout_p + c];
-          float va = acc[i][0][r] * e.x + e.y;
-          float vb = acc[i][1][r] * e.z + e.w;
-          va = va > 0.f ? va : 0.f;
-          vb = vb > 0.f ? vb : 0.f;
-          float s = va + vb;
-          a.y[obase + c] = s > 0.f ? s : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          int c = n0 + (wn * 2 + j) * 32 + (lane & 31);
-          if (mvalid && c < a.Cout_p) {
-            if (a.raw) {
-              a.y[obase + c] = acc[i][j][r];
-            } else {
-              float2 e = reinterpret_cast<const float2*>(a.ep)[(size_t)p * a.Cout_p + c];
-              float v = acc[i][j][r] * e.x + e.y;
-              a.y[obase + c] = v > 0.f ? v : 0.f;
-            }
-          }
-        }
-      }
-    }
-  }
+  X3_EPILOGUE
 }
 

@@ -18,11 +18,13 @@ ap.add_argument("--B", type=int, default=512)
 ap.add_argument("--size", type=int, default=19)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--x3", action="store_true")
+ap.add_argument("--zero", action="store_true", help="all-zero weights (DVFS probe: same instruction stream, low toggle power)")
 args = ap.parse_args()
 ctx = A.Ctx(0)
 S = args.size
 net = A.Net(ctx, args.K, args.L, 2 * args.K, S, S, 18, S * S + 1)
-net.init_random(1337)
+if not args.zero:
+    net.init_random(1337)
 net.commit()
 if args.x3:
     net.set_compute_mode(A.capi.COMPUTE_BF16X3)

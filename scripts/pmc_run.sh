@@ -1,0 +1,39 @@
+#!/bin/bash
+# PMC passes for one command (each --pmc group in its own rocprofv3 run, with --kernel-trace only — gpurun refuses
+# pmc + sys/hip/hsa traces).  usage: scripts/pmc_run.sh <outdir> <kernel-substring> -- <command...>
+# Prints a JSON summary {counter: average per launch over launches of kernels whose name contains the substring}.
+set -u
+out=$1; shift; pat=$1; shift; shift
+repo=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p "$repo/$out"
+cd /tmp && export TMPDIR=/tmp
+groups=(
+ "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY"
+ "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU"
+ "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS"
+ "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY"
+ "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INST_CYCLES_VMEM"
+ "FETCH_SIZE WRITE_SIZE"
+ "GRBM_GUI_ACTIVE"
+)
+i=0
+for g in "${groups[@]}"; do
+  timeout 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d "$repo/$out/p$i" -- "$@" > "$repo/$out/p$i.log" 2>&1
+  i=$((i+1))
+done
+python3 - "$repo/$out" "$pat" <<'PY'
+import csv, glob, json, sys, collections
+out, pat = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if pat in r["Kernel_Name"]:
+            a = agg[r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+res = {k: v[0] / max(v[1], 1) for k, v in sorted(agg.items())}
+res["_launches"] = max((v[1] for v in agg.values()), default=0)
+json.dump(res, open(out + "/summary.json", "w"), indent=1)
+print(json.dumps(res))
+PY
+# raw traces are large: keep only the summary + logs
+rm -rf "$repo/$out"/p*/
