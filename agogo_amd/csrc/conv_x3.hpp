@@ -14,7 +14,8 @@
 // Tile: 128 pixels x 128 GEMM columns ([64 branch-a | 64 branch-b] channels, same interleave as the fp32 kernel, so the
 // fused BN/ReLU/add epilogue is shared), 4 waves (2x2) of 64x64, K step 16 channels of one filter tap per iteration.
 // LDS per stage: A 3 pieces x 128 rows x 32 B + B the same = 24 KB; two stages.
-//   w3[tap][cc][piece][n][16] bf16: the 128 x 16 B-tile of one (tap, cc, piece) is one contiguous 4 KB run.
+//   w3[cc][tap][piece][n][16] bf16: the 128 x 16 B-tile of one (cc, tap, piece) is one contiguous 4 KB run, and the
+//   K loop (chunk outer, tap inner) walks the array front to back.
 //
 // Measured (MI355X, 19x19, K=256, 512 boards): 2.0-2.1 ms per dual block vs 3.23 ms for the fp32-MFMA kernel.  The
 // kernel is POWER-bound, not issue-bound: with all-zero weights the identical instruction stream runs in 1.70 ms, a
@@ -147,22 +148,20 @@ __global__ __launch_bounds__(256, 3) void conv3x3_x3_kernel(ConvArgs a, const un
   const char* wbase = reinterpret_cast<const char*>(w3);
   const unsigned a_gbyte = (unsigned)a_goff * 4u, b_gbyte = (unsigned)b_goff * 2u;
   const unsigned piece_bytes = (unsigned)(piece_stride * 2);
-  int f_tap = 0, f_cc = 0;
-  unsigned xo_ = a_gbyte + (unsigned)(((-1) * a.Wp + (-1)) * a.Cin_p * 4), wo_ = b_gbyte;
+  // K order: 16-channel chunk OUTER, filter tap INNER — the nine taps of a chunk re-read the same 64-byte slices of
+  // ~170 neighbouring pixels back to back, so they hit in L1/L2 instead of going back to the Infinity Cache nine times
+  // (tap-major order measured 3.2 GB of L2 fills per launch for 0.2 GB of activations).
+  int f_kx = 0, f_ky = 0, f_n = 0;
+  const unsigned row_step = (unsigned)(a.Cin_p * 4), line_step = (unsigned)((a.Wp - 2) * a.Cin_p * 4);
+  const unsigned chunk_back = (unsigned)((2 * a.Wp + 2) * a.Cin_p * 4) - 64u;   // from tap (2,2) back to tap (0,0), next chunk
+  unsigned xo_ = a_gbyte - (unsigned)((a.Wp + 1) * a.Cin_p * 4), wo_ = b_gbyte;
 #define X3_ADVANCE()                                                                          \
-  {                                                                                           \
-    f_cc++;                                                                                   \
-    xo_ += 64u; wo_ += 3u * piece_bytes;                                                      \
-    if (f_cc == NC) {                                                                         \
-      f_cc = 0;                                                                               \
-      if (f_tap < 8) {                                                                        \
-        f_tap++;                                                                              \
-        int ky_ = f_tap / 3, kx_ = f_tap - ky_ * 3;                                           \
-        xo_ = a_gbyte + (unsigned)(((ky_ - 1) * a.Wp + (kx_ - 1)) * a.Cin_p * 4);             \
-      } else { /* past the end: keep re-reading the last tile (never consumed) */             \
-        f_cc = NC - 1; xo_ -= 64u; wo_ -= 3u * piece_bytes;                                   \
-      }                                                                                       \
-    }                                                                                         \
+  if (f_n + 1 < NK) {  /* past the end: keep re-reading the last tile (never consumed) */     \
+    f_n++;                                                                                    \
+    wo_ += 3u * piece_bytes;                                                                  \
+    if (f_kx < 2) { f_kx++; xo_ += row_step; }                                                \
+    else if (f_ky < 2) { f_kx = 0; f_ky++; xo_ += line_step; }                                \
+    else { f_kx = 0; f_ky = 0; xo_ -= chunk_back; }                                           \
   }
 #define X3_GLOAD(A0, A1, B0, B1, B2)                                                          \
   A0 = *reinterpret_cast<const float4*>(xbase + xo_);                                         \

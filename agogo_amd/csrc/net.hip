@@ -901,7 +901,7 @@ int agz_net_commit(agz_net* n) {
     if ((r = upload(&n->d_w_dual[l], wt, s)) != AGZ_OK) return r;
     if ((r = upload(&n->d_ep_dual[l], ep, s)) != AGZ_OK) return r;
     if (n->cfg == 0) {
-      // bf16x3 image of the same (tile-interleaved) filter: w3[tap][cc16][piece][n][16], exact truncation split
+      // bf16x3 image of the same (tile-interleaved) filter: w3[cc16][tap][piece][n][16], exact truncation split
       const int NC16 = Kp / 16, Ntot = 2 * Kp;
       std::vector<unsigned short> w3((size_t)9 * NC16 * 3 * Ntot * 16);
       for (int t = 0; t < 9; t++) for (int nn = 0; nn < Ntot; nn++) for (int ci = 0; ci < Kp; ci++) {
@@ -911,7 +911,7 @@ int agz_net_commit(agz_net* n) {
         float r1 = v - hf; uint32_t ru; memcpy(&ru, &r1, 4);
         mu = ru & 0xffff0000u; float mf; memcpy(&mf, &mu, 4);
         float r2 = r1 - mf; memcpy(&lu, &r2, 4);
-        size_t base = (((size_t)(t * NC16 + ci / 16) * 3) * Ntot + nn) * 16 + (ci % 16);
+        size_t base = (((size_t)((ci / 16) * 9 + t) * 3) * Ntot + nn) * 16 + (ci % 16);
         w3[base] = (unsigned short)(hu >> 16);
         w3[base + (size_t)Ntot * 16] = (unsigned short)(mu >> 16);
         w3[base + (size_t)2 * Ntot * 16] = (unsigned short)(lu >> 16);

@@ -34,7 +34,7 @@ struct agz_net {
   float* d_ep_init = nullptr;   // float2 {scale,shift} [HW][Kp]
   std::vector<float*> d_w_dual;   // per layer [9][2*Kp][Kp] in block-tile order
   std::vector<float*> d_ep_dual;  // per layer float4 {sa,ta,sb,tb} [HW][Kp]
-  std::vector<unsigned short*> d_w3_dual;  // per layer bf16x3 image [9][Kp/16][3][2*Kp][16] (cfg 0 only), conv_x3.hpp
+  std::vector<unsigned short*> d_w3_dual;  // per layer bf16x3 image [Kp/16][9][3][2*Kp][16] (cfg 0 only), conv_x3.hpp
   bool x3_mode = false;          // agz_net_set_compute_mode
   float* d_head_conv = nullptr;  // [3][Kp] policy ch0, ch1, value ch0 (1x1 filters)
   float* d_head_bn = nullptr;    // [3][HW][2] scale, shift

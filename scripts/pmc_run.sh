@@ -7,15 +7,19 @@ out=$1; shift; pat=$1; shift; shift
 repo=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$repo/$out"
 cd /tmp && export TMPDIR=/tmp
-groups=(
- "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY"
- "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU"
- "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS"
- "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY"
- "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INST_CYCLES_VMEM"
- "FETCH_SIZE WRITE_SIZE"
- "GRBM_GUI_ACTIVE"
-)
+# counter groups (one rocprofv3 pass each); choose with PMC_GROUPS="sq fetch write grbm" (default: all)
+declare -A G
+G[sq]="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY"
+G[inst]="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU"
+G[lds]="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS"
+G[act]="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY"
+G[vmem]="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INST_CYCLES_VMEM"
+G[fetch]="FETCH_SIZE"          # FETCH_SIZE + WRITE_SIZE together exceed the hardware's counter budget
+G[write]="WRITE_SIZE"
+G[grbm]="GRBM_GUI_ACTIVE"
+sel=${PMC_GROUPS:-"sq inst lds act vmem fetch write grbm"}
+groups=()
+for n in $sel; do groups+=("${G[$n]}"); done
 i=0
 for g in "${groups[@]}"; do
   timeout 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d "$repo/$out/p$i" -- "$@" > "$repo/$out/p$i.log" 2>&1

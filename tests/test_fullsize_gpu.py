@@ -175,3 +175,58 @@ def test_config2_connect4_k64_l6_400sims(ctx):
 def test_config3_go9_k128_l10_400sims(ctx):
     """BASELINE config #3 (9x9 Go, K=128, 10 blocks, 400 sims/move): first plies."""
     _drive_with_gpu_net(ctx, capi.GAME_WQ, (9, 9), 7.5, capi.ENC_WQ, 18, 128, 10, 400, 3, (1, 0))
+
+
+def test_engine_with_bf16x3_network_bit_exact_vs_oracle(ctx):
+    """AGZ_COMPUTE_BF16X3 under the engine: 32 concurrent 9x9 games (2592 GEMM rows: the throughput regime, bf16x3 dual
+    blocks), device trees vs oracle trees.  The oracle's inferencer evaluates each leaf as a 32-row batch of the same
+    board, so it takes the same kernel; the bf16x3 kernel is batch-independent bit for bit (checked first)."""
+    S, K, L, F, G, budget = (9, 9), 128, 2, 18, 32, 24
+    net = make_net(ctx, K, L, S, F)
+    net.set_compute_mode(capi.COMPUTE_BF16X3)
+    rng = np.random.default_rng(4)
+    x = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), size=(G, F, 9, 9)).astype(np.float32)
+    p_all, v_all = net.infer(x)
+    p_rep, v_rep = net.infer(np.repeat(x[5:6], G, axis=0))
+    np.testing.assert_array_equal(p_rep[0], p_all[5])
+    np.testing.assert_array_equal(p_rep[17], p_all[5])
+    np.testing.assert_array_equal(v_rep[0], v_all[5])
+    net.set_compute_mode(capi.COMPUTE_F32_MFMA)
+    p_f32, _ = net.infer(x)
+    assert not np.array_equal(p_f32, p_all)            # the engine below really runs the other arithmetic
+    net.set_compute_mode(capi.COMPUTE_BF16X3)
+
+    arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, Budget=budget)
+    arena.set_inferencer(0, capi.INF_NET, net)
+    arena.set_inferencer(1, capi.INF_NET, net)
+    ab = np.array([1, 0] * (G // 2), dtype=np.uint8)
+    arena.reset(ab)
+
+    def cb(planes):
+        p, v = net.infer(np.repeat(planes.reshape(1, F, 9, 9), G, axis=0))
+        return p[0], float(v[0])
+
+    orcs = {}
+    for g in (0, 1):
+        o = O.Arena(O.WQ, 9, 9, 0, 7.5, enc=O.ENC_WQ, Budget=budget)
+        o.set_callback(0, cb, 82)
+        o.set_callback(1, cb, 82)
+        o.begin(int(ab[g]))
+        orcs[g] = o
+    for ply in range(3):
+        arena.begin_move()
+        arena.simulate(budget)
+        arena.end_move(True)
+        for g, o in orcs.items():
+            _, st0 = o.state()
+            agent = 0 if ((st0["to_move"] == O.BLACK) == bool(ab[g])) else 1
+            o.step(True)
+            omv, ovis, obs, _ = o.root_children(agent)
+            dmv, dvis, dbs, _ = arena.root_children(g, agent)
+            np.testing.assert_array_equal(dmv, omv, err_msg="game %d ply %d" % (g, ply))
+            np.testing.assert_array_equal(dvis, ovis, err_msg="game %d ply %d" % (g, ply))
+            np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+            assert arena.history(g)[-1] == o.history()[-1]
+        # games with the same colour assignment are identical (same net, same seedless search)
+        for g in range(2, G, 5):
+            assert np.array_equal(arena.history(g), arena.history(g % 2))
