@@ -93,6 +93,18 @@ func NewNet(ctx *Ctx, d *dual.Dual, bnMode int) (*Net, error) {
 	return n, nil
 }
 
+// SetComputeMode selects the dual-block conv arithmetic: ComputeF32MFMA (default) or ComputeBF16X3 (exact 3-way bf16
+// split, six bf16 MFMAs per product; same parity tolerance, ~1.6x faster at self-play batch sizes).
+func (n *Net) SetComputeMode(mode int) error {
+	defer n.ctx.enter()()
+	return lastErr(C.agz_net_set_compute_mode(n.h, C.int(mode)))
+}
+
+const (
+	ComputeF32MFMA = C.AGZ_COMPUTE_F32_MFMA
+	ComputeBF16X3  = C.AGZ_COMPUTE_BF16X3
+)
+
 func (n *Net) Close() error { defer n.ctx.enter()(); C.agz_net_destroy(n.h); n.h = nil; return nil }
 
 // Inferencer implements agogo.Inferer over a Net (the batch-1 path; the batched path is BatchedArena).
