@@ -20,8 +20,10 @@
 // Measured (MI355X, 19x19, K=256, 512 boards): 2.0-2.1 ms per dual block vs 3.23 ms for the fp32-MFMA kernel.  The
 // kernel is POWER-bound, not issue-bound: with all-zero weights the identical instruction stream runs in 1.70 ms, a
 // bare bf16 MFMA loop reaches 2130 TFLOP/s on non-zero data (2464 on zeros), and making the global loads cache-hot,
-// dropping the split, dropping the barrier, bypassing LDS for the weights or pinning the schedule all land within
-// +-4 % of each other.  What would move it is less data motion per MFMA (larger register tiles).
+// dropping the split, dropping the barrier, bypassing LDS for the weights, pinning the schedule, or a 128x256 block
+// tile with 64x128 per wave (25 % fewer LDS reads per MFMA) all land within +-4 % of each other: the MFMAs themselves
+// on real (toggling) data draw most of the power budget — a bare MFMA loop over random rotating operands sustains
+// 1772 TFLOP/s bf16 = 295 in algorithmic units, and this kernel runs at 0.70 of that.
 #pragma once
 // (included by net.hip INSIDE namespace agz, after ConvArgs / f32x16)
 
@@ -238,4 +240,5 @@ __global__ __launch_bounds__(256, 3) void conv3x3_x3_kernel(ConvArgs a, const un
 
   X3_EPILOGUE
 }
+
 

@@ -278,7 +278,7 @@ def main():
                                    else "conv3x3_mfma_kernel<2,2,2,DUAL> (fused dual-branch block)",
                          "peak_note": ("algorithmic fp32-grade FLOPs against the dense bf16 MFMA peak / 6 (six bf16 MFMAs per "
                                        "product); the same FLOPs are %.2fx the fp32-MFMA peak of 157.3; measured bare-MFMA "
-                                       "ceiling under the power cap: 2130 TFLOP/s bf16 = 355 in these units (DESIGN.md 4b)"
+                                       "ceiling under the power cap on random rotating operands: 1772 TFLOP/s bf16 = 295 in these units (DESIGN.md 4b)"
                                        % ((achieved or 0) / FP32_MFMA_PEAK_TFLOPS)) if x3 else "dense fp32 MFMA peak",
                          "flops_per_launch": conv_flops_launch, "avg_launch_ms": conv_ms,
                          "launches": prof["conv_dual"]["launches"]},

@@ -9,13 +9,26 @@ template <int NACC>
 __global__ __launch_bounds__(256) void k(float* out, int iters, short seed) {
   f32x16 acc[NACC];
   for (int i = 0; i < NACC; i++) for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-  bf16x8_t a, b;
-  for (int e = 0; e < 8; e++) { a[e] = (short)(seed + threadIdx.x + e); b[e] = (short)(seed * 3 + threadIdx.x * 7 + e); }
+  // six different operand pairs, rotated like a real K loop rotates fragments.  seed 0: zeros; seed 1: random bf16 in
+  // [-2,2) (random sign/exponent-low/mantissa bits = realistic toggling); other: a smooth small-integer pattern
+  bf16x8_t a[6], b[6];
+  unsigned x = 0x9E3779B9u * (threadIdx.x + 1) + blockIdx.x;
+  for (int u = 0; u < 6; u++)
+    for (int e = 0; e < 8; e++) {
+      x = x * 1664525u + 1013904223u; unsigned ra = x >> 16;
+      x = x * 1664525u + 1013904223u; unsigned rb = x >> 16;
+      if (seed == 0) { a[u][e] = 0; b[u][e] = 0; }
+      else if (seed == 1) { a[u][e] = (short)((ra & 0x807f) | (0x7e + (ra >> 7 & 1) * 1) << 7); b[u][e] = (short)((rb & 0x807f) | (0x7e + (rb >> 7 & 1)) << 7); }
+      else { a[u][e] = (short)(seed + threadIdx.x + e); b[u][e] = (short)(seed * 3 + threadIdx.x * 7 + e); }
+    }
   for (int it = 0; it < iters; it++) {
 #pragma unroll
     for (int u = 0; u < 6; u++)
 #pragma unroll
-      for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+      for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[(u + i) % 6], acc[i], 0, 0, 0);
+    // keep the accumulators bounded so they do not saturate to inf (which would stop toggling)
+    if ((it & 63) == 63)
+      for (int i = 0; i < NACC; i++) for (int r = 0; r < 16; r++) acc[i][r] *= 1e-3f;
   }
   float s = 0;
   for (int i = 0; i < NACC; i++) for (int r = 0; r < 16; r++) s += acc[i][r];
