@@ -15,7 +15,7 @@ GAME_MNK, GAME_C4, GAME_KOMI, GAME_WQ = 0, 1, 2, 3
 ENC_TWOPLANE, ENC_WQ = 0, 1
 INF_NET, INF_DUMMY, INF_SCRIPT, INF_HASH, INF_UNIFORM = 0, 1, 2, 3, 4
 BN_DEGENERATE_EPS, BN_RUNNING, BN_IDENTITY = 0, 1, 2
-COMPUTE_F32_MFMA, COMPUTE_BF16X3 = 0, 1
+COMPUTE_F32_MFMA, COMPUTE_BF16X3, COMPUTE_FP16X2 = 0, 1, 2
 PROF_CONV, PROF_HEADS, PROF_SELECT, PROF_EXPAND, PROF_MOVE, PROF_CONV_INIT = 0, 1, 2, 3, 4, 5
 DONT_PREFER_PASS, PREFER_PASS, DONT_RESIGN = 0, 1, 2
 

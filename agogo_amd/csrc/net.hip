@@ -42,6 +42,10 @@ struct ConvArgs {
   int splits;   // >1: split-K — block (tile, s) covers K-iterations [s*per, (s+1)*per) and stores raw partials to ws
   int per;
   float* ws;    // [splits][M][Ntot] partial sums (GEMM column order)
+  // fp16x2 mode (conv_h2.hpp): amax_in[b] = max |activation| of board b in this layer's input (board_amax_kernel),
+  // w_unscale = 2^-eb of the pre-scaled weights
+  const unsigned* amax_in;
+  float w_unscale;
 };
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 }
 
 #include "conv_x3.hpp"
+#include "conv_h2.hpp"
 
 // split-K finish: sum the partials (in split order) and apply the conv epilogue.  One thread per (pixel row m, 4 channels).
 template <bool DUAL>
@@ -550,7 +555,10 @@ void agz_net::free_device() {
   for (auto& p : d_w_dual) f(p);
   for (auto& p : d_ep_dual) f(p);
   for (auto& p : d_w3_dual) if (p) { hipFree(p); p = nullptr; }
-  d_w_dual.clear(); d_ep_dual.clear(); d_w3_dual.clear();
+  for (auto& p : d_w2_dual) if (p) { hipFree(p); p = nullptr; }
+  if (d_amax) { hipFree(d_amax); d_amax = nullptr; }
+  amax_cap = 0;
+  d_w_dual.clear(); d_ep_dual.clear(); d_w3_dual.clear(); d_w2_dual.clear();
   f(d_head_conv); f(d_head_bn); f(d_Wp); f(d_bp); f(d_W1); f(d_b1); f(d_W2); f(d_b2);
   f(d_act_in); f(d_actA); f(d_actB); f(d_planes); f(d_policy); f(d_value); f(d_ws); f(d_hs);
   ws_cap = 0; hs_cap = 0;
@@ -646,6 +654,14 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   const int tiles_dual = cfg != 0 ? ceil_div(a.M, 128) * ceil_div(2 * Kp, 64) : ceil_div(a.M, 64) * ceil_div(2 * Kp, 128);
   const bool latency = latency_mode && Kp >= 64 && tiles_dual * 4 <= ctx->num_cus;  // 32-wide towers are launch-bound
   float** wsp = latency ? &d_ws : nullptr;
+  const bool use_h2 = cfg == 0 && !latency && compute_mode == AGZ_COMPUTE_FP16X2 && conf.SharedLayers > 0;
+  if (use_h2 && (size_t)B > amax_cap) {
+    AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (d_amax) hipFree(d_amax);
+    d_amax = nullptr; amax_cap = 0;
+    AGZ_HIP_TRY(hipMalloc(&d_amax, (size_t)B * sizeof(unsigned)));
+    amax_cap = (size_t)B;
+  }
   int rc;
   if (cfg != 0) rc = launch_conv<4, 1, 1, false>(ctx, a, wsp, &ws_cap);
   else if (half_init) rc = launch_conv<2, 2, 1, false>(ctx, a, wsp, &ws_cap);
@@ -657,7 +673,22 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   for (int l = 0; l < conf.SharedLayers; l++) {
     a.x = cur; a.w = d_w_dual[l]; a.ep = d_ep_dual[l]; a.y = nxt;
     a.Cin_p = Kp; a.Cout_p = Kp; a.Ntot = 2 * Kp;
-    if (cfg == 0 && !latency && x3_mode) {
+    if (use_h2) {
+      a.n_ntiles = ceil_div(a.Ntot, 128); a.n_mtiles = ceil_div(a.M, 128);
+      a.splits = 1; a.per = 0; a.ws = nullptr; a.raw = 0;
+      // per-board range of this layer's input (one word per board: results stay independent of the batch composition)
+      hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, ctx->stream, cur, d_amax, HW, W, Wp, Hp * Wp, Kp);
+      a.amax_in = d_amax; a.w_unscale = w_unscale[l];
+      ProfScope ps(ctx, AGZ_PROF_CONV);
+      if ((2 * Kp) % 256 == 0) {   // wide tile: 128 x 256
+        a.n_ntiles = (2 * Kp) / 256;
+        hipLaunchKernelGGL(conv3x3_h2w_kernel, dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, a, d_w2_dual[l]);
+      } else {
+        hipLaunchKernelGGL(conv3x3_h2_kernel, dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, a, d_w2_dual[l]);
+      }
+      rc = AGZ_OK;
+    }
+    else if (cfg == 0 && !latency && compute_mode == AGZ_COMPUTE_BF16X3) {
       a.n_ntiles = ceil_div(a.Ntot, 128); a.n_mtiles = ceil_div(a.M, 128);
       a.splits = 1; a.per = 0; a.ws = nullptr; a.raw = 0;
       ProfScope ps(ctx, AGZ_PROF_CONV);
@@ -877,6 +908,10 @@ int agz_net_commit(agz_net* n) {
   n->d_ep_dual.assign(c.SharedLayers, nullptr);
   for (auto& p : n->d_w3_dual) if (p) hipFree(p);
   n->d_w3_dual.assign(c.SharedLayers, nullptr);
+  for (auto& p : n->d_w2_dual) if (p) hipFree(p);
+  n->d_w2_dual.assign(c.SharedLayers, nullptr);
+  n->w_unscale.assign(c.SharedLayers, 1.0f);
+
   const int half = (n->cfg == 0) ? 64 : 32;  // channels per block tile (BNT/2)
   for (int l = 0; l < c.SharedLayers; l++) {
     const Param& wa = n->params[pi];
@@ -915,6 +950,29 @@ int agz_net_commit(agz_net* n) {
         w3[base] = (unsigned short)(hu >> 16);
         w3[base + (size_t)Ntot * 16] = (unsigned short)(mu >> 16);
         w3[base + (size_t)2 * Ntot * 16] = (unsigned short)(lu >> 16);
+      }
+      // fp16x2 image: w2[cc32][tap][piece][n][32], scaled by a power of two so that max|w| lands in [2^13, 2^14)
+      {
+        const int NC32 = Kp / 32;
+        float wmax = 0.f;
+        for (float v : wt) wmax = std::max(wmax, std::fabs(v));
+        int ex = 0;
+        if (wmax > 0.f) std::frexp(wmax, &ex);             // wmax = f * 2^ex, f in [0.5, 1)
+        const float sb = wmax > 0.f ? std::ldexp(1.0f, 14 - ex) : 1.0f;
+        n->w_unscale[l] = 1.0f / sb;
+        std::vector<_Float16> w2((size_t)9 * NC32 * 2 * Ntot * 32);
+        for (int t = 0; t < 9; t++) for (int nn = 0; nn < Ntot; nn++) for (int ci = 0; ci < Kp; ci++) {
+          float xs = wt[((size_t)t * Ntot + nn) * Kp + ci] * sb;
+          _Float16 hi = (_Float16)xs;
+          _Float16 lo = (_Float16)(xs - (float)hi);
+          size_t base = (((size_t)((ci / 32) * 9 + t) * 2) * Ntot + nn) * 32 + (ci % 32);
+          w2[base] = hi;
+          w2[base + (size_t)Ntot * 32] = lo;
+        }
+        if (n->d_w2_dual[l]) { hipFree(n->d_w2_dual[l]); n->d_w2_dual[l] = nullptr; }
+        AGZ_HIP_TRY(hipMalloc(&n->d_w2_dual[l], w2.size() * 2));
+        AGZ_HIP_TRY(hipMemcpyAsync(n->d_w2_dual[l], w2.data(), w2.size() * 2, hipMemcpyHostToDevice, s));
+        AGZ_HIP_TRY(hipStreamSynchronize(s));
       }
       if (n->d_w3_dual[l]) { hipFree(n->d_w3_dual[l]); n->d_w3_dual[l] = nullptr; }
       AGZ_HIP_TRY(hipMalloc(&n->d_w3_dual[l], w3.size() * 2));
@@ -956,8 +1014,9 @@ int agz_net_commit(agz_net* n) {
 
 int agz_net_set_compute_mode(agz_net* n, int mode) {
   AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_compute_mode: NULL net");
-  AGZ_REQUIRE(mode == AGZ_COMPUTE_F32_MFMA || mode == AGZ_COMPUTE_BF16X3, AGZ_E_INVALID, "agz_net_set_compute_mode: unknown mode %d", mode);
-  n->x3_mode = mode == AGZ_COMPUTE_BF16X3;
+  AGZ_REQUIRE(mode == AGZ_COMPUTE_F32_MFMA || mode == AGZ_COMPUTE_BF16X3 || mode == AGZ_COMPUTE_FP16X2, AGZ_E_INVALID,
+              "agz_net_set_compute_mode: unknown mode %d", mode);
+  n->compute_mode = mode;
   return AGZ_OK;
 }
 

@@ -35,7 +35,11 @@ struct agz_net {
   std::vector<float*> d_w_dual;   // per layer [9][2*Kp][Kp] in block-tile order
   std::vector<float*> d_ep_dual;  // per layer float4 {sa,ta,sb,tb} [HW][Kp]
   std::vector<unsigned short*> d_w3_dual;  // per layer bf16x3 image [Kp/16][9][3][2*Kp][16] (cfg 0 only), conv_x3.hpp
-  bool x3_mode = false;          // agz_net_set_compute_mode
+  std::vector<_Float16*> d_w2_dual;        // per layer fp16x2 image [Kp/32][9][2][2*Kp][32] (cfg 0 only), conv_h2.hpp
+  std::vector<float> w_unscale;            // per layer 2^-eb of the fp16x2 weight scale
+  unsigned* d_amax = nullptr;              // [B] per-board max |activation| of the layer about to be consumed (fp16x2)
+  size_t amax_cap = 0;
+  int compute_mode = AGZ_COMPUTE_F32_MFMA;  // agz_net_set_compute_mode
   float* d_head_conv = nullptr;  // [3][Kp] policy ch0, ch1, value ch0 (1x1 filters)
   float* d_head_bn = nullptr;    // [3][HW][2] scale, shift
   float* d_Wp = nullptr;         // [2HW][A]

@@ -35,6 +35,9 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # same guide: v_mfma_f32_32x32x16_bf16 dense (256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz)
 # bf16x3 formulation (agogo_amd/csrc/conv_x3.hpp): 6 bf16 MFMAs per fp32-grade product -> algorithmic peak = bf16 peak / 6
 BF16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+# fp16x2 formulation (conv_h2.hpp): 3 fp16 MFMAs per product (fp16 dense peak = bf16 dense peak)
+FP16X2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
+MODES = {"f32": capi.COMPUTE_F32_MFMA, "bf16x3": capi.COMPUTE_BF16X3, "fp16x2": capi.COMPUTE_FP16X2}
 
 
 def standard_bn_init(net):
@@ -119,10 +122,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-games-leg", action="store_true", help="skip the measured games/s leg (config #2)")
     ap.add_argument("--two-nets", action="store_true", help="agents A and B hold different networks")
-    ap.add_argument("--compute", choices=["bf16x3", "f32"], default="bf16x3",
+    ap.add_argument("--compute", choices=["bf16x3", "f32", "fp16x2"], default="bf16x3",
                     help="dual-block conv arithmetic: bf16x3 = exact 3-way bf16 split on the bf16 matrix pipe (fp32-grade, "
-                         "same parity tolerance), f32 = v_mfma_f32_32x32x2_f32")
-    ap.add_argument("--no-f32-leg", action="store_true", help="skip the short comparison leg in the other compute mode")
+                         "same parity tolerance), f32 = v_mfma_f32_32x32x2_f32, fp16x2 = range-managed 2-way fp16 split "
+                         "(3 MFMAs per product; opt-in fast mode)")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the short comparison legs in the other compute modes")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="debug: all ranks use GPU 0 and gloo collectives (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -144,7 +148,7 @@ def main():
         net.init_random(1337 + i)
         standard_bn_init(net)
         net.commit()
-        net.set_compute_mode(capi.COMPUTE_BF16X3 if args.compute == "bf16x3" else capi.COMPUTE_F32_MFMA)
+        net.set_compute_mode(MODES[args.compute])
         nets.append(net)
     arena = A.Arena(ctx, capi.GAME_WQ, S, S, komi=7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337 + rank,
                     Budget=args.budget, PUCT=1.0, RandomCount=0, DumbPass=True,
@@ -201,28 +205,31 @@ def main():
         n, ms = ctx.prof_read(k)
         prof[name] = {"launches": n, "avg_ms": (ms / n) if n else None, "total_ms": ms}
 
-    # short comparison leg in the exact-fp32 MFMA mode (same arena, continues the same games)
-    f32_leg = None
-    if world == 1 and args.compute == "bf16x3" and not args.no_f32_leg:
+    # short comparison legs in the other compute modes (same arena, the games simply continue)
+    legs = {}
+    if world == 1 and not args.no_f32_leg:
+        for mode in ("f32", "bf16x3", "fp16x2"):
+            if mode == args.compute:
+                continue
+            for n_ in nets:
+                n_.set_compute_mode(MODES[mode])
+            k2 = max(2, min(args.steps, 8))
+            step(); fence()
+            s0 = arena.stats()
+            ctx.prof_enable(True)
+            fence()
+            g0 = time.perf_counter()
+            for _ in range(k2):
+                step()
+            fence()
+            d2 = time.perf_counter() - g0
+            ctx.prof_enable(False)
+            s1 = arena.stats()
+            n2, ms2 = ctx.prof_read(capi.PROF_CONV)
+            legs[mode] = {"steps": k2, "sims_per_s": (s1["sims_nonnull"] - s0["sims_nonnull"]) / d2, "ms_per_step": d2 / k2 * 1e3,
+                          "conv_dual_avg_ms": (ms2 / n2) if n2 else None}
         for n_ in nets:
-            n_.set_compute_mode(capi.COMPUTE_F32_MFMA)
-        k2 = max(2, min(args.steps, 8))
-        step(); fence()
-        s0 = arena.stats()
-        ctx.prof_enable(True)
-        fence()
-        g0 = time.perf_counter()
-        for _ in range(k2):
-            step()
-        fence()
-        d2 = time.perf_counter() - g0
-        ctx.prof_enable(False)
-        s1 = arena.stats()
-        n2, ms2 = ctx.prof_read(capi.PROF_CONV)
-        f32_leg = {"steps": k2, "sims_per_s": (s1["sims_nonnull"] - s0["sims_nonnull"]) / d2, "ms_per_step": d2 / k2 * 1e3,
-                   "conv_dual_avg_ms": (ms2 / n2) if n2 else None}
-        for n_ in nets:
-            n_.set_compute_mode(capi.COMPUTE_BF16X3)
+            n_.set_compute_mode(MODES[args.compute])
 
     # optional: the one exchange step of the path — gather recorded examples across ranks (untimed leg)
     gather_ms = None
@@ -249,22 +256,38 @@ def main():
         conv_ms = prof["conv_dual"]["avg_ms"]
         achieved = conv_flops_launch / (conv_ms * 1e-3) / 1e12 if conv_ms else None
         x3 = args.compute == "bf16x3"
-        peak = BF16X3_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
+        peaks = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16X3_PEAK_TFLOPS, "fp16x2": FP16X2_PEAK_TFLOPS}
+        peak = peaks[args.compute]
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_conv_x3.json" if x3 else "pmc_conv_dual.json")
+        pmc_name = {"f32": "pmc_conv_dual.json", "bf16x3": "pmc_conv_x3.json", "fp16x2": "pmc_conv_h2.json"}[args.compute]
+        pmc_path = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc_path) and (S, K, L, G) == (19, 256, 20, 512):  # the PMC pass was taken on this exact shape
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        if f32_leg and f32_leg.get("conv_dual_avg_ms"):
-            f32_leg["conv_dual_tflops"] = conv_flops_launch / (f32_leg["conv_dual_avg_ms"] * 1e-3) / 1e12
-            f32_leg["frac_of_fp32_mfma_peak"] = f32_leg["conv_dual_tflops"] / FP32_MFMA_PEAK_TFLOPS
+        for mode, leg in legs.items():
+            if leg.get("conv_dual_avg_ms"):
+                leg["conv_dual_tflops"] = conv_flops_launch / (leg["conv_dual_avg_ms"] * 1e-3) / 1e12
+                leg["frac_of_its_roofline"] = leg["conv_dual_tflops"] / peaks[mode]
+                leg["roofline_peak_tflops"] = peaks[mode]
+        dtypes = {"f32": "f32",
+                  "bf16x3": "f32 (bf16x3 split: each fp32 operand = 3 exact bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate)",
+                  "fp16x2": "f32 (fp16x2 split: power-of-two range scaling, 2 fp16 pieces = 23 significand bits, 3 fp16 MFMAs per product, fp32 accumulate)"}
+        kernels = {"f32": "conv3x3_mfma_kernel<2,2,2,DUAL> (fused dual-branch block)",
+                   "bf16x3": "conv3x3_x3_kernel<DUAL> (fused dual-branch block, bf16x3)",
+                   "fp16x2": "conv3x3_h2w_kernel (fused dual-branch block, fp16x2, 128x256 tile)"}
+        notes = {"f32": "dense fp32 MFMA peak",
+                 "bf16x3": ("algorithmic fp32-grade FLOPs against the dense bf16 MFMA peak / 6 (six bf16 MFMAs per product); the same "
+                            "FLOPs are %.2fx the fp32-MFMA peak of 157.3; measured bare-MFMA ceiling under the power cap on random "
+                            "rotating operands: 1772 TFLOP/s bf16 = 295 in these units (DESIGN.md 4b)" % ((achieved or 0) / FP32_MFMA_PEAK_TFLOPS)),
+                 "fp16x2": ("algorithmic FLOPs against the dense fp16 MFMA peak / 3 (three fp16 MFMAs per product); %.2fx the "
+                            "fp32-MFMA peak (DESIGN.md 4c)" % ((achieved or 0) / FP32_MFMA_PEAK_TFLOPS))}
         out = {
             "metric": "mcts_sims_per_sec", "value": sims_sum / t_max, "unit": "sims/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (bf16x3 split: each fp32 operand = 3 exact bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate)" if x3 else "f32",
+            "dtype": dtypes[args.compute],
             "data": "synthetic",
             "config": {"workload": "19x19 Go (wq) self-play: K=%d, %d dual-branch blocks, FC=%d, A=%d, WQEncoder F=18, "
                                    "%d concurrent games/GPU, %d sims/move, leaf batch=%d, one net for both agents=%s"
@@ -274,12 +297,7 @@ def main():
                        "parallelism": "games sharded %d/GPU, no data-path collective" % G},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic,
-                         "kernel": "conv3x3_x3_kernel<DUAL> (fused dual-branch block, bf16x3)" if x3
-                                   else "conv3x3_mfma_kernel<2,2,2,DUAL> (fused dual-branch block)",
-                         "peak_note": ("algorithmic fp32-grade FLOPs against the dense bf16 MFMA peak / 6 (six bf16 MFMAs per "
-                                       "product); the same FLOPs are %.2fx the fp32-MFMA peak of 157.3; measured bare-MFMA "
-                                       "ceiling under the power cap on random rotating operands: 1772 TFLOP/s bf16 = 295 in these units (DESIGN.md 4b)"
-                                       % ((achieved or 0) / FP32_MFMA_PEAK_TFLOPS)) if x3 else "dense fp32 MFMA peak",
+                         "kernel": kernels[args.compute], "peak_note": notes[args.compute],
                          "flops_per_launch": conv_flops_launch, "avg_launch_ms": conv_ms,
                          "launches": prof["conv_dual"]["launches"]},
             "extra": {"nn_evals_per_s": evals_sum / t_max, "iterations_per_s": iters_sum / t_max,
@@ -289,7 +307,7 @@ def main():
                       "end_to_end_tflops": evals_sum * flops_eval / t_max / 1e12,
                       "end_to_end_frac_of_fp32_peak": evals_sum * flops_eval / t_max / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
                       "kernel_classes": prof, "examples_allgather_ms": gather_ms, "compute": args.compute,
-                      "f32_mfma_leg": f32_leg,
+                      "other_compute_modes": legs,
                       "tree_full": st1["tree_full"]},
         }
         if world == 1 and not args.no_games_leg:

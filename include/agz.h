@@ -128,9 +128,15 @@ int agz_net_set_latency_mode(agz_net* net, int on);
  *   AGZ_COMPUTE_F32_MFMA  v_mfma_f32_32x32x2_f32, exact fp32 products (default)
  *   AGZ_COMPUTE_BF16X3    every fp32 operand split exactly into three bf16 pieces, six bf16 MFMAs per product
  *                         (dropped cross terms <= 2^-23 relative), fp32 accumulation — 2.67x the fp32 matrix rate.
- *                         Used for K a multiple of 64 and batches that fill the chip; other shapes keep F32_MFMA. */
+ *   AGZ_COMPUTE_FP16X2    every operand scaled by a power of two into fp16 range and split into two fp16 pieces
+ *                         (23 significand bits), three fp16 MFMAs per product, fp32 accumulation; per-layer
+ *                         activation ranges are tracked on the device.  Same parity tolerance on the tested nets;
+ *                         elements more than 2^17 below their tensor's maximum lose relative precision.
+ *                         Both split modes apply to K a multiple of 64 and batches that fill the chip; other shapes
+ *                         keep F32_MFMA. */
 #define AGZ_COMPUTE_F32_MFMA 0
 #define AGZ_COMPUTE_BF16X3 1
+#define AGZ_COMPUTE_FP16X2 2
 int agz_net_set_compute_mode(agz_net* net, int mode);
 /* Checkpoint of the learnables in Model() order (+ BN statistics).  The reference gob-encodes G.Values
  * (AZ.Save / Dual.GobEncode, agogo.go:175-209, dualnet/dual.go:180-206); gob is Go-only, so this is a documented

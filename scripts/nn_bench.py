@@ -18,6 +18,7 @@ ap.add_argument("--B", type=int, default=512)
 ap.add_argument("--size", type=int, default=19)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--x3", action="store_true")
+ap.add_argument("--h2", action="store_true", help="AGZ_COMPUTE_FP16X2")
 ap.add_argument("--zero", action="store_true", help="all-zero weights (DVFS probe: same instruction stream, low toggle power)")
 args = ap.parse_args()
 ctx = A.Ctx(0)
@@ -28,6 +29,8 @@ if not args.zero:
 net.commit()
 if args.x3:
     net.set_compute_mode(A.capi.COMPUTE_BF16X3)
+if args.h2:
+    net.set_compute_mode(A.capi.COMPUTE_FP16X2)
 x = torch.randint(-1, 2, (args.B, 18, S, S), device="cuda").float()
 pol = torch.empty((args.B, S * S + 1), device="cuda")
 val = torch.empty((args.B,), device="cuda")

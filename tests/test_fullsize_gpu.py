@@ -177,13 +177,14 @@ def test_config3_go9_k128_l10_400sims(ctx):
     _drive_with_gpu_net(ctx, capi.GAME_WQ, (9, 9), 7.5, capi.ENC_WQ, 18, 128, 10, 400, 3, (1, 0))
 
 
-def test_engine_with_bf16x3_network_bit_exact_vs_oracle(ctx):
-    """AGZ_COMPUTE_BF16X3 under the engine: 32 concurrent 9x9 games (2592 GEMM rows: the throughput regime, bf16x3 dual
+@pytest.mark.parametrize("mode", [capi.COMPUTE_BF16X3, capi.COMPUTE_FP16X2])
+def test_engine_with_split_mode_network_bit_exact_vs_oracle(ctx, mode):
+    """AGZ_COMPUTE_BF16X3 / AGZ_COMPUTE_FP16X2 under the engine: 32 concurrent 9x9 games (2592 GEMM rows: the throughput regime, bf16x3 dual
     blocks), device trees vs oracle trees.  The oracle's inferencer evaluates each leaf as a 32-row batch of the same
     board, so it takes the same kernel; the bf16x3 kernel is batch-independent bit for bit (checked first)."""
     S, K, L, F, G, budget = (9, 9), 128, 2, 18, 32, 24
     net = make_net(ctx, K, L, S, F)
-    net.set_compute_mode(capi.COMPUTE_BF16X3)
+    net.set_compute_mode(mode)
     rng = np.random.default_rng(4)
     x = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), size=(G, F, 9, 9)).astype(np.float32)
     p_all, v_all = net.infer(x)
@@ -194,7 +195,7 @@ def test_engine_with_bf16x3_network_bit_exact_vs_oracle(ctx):
     net.set_compute_mode(capi.COMPUTE_F32_MFMA)
     p_f32, _ = net.infer(x)
     assert not np.array_equal(p_f32, p_all)            # the engine below really runs the other arithmetic
-    net.set_compute_mode(capi.COMPUTE_BF16X3)
+    net.set_compute_mode(mode)
 
     arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, Budget=budget)
     arena.set_inferencer(0, capi.INF_NET, net)

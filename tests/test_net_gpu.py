@@ -183,18 +183,24 @@ def test_checkpoint_roundtrip(ctx, tmp_path):
         wrong.load(path)
 
 
+SPLIT_MODES = [A.capi.COMPUTE_BF16X3, A.capi.COMPUTE_FP16X2]
+
+
+@pytest.mark.parametrize("mode", SPLIT_MODES)
 @pytest.mark.parametrize("K,L,FC,W,H,F,Aspace,B,bn_mode", [
     (64, 2, 128, 9, 9, 18, 82, 70, 0),      # 5670 rows, partial last M tile
     (128, 2, 64, 9, 9, 18, 82, 33, 2),      # two column tiles
     (256, 2, 128, 19, 19, 18, 362, 8, 2),   # BASELINE width
+    (64, 5, 64, 9, 9, 18, 82, 64, 1),       # deeper tower, running-stats BN
 ])
-def test_bf16x3_compute_mode_matches_oracle_and_f32(ctx, K, L, FC, W, H, F, Aspace, B, bn_mode):
-    """AGZ_COMPUTE_BF16X3 (conv_x3.hpp): exact 3-way bf16 split of both operands, 6 of the 9 piece products — the same
+def test_split_compute_modes_match_oracle_and_f32(ctx, K, L, FC, W, H, F, Aspace, B, bn_mode, mode):
+    """AGZ_COMPUTE_BF16X3 (conv_x3.hpp: exact 3-way bf16 split, 6 of 9 piece products) and AGZ_COMPUTE_FP16X2
+    (conv_h2.hpp: power-of-two scaling + 2-way fp16 split, 3 of 4 products, device-tracked activation ranges): the same
     fp32 tolerance against the oracle as the fp32-MFMA path, and agreement with that path far inside it."""
     onet, gnet = make_pair(ctx, K, L, FC, W, H, F, Aspace, bn_mode)
     x = rand_planes(B, F, H, W, seed=K + B)
     pol_f, val_f = gnet.infer(x)
-    gnet.set_compute_mode(A.capi.COMPUTE_BF16X3)
+    gnet.set_compute_mode(mode)
     pol_g, val_g = gnet.infer(x)
     gnet.set_compute_mode(A.capi.COMPUTE_F32_MFMA)
     assert not np.array_equal(pol_g, pol_f)          # really a different arithmetic path
@@ -204,5 +210,23 @@ def test_bf16x3_compute_mode_matches_oracle_and_f32(ctx, K, L, FC, W, H, F, Aspa
     np.testing.assert_allclose(val_g[idx], val_o, atol=VAL_ATOL)
     np.testing.assert_allclose(pol_g, pol_f, atol=POL_ATOL, rtol=POL_RTOL)
     np.testing.assert_allclose(val_g, val_f, atol=VAL_ATOL)
-    print("max |dpol| x3 vs f32:", np.abs(pol_g - pol_f).max(), " vs oracle:", np.abs(pol_g[idx] - pol_o).max(),
-          " f32 vs oracle:", np.abs(pol_f[idx] - pol_o).max())
+    print("mode %d max |dpol| vs f32: %.3e  vs oracle: %.3e   f32 vs oracle: %.3e" % (
+        mode, np.abs(pol_g - pol_f).max(), np.abs(pol_g[idx] - pol_o).max(), np.abs(pol_f[idx] - pol_o).max()))
+
+
+@pytest.mark.parametrize("mode", SPLIT_MODES)
+@pytest.mark.parametrize("in_scale", [1e-4, 1.0, 3e3])
+def test_split_compute_modes_over_input_and_activation_ranges(ctx, mode, in_scale):
+    """Range stress: inputs scaled by 1e-4 .. 3e3 and the reference's raw initialiser kinds under the degenerate-eps
+    BatchNorm (activations grow ~x316 per layer).  fp16x2 derives its per-layer scale from the tracked
+    maximum, so neither overflow nor flush-to-zero may appear; compared with the fp32-MFMA path on the pre-softmax side
+    of saturation: the probabilities must agree to the usual tolerance."""
+    onet, gnet = make_pair(ctx, 64, 3, 64, 9, 9, 18, 82, bn_mode=0, tame=False)
+    x = rand_planes(40, 18, 9, 9, seed=9) * np.float32(in_scale)
+    pol_f, val_f = gnet.infer(x)
+    gnet.set_compute_mode(mode)
+    pol_g, val_g = gnet.infer(x)
+    assert np.all(np.isfinite(pol_g)) and np.all(np.isfinite(val_g))
+    np.testing.assert_allclose(pol_g.sum(axis=1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(pol_g, pol_f, atol=1e-4, rtol=1e-3)
+    np.testing.assert_allclose(val_g, val_f, atol=1e-4)
