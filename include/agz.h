@@ -129,9 +129,10 @@ int agz_net_set_latency_mode(agz_net* net, int on);
  *   AGZ_COMPUTE_BF16X3    every fp32 operand split exactly into three bf16 pieces, six bf16 MFMAs per product
  *                         (dropped cross terms <= 2^-23 relative), fp32 accumulation — 2.67x the fp32 matrix rate.
  *   AGZ_COMPUTE_FP16X2    every operand scaled by a power of two into fp16 range and split into two fp16 pieces
- *                         (23 significand bits), three fp16 MFMAs per product, fp32 accumulation; per-layer
- *                         activation ranges are tracked on the device.  Same parity tolerance on the tested nets;
- *                         elements more than 2^17 below their tensor's maximum lose relative precision.
+ *                         (23 significand bits), three fp16 MFMAs per product, fp32 accumulation; the scale of
+ *                         every board's activations is measured on the device per layer (results stay independent
+ *                         of the batch composition).  Same parity tolerance on the tested nets; elements more than
+ *                         2^17 below their board's maximum lose relative precision — opt-in.
  *                         Both split modes apply to K a multiple of 64 and batches that fill the chip; other shapes
  *                         keep F32_MFMA. */
 #define AGZ_COMPUTE_F32_MFMA 0
