@@ -654,7 +654,10 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   const int tiles_dual = cfg != 0 ? ceil_div(a.M, 128) * ceil_div(2 * Kp, 64) : ceil_div(a.M, 64) * ceil_div(2 * Kp, 128);
   const bool latency = latency_mode && Kp >= 64 && tiles_dual * 4 <= ctx->num_cus;  // 32-wide towers are launch-bound
   float** wsp = latency ? &d_ws : nullptr;
-  const bool use_h2 = cfg == 0 && !latency && compute_mode == AGZ_COMPUTE_FP16X2 && conf.SharedLayers > 0;
+  // the split kernels only pay once the 128-row tiles fill the chip (Connect-4, K=64, 256 games: 84 tiles -> the fp32
+  // half-tile kernel is faster: 187 vs 162 / 158 games/s measured)
+  const bool split_ok = cfg == 0 && !latency && (!half_dual || compute_force) && conf.SharedLayers > 0;
+  const bool use_h2 = split_ok && compute_mode == AGZ_COMPUTE_FP16X2;
   if (use_h2 && (size_t)B > amax_cap) {
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (d_amax) hipFree(d_amax);
@@ -688,7 +691,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       }
       rc = AGZ_OK;
     }
-    else if (cfg == 0 && !latency && compute_mode == AGZ_COMPUTE_BF16X3) {
+    else if (split_ok && compute_mode == AGZ_COMPUTE_BF16X3) {
       a.n_ntiles = ceil_div(a.Ntot, 128); a.n_mtiles = ceil_div(a.M, 128);
       a.splits = 1; a.per = 0; a.ws = nullptr; a.raw = 0;
       ProfScope ps(ctx, AGZ_PROF_CONV);
@@ -1014,9 +1017,11 @@ int agz_net_commit(agz_net* n) {
 
 int agz_net_set_compute_mode(agz_net* n, int mode) {
   AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_compute_mode: NULL net");
-  AGZ_REQUIRE(mode == AGZ_COMPUTE_F32_MFMA || mode == AGZ_COMPUTE_BF16X3 || mode == AGZ_COMPUTE_FP16X2, AGZ_E_INVALID,
+  const int base = mode & ~AGZ_COMPUTE_FORCE;
+  AGZ_REQUIRE(base == AGZ_COMPUTE_F32_MFMA || base == AGZ_COMPUTE_BF16X3 || base == AGZ_COMPUTE_FP16X2, AGZ_E_INVALID,
               "agz_net_set_compute_mode: unknown mode %d", mode);
-  n->compute_mode = mode;
+  n->compute_mode = base;
+  n->compute_force = (mode & AGZ_COMPUTE_FORCE) != 0;
   return AGZ_OK;
 }
 

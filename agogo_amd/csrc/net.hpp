@@ -40,6 +40,7 @@ struct agz_net {
   unsigned* d_amax = nullptr;              // [B] per-board max |activation| of the layer about to be consumed (fp16x2)
   size_t amax_cap = 0;
   int compute_mode = AGZ_COMPUTE_F32_MFMA;  // agz_net_set_compute_mode
+  bool compute_force = false;              // AGZ_COMPUTE_FORCE: split kernels even below the chip-filling threshold
   float* d_head_conv = nullptr;  // [3][Kp] policy ch0, ch1, value ch0 (1x1 filters)
   float* d_head_bn = nullptr;    // [3][HW][2] scale, shift
   float* d_Wp = nullptr;         // [2HW][A]

@@ -84,13 +84,14 @@ def cpu_baseline(size, K, L, budget_s=20.0):
             "evals_per_s": st["nn_evals"] / dt}
 
 
-def games_leg(ctx, seconds_cap=60.0):
+def games_leg(ctx, compute="bf16x3"):
     """Measured games/s (not an estimate) on BASELINE config #2: Connect-4, K=64, 6 blocks, 256 concurrent games,
     400 sims/move, continuous self-play until 256 games have finished."""
     net = A.Net(ctx, 64, 6, 128, 7, 6, 2, 8, bn_mode=capi.BN_IDENTITY)
     net.init_random(1337)
     standard_bn_init(net)
     net.commit()
+    net.set_compute_mode(MODES[compute])
     arena = A.Arena(ctx, capi.GAME_C4, 6, 7, 4, encoder=capi.ENC_TWOPLANE, n_games=256, seed=1337, Budget=400)
     arena.set_inferencer(0, capi.INF_NET, net)
     arena.set_inferencer(1, capi.INF_NET, net)
@@ -312,7 +313,7 @@ def main():
         }
         if world == 1 and not args.no_games_leg:
             try:
-                out["extra"]["games_leg"] = games_leg(ctx)
+                out["extra"]["games_leg"] = games_leg(ctx, args.compute)
             except Exception as e:
                 out["extra"]["games_leg"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

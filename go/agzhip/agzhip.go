@@ -93,8 +93,8 @@ func NewNet(ctx *Ctx, d *dual.Dual, bnMode int) (*Net, error) {
 	return n, nil
 }
 
-// SetComputeMode selects the dual-block conv arithmetic: ComputeF32MFMA (default) or ComputeBF16X3 (exact 3-way bf16
-// split, six bf16 MFMAs per product; same parity tolerance, ~1.6x faster at self-play batch sizes).
+// SetComputeMode selects the dual-block conv arithmetic: ComputeF32MFMA (default), ComputeBF16X3 (exact 3-way bf16
+// split, six bf16 MFMAs per product; same parity tolerance, ~1.6x faster at self-play batch sizes) or ComputeFP16X2.
 func (n *Net) SetComputeMode(mode int) error {
 	defer n.ctx.enter()()
 	return lastErr(C.agz_net_set_compute_mode(n.h, C.int(mode)))
@@ -103,6 +103,7 @@ func (n *Net) SetComputeMode(mode int) error {
 const (
 	ComputeF32MFMA = C.AGZ_COMPUTE_F32_MFMA
 	ComputeBF16X3  = C.AGZ_COMPUTE_BF16X3
+	ComputeFP16X2  = C.AGZ_COMPUTE_FP16X2 // opt-in: range-managed 2-way fp16 split, 3 MFMAs per product
 )
 
 func (n *Net) Close() error { defer n.ctx.enter()(); C.agz_net_destroy(n.h); n.h = nil; return nil }

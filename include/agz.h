@@ -133,11 +133,12 @@ int agz_net_set_latency_mode(agz_net* net, int on);
  *                         every board's activations is measured on the device per layer (results stay independent
  *                         of the batch composition).  Same parity tolerance on the tested nets; elements more than
  *                         2^17 below their board's maximum lose relative precision — opt-in.
- *                         Both split modes apply to K a multiple of 64 and batches that fill the chip; other shapes
- *                         keep F32_MFMA. */
+ *                         Both split modes apply to K a multiple of 64 and batches whose 128-row tiles fill the chip
+ *                         (>= one tile per CU); other shapes keep F32_MFMA, which is faster there. */
 #define AGZ_COMPUTE_F32_MFMA 0
 #define AGZ_COMPUTE_BF16X3 1
 #define AGZ_COMPUTE_FP16X2 2
+#define AGZ_COMPUTE_FORCE 0x100 /* OR-ed in: take the split kernel even below the chip-filling threshold (tests) */
 int agz_net_set_compute_mode(agz_net* net, int mode);
 /* Checkpoint of the learnables in Model() order (+ BN statistics).  The reference gob-encodes G.Values
  * (AZ.Save / Dual.GobEncode, agogo.go:175-209, dualnet/dual.go:180-206); gob is Go-only, so this is a documented

@@ -184,7 +184,7 @@ def test_engine_with_split_mode_network_bit_exact_vs_oracle(ctx, mode):
     board, so it takes the same kernel; the bf16x3 kernel is batch-independent bit for bit (checked first)."""
     S, K, L, F, G, budget = (9, 9), 128, 2, 18, 32, 24
     net = make_net(ctx, K, L, S, F)
-    net.set_compute_mode(mode)
+    net.set_compute_mode(mode | capi.COMPUTE_FORCE)   # 2592 rows: below the chip-filling threshold
     rng = np.random.default_rng(4)
     x = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), size=(G, F, 9, 9)).astype(np.float32)
     p_all, v_all = net.infer(x)
@@ -195,7 +195,7 @@ def test_engine_with_split_mode_network_bit_exact_vs_oracle(ctx, mode):
     net.set_compute_mode(capi.COMPUTE_F32_MFMA)
     p_f32, _ = net.infer(x)
     assert not np.array_equal(p_f32, p_all)            # the engine below really runs the other arithmetic
-    net.set_compute_mode(mode)
+    net.set_compute_mode(mode | capi.COMPUTE_FORCE)   # 2592 rows: below the chip-filling threshold
 
     arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, Budget=budget)
     arena.set_inferencer(0, capi.INF_NET, net)

@@ -14,7 +14,7 @@ def _cycle(ctx):
     net = A.Net(ctx, 64, 2, 64, 9, 9, 18, 82, bn_mode=capi.BN_IDENTITY)
     net.init_random(1)
     net.commit()
-    net.set_compute_mode(capi.COMPUTE_BF16X3)
+    net.set_compute_mode(capi.COMPUTE_BF16X3 | capi.COMPUTE_FORCE)
     x = np.zeros((40, 18, 9, 9), np.float32)
     net.infer(x)          # throughput regime (bf16x3 weights resident)
     net.infer(x[:1])      # latency regime (split-K workspace + spread heads scratch)
