@@ -567,6 +567,9 @@ void agz_net::free_device() {
 
 int agz_net::ensure_batch(int B) {
   if (B <= max_batch) return AGZ_OK;
+  // the conv kernels index activations with 32-bit element offsets (and GEMM rows with int)
+  AGZ_REQUIRE((size_t)B * Hp * Wp * (size_t)std::max(Kp, Fp) < ((size_t)1 << 31), AGZ_E_UNSUPPORTED,
+              "agz_net: batch %d too large for 32-bit activation offsets (%d x %d board, %d channels)", B, H, W, Kp);
   auto f = [](float*& p) { if (p) { hipFree(p); p = nullptr; } };
   f(d_act_in); f(d_actA); f(d_actB); f(d_planes); f(d_policy); f(d_value);
   size_t px = (size_t)B * Hp * Wp;
@@ -656,7 +659,9 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   float** wsp = latency ? &d_ws : nullptr;
   // the split kernels only pay once the 128-row tiles fill the chip (Connect-4, K=64, 256 games: 84 tiles -> the fp32
   // half-tile kernel is faster: 187 vs 162 / 158 games/s measured)
-  const bool split_ok = cfg == 0 && !latency && (!half_dual || compute_force) && conf.SharedLayers > 0;
+  // (the split kernels use 32-bit BYTE offsets: activation tensor below 4 GiB)
+  const bool split_ok = cfg == 0 && !latency && (!half_dual || compute_force) && conf.SharedLayers > 0 &&
+                        (size_t)B * Hp * Wp * Kp * sizeof(float) < ((size_t)1 << 32);
   const bool use_h2 = split_ok && compute_mode == AGZ_COMPUTE_FP16X2;
   if (use_h2 && (size_t)B > amax_cap) {
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -192,6 +192,8 @@ SPLIT_MODES = [A.capi.COMPUTE_BF16X3, A.capi.COMPUTE_FP16X2]
     (128, 2, 64, 9, 9, 18, 82, 33, 2),      # two column tiles
     (256, 2, 128, 19, 19, 18, 362, 8, 2),   # BASELINE width
     (64, 5, 64, 9, 9, 18, 82, 64, 1),       # deeper tower, running-stats BN
+    (192, 1, 64, 7, 6, 2, 8, 37, 2),        # K=192: three column tiles (fp16x2 takes its narrow kernel), 6x7 board, ragged M
+    (128, 1, 32, 5, 5, 2, 26, 90, 2),       # 5x5 board, 2250 rows: tiles straddle many boards, last tile partial
 ])
 def test_split_compute_modes_match_oracle_and_f32(ctx, K, L, FC, W, H, F, Aspace, B, bn_mode, mode):
     """AGZ_COMPUTE_BF16X3 (conv_x3.hpp: exact 3-way bf16 split, 6 of 9 piece products) and AGZ_COMPUTE_FP16X2
