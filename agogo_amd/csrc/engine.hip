@@ -723,7 +723,9 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
     for (int i = lane; i < c.cells; i += WAVE) d.ring[((size_t)g * RING + slot) * CELLS_PAD + i] = s.ring[slot][i];
   }
   if (lane == 0) {
-    d.to_move[g] = next_colour; d.ply[g] = st.ply; d.passes[g] = st.passes; d.zhash[g] = st.hash;
+    // a Resign is recorded in the move list (arena.go:125 / oracle Arena::Step: moves.push_back(best)) although it is
+    // never applied to the board: the stored ply is the history length
+    d.to_move[g] = next_colour; d.ply[g] = st.ply + (resigned ? 1 : 0); d.passes[g] = st.passes; d.zhash[g] = st.hash;
     d.pass_count[g] = pass_count; d.cap_b[g] = capb; d.cap_w[g] = capw; d.last_move[g] = best;
     d.ended[g] = ended; d.winner[g] = winner;
     atomicAdd(&d.counters[CNT_MOVES], 1ull);
