@@ -149,5 +149,5 @@ def test_more_games_than_compute_units(ctx):
         assert counts[g] == ne, g
     st = dev.stats()
     assert st["games_finished"] == G
-    aw, bw, dr = dev.results()
-    assert aw + bw + dr == G
+    r = dev.results()
+    assert r["a_wins"] + r["b_wins"] + r["draws"] == G
