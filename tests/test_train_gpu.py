@@ -52,6 +52,9 @@ CASES = [
     (32, 2, 64, 5, 5, 2, 26, 6),
     (64, 2, 64, 7, 6, 2, 8, 5),       # connect-4 shaped, K=64 (cfg0 conv kernels), non-square
     (128, 1, 64, 9, 9, 18, 82, 3),    # 9x9 go shaped
+    (3, 3, 8, 3, 3, 2, 10, 5),        # the README tic-tac-toe net (DefaultConf(3,3,10), K=3 SharedLayers=3): K padded 3 -> 32
+    (20, 1, 8, 4, 4, 2, 17, 1),       # BatchSize 1 (batch statistics over 16 pixels only), K=20 padded
+    (40, 2, 24, 5, 4, 3, 21, 7),      # nothing a multiple of anything
 ]
 
 
