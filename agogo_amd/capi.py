@@ -127,6 +127,7 @@ def lib():
     sig("agz_arena_begin_move", i32, vp)
     sig("agz_arena_simulate", i32, vp, i32)
     sig("agz_arena_end_move", i32, vp, i32)
+    sig("agz_arena_apply_moves", i32, vp, pi)
     sig("agz_arena_get_stats", i32, vp, C.POINTER(ArenaStats))
     sig("agz_arena_get_game", i32, vp, i32, pi, C.POINTER(GameState))
     sig("agz_arena_get_history", i32, vp, i32, pi, i32, pi)
@@ -438,6 +439,12 @@ class Arena:
 
     def end_move(self, record=True):
         _check(lib().agz_arena_end_move(self.h, int(record)), "agz_arena_end_move")
+
+    def apply_moves(self, moves):
+        """externally chosen moves (one per game) instead of a search: the opponent's reply in a tournament"""
+        m = np.ascontiguousarray(moves, dtype=np.int32)
+        assert m.size == self.n_games
+        _check(lib().agz_arena_apply_moves(self.h, _pi(m)), "agz_arena_apply_moves")
 
     def stats(self):
         s = ArenaStats()

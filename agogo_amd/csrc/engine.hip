@@ -500,7 +500,9 @@ __global__ __launch_bounds__(64) void k_expand(Dev d, GameCfg c, MctsCfg mc, Inf
 }
 
 // bestMove + Policies + Arena.Play's per-move bookkeeping (search.go:341-390,152-161; arena.go:98-138)
-__global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, int record, int restart) {
+// forced != nullptr: agz_arena_apply_moves — the move of every unfinished game comes from outside (no search, no
+// example, the mover's tree is left alone and re-roots over the extra plies at its next search).
+__global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, int record, int restart, const int32_t* forced) {
   __shared__ Sh s;
   __shared__ uint32_t cv[CELLS_PAD];   // child visits
   __shared__ int16_t ckn[CELLS_PAD];   // child kids_n
@@ -517,6 +519,22 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
   int off = d.kids_off[base], n = off >= 0 ? d.kids_n[base] : 0;
   int best = AGZ_PASS;
   float bestScore = 0.f;
+  const bool is_forced = forced != nullptr;
+  if (is_forced) {
+    n = 0; record = 0;
+    best = forced[g];
+    // State.Check (game/state.go:136): Resign always ends the game; Pass where the game has one; a board move must be legal
+    bool legal;
+    if (best == AGZ_RESIGN) legal = true;
+    else if (best == AGZ_PASS) legal = c.pass_legal;
+    else if (best < 0 || best >= c.A) legal = false;
+    else if (c.go_like) { analyse(c, s, nullptr, lane); legal = go_legal(c, s, best, player); }
+    else legal = s.board[best] == AGZ_NONE;
+    if (!legal) {
+      if (lane == 0) atomicAdd(&d.counters[CNT_ILLEGAL], 1ull);
+      return;
+    }
+  }
   if (n > 0) {
     // children -> LDS: fscore=prior, cv=visits, touch=bsum bits, fmove=move, gsize=kids_off, ckn=kids_n
     for (int i = lane; i < n; i += WAVE) {
@@ -646,7 +664,8 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
     }
   }
   // t.prev = t.current.Clone() (search.go:152)
-  for (int i = lane; i < c.cells; i += WAVE) d.prev_board[(size_t)t * CELLS_PAD + i] = s.board[i];
+  if (!is_forced)
+    for (int i = lane; i < c.cells; i += WAVE) d.prev_board[(size_t)t * CELLS_PAD + i] = s.board[i];
   if (lane == 0 && n > 0) { d.prev_ply[t] = st.ply; d.has_prev[t] = 1; }
   __syncthreads();
   // a.game = a.game.Apply(PlayerMove{player, best}) (arena.go:127-130)
@@ -783,6 +802,7 @@ struct agz_arena {
   float* d_policy[2] = {nullptr, nullptr};
   float* d_value[2] = {nullptr, nullptr};
   std::vector<uint8_t> a_is_black;
+  int32_t* d_forced = nullptr;   // agz_arena_apply_moves staging
   std::vector<int32_t> slot_host;
   int ply_parity = 0;       // all unfinished games are at the same ply
   int nA_slots = 0, nB_slots = 0;
@@ -955,6 +975,7 @@ void agz_arena_destroy(agz_arena* a) {
   hipStreamSynchronize(a->ctx->stream);
   for (void* p : a->allocs) hipFree(p);
   for (int i = 0; i < 2; i++) { if (a->d_policy[i]) hipFree(a->d_policy[i]); if (a->d_value[i]) hipFree(a->d_value[i]); }
+  if (a->d_forced) hipFree(a->d_forced);
   delete a;
 }
 
@@ -1031,12 +1052,33 @@ int agz_arena_end_move(agz_arena* a, int record) {
   AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
   {
     ProfScope ps(a->ctx, AGZ_PROF_MOVE);
-    hipLaunchKernelGGL(k_end_move, dim3(a->G), dim3(64), 0, a->ctx->stream, a->d, a->gc, a->mc, record, a->restart ? 1 : 0);
+    hipLaunchKernelGGL(k_end_move, dim3(a->G), dim3(64), 0, a->ctx->stream, a->d, a->gc, a->mc, record, a->restart ? 1 : 0, (const int32_t*)nullptr);
   }
   AGZ_HIP_TRY(hipGetLastError());
   a->in_move = false;
   a->ply_parity ^= 1;
   a->moves_done++;
+  return AGZ_OK;
+}
+
+int agz_arena_apply_moves(agz_arena* a, const int32_t* moves) {
+  AGZ_REQUIRE(a && moves, AGZ_E_INVALID, "agz_arena_apply_moves: NULL argument");
+  AGZ_REQUIRE(!a->in_move, AGZ_E_STATE, "agz_arena_apply_moves: a search is in progress (call agz_arena_end_move first)");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  hipStream_t s = a->ctx->stream;
+  if (!a->d_forced) AGZ_HIP_TRY(hipMalloc(&a->d_forced, (size_t)a->G * sizeof(int32_t)));
+  unsigned long long before = 0, after = 0;
+  AGZ_HIP_TRY(hipMemcpyAsync(&before, a->d.counters + CNT_ILLEGAL, 8, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(a->d_forced, moves, (size_t)a->G * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));   // `moves` is the caller's buffer
+  hipLaunchKernelGGL(k_end_move, dim3(a->G), dim3(64), 0, s, a->d, a->gc, a->mc, 0, 0, (const int32_t*)a->d_forced);
+  AGZ_HIP_TRY(hipGetLastError());
+  AGZ_HIP_TRY(hipMemcpyAsync(&after, a->d.counters + CNT_ILLEGAL, 8, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  a->ply_parity ^= 1;
+  a->moves_done++;
+  AGZ_REQUIRE(after == before, AGZ_E_INVALID, "agz_arena_apply_moves: %llu illegal move(s) (State.Check failed); those games were left unchanged",
+              after - before);
   return AGZ_OK;
 }
 

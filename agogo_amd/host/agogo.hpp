@@ -140,6 +140,14 @@ struct Arena {
     agz::check(agz_arena_set_inferencer(h, 0, a ? AGZ_INF_NET : AGZ_INF_DUMMY, a ? a->h : nullptr), "Agent A");
     agz::check(agz_arena_set_inferencer(h, 1, b ? AGZ_INF_NET : AGZ_INF_DUMMY, b ? b->h : nullptr), "Agent B");
   }
+  // Tournament use (Agent.Search against an outside opponent, agent.go:76-81): Search() decides and plays one move for
+  // every unfinished game; Opponent() applies the outside player's replies (State.Check'ed on the device).
+  void Search(int budget) {
+    agz::check(agz_arena_begin_move(h), "Agent.Search");
+    agz::check(agz_arena_simulate(h, budget), "Agent.Search");
+    agz::check(agz_arena_end_move(h, 0), "Agent.Search");
+  }
+  void Opponent(const std::vector<int32_t>& moves) { agz::check(agz_arena_apply_moves(h, moves.data()), "opponent move"); }
   // Play every game to the end, leaving the recorded examples on the device (see Examples::Append)
   void PlayOnDevice(bool record) {
     agz::check(agz_arena_reset(h, nullptr), "Arena.Play");

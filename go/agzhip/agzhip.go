@@ -140,6 +140,7 @@ type BatchedArena struct {
 	m, n   int
 	feats  int
 	action int
+	nGames, budget, maxMoves int
 }
 
 // NewBatchedArena mirrors MakeArena (arena.go:42-70) for nGames games: conf is the reference mcts.Config with
@@ -154,7 +155,7 @@ func NewBatchedArena(ctx *Ctx, kind GameKind, m, n, k int, komi float32, encoder
 	mc := C.agz_mcts_conf{PUCT: C.float(conf.PUCT), M: C.int32_t(conf.M), N: C.int32_t(conf.N), RandomCount: C.int32_t(conf.RandomCount),
 		Budget: C.int32_t(conf.Budget), RandomMinVisits: C.uint32_t(conf.RandomMinVisits), RandomTemperature: C.float(conf.RandomTemperature),
 		DumbPass: C.int32_t(dumb), ResignPercentage: C.float(conf.ResignPercentage), PassPreference: C.int32_t(conf.PassPreference)}
-	a := &BatchedArena{ctx: ctx, m: m, n: n}
+	a := &BatchedArena{ctx: ctx, m: m, n: n, nGames: nGames, budget: int(conf.Budget), maxMoves: 2 * m * n}
 	a.feats = 2
 	if encoder == C.AGZ_ENC_WQ {
 		a.feats = 18
@@ -253,6 +254,47 @@ func (e *Examples) Prepare(batchSize, maxExamples int, seed uint64) (int, error)
 }
 
 func (e *Examples) Close() error { defer e.ctx.enter()(); C.agz_examples_destroy(e.h); e.h = nil; return nil }
+
+// ---- tournament use: Agent.Search against an outside opponent (agent.go:76-81, BASELINE configs[4]) ----
+// The game state and both trees live on the device.  Search() = mcts.Search for the side to move (begin_move, Budget
+// simulations, end_move): it returns the chosen move and plays it.  Opponent(move) applies the outside player's reply
+// (State.Check'ed on the device); the next Search re-roots the tree over both plies (updateRoot, search.go:424-500).
+
+// Search runs one move decision for every unfinished game of the arena and returns the moves played.
+func (a *BatchedArena) Search() ([]game.Single, error) {
+	defer a.ctx.enter()()
+	if err := lastErr(C.agz_arena_begin_move(a.h)); err != nil {
+		return nil, err
+	}
+	if err := lastErr(C.agz_arena_simulate(a.h, C.int(a.budget))); err != nil {
+		return nil, err
+	}
+	if err := lastErr(C.agz_arena_end_move(a.h, 0)); err != nil {
+		return nil, err
+	}
+	out := make([]game.Single, a.nGames)
+	buf := make([]int32, a.maxMoves+4)
+	for g := 0; g < a.nGames; g++ {
+		var n C.int
+		if err := lastErr(C.agz_arena_get_history(a.h, C.int(g), (*C.int32_t)(unsafe.Pointer(&buf[0])), C.int(len(buf)), &n)); err != nil {
+			return nil, err
+		}
+		if n > 0 {
+			out[g] = game.Single(buf[n-1])
+		}
+	}
+	return out, nil
+}
+
+// Opponent applies the outside player's moves (one per game; ignored for finished games).
+func (a *BatchedArena) Opponent(moves []game.Single) error {
+	defer a.ctx.enter()()
+	m := make([]int32, a.nGames)
+	for i := range m {
+		m[i] = int32(moves[i])
+	}
+	return lastErr(C.agz_arena_apply_moves(a.h, (*C.int32_t)(unsafe.Pointer(&m[0]))))
+}
 
 var _ = game.Pass // keep the import: game.Single values cross the ABI as int32 (-1 pass, -2 resign)
 

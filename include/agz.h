@@ -250,6 +250,13 @@ int agz_arena_selfplay(agz_arena* arena, int64_t n_games_target, int record);
 int agz_arena_begin_move(agz_arena* arena);
 int agz_arena_simulate(agz_arena* arena, int k);
 int agz_arena_end_move(agz_arena* arena, int record);
+/* Apply externally chosen moves instead of searching — moves[g] (a game.Single: cell / column, AGZ_PASS, AGZ_RESIGN) for
+ * every game, ignored for finished games.  This is the opponent's reply in a tournament: the caller of Agent.Search
+ * (agent.go:76-81) applies the opponent's move to its game.State and hands the new state to the next Search; here the
+ * state lives on the device.  No example is recorded; the next search of either agent re-roots its tree by replaying
+ * the moves played since its last search (updateRoot, search.go:424-500).  Every move must pass State.Check: a game
+ * with an illegal move is left unchanged and AGZ_E_INVALID is returned (the other games are applied). */
+int agz_arena_apply_moves(agz_arena* arena, const int32_t* moves);
 
 /* --- observers (all copy into caller buffers) --- */
 typedef struct agz_arena_stats {

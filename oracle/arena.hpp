@@ -196,11 +196,14 @@ struct Arena {
     ended = game->Ended(&winner);
   }
   // one iteration of the loop body arena.go:96-138; returns false when the game is over
-  bool Step(bool record) {
+  // external != nullptr: the move comes from outside (the opponent of a tournament game: the caller of Agent.Search
+  // applies it to its game.State, agent.go:76-81) — no search, no example; returns false and changes nothing if illegal.
+  bool Step(bool record, const Single* external = nullptr) {
     if (ended) return false;
-    Single best = currentPlayer->Search(game);
+    if (external && *external != Resign && !game->Check(PlayerMove{currentPlayer->player, *external})) return false;
+    Single best = external ? *external : currentPlayer->Search(game);
     if (best == Pass) passCount++; else passCount = 0;
-    if (record) {
+    if (record && !external) {
       Example ex;
       ex.Board = enc(*game);
       ex.Policy = currentPlayer->mcts->Policies(*game);

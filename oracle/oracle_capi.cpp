@@ -194,6 +194,16 @@ int orc_arena_set_callback(void* h, int agent, infer_cb cb, void* user, int poli
 }
 void orc_arena_begin(void* h, int a_is_black) { ((ArenaBox*)h)->arena->Begin(a_is_black); }
 int orc_arena_step(void* h, int record) { return ((ArenaBox*)h)->arena->Step(record != 0) ? 1 : 0; }
+// apply an externally chosen move for the player to move; returns 1 if the game continues, 0 if it ended, -1 if illegal
+int orc_arena_apply_move(void* h, int move) {
+  Arena* a = ((ArenaBox*)h)->arena.get();
+  if (a->ended) return 0;
+  size_t before = a->moves.size();
+  Single m = (Single)move;
+  bool cont = a->Step(false, &m);
+  if (a->moves.size() == before) return -1;
+  return cont ? 1 : 0;
+}
 // plays up to n_moves plies (<=0: to the end); returns plies played
 int orc_arena_play(void* h, int n_moves, int record) {
   Arena* a = ((ArenaBox*)h)->arena.get();

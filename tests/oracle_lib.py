@@ -77,6 +77,7 @@ def lib():
     sig("orc_arena_set_callback", i32, vp, i32, INFER_CB, vp, i32)
     sig("orc_arena_begin", None, vp, i32)
     sig("orc_arena_step", i32, vp, i32)
+    sig("orc_arena_apply_move", i32, vp, i32)
     sig("orc_arena_play", i32, vp, i32, i32)
     sig("orc_arena_history", i32, vp, pi, i32)
     sig("orc_arena_state", None, vp, pi, pi)
@@ -301,6 +302,10 @@ class Arena:
 
     def begin(self, a_is_black=-1):
         lib().orc_arena_begin(self.h, a_is_black)
+
+    def apply_move(self, move):
+        """externally chosen move for the player to move: 1 continues, 0 game over, -1 illegal (nothing applied)"""
+        return lib().orc_arena_apply_move(self.h, int(move))
 
     def step(self, record=True):
         return bool(lib().orc_arena_step(self.h, int(record)))
