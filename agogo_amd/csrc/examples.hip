@@ -78,9 +78,11 @@ struct agz_examples {
     if (want <= cap) return AGZ_OK;
     size_t nc = std::max(want, cap + cap / 2);
     float *p = nullptr, *q = nullptr, *v = nullptr;
-    AGZ_HIP_TRY(hipMalloc(&p, nc * xs * 4));
-    AGZ_HIP_TRY(hipMalloc(&q, nc * A1 * 4));
-    AGZ_HIP_TRY(hipMalloc(&v, nc * 4));
+    if (hipMalloc(&p, nc * xs * 4) != hipSuccess || hipMalloc(&q, nc * A1 * 4) != hipSuccess || hipMalloc(&v, nc * 4) != hipSuccess) {
+      hipFree(p); hipFree(q); hipFree(v);
+      agz::set_error("agz_examples: out of device memory growing the store to %zu examples", nc);
+      return AGZ_E_HIP;
+    }
     if (n) {
       AGZ_HIP_TRY(hipMemcpyAsync(p, planes, n * xs * 4, hipMemcpyDeviceToDevice, ctx->stream));
       AGZ_HIP_TRY(hipMemcpyAsync(q, policy, n * A1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -227,9 +229,11 @@ int agz_examples_augment_rotate(agz_examples* e) {
   AGZ_HIP_TRY(hipSetDevice(e->ctx->device));
   const size_t n4 = e->n * 4;
   float *p = nullptr, *q = nullptr, *v = nullptr;
-  AGZ_HIP_TRY(hipMalloc(&p, n4 * e->xs * 4));
-  AGZ_HIP_TRY(hipMalloc(&q, n4 * e->A1 * 4));
-  AGZ_HIP_TRY(hipMalloc(&v, n4 * 4));
+  if (hipMalloc(&p, n4 * e->xs * 4) != hipSuccess || hipMalloc(&q, n4 * e->A1 * 4) != hipSuccess || hipMalloc(&v, n4 * 4) != hipSuccess) {
+    hipFree(p); hipFree(q); hipFree(v);
+    agz::set_error("agz_examples_augment_rotate: out of device memory for %zu examples", n4);
+    return AGZ_E_HIP;
+  }
   hipStream_t s = e->ctx->stream;
   const int m = e->H;
   hipLaunchKernelGGL(k_augment_rot, dim3(grid_for(n4 * e->xs)), dim3(256), 0, s, e->planes, p, e->F, m, 0, 4, 0, n4 * e->xs);
