@@ -11,6 +11,7 @@ _LIB = None
 # constants from include/agz.h
 NONE, BLACK, WHITE = 0, 1, 2
 PASS, RESIGN = -1, -2
+NO_MOVE = -32768
 GAME_MNK, GAME_C4, GAME_KOMI, GAME_WQ = 0, 1, 2, 3
 ENC_TWOPLANE, ENC_WQ = 0, 1
 INF_NET, INF_DUMMY, INF_SCRIPT, INF_HASH, INF_UNIFORM = 0, 1, 2, 3, 4

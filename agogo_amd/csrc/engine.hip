@@ -523,6 +523,7 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
   if (is_forced) {
     n = 0; record = 0;
     best = forced[g];
+    if (best == AGZ_NO_MOVE) return;   // this game is not advanced by the call
     // State.Check (game/state.go:136): Resign always ends the game; Pass where the game has one; a board move must be legal
     bool legal;
     if (best == AGZ_RESIGN) legal = true;

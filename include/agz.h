@@ -255,7 +255,10 @@ int agz_arena_end_move(agz_arena* arena, int record);
  * (agent.go:76-81) applies the opponent's move to its game.State and hands the new state to the next Search; here the
  * state lives on the device.  No example is recorded; the next search of either agent re-roots its tree by replaying
  * the moves played since its last search (updateRoot, search.go:424-500).  Every move must pass State.Check: a game
- * with an illegal move is left unchanged and AGZ_E_INVALID is returned (the other games are applied). */
+ * with an illegal move is left unchanged and AGZ_E_INVALID is returned (the other games are applied); AGZ_NO_MOVE
+ * skips a game (e.g. to re-send a corrected move for one game only).  With two different nets the arena evaluates the
+ * games in lockstep plies: keep all unfinished games at the same ply. */
+#define AGZ_NO_MOVE (-32768)
 int agz_arena_apply_moves(agz_arena* arena, const int32_t* moves);
 
 /* --- observers (all copy into caller buffers) --- */

@@ -102,6 +102,8 @@ def test_illegal_external_move_is_rejected(ctx):
     with pytest.raises(A.AgzError, match="illegal"):
         dev.apply_moves(np.array([capi.PASS, 9], dtype=np.int32))   # mnk has no pass; 9 is off the board
     assert list(dev.history(0)) == [4] and list(dev.history(1)) == [0, 1]
+    dev.apply_moves(np.array([0, capi.NO_MOVE], dtype=np.int32))      # only game 0 advances
+    assert list(dev.history(0)) == [4, 0] and list(dev.history(1)) == [0, 1]
     dev.begin_move()
     with pytest.raises(A.AgzError, match="in progress"):
         dev.apply_moves(np.array([0, 2], dtype=np.int32))
