@@ -119,6 +119,8 @@ def lib():
     sig("agz_trainer_grads_dev", i32, vp, pvp, C.POINTER(C.c_size_t))
     sig("agz_train", i32, vp, pf, pf, pf, i32, i32, u64, pf)
     sig("agz_trainer_export", i32, vp, vp)
+    sig("agz_trainer_save", i32, vp, C.c_char_p)
+    sig("agz_trainer_load", i32, vp, C.c_char_p)
     sig("agz_arena_create", i32, vp, C.POINTER(GameConf), C.POINTER(MctsConf), i32, u64, i32, pvp)
     sig("agz_arena_destroy", None, vp)
     sig("agz_arena_set_inferencer", i32, vp, i32, i32, vp)
@@ -380,6 +382,12 @@ class Trainer:
 
     def export(self, net):
         _check(lib().agz_trainer_export(self.h, net.h), "agz_trainer_export")
+
+    def save(self, path):
+        _check(lib().agz_trainer_save(self.h, str(path).encode()), "agz_trainer_save")
+
+    def load(self, path):
+        _check(lib().agz_trainer_load(self.h, str(path).encode()), "agz_trainer_load")
 
 
 class Arena:

@@ -813,6 +813,47 @@ int agz_train_dev(agz_trainer* t, const float* Xs_dev, const float* policies_dev
   return AGZ_OK;
 }
 
+// Checkpoint of the TRAINABLE network (AZ.Save / AZ.Load, agogo.go:175-209, for the side that keeps learning): every
+// learnable in its full batch-shaped form.  File: "AGZTRN01", agz_net_conf, count, then per tensor {n, n floats}.
+int agz_trainer_save(const agz_trainer* t, const char* path) {
+  AGZ_REQUIRE(t && path, AGZ_E_INVALID, "agz_trainer_save: NULL argument");
+  FILE* f = fopen(path, "wb");
+  AGZ_REQUIRE(f, AGZ_E_INVALID, "agz_trainer_save: cannot open %s", path);
+  bool ok = fwrite("AGZTRN01", 1, 8, f) == 8 && fwrite(&t->conf, sizeof(t->conf), 1, f) == 1;
+  uint64_t np = t->prefs.size();
+  ok = ok && fwrite(&np, 8, 1, f) == 1;
+  for (int i = 0; ok && i < (int)t->prefs.size(); i++) {
+    std::vector<float> v(pref_size(t->prefs[i]));
+    if (agz_trainer_get_param(t, i, v.data(), v.size()) != AGZ_OK) { fclose(f); return AGZ_E_HIP; }
+    uint64_t cnt = v.size();
+    ok = fwrite(&cnt, 8, 1, f) == 1 && fwrite(v.data(), 4, cnt, f) == cnt;
+  }
+  ok = (fclose(f) == 0) && ok;
+  AGZ_REQUIRE(ok, AGZ_E_INVALID, "agz_trainer_save: write to %s failed", path);
+  return AGZ_OK;
+}
+
+int agz_trainer_load(agz_trainer* t, const char* path) {
+  AGZ_REQUIRE(t && path, AGZ_E_INVALID, "agz_trainer_load: NULL argument");
+  FILE* f = fopen(path, "rb");
+  AGZ_REQUIRE(f, AGZ_E_INVALID, "agz_trainer_load: cannot open %s", path);
+  char magic[8];
+  agz_net_conf c;
+  uint64_t np = 0;
+  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "AGZTRN01", 8) == 0 && fread(&c, sizeof(c), 1, f) == 1 && fread(&np, 8, 1, f) == 1;
+  if (ok) ok = memcmp(&c, &t->conf, sizeof(c)) == 0 && np == t->prefs.size();
+  if (!ok) { fclose(f); agz::set_error("agz_trainer_load: %s is not a checkpoint of this trainer configuration", path); return AGZ_E_INVALID; }
+  for (int i = 0; ok && i < (int)t->prefs.size(); i++) {
+    uint64_t cnt = 0;
+    std::vector<float> v(pref_size(t->prefs[i]));
+    ok = fread(&cnt, 8, 1, f) == 1 && cnt == v.size() && fread(v.data(), 4, cnt, f) == cnt;
+    if (ok && agz_trainer_set_param(t, i, v.data(), v.size()) != AGZ_OK) { fclose(f); return AGZ_E_HIP; }
+  }
+  fclose(f);
+  AGZ_REQUIRE(ok, AGZ_E_INVALID, "agz_trainer_load: %s is truncated or mismatched", path);
+  return AGZ_OK;
+}
+
 // the copy loop of dual.Infer (meta.go:141-146): row 0 of every learnable -> the inference net, then commit
 int agz_trainer_export(const agz_trainer* t, agz_net* net) {
   AGZ_REQUIRE(t && net, AGZ_E_INVALID, "NULL argument");

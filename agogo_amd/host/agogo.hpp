@@ -87,6 +87,9 @@ struct Trainable {
   void Init(uint64_t seed) { agz::check(agz_trainer_init_random(h, seed), "Dual.Init"); }
   // dual.Infer (meta.go:125-162): copy row 0 of every learnable into an inference net
   void SwitchToInference(Dual& inf) const { agz::check(agz_trainer_export(h, inf.h), "SwitchToInference"); }
+  // AZ.Save / AZ.Load (agogo.go:175-209) of the learning side, full batch-shaped learnables
+  void Save(const std::string& path) const { agz::check(agz_trainer_save(h, path.c_str()), "AZ.Save"); }
+  void Load(const std::string& path) { agz::check(agz_trainer_load(h, path.c_str()), "AZ.Load"); }
 };
 // dual.Train(d, Xs, policies, values, batches, iterations) — shuffles the three arrays in place like the reference
 inline float Train(Trainable& d, std::vector<float>& Xs, std::vector<float>& policies, std::vector<float>& values, int batches,

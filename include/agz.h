@@ -180,6 +180,10 @@ int agz_train(agz_trainer* t, float* Xs, float* policies, float* values, int bat
  * them right after, agogo.go:133). */
 int agz_train_dev(agz_trainer* t, const float* Xs_dev, const float* policies_dev, const float* values_dev, int batches,
                   int iterations, uint64_t seed, float* last_cost);
+/* Checkpoint of the trainable network in its full batch-shaped form (AZ.Save/AZ.Load agogo.go:175-209 for the side that
+ * keeps learning; gob is Go-only, the format is documented in train.hip). load: the file must match the configuration. */
+int agz_trainer_save(const agz_trainer* t, const char* path);
+int agz_trainer_load(agz_trainer* t, const char* path);
 /* dual.Infer's copy loop (dualnet/meta.go:141-146): row 0 of every learnable -> the inference net; commits it. */
 int agz_trainer_export(const agz_trainer* t, agz_net* net);
 

@@ -132,3 +132,28 @@ def test_data_parallel_step_two_ranks(ctx):
     assert "DP_TRAIN_CHECK OK world 2" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     # phase 2 of the script: arena example buffers -> all-gather -> device Examples set, identical on both ranks
     assert "EXAMPLE_GATHER_CHECK OK world 2" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_trainer_checkpoint_resume(ctx, tmp_path):
+    """save after one step, load into a fresh trainer, continue: identical to the uninterrupted run (bitwise up to the
+    weight-gradient atomics: 1e-6 relative), and a mismatched configuration is refused."""
+    K, L, FC, W, H, F, Aspace, B = 32, 1, 16, 3, 3, 2, 10, 4
+    t1 = A.Trainer(ctx, K, L, FC, W, H, F, Aspace, B)
+    t1.init_random(5)
+    x, pi, v = batch_data(B, F, H, W, Aspace, seed=1)
+    x2, pi2, v2 = batch_data(B, F, H, W, Aspace, seed=2)
+    t1.batch(x, pi, v, 0.1)
+    path = tmp_path / "trainer.agz"
+    t1.save(path)
+    t1.batch(x2, pi2, v2, 0.1)
+    t2 = A.Trainer(ctx, K, L, FC, W, H, F, Aspace, B)
+    t2.load(path)
+    t2.batch(x2, pi2, v2, 0.1)
+    for i in range(t1.num_params()):
+        a, b = t1.get_param(i), t2.get_param(i)
+        assert np.abs(a - b).max() <= 1e-6 * max(np.abs(a).max(), 1e-3), t1.param_info(i)
+    other = A.Trainer(ctx, K, L, FC, W, H, F, Aspace, B + 1)
+    with pytest.raises(A.AgzError, match="not a checkpoint of this trainer"):
+        other.load(path)
+    with pytest.raises(A.AgzError):
+        t2.load(tmp_path / "missing.agz")
