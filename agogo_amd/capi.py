@@ -127,6 +127,7 @@ def lib():
     sig("agz_arena_reset", i32, vp, pu8)
     sig("agz_arena_play", i32, vp, i32, i32)
     sig("agz_arena_selfplay", i32, vp, C.c_int64, i32)
+    sig("agz_arena_set_parallel", i32, vp, i32)
     sig("agz_arena_begin_move", i32, vp)
     sig("agz_arena_simulate", i32, vp, i32)
     sig("agz_arena_end_move", i32, vp, i32)
@@ -439,6 +440,9 @@ class Arena:
 
     def selfplay(self, n_games_target, record=True):
         _check(lib().agz_arena_selfplay(self.h, n_games_target, int(record)), "agz_arena_selfplay")
+
+    def set_parallel(self, lanes):
+        _check(lib().agz_arena_set_parallel(self.h, int(lanes)), "agz_arena_set_parallel")
 
     def begin_move(self):
         _check(lib().agz_arena_begin_move(self.h), "agz_arena_begin_move")

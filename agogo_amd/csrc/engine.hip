@@ -37,7 +37,7 @@ __device__ __forceinline__ float evaluate(float bs, uint32_t visits, int player)
 }
 
 // Node.Select: mcts/node.go:170-237.  64 lanes over the contiguous child block; strict '>' keeps the first maximum.
-__device__ int select_child(const Dev& d, size_t base, int off, int n, int player, float PUCT, int lane) {
+__device__ int select_child(const Dev& d, size_t base, int off, int n, int player, float PUCT, int lane, bool use_vl) {
   uint32_t pv = 0;
   for (int i = lane; i < n; i += WAVE) pv += d.visits[base + off + i];
   for (int o = 32; o > 0; o >>= 1) pv += __shfl_xor(pv, o, 64);
@@ -47,6 +47,8 @@ __device__ int select_child(const Dev& d, size_t base, int off, int n, int playe
   for (int i = lane; i < n; i += WAVE) {
     uint32_t v = d.visits[base + off + i];
     float bs = d.bsum[base + off + i];
+    // Evaluate (node.go:147-159): only White's view includes the stored virtual loss (3.0 while a lane of this round is below)
+    if (use_vl && player == AGZ_WHITE) bs = __fadd_rn(bs, d.vl[base + off + i] ? 3.0f : 0.0f);
     float psa = d.prior[base + off + i];
     float qsa = evaluate(bs, v, player);
     float denominator = __fadd_rn(1.0f, (float)v);
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(64) void k_reset(Dev d, GameCfg c, const uint8_t* a
     d.to_move[g] = AGZ_BLACK;  // the agent holding Black starts: game.SetToMove(currentPlayer.Player), arena.go:91
     d.ply[g] = 0; d.passes[g] = 0; d.pass_count[g] = 0; d.ended[g] = 0; d.winner[g] = AGZ_NONE;
     d.last_move[g] = AGZ_PASS; d.cap_b[g] = 0.f; d.cap_w[g] = 0.f; d.zhash[g] = 0; d.ex_last[g] = -1;
-    d.leaf_kind[g] = LEAF_NONE;
+    for (int l = 0; l < d.V; l++) d.leaf_kind[(size_t)g * d.V + l] = LEAF_NONE;
     d.rng_game[g] = seed * 0x9E3779B97F4A7C15ull + (unsigned long long)g * 0xD1B54A32D192ED03ull + 7ull;
     for (int a = 0; a < 2; a++) {
       int t = a * d.G + g;
@@ -318,185 +320,227 @@ __global__ __launch_bounds__(64) void k_begin_move(Dev d, GameCfg c, MctsCfg mc)
 
 // pipeline() descent: mcts/search.go:209-257 up to (and excluding) the network call.
 // prep != 0 runs prepareRoot (search.go:392-408) instead: the root itself is the leaf if it is expandable.
-__global__ __launch_bounds__(64) void k_select(Dev d, GameCfg c, MctsCfg mc, float* act_in0, float* act_in1, int prep) {
+__global__ __launch_bounds__(64) void k_select(Dev d, GameCfg c, MctsCfg mc, float* act_in0, float* act_in1, int prep, int nl) {
   __shared__ Sh s;
   int g = blockIdx.x, lane = threadIdx.x;
-  if (d.ended[g]) { if (lane == 0) d.leaf_kind[g] = LEAF_NONE; return; }
+  const size_t q0 = (size_t)g * d.V;
+  if (d.ended[g]) { if (lane < nl) d.leaf_kind[q0 + lane] = LEAF_NONE; return; }
   int agent = agent_of(d, g);
   int t = agent * d.G + g;
-  if (d.stalled[t]) { if (lane == 0) { d.leaf_kind[g] = LEAF_NULL; d.path_len[g] = 0; } return; }
+  if (d.stalled[t]) { if (lane < nl) { d.leaf_kind[q0 + lane] = LEAF_NULL; d.path_len[q0 + lane] = 0; } return; }
   const bool use_ring = c.encoder == AGZ_ENC_WQ;
-  St st;
-  load_state(c, d, g, s, st, use_ring, lane);
+  const bool use_vl = d.V > 1;   // lanes of one round see each other's stored virtual loss (oracle: MCTS::parallelRound)
   size_t base = pool_base(d, t, d.cur_pool[t]);
-  int32_t* path = d.path + (size_t)g * MAXPATH;
-  int node = 0, depth = 1, plen = 1, kind = LEAF_NONE;
-  float result = 0.f;
-  if (lane == 0) path[0] = 0;
-  while (true) {
-    if (depth > mc.maxDepth) { kind = LEAF_NULL; break; }  // search.go:211-215
-    int off = d.kids_off[base + node];
-    if (off < 0) {  // IsExpandable(0)
-      if (c.has_passes && st.passes >= 2) {
-        if (prep) { kind = LEAF_TERMINAL; result = 0.f; }  // expandAndSimulate returns (0,false); root.Update(0)
-        else {  // combinedScore, utils.go:62-67
-          analyse(c, s, nullptr, lane);
-          float b, w;
-          area_scores(c, s, lane, &b, &w);
-          result = __fsub_rn(__fsub_rn(b, w), c.komi);
-          kind = LEAF_TERMINAL;
+  for (int l = 0; l < nl; l++) {
+    const size_t q = q0 + l;
+    if (l > 0) { __threadfence(); __syncthreads(); }   // the previous lane's vl marks
+    St st;
+    load_state(c, d, g, s, st, use_ring, lane);
+    int32_t* path = d.path + q * MAXPATH;
+    int node = 0, depth = 1, plen = 1, kind = LEAF_NONE;
+    float result = 0.f;
+    if (lane == 0) path[0] = 0;
+    while (true) {
+      if (depth > mc.maxDepth) { kind = LEAF_NULL; plen--; break; }  // search.go:211-215: returns before addVirtualLoss
+      if (use_vl && lane == 0) d.vl[base + node] = 1;              // n.addVirtualLoss() (search.go:222)
+      int off = d.kids_off[base + node];
+      if (off < 0) {  // IsExpandable(0)
+        if (c.has_passes && st.passes >= 2) {
+          if (prep) { kind = LEAF_TERMINAL; result = 0.f; }  // expandAndSimulate returns (0,false); root.Update(0)
+          else {  // combinedScore, utils.go:62-67
+            analyse(c, s, nullptr, lane);
+            float b, w;
+            area_scores(c, s, lane, &b, &w);
+            result = __fsub_rn(__fsub_rn(b, w), c.komi);
+            kind = LEAF_TERMINAL;
+          }
+        } else {
+          kind = LEAF_EXPAND;
         }
-      } else {
-        kind = LEAF_EXPAND;
+        break;
       }
-      break;
+      if (prep) { kind = LEAF_NONE; break; }  // root already has children: prepareRoot does nothing
+      int n = d.kids_n[base + node];
+      int ci = select_child(d, base, off, n, st.to_move, mc.PUCT, lane, use_vl);
+      if (ci < 0) { kind = LEAF_NULL; break; }
+      int child = off + ci;
+      int mv = d.nmove[base + child];
+      apply_move(c, d, s, st, mv, use_ring, lane);  // children were created from legal moves of this very state
+      if (lane == 0) path[plen] = child;
+      plen++;
+      node = child;
+      depth++;
     }
-    if (prep) { kind = LEAF_NONE; break; }  // root already has children: prepareRoot does nothing
-    int n = d.kids_n[base + node];
-    int ci = select_child(d, base, off, n, st.to_move, mc.PUCT, lane);
-    if (ci < 0) { kind = LEAF_NULL; break; }
-    int child = off + ci;
-    int mv = d.nmove[base + child];
-    apply_move(c, d, s, st, mv, use_ring, lane);  // children were created from legal moves of this very state
-    if (lane == 0) path[plen] = child;
-    plen++;
-    node = child;
-    depth++;
-  }
-  if (kind == LEAF_EXPAND) {
-    if (c.go_like) analyse(c, s, nullptr, lane);
-    legal_mask(c, s, st.to_move, d.leaf_legal + (size_t)g * CELLS_PAD, lane);
-    for (int i = lane; i < c.cells; i += WAVE) d.leaf_board[(size_t)g * CELLS_PAD + i] = s.board[i];
-    float* act = agent == 0 ? act_in0 : act_in1;
-    if (act) encode_nhwc(c, s, st, act + (size_t)d.slot_of_game[g] * (c.m + 2) * (c.n + 2) * 32, lane);
-  }
-  if (lane == 0) {
-    d.leaf_kind[g] = kind;
-    d.leaf_player[g] = st.to_move;
-    d.leaf_ply[g] = move_number(c, st.ply);
-    d.leaf_result[g] = result;
-    d.path_len[g] = plen;
+    if (kind == LEAF_EXPAND) {
+      if (c.go_like) analyse(c, s, nullptr, lane);
+      legal_mask(c, s, st.to_move, d.leaf_legal + q * CELLS_PAD, lane);
+      for (int i = lane; i < c.cells; i += WAVE) d.leaf_board[q * CELLS_PAD + i] = s.board[i];
+      float* act = agent == 0 ? act_in0 : act_in1;
+      // NN slots are lane-major ([lane][game slot]) so that a round of nl lanes is one dense batch of nl*G rows
+      if (act) encode_nhwc(c, s, st, act + ((size_t)l * d.G + d.slot_of_game[g]) * (c.m + 2) * (c.n + 2) * 32, lane);
+    }
+    if (lane == 0) {
+      d.leaf_kind[q] = kind;
+      d.leaf_player[q] = st.to_move;
+      d.leaf_ply[q] = move_number(c, st.ply);
+      d.leaf_result[q] = result;
+      d.path_len[q] = plen;
+    }
+    __syncthreads();
   }
 }
 
 // expandAndSimulate (mcts/search.go:259-339) after the network call + the BACKPROPAGATE half of pipeline().
-__global__ __launch_bounds__(64) void k_expand(Dev d, GameCfg c, MctsCfg mc, InfDesc inf, int prep) {
+__global__ __launch_bounds__(64) void k_expand(Dev d, GameCfg c, MctsCfg mc, InfDesc inf, int prep, int nl) {
   __shared__ Sh s;
   int g = blockIdx.x, lane = threadIdx.x;
   if (d.ended[g]) return;
-  int kind = d.leaf_kind[g];
   int agent = agent_of(d, g);
   int t = agent * d.G + g;
-  if (kind == LEAF_NONE) return;
-  if (!prep && lane == 0) atomicAdd(&d.counters[CNT_SIMS], 1ull);
-  if (kind == LEAF_NULL) { if (lane == 0) d.stalled[t] = 1; return; }
+  const size_t q0 = (size_t)g * d.V;
+  const bool use_vl = d.V > 1;
   size_t base = pool_base(d, t, d.cur_pool[t]);
-  const int32_t* path = d.path + (size_t)g * MAXPATH;
-  int plen = d.path_len[g];
-  int node = path[plen - 1];
-  float result = d.leaf_result[g];
-  bool have = true;
-  if (kind == LEAF_EXPAND) {
-    int player = d.leaf_player[g];
-    const uint8_t* legal = d.leaf_legal + (size_t)g * CELLS_PAD;
-    const int ik = inf.kind[agent];
-    const int plen_pol = inf.policy_len[agent];
-    const float* pol = nullptr;
-    float value = 0.f;
-    uint32_t ph = 0;
-    if (ik == AGZ_INF_NET) {
-      int slot = d.slot_of_game[g];
-      pol = inf.policy[agent] + (size_t)slot * plen_pol;
-      value = inf.value[agent][slot];
-    } else if (ik == AGZ_INF_DUMMY) {  // dummy.go:10-23
-      int dp = inf.dummy_player[agent];
-      value = dp == 1 ? 1.f : (dp == 2 ? -1.f : 0.f);
-    } else if (ik == AGZ_INF_SCRIPT) {  // mcts/example_test.go:40-72 (8 / 9 == 0)
-      int mn = d.leaf_ply[g];
-      value = (mn == 0 || mn == 1 || mn == 5) ? 0.5f : 0.f;
-    } else if (ik == AGZ_INF_HASH) {  // synthetic position hash (oracle/arena.hpp HashNN)
-      uint32_t h = 0;
-      for (int i = lane; i < c.cells; i += WAVE) h += mix32((uint32_t)i * 4u + (uint32_t)d.leaf_board[(size_t)g * CELLS_PAD + i] + 1u);
-      for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
-      h += mix32(0xABCD0000u + (uint32_t)player);
-      ph = h;
-      value = (float)(mix32(h ^ 0xDEADBEEFu) >> 8) * (1.0f / 16777216.0f);
-    } else {  // AGZ_INF_UNIFORM, mcts/example_test.go:158-166
-      value = 1 / 25.0f;
+  int n_null = 0, n_lanes = 0;
+  unsigned have_mask = 0;   // lanes of this round that backed a value up
+  // lanes in order (oracle: MCTS::parallelRound phase 2): expand / follow, Update along the path, undoVirtualLoss
+  for (int l = 0; l < nl; l++) {
+    const size_t q = q0 + l;
+    if (l > 0) { __threadfence(); __syncthreads(); }   // the previous lane's children, visits, sums
+    int kind = d.leaf_kind[q];
+    if (kind == LEAF_NONE) continue;
+    n_lanes++;
+    if (!prep && lane == 0) atomicAdd(&d.counters[CNT_SIMS], 1ull);
+    const int32_t* path = d.path + q * MAXPATH;
+    int plen = d.path_len[q];
+    if (kind == LEAF_NULL) {
+      n_null++;
+      if (use_vl) for (int j = lane; j < plen; j += WAVE) d.vl[base + path[j]] = 0;
+      continue;
     }
-    auto policy_at = [&](int i) -> float {
-      switch (ik) {
-        case AGZ_INF_NET: return pol[i];
-        case AGZ_INF_DUMMY: return __fdiv_rn(1.f, (float)plen_pol);
-        case AGZ_INF_SCRIPT: {
-          int mn = d.leaf_ply[g];
-          const int8_t cell[9] = {4, 0, 2, 6, 3, 5, 1, 7, 8};
-          if (mn >= 0 && mn < 9 && i == cell[mn]) return (mn & 1) ? 0.1f : 0.9f;
-          return 0.f;
+    int node = path[plen - 1];
+    float result = d.leaf_result[q];
+    bool have = true;
+    bool follower = false;
+    if (kind == LEAF_EXPAND && l > 0) {
+      // an earlier lane of this round already expanded this very node: the reference's second goroutine arriving while the
+      // expansion is in flight — same state, same evaluation, findChild stops duplicate children; the value is backed up again
+      for (int l2 = 0; l2 < l && !follower; l2++) {
+        const size_t q2 = q0 + l2;
+        if (d.leaf_kind[q2] == LEAF_EXPAND && d.path_len[q2] == plen && d.path[q2 * MAXPATH + plen - 1] == node) {
+          follower = true;
+          result = d.leaf_result[q2];
+          have = (have_mask >> l2) & 1u;
         }
-        case AGZ_INF_HASH: return (float)((mix32(ph + (uint32_t)i * 0x9E3779B9u) >> 8) + 1u) * (1.0f / 16777216.0f);
-        default: return 1 / 25.0f;
       }
-    };
-    if (player == AGZ_WHITE) value = __fsub_rn(1.f, value);  // search.go:278-280
-    // nodelist in move order, Pass last (search.go:285-296)
-    int n = 0;
-    for (int b0 = 0; b0 < c.A; b0 += WAVE) {
-      int i = b0 + lane;
-      bool ok = i < c.A && legal[i];
-      unsigned long long m = __ballot(ok);
-      if (ok) {
-        int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-        s.fscore[pos] = policy_at(i);
-        s.fmove[pos] = i;
+    }
+    if (kind == LEAF_EXPAND && !follower) {
+      int player = d.leaf_player[q];
+      const uint8_t* legal = d.leaf_legal + q * CELLS_PAD;
+      const int ik = inf.kind[agent];
+      const int plen_pol = inf.policy_len[agent];
+      const float* pol = nullptr;
+      float value = 0.f;
+      uint32_t ph = 0;
+      if (ik == AGZ_INF_NET) {
+        int slot = l * d.G + d.slot_of_game[g];   // lane-major NN slots (k_select)
+        pol = inf.policy[agent] + (size_t)slot * plen_pol;
+        value = inf.value[agent][slot];
+      } else if (ik == AGZ_INF_DUMMY) {  // dummy.go:10-23
+        int dp = inf.dummy_player[agent];
+        value = dp == 1 ? 1.f : (dp == 2 ? -1.f : 0.f);
+      } else if (ik == AGZ_INF_SCRIPT) {  // mcts/example_test.go:40-72 (8 / 9 == 0)
+        int mn = d.leaf_ply[q];
+        value = (mn == 0 || mn == 1 || mn == 5) ? 0.5f : 0.f;
+      } else if (ik == AGZ_INF_HASH) {  // synthetic position hash (oracle/arena.hpp HashNN)
+        uint32_t h = 0;
+        for (int i = lane; i < c.cells; i += WAVE) h += mix32((uint32_t)i * 4u + (uint32_t)d.leaf_board[q * CELLS_PAD + i] + 1u);
+        for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+        h += mix32(0xABCD0000u + (uint32_t)player);
+        ph = h;
+        value = (float)(mix32(h ^ 0xDEADBEEFu) >> 8) * (1.0f / 16777216.0f);
+      } else {  // AGZ_INF_UNIFORM, mcts/example_test.go:158-166
+        value = 1 / 25.0f;
       }
-      n += __popcll(m);
-    }
-    if (legal[c.A]) {
-      if (lane == 0) { s.fscore[n] = policy_at(plen_pol - 1); s.fmove[n] = AGZ_PASS; }  // passProb = policy[len-1]
-      n++;
-    }
-    __syncthreads();
-    // legalSum: sequential float32 sum in list order, as the reference accumulates it
-    float legalSum = 0.f;
-    if (lane == 0) { for (int i = 0; i < n; i++) legalSum = __fadd_rn(legalSum, s.fscore[i]); }
-    legalSum = __shfl(legalSum, 0, 64);
-    if (legalSum > 1.401298464e-45f) {
-      for (int i = lane; i < n; i += WAVE) s.fscore[i] = __fdiv_rn(s.fscore[i], legalSum);
-    } else {
-      float prob = __fdiv_rn(1.f, (float)n);
-      for (int i = lane; i < n; i += WAVE) s.fscore[i] = prob;
-    }
-    __syncthreads();
-    result = value;
-    if (n > 0) {
-      int off = d.n_nodes[t];
-      if (off + n > d.cap) {  // pool exhausted: reported, the tree stops growing (AGZ_E_TREE_FULL)
-        if (lane == 0) { if (!d.overflow[t]) atomicAdd(&d.counters[CNT_FULL], 1ull); d.overflow[t] = 1; d.stalled[t] = 1; }
-        have = false;
+      auto policy_at = [&](int i) -> float {
+        switch (ik) {
+          case AGZ_INF_NET: return pol[i];
+          case AGZ_INF_DUMMY: return __fdiv_rn(1.f, (float)plen_pol);
+          case AGZ_INF_SCRIPT: {
+            int mn = d.leaf_ply[q];
+            const int8_t cell[9] = {4, 0, 2, 6, 3, 5, 1, 7, 8};
+            if (mn >= 0 && mn < 9 && i == cell[mn]) return (mn & 1) ? 0.1f : 0.9f;
+            return 0.f;
+          }
+          case AGZ_INF_HASH: return (float)((mix32(ph + (uint32_t)i * 0x9E3779B9u) >> 8) + 1u) * (1.0f / 16777216.0f);
+          default: return 1 / 25.0f;
+        }
+      };
+      if (player == AGZ_WHITE) value = __fsub_rn(1.f, value);  // search.go:278-280
+      // nodelist in move order, Pass last (search.go:285-296)
+      int n = 0;
+      for (int b0 = 0; b0 < c.A; b0 += WAVE) {
+        int i = b0 + lane;
+        bool ok = i < c.A && legal[i];
+        unsigned long long m = __ballot(ok);
+        if (ok) {
+          int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+          s.fscore[pos] = policy_at(i);
+          s.fmove[pos] = i;
+        }
+        n += __popcll(m);
+      }
+      if (legal[c.A]) {
+        if (lane == 0) { s.fscore[n] = policy_at(plen_pol - 1); s.fmove[n] = AGZ_PASS; }  // passProb = policy[len-1]
+        n++;
+      }
+      __syncthreads();
+      // legalSum: sequential float32 sum in list order, as the reference accumulates it
+      float legalSum = 0.f;
+      if (lane == 0) { for (int i = 0; i < n; i++) legalSum = __fadd_rn(legalSum, s.fscore[i]); }
+      legalSum = __shfl(legalSum, 0, 64);
+      if (legalSum > 1.401298464e-45f) {
+        for (int i = lane; i < n; i += WAVE) s.fscore[i] = __fdiv_rn(s.fscore[i], legalSum);
       } else {
-        // sort.Sort(byScore) as a STABLE descending sort: rank = #greater + #equal-before
-        for (int i = lane; i < n; i += WAVE) {
-          float si = s.fscore[i];
-          int rank = 0;
-          for (int j = 0; j < n; j++) { float sj = s.fscore[j]; rank += (sj > si) || (sj == si && j < i); }
-          size_t o = base + off + rank;
-          d.prior[o] = si; d.visits[o] = 1; d.bsum[o] = 0.f; d.kids_off[o] = -1; d.kids_n[o] = 0;  // tree.go:106-117
-          d.nmove[o] = (int16_t)s.fmove[i];
-        }
-        if (lane == 0) { d.kids_off[base + node] = off; d.kids_n[base + node] = (int16_t)n; d.n_nodes[t] = off + n; }
+        float prob = __fdiv_rn(1.f, (float)n);
+        for (int i = lane; i < n; i += WAVE) s.fscore[i] = prob;
       }
+      __syncthreads();
+      result = value;
+      if (n > 0) {
+        int off = d.n_nodes[t];
+        if (off + n > d.cap) {  // pool exhausted: reported, the tree stops growing (AGZ_E_TREE_FULL)
+          if (lane == 0) { if (!d.overflow[t]) atomicAdd(&d.counters[CNT_FULL], 1ull); d.overflow[t] = 1; d.stalled[t] = 1; }
+          have = false;
+        } else {
+          // sort.Sort(byScore) as a STABLE descending sort: rank = #greater + #equal-before
+          for (int i = lane; i < n; i += WAVE) {
+            float si = s.fscore[i];
+            int rank = 0;
+            for (int j = 0; j < n; j++) { float sj = s.fscore[j]; rank += (sj > si) || (sj == si && j < i); }
+            size_t o = base + off + rank;
+            d.prior[o] = si; d.visits[o] = 1; d.bsum[o] = 0.f; d.kids_off[o] = -1; d.kids_n[o] = 0;  // tree.go:106-117
+            d.nmove[o] = (int16_t)s.fmove[i];
+          }
+          if (lane == 0) { d.kids_off[base + node] = off; d.kids_n[base + node] = (int16_t)n; d.n_nodes[t] = off + n; }
+        }
+      }
+      if (lane == 0) atomicAdd(&d.counters[CNT_EVALS], 1ull);
     }
-    if (lane == 0) atomicAdd(&d.counters[CNT_EVALS], 1ull);
-  }
-  if (have) {  // Update along the path (search.go:251-253, node.go:70-76): same black-perspective value at every level
-    for (int j = lane; j < plen; j += WAVE) {
-      size_t o = base + path[j];
-      d.visits[o] = d.visits[o] + 1;
-      d.bsum[o] = __fadd_rn(d.bsum[o], result);
+    __syncthreads();
+    if (lane == 0) d.leaf_result[q] = result;   // what this lane backs up (read by followers)
+    if (have) have_mask |= 1u << l;
+    if (have) {  // Update along the path (search.go:251-253, node.go:70-76): same black-perspective value at every level
+      for (int j = lane; j < plen; j += WAVE) {
+        size_t o = base + path[j];
+        d.visits[o] = d.visits[o] + 1;
+        d.bsum[o] = __fadd_rn(d.bsum[o], result);
+      }
+      if (!prep && lane == 0) atomicAdd(&d.counters[CNT_NONNULL], 1ull);
     }
-    if (!prep && lane == 0) atomicAdd(&d.counters[CNT_NONNULL], 1ull);
+    if (use_vl) for (int j = lane; j < plen; j += WAVE) d.vl[base + path[j]] = 0;   // undoVirtualLoss (search.go:254)
   }
+  // a round of nothing but null simulations repeats forever in a deterministic search
+  if (n_lanes > 0 && n_null == n_lanes && lane == 0) d.stalled[t] = 1;
 }
 
 // bestMove + Policies + Arena.Play's per-move bookkeeping (search.go:341-390,152-161; arena.go:98-138)
@@ -822,7 +866,7 @@ struct agz_arena {
   }
   bool split_nets() const { return inf_kind[0] == AGZ_INF_NET && inf_kind[1] == AGZ_INF_NET && net[0] != net[1]; }
   int update_slots();
-  int nn_step(int prep);
+  int nn_step(int prep, int nl = 1);   // nl lanes per tree in this round (<= d.V)
 };
 
 // NN batch slots.  One shared net (or synthetic inferencers): slot = game.  Two different nets: games whose
@@ -844,7 +888,7 @@ int agz_arena::update_slots() {
   return AGZ_OK;
 }
 
-int agz_arena::nn_step(int prep) {
+int agz_arena::nn_step(int prep, int nl) {
   // select -> network -> expand, all asynchronous on the ctx stream
   float* act0 = nullptr; float* act1 = nullptr;
   const size_t slot_elems = (size_t)(gc.m + 2) * (gc.n + 2) * 32;
@@ -853,7 +897,7 @@ int agz_arena::nn_step(int prep) {
   if (split_nets()) { /* both nets see global slot indices; net B's sub-batch starts at slot nA */ }
   {
     ProfScope ps(ctx, AGZ_PROF_SELECT);
-    hipLaunchKernelGGL(k_select, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, act0, act1, prep);
+    hipLaunchKernelGGL(k_select, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, act0, act1, prep, nl);
   }
   InfDesc inf{};
   for (int a = 0; a < 2; a++) {
@@ -872,7 +916,7 @@ int agz_arena::nn_step(int prep) {
     agz_net* n = inf_kind[0] == AGZ_INF_NET ? net[0] : (inf_kind[1] == AGZ_INF_NET ? net[1] : nullptr);
     if (n) {
       int a = inf_kind[0] == AGZ_INF_NET ? 0 : 1;
-      int r = n->forward_packed(G, d_policy[a], d_value[a]);
+      int r = n->forward_packed(G * nl, d_policy[a], d_value[a]);   // lane-major slots: one dense batch
       if (r != AGZ_OK) return r;
       if (inf_kind[0] == AGZ_INF_NET && inf_kind[1] == AGZ_INF_NET) { inf.policy[1] = d_policy[0]; inf.value[1] = d_value[0]; }
     }
@@ -890,7 +934,7 @@ int agz_arena::nn_step(int prep) {
   }
   {
     ProfScope ps(ctx, AGZ_PROF_EXPAND);
-    hipLaunchKernelGGL(k_expand, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, inf, prep);
+    hipLaunchKernelGGL(k_expand, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, inf, prep, nl);
   }
   AGZ_HIP_TRY(hipGetLastError());
   return AGZ_OK;
@@ -943,6 +987,8 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
   AL(prior, pool) AL(visits, pool) AL(bsum, pool) AL(kids_off, pool) AL(kids_n, pool) AL(nmove, pool)
   AL(n_nodes, T) AL(cur_pool, T) AL(has_root, T) AL(has_prev, T) AL(prev_ply, T) AL(prev_board, (size_t)T * CELLS_PAD)
   AL(stalled, T) AL(overflow, T) AL(pc_hash, (size_t)T * d.moves_stride) AL(pc_move, (size_t)T * d.moves_stride) AL(pc_n, T) AL(rng, T) AL(rng_game, G)
+  d.V = 1;
+  AL(vl, pool)
   AL(slot_of_game, G) AL(leaf_kind, G) AL(leaf_player, G) AL(leaf_ply, G) AL(leaf_result, G) AL(leaf_board, (size_t)G * CELLS_PAD)
   AL(leaf_legal, (size_t)G * CELLS_PAD) AL(path, (size_t)G * MAXPATH) AL(path_len, G) AL(counters, CNT_N)
   {
@@ -991,16 +1037,39 @@ int agz_arena_set_inferencer(agz_arena* a, int agent, int kind, agz_net* net) {
                 net->conf.Features, a->gc.m, a->gc.n, a->gc.F);
     AGZ_REQUIRE(net->conf.ActionSpace >= a->gc.A, AGZ_E_INVALID, "net ActionSpace %d < game ActionSpace %d", net->conf.ActionSpace, a->gc.A);
     AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
-    int r = net->ensure_batch(a->G);
+    int r = net->ensure_batch(a->G * a->d.V);
     if (r != AGZ_OK) return r;
     if (a->d_policy[agent]) { hipFree(a->d_policy[agent]); a->d_policy[agent] = nullptr; }
     if (a->d_value[agent]) { hipFree(a->d_value[agent]); a->d_value[agent] = nullptr; }
-    AGZ_HIP_TRY(hipMalloc(&a->d_policy[agent], (size_t)a->G * net->conf.ActionSpace * sizeof(float)));
-    AGZ_HIP_TRY(hipMalloc(&a->d_value[agent], (size_t)a->G * sizeof(float)));
+    AGZ_HIP_TRY(hipMalloc(&a->d_policy[agent], (size_t)a->G * a->d.V * net->conf.ActionSpace * sizeof(float)));
+    AGZ_HIP_TRY(hipMalloc(&a->d_value[agent], (size_t)a->G * a->d.V * sizeof(float)));
   }
   a->inf_kind[agent] = kind;
   a->net[agent] = kind == AGZ_INF_NET ? net : nullptr;
   return a->update_slots();
+}
+
+int agz_arena_set_parallel(agz_arena* a, int lanes) {
+  AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
+  AGZ_REQUIRE(lanes >= 1 && lanes <= 16, AGZ_E_INVALID, "agz_arena_set_parallel: lanes must be in [1,16], got %d", lanes);
+  AGZ_REQUIRE(!a->in_move, AGZ_E_STATE, "agz_arena_set_parallel: a search is in progress");
+  AGZ_REQUIRE(lanes == 1 || !a->split_nets(), AGZ_E_UNSUPPORTED, "agz_arena_set_parallel: agents with two different nets search one lane at a time");
+  if (lanes == a->d.V) return AGZ_OK;
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  Dev& d = a->d;
+  const size_t n = (size_t)a->G * lanes;
+  int r = AGZ_OK;
+  // the previous (smaller) scratch arrays stay on the arena's allocation list and are released with it
+#define RL(p, cnt) if ((r = a->alloc(&d.p, (size_t)(cnt))) != AGZ_OK) return r;
+  RL(leaf_kind, n) RL(leaf_player, n) RL(leaf_ply, n) RL(leaf_result, n) RL(leaf_board, n * CELLS_PAD) RL(leaf_legal, n * CELLS_PAD)
+  RL(path, n * MAXPATH) RL(path_len, n)
+#undef RL
+  d.V = lanes;
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  for (int agent = 0; agent < 2; agent++)   // network batch and output buffers grow to G*lanes rows
+    if (a->inf_kind[agent] == AGZ_INF_NET) { r = agz_arena_set_inferencer(a, agent, AGZ_INF_NET, a->net[agent]); if (r != AGZ_OK) return r; }
+  return AGZ_OK;
 }
 
 int agz_arena_reset(agz_arena* a, const uint8_t* a_is_black) {
@@ -1043,7 +1112,13 @@ int agz_arena_simulate(agz_arena* a, int k) {
   AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
   AGZ_REQUIRE(a->in_move, AGZ_E_STATE, "agz_arena_simulate: call agz_arena_begin_move first");
   AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
-  for (int i = 0; i < k; i++) { int r = a->nn_step(0); if (r != AGZ_OK) return r; }
+  // k simulations per tree, in rounds of up to V lanes (agz_arena_set_parallel; V = 1: one at a time)
+  for (int done = 0; done < k;) {
+    int nl = std::min(a->d.V, k - done);
+    int r = a->nn_step(0, nl);
+    if (r != AGZ_OK) return r;
+    done += nl;
+  }
   return AGZ_OK;
 }
 

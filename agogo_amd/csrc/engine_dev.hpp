@@ -51,6 +51,8 @@ struct MctsCfg {
 // All device buffers of an arena.  T = 2*G trees: tree(agent, g) = agent*G + g.
 struct Dev {
   int G, T, cap;          // games, trees, node-pool capacity per (tree, pool)
+  int V;                  // lanes per tree and round (agz_arena_set_parallel; 1 = the sequential search).  Per-simulation
+                          // scratch below is indexed q = g*V + lane.
   // ---- game.State per game
   int8_t* board;          // [G][CELLS_PAD]
   int8_t* ring;           // [G][RING][CELLS_PAD]  board after move j at slot j % RING
@@ -74,6 +76,7 @@ struct Dev {
   int32_t* kids_off;      // first child index in the same pool, -1 = not expanded
   int16_t* kids_n;
   int16_t* nmove;         // game.Single of the node
+  uint8_t* vl;            // virtualLoss flag (3.0 when set, node.go:248-260); only written when V > 1
   int32_t* n_nodes;       // [T]
   int32_t* cur_pool;      // [T]
   int32_t* has_root;      // [T]
@@ -89,14 +92,14 @@ struct Dev {
   uint64_t* rng_game;     // [G] SplitMix64 state of Arena.r (colour draws on restart)
   // ---- per-simulation scratch
   int32_t* slot_of_game;  // [G] NN batch slot
-  int32_t* leaf_kind;     // [G]
-  int32_t* leaf_player;   // [G]
-  int32_t* leaf_ply;      // [G]
-  float* leaf_result;     // [G] terminal score
-  int8_t* leaf_board;     // [G][CELLS_PAD]
-  uint8_t* leaf_legal;    // [G][CELLS_PAD]  (index A = pass)
-  int32_t* path;          // [G][MAXPATH]
-  int32_t* path_len;      // [G]
+  int32_t* leaf_kind;     // [G*V]
+  int32_t* leaf_player;   // [G*V]
+  int32_t* leaf_ply;      // [G*V]
+  float* leaf_result;     // [G*V] terminal score; after k_expand: the value backed up by this lane
+  int8_t* leaf_board;     // [G*V][CELLS_PAD]
+  uint8_t* leaf_legal;    // [G*V][CELLS_PAD]  (index A = pass)
+  int32_t* path;          // [G*V][MAXPATH]
+  int32_t* path_len;      // [G*V]
   // ---- counters [8]: sims_total, sims_nonnull, nn_evals, moves_played, games_finished, examples, tree_full
   unsigned long long* counters;
   // ---- examples

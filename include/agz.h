@@ -251,6 +251,13 @@ int agz_arena_selfplay(agz_arena* arena, int64_t n_games_target, int record);
  *   simulate(k)  = k x { pipeline (search.go:209-257) for every game, leaves coalesced into one
  *                  batched inference }
  *   end_move     = bestMove + Policies + Apply (search.go:151-161, arena.go:105-138) */
+/* BUILD EXTENSION (no mcts.Config field): the simulations of one tree run in rounds of `lanes` (1..16) whose leaves are
+ * evaluated as one batch — the deterministic, lane-ordered form of the reference's NumCPU goroutines sharing a tree with
+ * the stored virtual loss (search.go:112-131, node.go:147-159,248-260; restated in oracle/mcts.hpp parallelRound, which
+ * the device matches bit for bit).  For tournament latency: a single tree no longer evaluates one board at a time.
+ * 1 (default) is the sequential search, the declared semantics of everything else in this library.  Changes the search
+ * result (different, not worse, simulations); call between searches. */
+int agz_arena_set_parallel(agz_arena* arena, int lanes);
 int agz_arena_begin_move(agz_arena* arena);
 int agz_arena_simulate(agz_arena* arena, int k);
 int agz_arena_end_move(agz_arena* arena, int record);

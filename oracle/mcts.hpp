@@ -40,6 +40,10 @@ struct MCTSConfig {
   bool DumbPass = true;
   float ResignPercentage = 0;
   int PassPreference = DontPreferPass;
+  // BUILD EXTENSION (not in mcts.Config): simulations of one tree run in rounds of `Parallel` lanes whose leaves are
+  // evaluated as one batch — the deterministic, lane-ordered form of the reference's NumCPU goroutines sharing a tree
+  // with a stored virtual loss (search.go:112-131, node.go:248-260).  1 = the sequential search (declared semantics).
+  int Parallel = 1;
   bool IsValid() const { return PUCT > 0 && PUCT <= 1; }  // tree.go:42-44
 };
 
@@ -57,6 +61,7 @@ struct Node {
   float minPSARatioChildren = 2.0f;  // defaultMinPsaRatio, mcts.go:28
   float score = 0;
   float value = 0;
+  float virtualLoss = 0;  // node.go:41, set to virtualLoss1 = 3.0 by addVirtualLoss, 0 by undoVirtualLoss (mcts.go:27)
   naughty id = 0;
 };
 
@@ -116,7 +121,7 @@ struct MCTS {
     freelist.push_back(n);
     Node& nd = N(n);
     nd.move = -1; nd.visits = 0; nd.status = 0; nd.blackScores = 0;
-    nd.minPSARatioChildren = 2.0f; nd.score = 0; nd.value = 0;
+    nd.minPSARatioChildren = 2.0f; nd.score = 0; nd.value = 0; nd.virtualLoss = 0;
   }
   void SetGame(StatePtr g) { current = g; }  // tree.go:120-124
   int Nodes() const { return (int)nodes.size(); }
@@ -125,7 +130,8 @@ struct MCTS {
   bool HasChildren(const Node& n) const { return n.minPSARatioChildren <= 1; }                 // :129
   bool IsExpandable(const Node& n, float r) const { return r < n.minPSARatioChildren; }        // :132
   static float Evaluate(const Node& n, Player player) {                                        // :147-159
-    float bs = n.blackScores;  // virtualLoss is 0 whenever observable (q2)
+    float bs = n.blackScores;
+    if (player == White) bs += n.virtualLoss;  // node.go:150-152 (0 whenever observable in the sequential search, q2)
     float score = bs / (float)n.visits;
     if (player == White) score = 1 - score;
     return score;
@@ -270,6 +276,67 @@ struct MCTS {
     depth--;
     *result = ret;
     return have;
+  }
+
+  // One round of `lanes` simulations on this tree (MCTSConfig::Parallel).  Phase 1: the lanes descend one after the
+  // other; every node entered gets addVirtualLoss (a STORE of 3.0, node.go:248-253) which stays until that lane's own
+  // backup — later lanes of the round see it through Evaluate (only White's evaluation includes it, node.go:150-152,
+  // reproduced as is).  A lane stops at the first expandable node (the leaf), at a two-pass terminal, or at the depth
+  // cap.  Phase 2, in lane order: the leaf is expanded with its network evaluation (one batch on the device) unless an
+  // earlier lane of the round already expanded the very same node — then this lane is the reference's second goroutine
+  // arriving at a node whose expansion is in flight: hadChildren was false for it too, its own Infer of the same state
+  // returns the same value, findChild stops it adding the children twice (search.go:229-234,318-323) — the value is
+  // backed up again; then Update along the path and undoVirtualLoss.  Returns the number of non-null results.
+  int parallelRound(int lanes) {
+    struct Lane { std::vector<naughty> path; StatePtr state; int kind = 0; float result = 0; };  // kind 0 null, 1 expand, 2 terminal
+    std::vector<Lane> L(lanes);
+    for (int l = 0; l < lanes; l++) {
+      Lane& ln = L[l];
+      StatePtr cur = current->Clone();
+      naughty node = root;
+      int dep = 0;
+      while (true) {
+        dep++;
+        if (dep > maxDepth) { ln.kind = 0; break; }           // search.go:211-215 (before addVirtualLoss)
+        ln.path.push_back(node);
+        N(node).virtualLoss = 3.0f;
+        Player player = cur->ToMove();
+        bool isExpandable = IsExpandable(N(node), 0);
+        if (isExpandable && cur->Passes() >= 2) { ln.kind = 2; ln.result = combinedScore(*cur); break; }
+        if (isExpandable && nc < MAXTREESIZE) { ln.kind = 1; ln.state = cur; break; }
+        if (!HasChildren(N(node))) { ln.kind = 0; break; }
+        naughty next = Select(node, player);
+        PlayerMove pm{player, N(next).move};
+        if (!cur->Check(pm)) { ln.kind = 0; break; }
+        cur = cur->Apply(pm);
+        node = next;
+      }
+    }
+    int nonnull = 0;
+    std::map<naughty, float> expanded;   // leaf -> value, this round
+    for (int l = 0; l < lanes; l++) {
+      Lane& ln = L[l];
+      bool have = false;
+      float ret = 0;
+      if (ln.kind == 2) { have = true; ret = ln.result; }
+      else if (ln.kind == 1) {
+        naughty leaf = ln.path.back();
+        auto it = expanded.find(leaf);
+        if (it != expanded.end()) { have = true; ret = it->second; }
+        else {
+          float value;
+          bool ok = expandAndSimulate(leaf, *ln.state, minPsaRatio(), &value);
+          if (ok) { have = true; ret = value; expanded[leaf] = value; }
+        }
+      }
+      for (size_t j = ln.path.size(); j-- > 0;) {
+        Node& nd = N(ln.path[j]);
+        if (have) Update(nd, ret);
+        nd.virtualLoss = 0.0f;
+      }
+      if (have) nonnull++;
+    }
+    return nonnull;
   }
 
   // tree.go:183-209
@@ -445,6 +512,13 @@ struct MCTS {
     prepareRoot(player, *current);
     int32_t iter = 0;
     // q1: exactly Budget iterations of doSearch's body (search.go:170-181)
+    if (conf.Parallel > 1) {
+      while (iter < conf.Budget) {
+        int lanes = std::min<int32_t>(conf.Parallel, conf.Budget - iter);
+        playouts += parallelRound(lanes);
+        iter += lanes;
+      }
+    } else
     for (; iter < conf.Budget; iter++) {
       StatePtr cur = current->Clone();
       float res;

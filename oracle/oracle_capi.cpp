@@ -192,6 +192,8 @@ int orc_arena_set_callback(void* h, int agent, infer_cb cb, void* user, int poli
   (agent == 0 ? b->arena->A : b->arena->B).nn = inf;
   return 0;
 }
+// MCTSConfig::Parallel (lanes per tree and round); call before orc_arena_begin
+void orc_arena_set_parallel(void* h, int lanes) { ((ArenaBox*)h)->arena->conf.Parallel = lanes < 1 ? 1 : lanes; }
 void orc_arena_begin(void* h, int a_is_black) { ((ArenaBox*)h)->arena->Begin(a_is_black); }
 int orc_arena_step(void* h, int record) { return ((ArenaBox*)h)->arena->Step(record != 0) ? 1 : 0; }
 // apply an externally chosen move for the player to move; returns 1 if the game continues, 0 if it ended, -1 if illegal

@@ -75,6 +75,7 @@ def lib():
     sig("orc_arena_free", None, vp)
     sig("orc_arena_set_inferencer", i32, vp, i32, i32, vp, i32, i32)
     sig("orc_arena_set_callback", i32, vp, i32, INFER_CB, vp, i32)
+    sig("orc_arena_set_parallel", None, vp, i32)
     sig("orc_arena_begin", None, vp, i32)
     sig("orc_arena_step", i32, vp, i32)
     sig("orc_arena_apply_move", i32, vp, i32)
@@ -302,6 +303,10 @@ class Arena:
 
     def begin(self, a_is_black=-1):
         lib().orc_arena_begin(self.h, a_is_black)
+
+    def set_parallel(self, lanes):
+        """MCTSConfig.Parallel: rounds of `lanes` simulations per tree (before begin())"""
+        lib().orc_arena_set_parallel(self.h, int(lanes))
 
     def apply_move(self, move):
         """externally chosen move for the player to move: 1 continues, 0 game over, -1 illegal (nothing applied)"""

@@ -20,19 +20,23 @@ def f32bits(a):
 
 
 def run_pair(ctx, kind, m, n, k=0, komi=0.0, enc=capi.ENC_TWOPLANE, budget=50, inf=capi.INF_HASH, a_is_black=(1,),
-             max_moves=0, n_plies=0, policy_len=0, max_nodes=0, **mcts_kw):
+             max_moves=0, n_plies=0, policy_len=0, max_nodes=0, parallel=1, **mcts_kw):
     """plays len(a_is_black) device games in one arena and one oracle arena per game, comparing every ply."""
     G = len(a_is_black)
     dev = A.Arena(ctx, kind, m, n, k, komi, encoder=enc, n_games=G, Budget=budget, max_moves=max_moves,
                   max_nodes=max_nodes, **mcts_kw)
     dev.set_inferencer(0, inf)
     dev.set_inferencer(1, inf)
+    if parallel > 1:
+        dev.set_parallel(parallel)
     dev.reset(np.array(a_is_black, dtype=np.uint8))
     orcs = []
     for g in range(G):
         o = O.Arena(kind, m, n, k, komi, enc=enc, Budget=budget, max_moves=max_moves, **mcts_kw)
         o.set_inferencer(0, inf, policy_len=policy_len)
         o.set_inferencer(1, inf, policy_len=policy_len)
+        if parallel > 1:
+            o.set_parallel(parallel)
         o.begin(int(a_is_black[g]))
         orcs.append(o)
     ply = 0
