@@ -655,7 +655,11 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   // latency regime (one decision per forward, so every layer and the heads agree): the dual layers would occupy
   // at most a quarter of the CUs.  Tournament Agent.Search (one tree, batch 1) lands here.
   const int tiles_dual = cfg != 0 ? ceil_div(a.M, 128) * ceil_div(2 * Kp, 64) : ceil_div(a.M, 64) * ceil_div(2 * Kp, 128);
-  const bool latency = latency_mode && Kp >= 64 && tiles_dual * 4 <= ctx->num_cus;  // 32-wide towers are launch-bound
+  // ... or, for wide towers (K >= 256: 72 K-iterations per tile), would not even give every CU one tile: a round of 8-16
+  // lanes of a single tree (agz_arena_set_parallel) — measured 1.135 -> 1.05 s per move at 8 lanes.  Narrow towers must
+  // not take this branch (Connect-4, K=64, 168 tiles: 183 -> 139 games/s).
+  const bool latency = latency_mode && Kp >= 64 &&
+                       (tiles_dual * 4 <= ctx->num_cus || (Kp >= 256 && tiles_dual <= ctx->num_cus));  // 32-wide towers are launch-bound
   float** wsp = latency ? &d_ws : nullptr;
   // the split kernels only pay once the 128-row tiles fill the chip (Connect-4, K=64, 256 games: 84 tiles -> the fp32
   // half-tile kernel is faster: 187 vs 162 / 158 games/s measured)

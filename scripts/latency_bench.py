@@ -24,6 +24,7 @@ ap.add_argument("--size", type=int, default=19)
 ap.add_argument("--sims", type=int, default=1600)
 ap.add_argument("--moves", type=int, default=12)
 ap.add_argument("--games", type=int, default=1)
+ap.add_argument("--lanes", type=int, default=1, help="agz_arena_set_parallel: simulations per tree and round")
 args = ap.parse_args()
 
 ctx = A.Ctx(0)
@@ -35,6 +36,7 @@ arena = A.Arena(ctx, capi.GAME_WQ, S, S, komi=7.5, encoder=capi.ENC_WQ, n_games=
                 max_moves=S * S * 2)
 arena.set_inferencer(0, capi.INF_NET, net)
 arena.set_inferencer(1, capi.INF_NET, net)
+arena.set_parallel(args.lanes)
 arena.reset()
 lat = []
 for mv in range(args.moves + 3):
@@ -56,7 +58,7 @@ n_exp, ms_exp = ctx.prof_read(capi.PROF_EXPAND)
 lat = np.array(lat)
 print(json.dumps({
     "workload": f"{S}x{S} wq Agent.Search, K={args.K}, L={args.L}, {args.sims} sims/move, {args.games} tree(s)",
-    "moves_timed": len(lat), "p50_move_s": float(np.percentile(lat, 50)), "p90_move_s": float(np.percentile(lat, 90)),
+    "lanes": args.lanes, "moves_timed": len(lat), "p50_move_s": float(np.percentile(lat, 50)), "p90_move_s": float(np.percentile(lat, 90)),
     "ms_per_sim": float(np.median(lat)) / args.sims * 1e3,
     "dual_conv_ms": ms_conv / max(n_conv, 1), "init_conv_ms": ms_init / max(n_init, 1),
     "heads_ms": ms_head / max(n_head, 1), "select_ms": ms_sel / max(n_sel, 1), "expand_ms": ms_exp / max(n_exp, 1),

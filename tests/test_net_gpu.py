@@ -190,7 +190,7 @@ SPLIT_MODES = [A.capi.COMPUTE_BF16X3, A.capi.COMPUTE_FP16X2]
 @pytest.mark.parametrize("K,L,FC,W,H,F,Aspace,B,bn_mode", [
     (64, 2, 128, 9, 9, 18, 82, 70, 0),      # 5670 rows, partial last M tile
     (128, 2, 64, 9, 9, 18, 82, 33, 2),      # two column tiles
-    (256, 2, 128, 19, 19, 18, 362, 8, 2),   # BASELINE width
+    (256, 2, 128, 19, 19, 18, 362, 12, 2),  # BASELINE width (12 boards: just above the K>=256 latency-regime bound)
     (64, 5, 64, 9, 9, 18, 82, 64, 1),       # deeper tower, running-stats BN
     (192, 1, 64, 7, 6, 2, 8, 37, 2),        # K=192: three column tiles (fp16x2 takes its narrow kernel), 6x7 board, ragged M
     (128, 1, 32, 5, 5, 2, 26, 90, 2),       # 5x5 board, 2250 rows: tiles straddle many boards, last tile partial
