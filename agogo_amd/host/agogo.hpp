@@ -150,6 +150,7 @@ struct Arena {
     agz::check(agz_arena_simulate(h, budget), "Agent.Search");
     agz::check(agz_arena_end_move(h, 0), "Agent.Search");
   }
+  void SetParallel(int lanes) { agz::check(agz_arena_set_parallel(h, lanes), "SetParallel"); }  // lane-ordered tree-parallel rounds
   void Opponent(const std::vector<int32_t>& moves) { agz::check(agz_arena_apply_moves(h, moves.data()), "opponent move"); }
   // Play every game to the end, leaving the recorded examples on the device (see Examples::Append)
   void PlayOnDevice(bool record) {

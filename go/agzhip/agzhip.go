@@ -286,6 +286,13 @@ func (a *BatchedArena) Search() ([]game.Single, error) {
 	return out, nil
 }
 
+// SetParallel runs the simulations of every tree in rounds of `lanes` (1..16) whose leaves are one network batch: the
+// deterministic, lane-ordered form of the reference's NumCPU goroutines sharing a tree (search.go:112-131).  1 = sequential.
+func (a *BatchedArena) SetParallel(lanes int) error {
+	defer a.ctx.enter()()
+	return lastErr(C.agz_arena_set_parallel(a.h, C.int(lanes)))
+}
+
 // Opponent applies the outside player's moves (one per game; ignored for finished games).
 func (a *BatchedArena) Opponent(moves []game.Single) error {
 	defer a.ctx.enter()()
