@@ -117,6 +117,7 @@ def lib():
     sig("agz_trainer_forward_backward", i32, vp, pf, pf, pf, pf)
     sig("agz_trainer_apply", i32, vp, C.c_float, C.c_float)
     sig("agz_trainer_grads_dev", i32, vp, pvp, C.POINTER(C.c_size_t))
+    sig("agz_trainer_set_compute_mode", i32, vp, i32)
     sig("agz_train", i32, vp, pf, pf, pf, i32, i32, u64, pf)
     sig("agz_trainer_export", i32, vp, vp)
     sig("agz_trainer_save", i32, vp, C.c_char_p)
@@ -361,6 +362,9 @@ class Trainer:
 
     def apply(self, lr=0.1, grad_scale=1.0):
         _check(lib().agz_trainer_apply(self.h, lr, grad_scale), "agz_trainer_apply")
+
+    def set_compute_mode(self, mode):
+        _check(lib().agz_trainer_set_compute_mode(self.h, int(mode)), "agz_trainer_set_compute_mode")
 
     def grads_dev(self):
         ptr, n = C.c_void_p(), C.c_size_t(0)

@@ -297,6 +297,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 #include "conv_x3.hpp"
 #include "conv_h2.hpp"
 
+
+// device-side weight split for the trainer (weights change every step): one thread per (tap, n, ci)
+__global__ void split_w3_kernel(const float* __restrict__ w, unsigned short* __restrict__ w3, int N, int Cin_p) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)9 * N * Cin_p;
+  if (idx >= total) return;
+  int ci = (int)(idx % Cin_p);
+  size_t r = idx / Cin_p;
+  int n = (int)(r % N), t = (int)(r / N);
+  unsigned h, m, l;
+  x3_split(w[idx], h, m, l);
+  size_t base = (((size_t)((ci >> 4) * 9 + t) * 3) * N + n) * 16 + (ci & 15);
+  w3[base] = (unsigned short)(h >> 16);
+  w3[base + (size_t)N * 16] = (unsigned short)(m >> 16);
+  w3[base + (size_t)2 * N * 16] = (unsigned short)(l >> 16);
+}
+
 // split-K finish: sum the partials (in split order) and apply the conv epilogue.  One thread per (pixel row m, 4 channels).
 template <bool DUAL>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvArgs a, int half) {
@@ -635,6 +652,26 @@ int agz::conv3x3_raw(agz_ctx* ctx, const float* x, const float* w, float* y, int
   a.M = B * H * W; a.HW = H * W; a.W = W; a.Wp = W + 2; a.HpWp = (H + 2) * (W + 2);
   a.x = x; a.w = w; a.ep = nullptr; a.y = y; a.Cin_p = Cin_p; a.Cout_p = Cout_p; a.Ntot = Cout_p; a.raw = 1;
   if (Cout_p % 128 == 0) launch_conv<2, 2, 2, false>(ctx, a); else launch_conv<4, 1, 1, false>(ctx, a);
+  AGZ_HIP_TRY(hipGetLastError());
+  return AGZ_OK;
+}
+
+int agz::split_w3(agz_ctx* ctx, const float* w, unsigned short* w3, int N, int Cin_p) {
+  size_t total = (size_t)9 * N * Cin_p;
+  hipLaunchKernelGGL(split_w3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w, w3, N, Cin_p);
+  AGZ_HIP_TRY(hipGetLastError());
+  return AGZ_OK;
+}
+
+int agz::conv3x3_raw_x3(agz_ctx* ctx, const float* x, const unsigned short* w3, float* y, int B, int H, int W, int Cin_p, int Cout_p) {
+  AGZ_REQUIRE(Cin_p % 16 == 0, AGZ_E_INVALID, "conv3x3_raw_x3: Cin %d not a multiple of 16", Cin_p);
+  AGZ_REQUIRE((size_t)B * (H + 2) * (W + 2) * Cin_p * sizeof(float) < ((size_t)1 << 32), AGZ_E_UNSUPPORTED, "conv3x3_raw_x3: tensor above 4 GiB");
+  ConvArgs a{};
+  a.M = B * H * W; a.HW = H * W; a.W = W; a.Wp = W + 2; a.HpWp = (H + 2) * (W + 2);
+  a.x = x; a.w = nullptr; a.ep = nullptr; a.y = y; a.Cin_p = Cin_p; a.Cout_p = Cout_p; a.Ntot = Cout_p; a.raw = 1;
+  a.n_ntiles = ceil_div(Cout_p, 128); a.n_mtiles = ceil_div(a.M, 128); a.splits = 1;
+  ProfScope ps(ctx, AGZ_PROF_CONV_INIT);
+  hipLaunchKernelGGL((conv3x3_x3_kernel<false>), dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, a, w3);
   AGZ_HIP_TRY(hipGetLastError());
   return AGZ_OK;
 }

@@ -14,6 +14,11 @@ struct Param {
 };
 struct BNStats { std::vector<float> mean, var; };
 int conv3x3_raw(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p);
+// the same GEMM on the bf16 matrix pipe (conv_x3.hpp): w3 = split_w3() image of w; Cin_p % 16 == 0
+int conv3x3_raw_x3(agz_ctx* ctx, const float* x, const unsigned short* w3, float* y, int B, int H, int W, int Cin_p, int Cout_p);
+// w [9][N][Cin_p] fp32 (device) -> w3 [Cin_p/16][9][3][N][16] bf16 pieces (device); exact truncation split
+int split_w3(agz_ctx* ctx, const float* w, unsigned short* w3, int N, int Cin_p);
+inline size_t w3_elems(int N, int Cin_p) { return (size_t)9 * 3 * N * Cin_p; }
 }  // namespace agz
 
 struct agz_net {

@@ -16,6 +16,7 @@
 // Status: correct (parity vs oracle/train.hpp within fp32 tolerance); k_wgrad is not tuned yet.
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "net.hpp"
@@ -406,6 +407,7 @@ struct TLayer {
   int Cin_p, Cout_p, nbr;
   size_t o_wf, o_gamma, o_beta;   // offsets in the flat P / G buffers
   float *wt = nullptr, *z = nullptr, *out = nullptr, *mean = nullptr, *inv = nullptr;
+  unsigned short *w3f = nullptr, *w3t = nullptr;   // bf16x3 images of the forward / transposed filter (AGZ_COMPUTE_BF16X3)
 };
 struct TParamRef { std::string name; int kind; std::vector<int> shape; int layer; int sub; };  // sub: 0 filter(a) 1 gamma 2 beta, for dual +10 = branch b
 
@@ -426,6 +428,12 @@ struct agz_trainer {
   float *zh = nullptr, *yh = nullptr, *dyh = nullptr, *dzh = nullptr, *hmean = nullptr, *hinv = nullptr;
   float *logits = nullptr, *hpre = nullptr, *o = nullptr, *cost = nullptr;
   float *d_planes = nullptr, *d_pi = nullptr, *d_v = nullptr;
+  bool x3 = false, x3_force = false;   // agz_trainer_set_compute_mode (FORCE: also below the chip-filling threshold, tests)
+  // bf16x3 only where the 128-row tiles fill the chip (same rule as inference) and the filter has whole 16-channel chunks
+  bool use_x3(const TLayer& ly, int cin, int cout) const {
+    return x3 && ly.w3f && cin % 16 == 0 && cin >= 64 &&
+           (x3_force || (size_t)((g.M + 127) / 128) * ((cout + 127) / 128) >= (size_t)ctx->num_cus);
+  }
   std::vector<void*> allocs;
   template <typename T> int alloc(T** p, size_t n) {
     void* q = nullptr;
@@ -447,7 +455,13 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   const float* cur = x0;
   for (int l = 0; l <= L; l++) {
     TLayer& ly = layers[l];
-    int r = conv3x3_raw(ctx, cur, P + ly.o_wf, ly.z, B, g.H, g.W, ly.Cin_p, ly.Cout_p);
+    int r;
+    if (use_x3(ly, ly.Cin_p, ly.Cout_p)) {
+      if ((r = split_w3(ctx, P + ly.o_wf, ly.w3f, ly.Cout_p, ly.Cin_p)) != AGZ_OK) return r;
+      r = conv3x3_raw_x3(ctx, cur, ly.w3f, ly.z, B, g.H, g.W, ly.Cin_p, ly.Cout_p);
+    } else {
+      r = conv3x3_raw(ctx, cur, P + ly.o_wf, ly.z, B, g.H, g.W, ly.Cin_p, ly.Cout_p);
+    }
     if (r != AGZ_OK) return r;
     int C = ly.Cout_p;
     hipLaunchKernelGGL(k_bn_sum, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, C, (const float*)nullptr, acc, RPB);
@@ -496,7 +510,13 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     hipLaunchKernelGGL(k_wgrad, dim3(wa.n_tiles * wa.c_tiles * 9 * chunks), dim3(256), 0, s, wa);
     if (l > 0) {  // data gradient: the forward GEMM with flipped/transposed weights over the [a|b] channels of dz
       hipLaunchKernelGGL(k_make_wt, dim3(nblk((size_t)9 * C * ly.Cin_p)), dim3(256), 0, s, P + ly.o_wf, ly.wt, C, ly.Cin_p);
-      int r = conv3x3_raw(ctx, dz, ly.wt, dnext, B, g.H, g.W, C, ly.Cin_p);
+      int r;
+      if (use_x3(ly, C, ly.Cin_p)) {
+        if ((r = split_w3(ctx, ly.wt, ly.w3t, ly.Cin_p, C)) != AGZ_OK) return r;
+        r = conv3x3_raw_x3(ctx, dz, ly.w3t, dnext, B, g.H, g.W, C, ly.Cin_p);
+      } else {
+        r = conv3x3_raw(ctx, dz, ly.wt, dnext, B, g.H, g.W, C, ly.Cin_p);
+      }
       if (r != AGZ_OK) return r;
       std::swap(dcur, dnext);
     }
@@ -681,20 +701,51 @@ int agz_trainer_get_grad(const agz_trainer* t, int i, float* host, size_t n) {
 
 int agz_trainer_init_random(agz_trainer* t, uint64_t seed) {  // same recipe as agz_net_init_random over the FULL shapes
   AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
-  SplitMix64 r(seed);
+  // SplitMix64 is counter based (state_n = seed + n * golden), so the sequential stream of the oracle's initialiser can be
+  // generated in parallel: the batch-shaped gamma/beta of a 19x19, K=256, B=256 trainer are 1.9 G normals (37 s on one core).
+  const uint64_t GOLD = 0x9E3779B97F4A7C15ull;
+  uint64_t draws = 0;   // draws consumed so far
+  unsigned nthr = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
   for (int i = 0; i < (int)t->prefs.size(); i++) {
     const TParamRef& p = t->prefs[i];
     std::vector<float> v(pref_size(p));
     double field = 1; for (size_t k = 2; k < p.shape.size(); k++) field *= p.shape[k];
-    double stdev = std::sqrt(2.0 / ((double)(p.shape[0] + p.shape[1]) * field));
-    if (p.kind == 0) { double lim = stdev * std::sqrt(3.0); for (float& x : v) x = (float)((r.float64() * 2.0 - 1.0) * lim); }
-    else if (p.kind == 1 || p.kind == 2) {
-      for (size_t k = 0; k < v.size(); k += 2) {
-        double u1 = 1.0 - r.float64(), u2 = r.float64();
-        double rad = std::sqrt(-2.0 * std::log(u1)), th = 6.283185307179586476925 * u2;
-        v[k] = (float)(rad * std::cos(th) * stdev);
-        if (k + 1 < v.size()) v[k + 1] = (float)(rad * std::sin(th) * stdev);
+    const double stdev = std::sqrt(2.0 / ((double)(p.shape[0] + p.shape[1]) * field));
+    const size_t n = v.size();
+    const uint64_t d0 = draws;
+    if (p.kind == 0) {           // GlorotU: one draw per element
+      const double lim = stdev * std::sqrt(3.0);
+      auto work = [&](size_t lo, size_t hi) {
+        SplitMix64 r(seed + (d0 + lo) * GOLD);
+        for (size_t k = lo; k < hi; k++) v[k] = (float)((r.float64() * 2.0 - 1.0) * lim);
+      };
+      if (n < (1u << 16)) work(0, n);
+      else {
+        std::vector<std::thread> th;
+        size_t per = (n + nthr - 1) / nthr;
+        for (unsigned q = 0; q < nthr; q++) { size_t lo = q * per, hi = std::min(n, lo + per); if (lo < hi) th.emplace_back(work, lo, hi); }
+        for (auto& x : th) x.join();
       }
+      draws += n;
+    } else if (p.kind == 1 || p.kind == 2) {   // GlorotN by Box-Muller: two draws per PAIR of elements
+      const size_t pairs = (n + 1) / 2;
+      auto work = [&](size_t lo, size_t hi) {   // pair indices
+        SplitMix64 r(seed + (d0 + 2 * lo) * GOLD);
+        for (size_t q = lo; q < hi; q++) {
+          double u1 = 1.0 - r.float64(), u2 = r.float64();
+          double rad = std::sqrt(-2.0 * std::log(u1)), th = 6.283185307179586476925 * u2;
+          v[2 * q] = (float)(rad * std::cos(th) * stdev);
+          if (2 * q + 1 < n) v[2 * q + 1] = (float)(rad * std::sin(th) * stdev);
+        }
+      };
+      if (pairs < (1u << 15)) work(0, pairs);
+      else {
+        std::vector<std::thread> th;
+        size_t per = (pairs + nthr - 1) / nthr;
+        for (unsigned q = 0; q < nthr; q++) { size_t lo = q * per, hi = std::min(pairs, lo + per); if (lo < hi) th.emplace_back(work, lo, hi); }
+        for (auto& x : th) x.join();
+      }
+      draws += 2 * pairs;
     }
     int rc = agz_trainer_set_param(t, i, v.data(), v.size());
     if (rc != AGZ_OK) return rc;
@@ -732,6 +783,26 @@ int agz_trainer_batch(agz_trainer* t, const float* planes, const float* pi, cons
   r = agz_trainer_apply(t, lr, 1.0f);
   if (r != AGZ_OK) return r;
   AGZ_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+  return AGZ_OK;
+}
+
+// AGZ_COMPUTE_F32_MFMA (default) or AGZ_COMPUTE_BF16X3 for the forward and data-gradient convolutions (the weight
+// gradient keeps its fp32-MFMA kernel).  Same gradient tolerance against the oracle in both modes.
+int agz_trainer_set_compute_mode(agz_trainer* t, int mode) {
+  AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
+  const bool force = (mode & AGZ_COMPUTE_FORCE) != 0;
+  mode &= ~AGZ_COMPUTE_FORCE;
+  AGZ_REQUIRE(mode == AGZ_COMPUTE_F32_MFMA || mode == AGZ_COMPUTE_BF16X3, AGZ_E_INVALID, "agz_trainer_set_compute_mode: mode %d not available for training", mode);
+  AGZ_HIP_TRY(hipSetDevice(t->ctx->device));
+  t->x3_force = force;
+  if (mode == AGZ_COMPUTE_BF16X3)
+    for (auto& ly : t->layers)
+      if (!ly.w3f) {
+        int r = t->alloc(&ly.w3f, w3_elems(ly.Cout_p, ly.Cin_p));
+        if (r == AGZ_OK) r = t->alloc(&ly.w3t, w3_elems(ly.Cin_p, ly.Cout_p));
+        if (r != AGZ_OK) return r;
+      }
+  t->x3 = mode == AGZ_COMPUTE_BF16X3;
   return AGZ_OK;
 }
 

@@ -85,6 +85,7 @@ struct Trainable {
   Trainable(const Trainable&) = delete;
   Trainable& operator=(const Trainable&) = delete;
   void Init(uint64_t seed) { agz::check(agz_trainer_init_random(h, seed), "Dual.Init"); }
+  void SetComputeMode(int mode) { agz::check(agz_trainer_set_compute_mode(h, mode), "compute mode"); }  // AGZ_COMPUTE_BF16X3: faster fwd/dgrad
   // dual.Infer (meta.go:125-162): copy row 0 of every learnable into an inference net
   void SwitchToInference(Dual& inf) const { agz::check(agz_trainer_export(h, inf.h), "SwitchToInference"); }
   // AZ.Save / AZ.Load (agogo.go:175-209) of the learning side, full batch-shaped learnables

@@ -170,6 +170,9 @@ int agz_trainer_batch(agz_trainer* t, const float* planes, const float* pi, cons
 int agz_trainer_forward_backward(agz_trainer* t, const float* planes, const float* pi, const float* v, float* cost);
 int agz_trainer_apply(agz_trainer* t, float lr, float grad_scale);
 int agz_trainer_grads_dev(agz_trainer* t, float** dev_ptr, size_t* n_floats);
+/* AGZ_COMPUTE_F32_MFMA (default) or AGZ_COMPUTE_BF16X3 for the forward and data-gradient convolutions of training
+ * (weights are re-split on the device every step; the weight gradient keeps its fp32-MFMA kernel). */
+int agz_trainer_set_compute_mode(agz_trainer* t, int mode);
 /* dual.Train(d, Xs, policies, values, batches, iterations) (dualnet/meta.go:16-54): lr 0.1 vanilla SGD, shuffleBatch
  * after every iteration (build RNG; Xs/policies/values are shuffled in place like the reference). */
 int agz_train(agz_trainer* t, float* Xs, float* policies, float* values, int batches, int iterations, uint64_t seed,

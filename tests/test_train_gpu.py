@@ -58,9 +58,12 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("x3", [False, True])
 @pytest.mark.parametrize("K,L,FC,W,H,F,Aspace,B", CASES)
-def test_forward_backward_matches_oracle(ctx, K, L, FC, W, H, F, Aspace, B):
+def test_forward_backward_matches_oracle(ctx, K, L, FC, W, H, F, Aspace, B, x3):
     ot, dt = make_pair(ctx, K, L, FC, W, H, F, Aspace, B)
+    if x3:   # bf16x3 forward / data-gradient convolutions (taken for Cin >= 64; forced below the chip-filling threshold)
+        dt.set_compute_mode(capi.COMPUTE_BF16X3 | capi.COMPUTE_FORCE)
     x, pi, v = batch_data(B, F, H, W, Aspace, seed=K + B)
     co = ot.batch(x, pi, v, lr=0.0)
     cd = dt.forward_backward(x, pi, v)
@@ -157,3 +160,15 @@ def test_trainer_checkpoint_resume(ctx, tmp_path):
         other.load(path)
     with pytest.raises(A.AgzError):
         t2.load(tmp_path / "missing.agz")
+
+
+def test_trainer_init_random_is_the_oracles_sequential_stream(ctx):
+    """agz_trainer_init_random generates the oracle's SplitMix64/Box-Muller stream in parallel chunks (counter-based RNG):
+    bit-identical to the sequential restatement, including tensors large enough for the threaded path."""
+    K, L, FC, W, H, F, Aspace, B = 64, 1, 32, 9, 9, 18, 82, 16    # gamma/beta: 16*64*81 = 82,944 floats per tensor
+    ot = O.TrainNet(K, L, FC, W, H, F, Aspace, B)
+    ot.init_random(4242)
+    dt = A.Trainer(ctx, K, L, FC, W, H, F, Aspace, B)
+    dt.init_random(4242)
+    for i in range(ot.num_params()):
+        np.testing.assert_array_equal(dt.get_param(i).view(np.uint32), ot.get_param(i).view(np.uint32), err_msg=ot.param_name(i))
