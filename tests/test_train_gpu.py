@@ -172,3 +172,24 @@ def test_trainer_init_random_is_the_oracles_sequential_stream(ctx):
     dt.init_random(4242)
     for i in range(ot.num_params()):
         np.testing.assert_array_equal(dt.get_param(i).view(np.uint32), ot.get_param(i).view(np.uint32), err_msg=ot.param_name(i))
+
+
+def test_learn_epoch_two_ranks_end_to_end(ctx):
+    """scripts/learn_epoch_dist.py: sharded self-play -> example all-gather -> shared-seed prepareExamples -> data-parallel
+    dual.Train (one gradient all-reduce per step) -> SwitchToInference -> sharded arena games; two ranks on GPU 0 (gloo).
+    The replicas must end with identical learnables."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29591", os.path.join(root, "scripts", "learn_epoch_dist.py"), "--shared-gpu"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{") and "LEARN_EPOCH" in l]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    r = json.loads(line[-1])
+    assert r["LEARN_EPOCH"] == "OK" and r["world"] == 2 and r["replicas_identical"]
+    assert r["examples_gathered"] > 64 and r["dp_steps_per_rank"] >= 2
+    assert r["arena"]["a_wins"] + r["arena"]["b_wins"] + r["arena"]["draws"] == 32
