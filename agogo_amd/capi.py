@@ -115,6 +115,7 @@ def lib():
     sig("agz_trainer_init_random", i32, vp, u64)
     sig("agz_trainer_batch", i32, vp, pf, pf, pf, C.c_float, pf)
     sig("agz_trainer_forward_backward", i32, vp, pf, pf, pf, pf)
+    sig("agz_trainer_forward_backward_dev", i32, vp, vp, vp, vp, pf)
     sig("agz_trainer_apply", i32, vp, C.c_float, C.c_float)
     sig("agz_trainer_grads_dev", i32, vp, pvp, C.POINTER(C.c_size_t))
     sig("agz_trainer_set_compute_mode", i32, vp, i32)
@@ -359,6 +360,12 @@ class Trainer:
         c = C.c_float(0)
         _check(lib().agz_trainer_forward_backward(self.h, _pf(x), _pf(p), _pf(vv), C.byref(c)), "agz_trainer_forward_backward")
         return c.value
+
+    def forward_backward_dev(self, planes_ptr, pi_ptr, v_ptr, want_cost=True):
+        c = C.c_float(0)
+        _check(lib().agz_trainer_forward_backward_dev(self.h, C.c_void_p(planes_ptr), C.c_void_p(pi_ptr), C.c_void_p(v_ptr),
+                                                      C.byref(c) if want_cost else None), "agz_trainer_forward_backward_dev")
+        return c.value if want_cost else None
 
     def apply(self, lr=0.1, grad_scale=1.0):
         _check(lib().agz_trainer_apply(self.h, lr, grad_scale), "agz_trainer_apply")

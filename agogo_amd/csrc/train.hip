@@ -769,6 +769,21 @@ int agz_trainer_forward_backward(agz_trainer* t, const float* planes, const floa
   return AGZ_OK;
 }
 
+// forward_backward on DEVICE buffers (a batch sliced out of agz_examples_tensors_dev): no staging copy
+int agz_trainer_forward_backward_dev(agz_trainer* t, const float* planes_dev, const float* pi_dev, const float* v_dev, float* cost) {
+  AGZ_REQUIRE(t && planes_dev && pi_dev && v_dev, AGZ_E_INVALID, "agz_trainer_forward_backward_dev: NULL argument");
+  AGZ_HIP_TRY(hipSetDevice(t->ctx->device));
+  int r = t->forward_backward_dev(planes_dev, pi_dev, v_dev);
+  if (r != AGZ_OK) return r;
+  if (cost) {
+    float c[2] = {0, 0};
+    AGZ_HIP_TRY(hipMemcpyAsync(c, t->cost, 8, hipMemcpyDeviceToHost, t->ctx->stream));
+    AGZ_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    *cost = c[0] + c[1];
+  }
+  return AGZ_OK;
+}
+
 int agz_trainer_apply(agz_trainer* t, float lr, float grad_scale) {  // solver.Step (meta.go:40): w -= lr * grad
   AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
   AGZ_HIP_TRY(hipSetDevice(t->ctx->device));

@@ -106,6 +106,7 @@ def allreduce_gradients(trainer, local_device, group=None):
         return 1
     world = dist.get_world_size(group)
     ptr, n = trainer.grads_dev()
+    trainer.ctx.sync()   # the gradients were produced on the ctx stream; the collective runs on torch's
     g = device_tensor(ptr, (n,), torch.device("cuda", local_device))
     if dist.get_backend(group) == "gloo":
         h = g.cpu()

@@ -168,6 +168,8 @@ int agz_trainer_batch(agz_trainer* t, const float* planes, const float* pi, cons
 /* Split form for data-parallel training: forward_backward fills the flat gradient buffer; all-reduce it over RCCL
  * (agz_trainer_grads_dev gives the device pointer: ONE collective per step); apply does w -= lr*grad_scale*grad. */
 int agz_trainer_forward_backward(agz_trainer* t, const float* planes, const float* pi, const float* v, float* cost);
+/* the same on device buffers (e.g. one batch of agz_examples_tensors_dev); cost may be NULL (no synchronisation) */
+int agz_trainer_forward_backward_dev(agz_trainer* t, const float* planes_dev, const float* pi_dev, const float* v_dev, float* cost);
 int agz_trainer_apply(agz_trainer* t, float lr, float grad_scale);
 int agz_trainer_grads_dev(agz_trainer* t, float** dev_ptr, size_t* n_floats);
 /* AGZ_COMPUTE_F32_MFMA (default) or AGZ_COMPUTE_BF16X3 for the forward and data-gradient convolutions of training

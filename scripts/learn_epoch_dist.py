@@ -70,17 +70,18 @@ if batches < world:
     raise SystemExit("too few examples (%d) for %d ranks x batch %d" % (n_all, world, args.batch))
 
 # 4. data-parallel dual.Train: gather rows of this rank's batch on the device, one all-reduce per step
-dev = torch.device("cuda", local)
-X = adist.device_tensor(xd, (rows, 2 * S * S), dev)
-P = adist.device_tensor(pd, (rows, Aspace), dev)
-V = adist.device_tensor(vd, (rows,), dev)
 steps = 0
 cost = 0.0
+xs, ps = 2 * S * S * 4, Aspace * 4     # row sizes in bytes: batches are contiguous row ranges of the prepared device tensors
+n_local = batches // world
 for it in range(args.nniters):
-    for s in range(batches // world):
+    for s in range(n_local):
         b = s * world + rank
-        sl = slice(b * args.batch, (b + 1) * args.batch)
-        cost = trainB.forward_backward(X[sl].cpu().numpy().reshape(args.batch, 2, S, S), P[sl].cpu().numpy(), V[sl].cpu().numpy())
+        row0 = b * args.batch
+        last = it == args.nniters - 1 and s == n_local - 1
+        c = trainB.forward_backward_dev(xd + row0 * xs, pd + row0 * ps, vd + row0 * 4, want_cost=last)
+        if last:
+            cost = c
         w = adist.allreduce_gradients(trainB, local)
         trainB.apply(0.1, 1.0 / w)
         steps += 1
