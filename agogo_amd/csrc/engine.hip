@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void k_reset(Dev d, GameCfg c, const uint8_t* a
     }
     d.a_is_black[g] = ab;
     d.to_move[g] = AGZ_BLACK;  // the agent holding Black starts: game.SetToMove(currentPlayer.Player), arena.go:91
-    d.ply[g] = 0; d.passes[g] = 0; d.pass_count[g] = 0; d.ended[g] = 0; d.winner[g] = AGZ_NONE;
+    d.ply[g] = 0; d.passes[g] = 0; d.pass_count[g] = 0; d.ended[g] = 0; d.winner[g] = AGZ_NONE; d.n_amoves[g] = 0;
     d.last_move[g] = AGZ_PASS; d.cap_b[g] = 0.f; d.cap_w[g] = 0.f; d.zhash[g] = 0; d.ex_last[g] = -1;
     for (int l = 0; l < d.V; l++) d.leaf_kind[(size_t)g * d.V + l] = LEAF_NONE;
     d.rng_game[g] = seed * 0x9E3779B97F4A7C15ull + (unsigned long long)g * 0xD1B54A32D192ED03ull + 7ull;
@@ -718,7 +718,11 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
   int pass_count = d.pass_count[g];
   pass_count = (best == AGZ_PASS) ? pass_count + 1 : 0;
   float capb = d.cap_b[g], capw = d.cap_w[g];
-  if (lane == 0) d.moves[(size_t)g * d.moves_stride + st.ply] = (int16_t)best;
+  if (lane == 0) {
+    d.moves[(size_t)g * d.moves_stride + st.ply] = (int16_t)best;
+    int na = d.n_amoves[g];
+    if (na < d.moves_stride) { d.amoves[(size_t)g * d.moves_stride + na] = (int16_t)best; d.n_amoves[g] = na + 1; }
+  }
   bool resigned = best == AGZ_RESIGN;
   if (!resigned) {
     bool legal_pass = c.pass_legal;
@@ -787,9 +791,7 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
     for (int i = lane; i < c.cells; i += WAVE) d.ring[((size_t)g * RING + slot) * CELLS_PAD + i] = s.ring[slot][i];
   }
   if (lane == 0) {
-    // a Resign is recorded in the move list (arena.go:125 / oracle Arena::Step: moves.push_back(best)) although it is
-    // never applied to the board: the stored ply is the history length
-    d.to_move[g] = next_colour; d.ply[g] = st.ply + (resigned ? 1 : 0); d.passes[g] = st.passes; d.zhash[g] = st.hash;
+    d.to_move[g] = next_colour; d.ply[g] = st.ply; d.passes[g] = st.passes; d.zhash[g] = st.hash;
     d.pass_count[g] = pass_count; d.cap_b[g] = capb; d.cap_w[g] = capw; d.last_move[g] = best;
     d.ended[g] = ended; d.winner[g] = winner;
     atomicAdd(&d.counters[CNT_MOVES], 1ull);
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
       z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
       d.a_is_black[g] = (z >> 63) == 0 ? 1 : 0;
       d.to_move[g] = AGZ_BLACK; d.ply[g] = 0; d.passes[g] = 0; d.pass_count[g] = 0; d.ended[g] = 0; d.winner[g] = AGZ_NONE;
-      d.last_move[g] = AGZ_PASS; d.cap_b[g] = 0.f; d.cap_w[g] = 0.f; d.zhash[g] = 0;
+      d.last_move[g] = AGZ_PASS; d.cap_b[g] = 0.f; d.cap_w[g] = 0.f; d.zhash[g] = 0; d.n_amoves[g] = 0;
       for (int ag = 0; ag < 2; ag++) {
         int tt = ag * d.G + g;
         d.n_nodes[tt] = 0; d.cur_pool[tt] = 0; d.has_root[tt] = 0; d.has_prev[tt] = 0; d.prev_ply[tt] = 0; d.stalled[tt] = 0;
@@ -982,7 +984,7 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
 #define AL(p, n) if ((r = a->alloc(&d.p, (size_t)(n))) != AGZ_OK) { agz_arena_destroy(a); return r; }
   AL(board, (size_t)G * CELLS_PAD) AL(ring, (size_t)G * RING * CELLS_PAD) AL(to_move, G) AL(ply, G) AL(passes, G)
   AL(pass_count, G) AL(ended, G) AL(winner, G) AL(a_is_black, G) AL(last_move, G) AL(cap_b, G) AL(cap_w, G) AL(zhash, G)
-  AL(moves, (size_t)G * d.moves_stride)
+  AL(moves, (size_t)G * d.moves_stride) AL(amoves, (size_t)G * d.moves_stride) AL(n_amoves, G)
   size_t pool = (size_t)T * 2 * d.cap;
   AL(prior, pool) AL(visits, pool) AL(bsum, pool) AL(kids_off, pool) AL(kids_n, pool) AL(nmove, pool)
   AL(n_nodes, T) AL(cur_pool, T) AL(has_root, T) AL(has_prev, T) AL(prev_ply, T) AL(prev_board, (size_t)T * CELLS_PAD)
@@ -1258,11 +1260,10 @@ int agz_arena_get_history(agz_arena* a, int g, int32_t* moves, int cap, int* n) 
   AGZ_REQUIRE(a && g >= 0 && g < a->G && n, AGZ_E_INVALID, "bad argument");
   AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
   AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
-  int32_t ply = 0;
-  AGZ_HIP_TRY(hipMemcpy(&ply, a->d.ply + g, sizeof(int32_t), hipMemcpyDeviceToHost));
-  // plies recorded = number of end_move calls the game took part in: moves[] is indexed by ply-at-search time
+  int32_t ply = 0;   // length of the arena's move list (every Search result, arena.go:125), not the game's MoveNumber
+  AGZ_HIP_TRY(hipMemcpy(&ply, a->d.n_amoves + g, sizeof(int32_t), hipMemcpyDeviceToHost));
   std::vector<int16_t> mv(a->d.moves_stride);
-  AGZ_HIP_TRY(hipMemcpy(mv.data(), a->d.moves + (size_t)g * a->d.moves_stride, mv.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+  AGZ_HIP_TRY(hipMemcpy(mv.data(), a->d.amoves + (size_t)g * a->d.moves_stride, mv.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
   *n = ply;
   for (int i = 0; i < ply && i < cap; i++) moves[i] = mv[i];
   return AGZ_OK;

@@ -67,7 +67,10 @@ struct Dev {
   float* cap_b;           // komi: bs ; wq: captures by black
   float* cap_w;
   uint32_t* zhash;        // running zobrist hash (komi, wq)
-  int16_t* moves;         // [G][max_moves + 4]
+  int16_t* moves;         // [G][max_moves + 4]   the GAME's history: moves applied to the board (LastMove/UndoLastMove/Fwd)
+  int16_t* amoves;        // [G][max_moves + 4]   the ARENA's move list: every `best`, including a Resign and a Pass the game
+                          //                      ignored (mnk/komi Apply of a pass is a no-op) — arena.go:125, agz_arena_get_history
+  int32_t* n_amoves;      // [G]
   const int32_t* ztable;  // [2*cells] zobrist keys
   // ---- trees
   float* prior;           // [T][2][cap]   P(s,a)  (Node.score)

@@ -1,0 +1,51 @@
+"""GPU parity, randomised configurations (fixed seeds): game kind, board size, budget, pass/resign policy, randomised
+opening, inferencer, lanes, colour assignment — device vs oracle, bit-exact, a handful of plies each.  Catches
+interactions the hand-written cases do not enumerate."""
+import numpy as np
+import pytest
+
+import agogo_amd as A
+import oracle_lib as O
+from agogo_amd import capi
+from test_engine_gpu import run_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def draw_config(rng):
+    kind = int(rng.choice([capi.GAME_MNK, capi.GAME_C4, capi.GAME_KOMI, capi.GAME_WQ]))
+    cfg = dict(kind=kind)
+    if kind == capi.GAME_MNK:
+        m, n = int(rng.integers(3, 6)), int(rng.integers(3, 6))
+        cfg.update(m=m, n=n, k=int(rng.integers(3, min(m, n) + 1)), komi=0.0, enc=capi.ENC_TWOPLANE)
+    elif kind == capi.GAME_C4:
+        cfg.update(m=6, n=7, k=4, komi=0.0, enc=capi.ENC_TWOPLANE)
+    elif kind == capi.GAME_KOMI:
+        s = int(rng.integers(3, 7))
+        cfg.update(m=s, n=s, k=int(rng.integers(1, 4)), komi=0.0, enc=capi.ENC_TWOPLANE)
+    else:
+        s = int(rng.integers(3, 8))
+        cfg.update(m=s, n=s, k=0, komi=float(rng.choice([0.5, 5.5, 7.5])), enc=capi.ENC_WQ)
+    cfg["budget"] = int(rng.choice([1, 3, 10, 25, 60]))
+    cfg["inf"] = int(rng.choice([capi.INF_HASH, capi.INF_HASH, capi.INF_DUMMY, capi.INF_UNIFORM]))
+    cfg["parallel"] = int(rng.choice([1, 1, 2, 5, 8]))
+    cfg["a_is_black"] = tuple(int(x) for x in rng.integers(0, 2, size=int(rng.integers(1, 4))))
+    cfg["DumbPass"] = bool(rng.integers(0, 2))
+    cfg["PassPreference"] = int(rng.choice([capi.DONT_PREFER_PASS, capi.PREFER_PASS, capi.DONT_RESIGN]))
+    cfg["ResignPercentage"] = float(rng.choice([0.0, 0.0, 0.3, -1.0]))
+    cfg["PUCT"] = float(rng.choice([1.0, 0.5, 0.25]))
+    return cfg
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration(ctx, seed):
+    rng = np.random.default_rng(1000 + seed)
+    c = draw_config(rng)
+    policy_len = 25 if c["inf"] == capi.INF_UNIFORM else 0
+    if c["inf"] == capi.INF_UNIFORM and (c["m"] * c["n"] + 1 > 25 or c["kind"] == capi.GAME_C4 and 8 > 25):
+        c["inf"] = capi.INF_HASH          # the uniform example inferencer serves a 25-entry policy (5x5 boards at most)
+        policy_len = 0
+    run_pair(ctx, c["kind"], c["m"], c["n"], c["k"], c["komi"], enc=c["enc"], budget=c["budget"], inf=c["inf"],
+             a_is_black=c["a_is_black"], max_moves=3 * c["m"] * c["n"], n_plies=14, policy_len=policy_len,
+             parallel=c["parallel"], DumbPass=c["DumbPass"], PassPreference=c["PassPreference"],
+             ResignPercentage=c["ResignPercentage"], PUCT=c["PUCT"])
