@@ -1,5 +1,5 @@
 """GPU parity, randomised configurations (fixed seeds): game kind, board size, budget, pass/resign policy, randomised
-opening, inferencer, lanes, colour assignment — device vs oracle, bit-exact, a handful of plies each.  Catches
+opening (count, temperature, visit floor), inferencer, lanes, colour assignment, whole games on small boards — device vs oracle, bit-exact, a handful of plies each.  Catches
 interactions the hand-written cases do not enumerate."""
 import numpy as np
 import pytest
@@ -34,10 +34,14 @@ def draw_config(rng):
     cfg["PassPreference"] = int(rng.choice([capi.DONT_PREFER_PASS, capi.PREFER_PASS, capi.DONT_RESIGN]))
     cfg["ResignPercentage"] = float(rng.choice([0.0, 0.0, 0.3, -1.0]))
     cfg["PUCT"] = float(rng.choice([1.0, 0.5, 0.25]))
+    cfg["RandomCount"] = int(rng.choice([0, 0, 3, 6]))
+    cfg["RandomTemperature"] = float(rng.choice([1.0, 0.7, 1.5]))
+    cfg["RandomMinVisits"] = int(rng.choice([0, 0, 2]))
+    cfg["full_game"] = bool(rng.integers(0, 3) == 0) and cfg["m"] * cfg["n"] <= 25
     return cfg
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(120))
 def test_random_configuration(ctx, seed):
     rng = np.random.default_rng(1000 + seed)
     c = draw_config(rng)
@@ -46,6 +50,7 @@ def test_random_configuration(ctx, seed):
         c["inf"] = capi.INF_HASH          # the uniform example inferencer serves a 25-entry policy (5x5 boards at most)
         policy_len = 0
     run_pair(ctx, c["kind"], c["m"], c["n"], c["k"], c["komi"], enc=c["enc"], budget=c["budget"], inf=c["inf"],
-             a_is_black=c["a_is_black"], max_moves=3 * c["m"] * c["n"], n_plies=14, policy_len=policy_len,
+             a_is_black=c["a_is_black"], max_moves=3 * c["m"] * c["n"], n_plies=0 if c["full_game"] else 14, policy_len=policy_len,
              parallel=c["parallel"], DumbPass=c["DumbPass"], PassPreference=c["PassPreference"],
-             ResignPercentage=c["ResignPercentage"], PUCT=c["PUCT"])
+             ResignPercentage=c["ResignPercentage"], PUCT=c["PUCT"], RandomCount=c["RandomCount"],
+             RandomTemperature=c["RandomTemperature"], RandomMinVisits=c["RandomMinVisits"])

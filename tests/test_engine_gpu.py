@@ -32,7 +32,8 @@ def run_pair(ctx, kind, m, n, k=0, komi=0.0, enc=capi.ENC_TWOPLANE, budget=50, i
     dev.reset(np.array(a_is_black, dtype=np.uint8))
     orcs = []
     for g in range(G):
-        o = O.Arena(kind, m, n, k, komi, enc=enc, Budget=budget, max_moves=max_moves, **mcts_kw)
+        # device arena seed S (default 1337), game g <-> oracle Arena(seed=S+g): the per-tree RNG streams of randomizeChildren
+        o = O.Arena(kind, m, n, k, komi, enc=enc, Budget=budget, max_moves=max_moves, seed=1337 + g, **mcts_kw)
         o.set_inferencer(0, inf, policy_len=policy_len)
         o.set_inferencer(1, inf, policy_len=policy_len)
         if parallel > 1:
