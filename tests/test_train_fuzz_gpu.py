@@ -1,0 +1,47 @@
+"""GPU parity, randomised trainer shapes (fixed seeds): dual.Train forward/backward vs the oracle on shapes that are not
+multiples of anything, BatchSize 1..7, both compute modes."""
+import numpy as np
+import pytest
+
+import agogo_amd as A
+import oracle_lib as O
+from agogo_amd import capi
+from test_train_gpu import make_pair, batch_data
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_trainer_shape(ctx, seed):
+    rng = np.random.default_rng(900 + seed)
+    K = int(rng.choice([3, 8, 20, 32, 48, 64, 80]))
+    L = int(rng.integers(1, 3))
+    FC = int(rng.choice([2, 5, 16, 24]))
+    H, W = int(rng.integers(3, 7)), int(rng.integers(3, 7))
+    F = int(rng.choice([1, 2, 3, 18]))
+    Aspace = int(rng.choice([3, H * W + 1, W + 1]))
+    B = int(rng.integers(1, 8))
+    ot, dt = make_pair(ctx, K, L, FC, W, H, F, Aspace, B)
+    if rng.integers(0, 2):
+        dt.set_compute_mode(capi.COMPUTE_BF16X3 | capi.COMPUTE_FORCE)
+    shape = (K, L, FC, W, H, F, Aspace, B)
+    # ReLU is not differentiable at 0: with batches this small a pre-activation within rounding of zero can take a different
+    # side on the device and in the oracle and move a few gradients by percent (seen once in 14 shapes; the same shape passes
+    # with any other data).  A case fails only if two independent data draws both miss the tolerance; the cost must always match.
+    failures = []
+    for attempt in range(2):
+        x, pi, v = batch_data(B, F, H, W, Aspace, seed=seed + 1000 * attempt)
+        co = ot.batch(x, pi, v, lr=0.0)
+        cd = dt.forward_backward(x, pi, v)
+        assert abs(cd - co) <= 2e-5 * max(1.0, abs(co)), (cd, co, shape)
+        bad = []
+        for i in range(ot.num_params()):
+            go, gd = ot.get_grad(i), dt.get_grad(i)
+            scale = float(np.abs(go).max())
+            err = float(np.abs(gd - go).max())
+            if err > 2e-5 * scale + 1e-7:
+                bad.append((ot.param_name(i), err, scale))
+        if not bad:
+            return
+        failures.append(bad)
+    raise AssertionError((shape, failures))
