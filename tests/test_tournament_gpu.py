@@ -107,3 +107,62 @@ def test_illegal_external_move_is_rejected(ctx):
     dev.begin_move()
     with pytest.raises(A.AgzError, match="in progress"):
         dev.apply_moves(np.array([0, 2], dtype=np.int32))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_tournament_fuzz(ctx, seed):
+    """random game / size / budget / lanes / pass policy; the outsider plays random candidate moves, the oracle's Check is
+    the referee and the device must accept and reject exactly the same candidates; trees, boards, move lists bit-exact."""
+    rng = np.random.default_rng(7000 + seed)
+    kind = int(rng.choice([capi.GAME_MNK, capi.GAME_KOMI, capi.GAME_WQ]))
+    s = int(rng.integers(3, 7))
+    k = int(rng.integers(3, min(s, 4) + 1)) if kind != capi.GAME_WQ else 0
+    enc = capi.ENC_WQ if kind == capi.GAME_WQ else capi.ENC_TWOPLANE
+    komi = 0.5 if kind == capi.GAME_WQ else 0.0
+    budget = int(rng.choice([1, 5, 20, 40]))
+    lanes = int(rng.choice([1, 1, 3, 8]))
+    a_black = int(rng.integers(0, 2))
+    kw = dict(DumbPass=bool(rng.integers(0, 2)), PassPreference=int(rng.choice([capi.DONT_PREFER_PASS, capi.PREFER_PASS])))
+    dev = A.Arena(ctx, kind, s, s, k, komi, encoder=enc, n_games=1, Budget=budget, max_moves=3 * s * s, **kw)
+    dev.set_inferencer(0, capi.INF_HASH)
+    dev.set_inferencer(1, capi.INF_HASH)
+    dev.set_parallel(lanes)
+    dev.reset(np.array([a_black], dtype=np.uint8))
+    o = O.Arena(kind, s, s, k, komi, enc=enc, Budget=budget, max_moves=3 * s * s, **kw)
+    o.set_inferencer(0, O.INF_HASH)
+    o.set_inferencer(1, O.INF_HASH)
+    o.set_parallel(lanes)
+    o.begin(a_black)
+    for ply in range(24):
+        if o.state()[1]["ended"]:
+            break
+        a_to_move = (ply % 2 == 0) == bool(a_black)
+        if a_to_move:
+            dev.begin_move()
+            dev.simulate(budget)
+            dev.end_move(True)
+            o.step(True)
+            omv, ovis, obs, _ = o.root_children(0)
+            dmv, dvis, dbs, _ = dev.root_children(0, 0)
+            np.testing.assert_array_equal(dmv, omv, err_msg="ply %d" % ply)
+            np.testing.assert_array_equal(dvis, ovis, err_msg="ply %d" % ply)
+            np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+        else:
+            cands = list(rng.permutation(s * s)[:6]) + [capi.PASS]
+            played = False
+            for cnd in cands:
+                r = o.apply_move(int(cnd))
+                if r >= 0:
+                    dev.apply_moves(np.array([cnd], dtype=np.int32))
+                    played = True
+                    break
+                with pytest.raises(A.AgzError, match="illegal"):
+                    dev.apply_moves(np.array([cnd], dtype=np.int32))
+            if not played:   # nothing legal among the candidates (mnk/komi have no pass): resign
+                assert o.apply_move(capi.RESIGN) >= 0
+                dev.apply_moves(np.array([capi.RESIGN], dtype=np.int32))
+        ob, ost = o.state()
+        db, dst = dev.game(0)
+        np.testing.assert_array_equal(db, ob)
+        assert dst["ended"] == ost["ended"] and (not ost["ended"] or dst["winner"] == ost["winner"])
+        np.testing.assert_array_equal(dev.history(0), o.history())
