@@ -54,3 +54,17 @@ def test_random_configuration(ctx, seed):
              parallel=c["parallel"], DumbPass=c["DumbPass"], PassPreference=c["PassPreference"],
              ResignPercentage=c["ResignPercentage"], PUCT=c["PUCT"], RandomCount=c["RandomCount"],
              RandomTemperature=c["RandomTemperature"], RandomMinVisits=c["RandomMinVisits"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_large_go_board(ctx, seed):
+    """wq / komi on 9..19 boards (LDS board + wave-parallel group analysis at full width), small budgets, a few plies"""
+    rng = np.random.default_rng(3000 + seed)
+    kind = int(rng.choice([capi.GAME_WQ, capi.GAME_WQ, capi.GAME_KOMI]))
+    s = int(rng.choice([9, 11, 13, 16, 19]))
+    budget = int(rng.choice([2, 6, 12]))
+    lanes = int(rng.choice([1, 1, 4]))
+    enc = capi.ENC_WQ if kind == capi.GAME_WQ else capi.ENC_TWOPLANE
+    run_pair(ctx, kind, s, s, 0 if kind == capi.GAME_WQ else 5, 6.5 if kind == capi.GAME_WQ else 0.0, enc=enc, budget=budget,
+             inf=capi.INF_HASH, a_is_black=(int(rng.integers(0, 2)), int(rng.integers(0, 2))), n_plies=int(rng.integers(4, 9)),
+             parallel=lanes, DumbPass=bool(rng.integers(0, 2)), PassPreference=int(rng.choice([0, 1, 2])))

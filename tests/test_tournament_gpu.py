@@ -166,3 +166,61 @@ def test_tournament_fuzz(ctx, seed):
         np.testing.assert_array_equal(db, ob)
         assert dst["ended"] == ost["ended"] and (not ost["ended"] or dst["winner"] == ost["winner"])
         np.testing.assert_array_equal(dev.history(0), o.history())
+
+
+@pytest.mark.parametrize("kind,s,seed", [(capi.GAME_WQ, 9, 0), (capi.GAME_WQ, 7, 1), (capi.GAME_WQ, 13, 2), (capi.GAME_KOMI, 7, 3),
+                                         (capi.GAME_KOMI, 9, 4), (capi.GAME_WQ, 5, 5)])
+def test_go_rules_long_random_rollout(ctx, kind, s, seed):
+    """Both sides' moves injected at random (the oracle's Check referees; rejected candidates must be rejected by the device
+    too) for up to 160 plies: dense boards, captures, merges, the reference's suicide rule — board, captures-so-far,
+    end state compared after every ply, a search every 16 plies compared tree for tree."""
+    rng = np.random.default_rng(8000 + seed)
+    k = 0 if kind == capi.GAME_WQ else 200          # komi: capture target high enough not to end the game early
+    enc = capi.ENC_WQ if kind == capi.GAME_WQ else capi.ENC_TWOPLANE
+    komi = 6.5 if kind == capi.GAME_WQ else 0.0
+    budget = 6
+    dev = A.Arena(ctx, kind, s, s, k, komi, encoder=enc, n_games=1, Budget=budget, max_moves=400)
+    dev.set_inferencer(0, capi.INF_HASH)
+    dev.set_inferencer(1, capi.INF_HASH)
+    dev.reset(np.array([1], dtype=np.uint8))
+    o = O.Arena(kind, s, s, k, komi, enc=enc, Budget=budget, max_moves=400)
+    o.set_inferencer(0, O.INF_HASH)
+    o.set_inferencer(1, O.INF_HASH)
+    o.begin(1)
+    rejected = 0
+    for ply in range(160):
+        _, ost = o.state()
+        if ost["ended"]:
+            break
+        if ply % 16 == 15:
+            agent = 0 if ost["to_move"] == O.BLACK else 1
+            dev.begin_move()
+            dev.simulate(budget)
+            dev.end_move(False)
+            o.step(False)
+            omv, ovis, obs, _ = o.root_children(agent)
+            dmv, dvis, dbs, _ = dev.root_children(0, agent)
+            np.testing.assert_array_equal(dmv, omv, err_msg="ply %d" % ply)
+            np.testing.assert_array_equal(dvis, ovis, err_msg="ply %d" % ply)
+            np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+        else:
+            played = False
+            for cnd in rng.permutation(s * s)[:12]:
+                r = o.apply_move(int(cnd))
+                if r >= 0:
+                    dev.apply_moves(np.array([cnd], dtype=np.int32))
+                    played = True
+                    break
+                rejected += 1
+                with pytest.raises(A.AgzError, match="illegal"):
+                    dev.apply_moves(np.array([cnd], dtype=np.int32))
+            if not played:
+                mv = capi.PASS if kind == capi.GAME_WQ else capi.RESIGN
+                assert o.apply_move(mv) >= 0
+                dev.apply_moves(np.array([mv], dtype=np.int32))
+        ob, ost = o.state()
+        db, dst = dev.game(0)
+        np.testing.assert_array_equal(db, ob, err_msg="board after ply %d" % ply)
+        assert dst["ended"] == ost["ended"] and (not ost["ended"] or dst["winner"] == ost["winner"]), ply
+        np.testing.assert_array_equal(dev.history(0), o.history())
+    assert rejected > 0      # occupied points / suicides were met: the rejection path was exercised
