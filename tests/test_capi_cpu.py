@@ -75,3 +75,37 @@ def test_product_path_never_touches_the_oracle():
     assert not bad, bad
     mk = open(os.path.join(ROOT, "Makefile")).read()
     assert "liboracle" not in mk.split("$(OUT)/libagz.so: $(OBJS)")[1].split("\n")[1]
+
+
+def test_header_is_plain_c99_and_links(tmp_path):
+    """cgo compiles include/agz.h with a C compiler: the header must be valid C99 (no C++-isms), and a C program using it
+    must link against libagz.so.  Without a GPU the one call it makes fails loudly (no CPU fallback)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi_c.c"
+    src.write_text('''#include "agz.h"
+#include <stdio.h>
+#include <string.h>
+int main(void) {
+  agz_ctx* c = 0;
+  agz_net_conf nc = {3, 3, 8, 1, 3, 3, 2, 10, AGZ_BN_DEGENERATE_EPS, 1e-5f};
+  agz_game_conf gc = {AGZ_GAME_MNK, 3, 3, 3, 0.0f, 0, AGZ_ENC_TWOPLANE};
+  agz_mcts_conf mc = {1.0f, 3, 3, 0, 10, 0, 0.0f, 1, 0.0f, AGZ_DONT_PREFER_PASS};
+  int r = agz_ctx_create(0, &c);
+  (void)nc; (void)gc; (void)mc;
+  printf("%d|%s\\n", r, r ? agz_last_error() : "ok");
+  if (r == 0) agz_ctx_destroy(c);
+  return 0;
+}
+''')
+    exe = tmp_path / "abi_c"
+    lib_dir = os.path.join(root, "agogo_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
+                           "-o", str(exe), "-L", lib_dir, "-lagz", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60).stdout.strip()
+    code, msg = out.split("|", 1)
+    import torch
+    if torch.cuda.is_available():
+        assert code == "0"
+    else:
+        assert int(code) < 0 and "no CPU fallback" in msg
