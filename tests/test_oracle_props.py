@@ -122,3 +122,49 @@ def test_policies_are_one_hot_on_the_chosen_move():
     _, st = a.state()
     assert st["ended"] == 1
     assert set(np.unique(V)).issubset({-1.0, 0.0, 1.0})
+
+
+@pytest.mark.parametrize("lanes", [2, 4, 8])
+def test_lane_parallel_rounds_conserve_visits_and_are_deterministic(lanes):
+    """oracle/mcts.hpp MCTS::parallelRound (MCTSConfig::Parallel): every lane of a round backs exactly one value up (or
+    none, for a null lane), so the root's child visits still sum to Budget + #children; same inputs, same tree."""
+    def one():
+        a = O.Arena(O.WQ, 5, 5, komi=0.5, enc=O.ENC_WQ, Budget=37)      # 37: the last round is partial
+        a.set_inferencer(0, O.INF_HASH)
+        a.set_inferencer(1, O.INF_HASH)
+        a.set_parallel(lanes)
+        a.begin(1)
+        a.step(True)
+        return a.root_children(0)
+    mv, vis, bs, pr = one()
+    assert int(vis.sum()) - len(vis) == 37
+    mv2, vis2, bs2, _ = one()
+    assert np.array_equal(mv, mv2) and np.array_equal(vis, vis2) and np.array_equal(bs.view(np.uint32), bs2.view(np.uint32))
+
+
+def test_lane_parallel_virtual_loss_only_steers_white():
+    """node.go:147-159: the stored virtual loss enters Evaluate for White only.  With Black to move at the root all lanes
+    of a round share the first move; with White to move they fan out over the root's children."""
+    def first_round_spread(a_is_black):
+        # one round of 8 lanes on a fresh tree: budget 8
+        a = O.Arena(O.MNK, 5, 5, 4, Budget=8)
+        a.set_inferencer(0, O.INF_HASH)
+        a.set_inferencer(1, O.INF_HASH)
+        a.set_parallel(8)
+        a.begin(a_is_black)
+        a.step(True)            # Black's move (agent A or B)
+        a.step(True)            # White's move: its root search is the one we look at
+        agent_white = 1 if a_is_black else 0
+        mv, vis, _, _ = a.root_children(agent_white)
+        return int((vis > 1).sum())
+    # White to move at ITS root: the 8 lanes are steered apart by the virtual loss -> several children visited
+    assert first_round_spread(1) >= 3
+    # Black to move at its root (first ply): no steering at the root level
+    a = O.Arena(O.MNK, 5, 5, 4, Budget=8)
+    a.set_inferencer(0, O.INF_HASH)
+    a.set_inferencer(1, O.INF_HASH)
+    a.set_parallel(8)
+    a.begin(1)
+    a.step(True)
+    _, vis, _, _ = a.root_children(0)
+    assert int((vis > 1).sum()) == 1
