@@ -631,15 +631,36 @@ static int xfer_param(const agz_trainer* t, float* buf, int i, float* host, int 
       if (dir == 0) return dev_rw(ly.o_wf, tmp);
       return AGZ_OK;
     }
-    // gamma/beta [B][K][H][W] <-> [r = b*HW+p][br*Kp + c]
+    // gamma/beta [B][K][H][W] <-> [r = b*HW+p][br*Kp + c]: only this tensor's Kp-wide column block moves (strided 2-D
+    // copy), the host-side transpose runs on all cores — a 19x19 / K=256 / B=256 trainer has 82 such tensors of 94 MB
     size_t off = sub == 1 ? ly.o_gamma : ly.o_beta;
-    std::vector<float> tmp((size_t)t->g.M * C);
-    if (hipMemcpy(tmp.data(), buf + off, tmp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { agz::set_error("xfer: D2H failed"); return AGZ_E_HIP; }
-    for (int b = 0; b < B; b++) for (int c = 0; c < K; c++) for (int q = 0; q < HW; q++) {
-      size_t di = ((size_t)b * HW + q) * C + br * Kp + c, hi = ((size_t)b * K + c) * HW + q;
-      if (dir == 0) tmp[di] = host[hi]; else host[hi] = tmp[di];
+    const size_t M = (size_t)t->g.M;
+    std::vector<float> tmp(M * Kp, 0.f);
+    float* dcol = buf + off + (size_t)br * Kp;
+    if (dir == 1 && hipMemcpy2D(tmp.data(), (size_t)Kp * 4, dcol, (size_t)C * 4, (size_t)Kp * 4, M, hipMemcpyDeviceToHost) != hipSuccess) {
+      agz::set_error("xfer: D2H failed"); return AGZ_E_HIP;
     }
-    if (dir == 0) return dev_rw(off, tmp);
+    auto work = [&](int b_lo, int b_hi) {
+      for (int b = b_lo; b < b_hi; b++)
+        for (int q = 0; q < HW; q++) {
+          float* trow = tmp.data() + ((size_t)b * HW + q) * Kp;
+          for (int c = 0; c < K; c++) {
+            size_t hi = ((size_t)b * K + c) * HW + q;
+            if (dir == 0) trow[c] = host[hi]; else host[hi] = trow[c];
+          }
+        }
+    };
+    unsigned nthr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    if ((size_t)B * K * HW < (1u << 16) || nthr == 1) work(0, B);
+    else {
+      std::vector<std::thread> th;
+      int per = (B + (int)nthr - 1) / (int)nthr;
+      for (int lo = 0; lo < B; lo += per) th.emplace_back(work, lo, std::min(B, lo + per));
+      for (auto& x : th) x.join();
+    }
+    if (dir == 0 && hipMemcpy2D(dcol, (size_t)C * 4, tmp.data(), (size_t)Kp * 4, (size_t)Kp * 4, M, hipMemcpyHostToDevice) != hipSuccess) {
+      agz::set_error("xfer: H2D failed"); return AGZ_E_HIP;
+    }
     return AGZ_OK;
   }
   // heads
