@@ -607,9 +607,10 @@ int agz_trainer_param_info(const agz_trainer* t, int i, char* name, size_t cap, 
 }
 
 // reference layout <-> device layout for parameter i of flat buffer `buf` (P or G). dir 0: host -> device, 1: device -> host
-static int xfer_param(const agz_trainer* t, float* buf, int i, float* host, int dir) {
+// nb_sel > 0: only the first nb_sel batch rows of a conv-layer gamma/beta (agz_trainer_export needs row 0 only)
+static int xfer_param(const agz_trainer* t, float* buf, int i, float* host, int dir, int nb_sel = 0) {
   const TParamRef& p = t->prefs[i];
-  const int K = t->K, Kp = t->Kp, HW = t->g.HW, B = t->B, A = t->A, FCn = t->FC, F = t->F, Fp = t->Fp;
+  const int K = t->K, Kp = t->Kp, HW = t->g.HW, B = (nb_sel > 0 && nb_sel < t->B && t->prefs[i].layer >= 0 && (t->prefs[i].sub % 10) != 0) ? nb_sel : t->B, A = t->A, FCn = t->FC, F = t->F, Fp = t->Fp;
   hipStream_t s = t->ctx->stream;
   auto dev_rw = [&](size_t off, std::vector<float>& tmp) -> int {
     if (dir == 0) AGZ_HIP_TRY(hipMemcpyAsync(buf + off, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, s));
@@ -634,7 +635,7 @@ static int xfer_param(const agz_trainer* t, float* buf, int i, float* host, int 
     // gamma/beta [B][K][H][W] <-> [r = b*HW+p][br*Kp + c]: only this tensor's Kp-wide column block moves (strided 2-D
     // copy), the host-side transpose runs on all cores — a 19x19 / K=256 / B=256 trainer has 82 such tensors of 94 MB
     size_t off = sub == 1 ? ly.o_gamma : ly.o_beta;
-    const size_t M = (size_t)t->g.M;
+    const size_t M = (size_t)B * HW;   // (B is nb_sel when only the leading rows are wanted)
     std::vector<float> tmp(M * Kp, 0.f);
     float* dcol = buf + off + (size_t)br * Kp;
     if (dir == 1 && hipMemcpy2D(tmp.data(), (size_t)Kp * 4, dcol, (size_t)C * 4, (size_t)Kp * 4, M, hipMemcpyDeviceToHost) != hipSuccess) {
@@ -965,12 +966,16 @@ int agz_trainer_load(agz_trainer* t, const char* path) {
 int agz_trainer_export(const agz_trainer* t, agz_net* net) {
   AGZ_REQUIRE(t && net, AGZ_E_INVALID, "NULL argument");
   AGZ_REQUIRE((int)t->prefs.size() == agz_net_num_params(net), AGZ_E_INVALID, "agz_trainer_export: network shapes differ");
+  AGZ_HIP_TRY(hipSetDevice(t->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
   for (int i = 0; i < (int)t->prefs.size(); i++) {
-    std::vector<float> v(pref_size(t->prefs[i]));
-    int r = agz_trainer_get_param(t, i, v.data(), v.size());
-    if (r != AGZ_OK) return r;
     size_t want = 0;
-    r = agz_net_param_info(net, i, nullptr, 0, &want);
+    int r = agz_net_param_info(net, i, nullptr, 0, &want);
+    if (r != AGZ_OK) return r;
+    const TParamRef& p = t->prefs[i];
+    const bool conv_bn = p.layer >= 0 && (p.sub % 10) != 0;   // batch-shaped [B][K][H][W]: only row 0 is transferred
+    std::vector<float> v(conv_bn ? want : pref_size(p));
+    r = xfer_param(t, t->P, i, v.data(), 1, conv_bn ? 1 : 0);
     if (r != AGZ_OK) return r;
     AGZ_REQUIRE(v.size() >= want, AGZ_E_INVALID, "agz_trainer_export: parameter %d too small", i);
     r = agz_net_set_param(net, i, v.data(), v.size());  // takes row 0 of batch-shaped tensors
