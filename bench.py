@@ -51,9 +51,12 @@ def standard_bn_init(net):
             net.set_param(i, np.zeros(n, np.float32))
 
 
-def cpu_baseline(size, K, L, budget_s=20.0):
-    """The oracle (CPU restatement of the reference algorithm: per-leaf inference, sequential pipeline) timed on
-    ONE host core, on a bounded sample of the same workload: one 19x19 game, one move, a few simulations."""
+def cpu_baseline(size, K, L, budget_s=20.0, max_threads=32):
+    """The oracle (CPU restatement of the reference algorithm: per-leaf inference, sequential pipeline) timed on the box's
+    host cores, on a bounded sample of the same workload: T threads (one independent 19x19 game each, the way the
+    reference would use its cores: SURVEY 8(d)), one move of a few simulations per game.  The oracle calls run outside the
+    GIL (ctypes), so the threads are real."""
+    import threading
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     A_ = size * size + 1
@@ -70,18 +73,28 @@ def cpu_baseline(size, K, L, budget_s=20.0):
     net.infer(x)
     t_eval = time.perf_counter() - t0
     sims = int(max(2, min(64, budget_s / max(t_eval, 1e-3) - 1)))
-    ar = O.Arena(O.WQ, size, size, komi=7.5, enc=O.ENC_WQ, Budget=sims)
-    ar.set_inferencer(0, O.INF_NET, net)
-    ar.set_inferencer(1, O.INF_NET, net)
-    ar.begin(1)
+    T = max(1, min(max_threads, os.cpu_count() or 1))
+    arenas = []
+    for g in range(T):
+        ar = O.Arena(O.WQ, size, size, komi=7.5, enc=O.ENC_WQ, Budget=sims, seed=1337 + g)
+        ar.set_inferencer(0, O.INF_NET, net)     # the net is read-only during inference
+        ar.set_inferencer(1, O.INF_NET, net)
+        ar.begin(g % 2)
+        arenas.append(ar)
+    threads = [threading.Thread(target=ar.step, args=(True,)) for ar in arenas]
     t0 = time.perf_counter()
-    ar.step(record=True)
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
     dt = time.perf_counter() - t0
-    st = ar.tree_stats(0)
-    return {"value": st["playouts"] / dt, "unit": "sims/s", "cores": 1, "kind": "port",
-            "sample": "oracle (C++ restatement, per-leaf inference): 1 game, 1 move, %d sims + root eval = %d evals "
-                      "in %.1f s on one host core of %d" % (sims, st["nn_evals"], dt, os.cpu_count() or 0),
-            "evals_per_s": st["nn_evals"] / dt}
+    stats = [ar.tree_stats(0 if g % 2 == 1 else 1) for g, ar in enumerate(arenas)]   # the agent holding Black searched
+    playouts = sum(st["playouts"] for st in stats)
+    evals = sum(st["nn_evals"] for st in stats)
+    return {"value": playouts / dt, "unit": "sims/s", "cores": T, "kind": "port",
+            "sample": "oracle (C++ restatement, per-leaf inference): %d threads x (1 game, 1 move, %d sims + root eval) = %d evals "
+                      "in %.1f s on %d of the box's %d host cores" % (T, sims, evals, dt, T, os.cpu_count() or 0),
+            "evals_per_s": evals / dt, "per_core_sims_per_s": playouts / dt / T}
 
 
 def games_leg(ctx, compute="bf16x3"):
