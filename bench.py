@@ -51,7 +51,7 @@ def standard_bn_init(net):
             net.set_param(i, np.zeros(n, np.float32))
 
 
-def cpu_baseline(size, K, L, budget_s=20.0, max_threads=32):
+def cpu_baseline(size, K, L, budget_s=10.0, max_threads=32):
     """The oracle (CPU restatement of the reference algorithm: per-leaf inference, sequential pipeline) timed on the box's
     host cores, on a bounded sample of the same workload: T threads (one independent 19x19 game each, the way the
     reference would use its cores: SURVEY 8(d)), one move of a few simulations per game.  The oracle calls run outside the
