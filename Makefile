@@ -11,10 +11,14 @@ SRCS := $(CS)/ctx.hip $(CS)/net.hip $(CS)/engine.hip $(CS)/train.hip $(CS)/examp
 OBJS := $(OUT)/ctx.o $(OUT)/net.o $(OUT)/engine.o $(OUT)/train.o $(OUT)/examples.o
 HDRS := $(wildcard $(CS)/*.hpp) include/agz.h
 
-all: $(OUT)/libagz.so oracle tests/cpp/az_learn_ttt
+all: $(OUT)/libagz.so oracle tests/cpp/az_learn_ttt tests/cpp/gtp_main
 
 # host-side C++ mirror of the reference API (agogo_amd/host/agogo.hpp) exercised over the C ABI
 tests/cpp/az_learn_ttt: tests/cpp/az_learn_ttt.cpp agogo_amd/host/agogo.hpp include/agz.h $(OUT)/libagz.so
+	g++ -std=c++17 -O1 -Iinclude $< -o $@ -L$(OUT) -lagz -Wl,-rpath,'$$ORIGIN/../../agogo_amd/lib'
+
+# GTP front end over the C ABI (agogo_amd/host/gtp.hpp)
+tests/cpp/gtp_main: tests/cpp/gtp_main.cpp agogo_amd/host/gtp.hpp agogo_amd/host/agogo.hpp include/agz.h $(OUT)/libagz.so
 	g++ -std=c++17 -O1 -Iinclude $< -o $@ -L$(OUT) -lagz -Wl,-rpath,'$$ORIGIN/../../agogo_amd/lib'
 
 $(OUT)/ctx.o: $(CS)/ctx.hip $(HDRS)
