@@ -1008,8 +1008,12 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
     for (int i = 0; i < lim; i++) zt[i] = rr.int31();
     int32_t* zp = nullptr;
     if ((r = a->alloc(&zp, zt.size())) != AGZ_OK) { agz_arena_destroy(a); return r; }
-    hipMemcpyAsync(zp, zt.data(), zt.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
-    hipStreamSynchronize(ctx->stream);
+    if (hipMemcpyAsync(zp, zt.data(), zt.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      agz_arena_destroy(a);
+      agz::set_error("arena: zobrist table upload failed");
+      return AGZ_E_HIP;
+    }
     d.ztable = zp;
   }
 #undef AL

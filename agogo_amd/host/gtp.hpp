@@ -3,6 +3,8 @@
 // id optional and the line lower-cased :83-112, replies "= [id] result\n\n" / "? [id] error\n\n" :139-154); the
 // reference's Generate hook (gtp.go:42) is Agent.Search, here BatchedArena-style begin_move/simulate/end_move on ONE game
 // held on the device, and `play` is agz_arena_apply_moves (State.Check'ed on the device).
+// Replies without an id are byte-identical to the reference's (its Test_General strings are pinned in tests/test_gtp_protocol.py);
+// with an id the reference prints "= 7 result" (gtp.go:150), which GTP controllers reject — the spec's "=7 result" is used.
 // Host-side glue only: no GPU code here.  Moves must alternate colours (the device game alternates; GTP's free-form
 // "same colour twice" is answered with an error rather than by inventing passes).
 #pragma once
@@ -19,7 +21,60 @@
 
 namespace gtp {
 
-struct Engine {
+// The protocol without a game (the reference's gtp.New(nil, name, version, nil)): administrative commands, parsing, framing.
+struct Protocol {
+  std::string name, version;
+  Protocol(const std::string& n = "agz-hip", const std::string& v = "r01") : name(n), version(v) {}
+  virtual ~Protocol() {}
+  static const std::vector<std::string>& known() {
+    static const std::vector<std::string> k = {"protocol_version", "name", "version", "known_command", "list_commands", "quit", "boardsize",
+                                               "clear_board", "komi", "play", "genmove", "showboard"};
+    return k;
+  }
+  // board commands; the game-less protocol has none to offer
+  virtual bool board_command(const std::string&, const std::vector<std::string>&, std::string* out) { *out = "no game attached"; return false; }
+
+  // one command -> one reply (without the id prefix); returns false on failure with the message in *out
+  bool command(const std::string& cmd, const std::vector<std::string>& args, std::string* out, bool* quit) {
+    *out = "";
+    bool is_known = false;
+    for (const std::string& k : known()) is_known = is_known || k == cmd;
+    if (!is_known) { *out = "Unknown command \"" + cmd + "\""; return false; }   // gtp.go:103
+    if (cmd == "protocol_version") { *out = "2"; return true; }
+    if (cmd == "name") { *out = name; return true; }
+    if (cmd == "version") { *out = version; return true; }
+    if (cmd == "list_commands") { for (const std::string& k : known()) { if (!out->empty()) *out += "\n"; *out += k; } return true; }
+    if (cmd == "known_command") { bool f = false; for (const std::string& k : known()) f = f || (!args.empty() && args[0] == k); *out = f ? "true" : "false"; return true; }
+    if (cmd == "quit") { *quit = true; return true; }
+    return board_command(cmd, args, out);
+  }
+
+  // the protocol loop (internal/gtp/gtp.go:66-81,139-154)
+  void run(std::istream& in, std::ostream& os) {
+    std::string line;
+    bool quit = false;
+    while (!quit && std::getline(in, line)) {
+      size_t hash = line.find('#');
+      if (hash != std::string::npos) line.erase(hash);
+      for (char& ch : line) ch = (char)std::tolower((unsigned char)ch);
+      std::istringstream ss(line);
+      std::vector<std::string> tok;
+      for (std::string t; ss >> t;) tok.push_back(t);
+      if (tok.empty()) continue;
+      std::string id;
+      if (std::isdigit((unsigned char)tok[0][0])) { id = tok[0]; tok.erase(tok.begin()); }
+      if (tok.empty()) continue;   // an id alone is ignored (gtp.go:96-98)
+      std::string cmd = tok[0], reply;
+      tok.erase(tok.begin());
+      bool ok;
+      try { ok = command(cmd, tok, &reply, &quit); } catch (const std::exception& e) { ok = false; reply = e.what(); }
+      os << (ok ? "=" : "?") << id << (reply.empty() ? "" : " ") << reply << "\n\n";
+      os.flush();
+    }
+  }
+};
+
+struct Engine : Protocol {
   agz::Ctx& ctx;
   dual::Dual& net;
   mcts::Config mc;
@@ -27,7 +82,6 @@ struct Engine {
   float komi = 7.5f;
   int lanes = 1;
   std::unique_ptr<agogo::Arena> arena;
-  std::string name = "agz-hip", version = "r01";
 
   Engine(agz::Ctx& c, dual::Dual& n, const mcts::Config& m, int boardsize, int lanes_ = 1) : ctx(c), net(n), mc(m), size(boardsize), lanes(lanes_) { clear(); }
 
@@ -62,17 +116,7 @@ struct Engine {
   static int colour(const std::string& s) { return (s == "b" || s == "black") ? AGZ_BLACK : (s == "w" || s == "white") ? AGZ_WHITE : 0; }
   agz_game_state state() const { agz_game_state st{}; agz::check(agz_arena_get_game(arena->h, 0, nullptr, &st), "state"); return st; }
 
-  // one command line -> one reply (without the id prefix); returns false on failure with the message in *out
-  bool command(const std::string& cmd, const std::vector<std::string>& args, std::string* out, bool* quit) {
-    static const char* known[] = {"protocol_version", "name", "version", "known_command", "list_commands", "quit", "boardsize",
-                                  "clear_board", "komi", "play", "genmove", "showboard"};
-    *out = "";
-    if (cmd == "protocol_version") { *out = "2"; return true; }
-    if (cmd == "name") { *out = name; return true; }
-    if (cmd == "version") { *out = version; return true; }
-    if (cmd == "list_commands") { for (const char* k : known) { if (!out->empty()) *out += "\n"; *out += k; } return true; }
-    if (cmd == "known_command") { bool f = false; for (const char* k : known) f = f || (!args.empty() && args[0] == k); *out = f ? "true" : "false"; return true; }
-    if (cmd == "quit") { *quit = true; return true; }
+  bool board_command(const std::string& cmd, const std::vector<std::string>& args, std::string* out) override {
     if (cmd == "boardsize") {
       if (args.empty() || std::atoi(args[0].c_str()) != size) { *out = "unacceptable size"; return false; }   // the network fixes the size
       return true;
@@ -107,32 +151,8 @@ struct Engine {
       *out = vertex(n > 0 ? hist[n - 1] : AGZ_PASS);
       return true;
     }
-    *out = "unknown command";
+    *out = "not implemented";
     return false;
-  }
-
-  // the protocol loop (internal/gtp/gtp.go:66-81,139-154)
-  void run(std::istream& in, std::ostream& os) {
-    std::string line;
-    bool quit = false;
-    while (!quit && std::getline(in, line)) {
-      size_t hash = line.find('#');
-      if (hash != std::string::npos) line.erase(hash);
-      for (char& ch : line) ch = (char)std::tolower((unsigned char)ch);
-      std::istringstream ss(line);
-      std::vector<std::string> tok;
-      for (std::string t; ss >> t;) tok.push_back(t);
-      if (tok.empty()) continue;
-      std::string id;
-      if (std::isdigit((unsigned char)tok[0][0])) { id = tok[0]; tok.erase(tok.begin()); }
-      if (tok.empty()) continue;   // an id alone is ignored (gtp.go:96-98)
-      std::string cmd = tok[0], reply;
-      tok.erase(tok.begin());
-      bool ok;
-      try { ok = command(cmd, tok, &reply, &quit); } catch (const std::exception& e) { ok = false; reply = e.what(); }
-      os << (ok ? "=" : "?") << id << (reply.empty() ? "" : " ") << reply << "\n\n";
-      os.flush();
-    }
   }
 };
 

@@ -1,10 +1,16 @@
 // GTP engine over libagz (agogo_amd/host/gtp.hpp): reads commands on stdin.  gtp_main [size K blocks sims lanes]
+// gtp_main proto NAME VERSION : the game-less protocol (the reference's gtp.New(nil, name, version, nil)); needs no GPU.
 #include <cstdio>
 #include <iostream>
 
 #include "../../agogo_amd/host/gtp.hpp"
 
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "proto") {
+    gtp::Protocol p(argc > 2 ? argv[2] : "agz-hip", argc > 3 ? argv[3] : "r01");
+    p.run(std::cin, std::cout);
+    return 0;
+  }
   int size = argc > 1 ? atoi(argv[1]) : 9, K = argc > 2 ? atoi(argv[2]) : 64, L = argc > 3 ? atoi(argv[3]) : 4,
       sims = argc > 4 ? atoi(argv[4]) : 64, lanes = argc > 5 ? atoi(argv[5]) : 1;
   try {

@@ -40,7 +40,7 @@ def test_protocol_framing_and_commands():
     assert replies[2] == "= true" and replies[3] == "= false"
     assert replies[4] == "="                              # boardsize 5 accepted (the network's size)
     assert replies[5].startswith("? unacceptable size")
-    assert replies[6].startswith("?12 unknown command")
+    assert replies[6] == '?12 Unknown command "frobnicate"'
     assert "genmove" in replies[7] and "play" in replies[7]
     assert replies[8] == "="                              # quit
 
