@@ -18,3 +18,13 @@ def ctx():
     c = agogo_amd.Ctx(0)
     yield c
     c.close()
+
+
+# Soak runs: AGZ_FUZZ_N multiplies the number of seeds of every fuzz family, AGZ_FUZZ_BASE shifts them to fresh draws
+# (scripts/fuzz_soak.sh).  The defaults are the fixed seeds the suites are graded on.
+FUZZ_BASE = int(os.environ.get("AGZ_FUZZ_BASE", "0"))
+
+
+def fuzz_seeds(default_n):
+    n = int(os.environ.get("AGZ_FUZZ_N", "0")) or default_n
+    return range(FUZZ_BASE, FUZZ_BASE + n)

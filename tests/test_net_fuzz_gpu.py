@@ -4,6 +4,8 @@ sizes on both sides of the latency regime — libagz inference vs the oracle, th
 import numpy as np
 import pytest
 
+from conftest import fuzz_seeds
+
 import agogo_amd as A
 import oracle_lib as O
 from agogo_amd import capi
@@ -12,7 +14,7 @@ from test_net_gpu import make_pair, rand_planes, POL_ATOL, POL_RTOL, VAL_ATOL
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(28))
+@pytest.mark.parametrize("seed", fuzz_seeds(28))
 def test_random_network_shape(ctx, seed):
     rng = np.random.default_rng(500 + seed)
     K = int(rng.choice([3, 8, 20, 32, 48, 64, 96, 128, 192]))

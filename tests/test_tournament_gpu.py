@@ -5,6 +5,8 @@ search.go:424-500) exactly like the oracle's."""
 import numpy as np
 import pytest
 
+from conftest import fuzz_seeds
+
 import agogo_amd as A
 import oracle_lib as O
 from agogo_amd import capi
@@ -109,7 +111,7 @@ def test_illegal_external_move_is_rejected(ctx):
         dev.apply_moves(np.array([0, 2], dtype=np.int32))
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", fuzz_seeds(16))
 def test_tournament_fuzz(ctx, seed):
     """random game / size / budget / lanes / pass policy; the outsider plays random candidate moves, the oracle's Check is
     the referee and the device must accept and reject exactly the same candidates; trees, boards, move lists bit-exact."""

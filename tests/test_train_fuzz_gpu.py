@@ -3,6 +3,8 @@ multiples of anything, BatchSize 1..7, both compute modes."""
 import numpy as np
 import pytest
 
+from conftest import fuzz_seeds
+
 import agogo_amd as A
 import oracle_lib as O
 from agogo_amd import capi
@@ -11,7 +13,7 @@ from test_train_gpu import make_pair, batch_data
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(14))
+@pytest.mark.parametrize("seed", fuzz_seeds(14))
 def test_random_trainer_shape(ctx, seed):
     rng = np.random.default_rng(900 + seed)
     K = int(rng.choice([3, 8, 20, 32, 48, 64, 80]))
