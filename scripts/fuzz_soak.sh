@@ -5,6 +5,6 @@ BASE=${1:-100000}; NE=${2:-2000}; NO=${3:-200}   # AGZ_FUZZ_WIDE=1 in the enviro
 mkdir -p gpurun_out
 LOG=gpurun_out/fuzz_soak_$BASE.log
 : > $LOG
-AGZ_FUZZ_BASE=$BASE AGZ_FUZZ_N=$NE timeout 300 python -m pytest tests/test_engine_fuzz_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | tail -40 >> $LOG
-AGZ_FUZZ_BASE=$BASE AGZ_FUZZ_N=$NO timeout 200 python -m pytest tests/test_net_fuzz_gpu.py tests/test_train_fuzz_gpu.py tests/test_tournament_gpu.py -q -m gpu -p no:cacheprovider -k "fuzz or random" 2>&1 | tail -40 >> $LOG
+AGZ_FUZZ_BASE=$BASE AGZ_FUZZ_N=$NE timeout 300 python -m pytest tests/test_engine_fuzz_gpu.py -q -m gpu -p no:cacheprovider --tb=line 2>&1 | grep -v "^\.*  *\[" | tail -60 >> $LOG
+AGZ_FUZZ_BASE=$BASE AGZ_FUZZ_N=$NO timeout 200 python -m pytest tests/test_net_fuzz_gpu.py tests/test_train_fuzz_gpu.py tests/test_tournament_gpu.py -q -m gpu -p no:cacheprovider --tb=line -k "fuzz or random" 2>&1 | grep -v "^\.*  *\[" | tail -60 >> $LOG
 cat $LOG | tail -60

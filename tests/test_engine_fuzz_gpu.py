@@ -70,7 +70,7 @@ def draw_wide(rng, cfg):
     cfg["DumbPass"] = bool(rng.integers(0, 2))
     cfg["PassPreference"] = int(rng.choice([capi.DONT_PREFER_PASS, capi.PREFER_PASS, capi.DONT_RESIGN]))
     cfg["ResignPercentage"] = float(rng.choice([0.0, 0.1, 0.3, 0.6, -1.0]))
-    cfg["PUCT"] = float(rng.choice([1.0, 0.5, 0.25, 2.0, 4.0]))
+    cfg["PUCT"] = float(rng.choice([1.0, 0.5, 0.25, 0.75, 0.1]))   # (0,1]: tree.go:42-44 rejects the rest
     cfg["RandomCount"] = int(rng.choice([0, 2, 5, 12]))
     cfg["RandomTemperature"] = float(rng.choice([1.0, 0.5, 0.7, 1.5, 3.0]))
     cfg["RandomMinVisits"] = int(rng.choice([0, 1, 2, 5]))
