@@ -35,7 +35,10 @@ def test_random_trainer_shape(ctx, seed):
         x, pi, v = batch_data(B, F, H, W, Aspace, seed=seed + 1000 * attempt)
         co = ot.batch(x, pi, v, lr=0.0)
         cd = dt.forward_backward(x, pi, v)
-        assert abs(cd - co) <= 2e-5 * max(1.0, abs(co)), (cd, co, shape)
+        # cost: the device and the oracle are each within 2e-5 of the float64 value (weights x3 make the logits large and the
+        # mean cancels); in a 1200-shape soak two draws had them on opposite sides of it, 2.4e-5 apart
+        # (profiles/r01/fuzz_soak.txt) -> mutual tolerance 4e-5
+        assert abs(cd - co) <= 4e-5 * max(1.0, abs(co)), (cd, co, shape)
         bad = []
         for i in range(ot.num_params()):
             go, gd = ot.get_grad(i), dt.get_grad(i)
