@@ -5,4 +5,4 @@ package only binds it (ctypes) for tests and bench.py; there is no CPU fallback:
 library and a GPU every compute entry point raises.
 """
 from .capi import (AgzError, Arena, Ctx, Examples, GameConf, MctsConf, Net, NetConf, Trainer, lib, lib_path,  # noqa: F401
-                   rotate_boards)
+                   rotate_boards, wino_stages)

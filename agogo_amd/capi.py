@@ -16,9 +16,10 @@ GAME_MNK, GAME_C4, GAME_KOMI, GAME_WQ = 0, 1, 2, 3
 ENC_TWOPLANE, ENC_WQ = 0, 1
 INF_NET, INF_DUMMY, INF_SCRIPT, INF_HASH, INF_UNIFORM = 0, 1, 2, 3, 4
 BN_DEGENERATE_EPS, BN_RUNNING, BN_IDENTITY = 0, 1, 2
-COMPUTE_F32_MFMA, COMPUTE_BF16X3, COMPUTE_FP16X2 = 0, 1, 2
+COMPUTE_F32_MFMA, COMPUTE_BF16X3, COMPUTE_FP16X2, COMPUTE_WINO = 0, 1, 2, 3
 COMPUTE_FORCE = 0x100
 PROF_CONV, PROF_HEADS, PROF_SELECT, PROF_EXPAND, PROF_MOVE, PROF_CONV_INIT = 0, 1, 2, 3, 4, 5
+PROF_WINO_IN, PROF_WINO_GEMM, PROF_WINO_OUT = 6, 7, 8
 DONT_PREFER_PASS, PREFER_PASS, DONT_RESIGN = 0, 1, 2
 
 
@@ -158,6 +159,7 @@ def lib():
     sig("agz_examples_get_tensors", i32, vp, pf, pf, pf)
     sig("agz_examples_raw_dev", i32, vp, pvp, pvp, pvp)
     sig("agz_rotate_boards", i32, vp, pf, i32, i32, i32, pf)
+    sig("agz_wino_stages", i32, vp, pf, pf, i32, i32, i32, i32, i32, pf, pf)
     _LIB = L
     return L
 
@@ -608,6 +610,19 @@ class Examples:
         v = np.zeros(rows, np.float32)
         _check(lib().agz_examples_get_tensors(self.h, _pf(x), _pf(p), _pf(v)), "agz_examples_get_tensors")
         return x, p, v
+
+
+def wino_stages(ctx, x, w):
+    """diagnostics: Winograd F(4x4,3x3) input transform and transform-domain GEMMs. x [B,H,W,C], w [N,C,3,3] -> V [36,T,C], M [36,T,N]"""
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    B, H, W, Cc = x.shape
+    N = w.shape[0]
+    T = B * ((H + 3) // 4) * ((W + 3) // 4)
+    V = np.zeros((36, T, Cc), np.float32)
+    M = np.zeros((36, T, N), np.float32)
+    _check(lib().agz_wino_stages(ctx.h, _pf(x), _pf(w), B, H, W, Cc, N, _pf(V), _pf(M)), "agz_wino_stages")
+    return V, M
 
 
 def rotate_boards(ctx, boards, m, n):

@@ -46,6 +46,7 @@ struct agz_ctx {
   hipStream_t stream = nullptr;
   bool prof_on = false;
   agz::ProfClass prof[AGZ_PROF_NCLASS];
+  int prof_open = 0;   // scopes begun and not yet ended (classes nest: a layer scope around its kernels' scopes)
   int num_cus = 256;
 
   // record a start event for a kernel class (no-op unless profiling)

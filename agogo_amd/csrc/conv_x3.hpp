@@ -229,14 +229,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_x3_kernel(ConvArgs a, const un
     X3_ITER(0, xa0, xa1, xb0, xb1, xb2, ya0, ya1, yb0, yb1, yb2)
     if (it + 1 < NK) X3_ITER(1, ya0, ya1, yb0, yb1, yb2, xa0, xa1, xb0, xb1, xb2)
   }
-#undef X3_ITER
-#undef X3_QUAD
-#undef X3_MF
-#undef X3_SB
-#undef X3_STORE_B
-#undef X3_STORE_A
-#undef X3_GLOAD
-#undef X3_ADVANCE
+  // (the X3_* staging / pipeline macros stay defined for conv_wino.hpp, included next, which #undefs them)
 
   X3_EPILOGUE
 }

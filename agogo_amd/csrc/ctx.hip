@@ -20,13 +20,15 @@ void agz_ctx::prof_begin(int klass) {
     p.pairs.push_back({a, b});
   }
   hipEventRecord(p.pairs[p.used].first, stream);
+  prof_open++;
 }
 void agz_ctx::prof_end(int klass) {
   agz::ProfClass& p = prof[klass];
   if (p.used >= p.pairs.size()) return;
   hipEventRecord(p.pairs[p.used].second, stream);
   p.used++;
-  if (p.used >= 4096) prof_collect();  // bound the number of live events
+  if (prof_open > 0) prof_open--;
+  if (p.used >= 4096 && prof_open == 0) prof_collect();  // bound the number of live events (never while an outer scope is open)
 }
 int agz_ctx::prof_collect() {
   AGZ_HIP_TRY(hipStreamSynchronize(stream));

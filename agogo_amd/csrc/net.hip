@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 }
 
 #include "conv_x3.hpp"
+#include "conv_wino.hpp"
 #include "conv_h2.hpp"
 
 
@@ -575,7 +576,10 @@ void agz_net::free_device() {
   for (auto& p : d_w2_dual) if (p) { hipFree(p); p = nullptr; }
   if (d_amax) { hipFree(d_amax); d_amax = nullptr; }
   amax_cap = 0;
-  d_w_dual.clear(); d_ep_dual.clear(); d_w3_dual.clear(); d_w2_dual.clear();
+  for (auto& p : d_u3_dual) if (p) { hipFree(p); p = nullptr; }
+  f(d_wV); f(d_wM);
+  wino_chunk_cap = 0;
+  d_w_dual.clear(); d_ep_dual.clear(); d_w3_dual.clear(); d_w2_dual.clear(); d_u3_dual.clear();
   f(d_head_conv); f(d_head_bn); f(d_Wp); f(d_bp); f(d_W1); f(d_b1); f(d_W2); f(d_b2);
   f(d_act_in); f(d_actA); f(d_actB); f(d_planes); f(d_policy); f(d_value); f(d_ws); f(d_hs);
   ws_cap = 0; hs_cap = 0;
@@ -676,6 +680,31 @@ int agz::conv3x3_raw_x3(agz_ctx* ctx, const float* x, const unsigned short* w3, 
   return AGZ_OK;
 }
 
+// Winograd-domain weights of every dual block (conv_wino.hpp): columns [0,Kp) branch a, [Kp,2Kp) branch b, natural order
+int agz_net::build_wino_weights() {
+  AGZ_REQUIRE(cfg == 0, AGZ_E_UNSUPPORTED, "agz_net: the Winograd path needs K a multiple of 64");
+  AGZ_HIP_TRY(hipSetDevice(ctx->device));
+  for (auto& p : d_u3_dual) if (p) hipFree(p);
+  d_u3_dual.assign(conf.SharedLayers, nullptr);
+  const int K = conf.K;
+  size_t pi = 3;   // parameters: init conv (w, gamma, beta), then per block a: (w, gamma, beta), b: (w, gamma, beta)
+  std::vector<unsigned short> u3;
+  for (int l = 0; l < conf.SharedLayers; l++, pi += 6) {
+    const std::vector<float>& wa = params[pi].v;
+    const std::vector<float>& wb = params[pi + 3].v;
+    const int Kp_ = Kp;
+    agz::wino_build_u3(u3, 2 * Kp, Kp, [&](int n, int ci, int tap) -> double {
+      const int o = n < Kp_ ? n : n - Kp_;
+      if (o >= K || ci >= K) return 0.0;
+      return (double)(n < Kp_ ? wa : wb)[((size_t)o * K + ci) * 9 + tap];
+    });
+    AGZ_HIP_TRY(hipMalloc(&d_u3_dual[l], u3.size() * 2));
+    AGZ_HIP_TRY(hipMemcpyAsync(d_u3_dual[l], u3.data(), u3.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return AGZ_OK;
+}
+
 int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   AGZ_REQUIRE(committed, AGZ_E_STATE, "agz_net: infer before agz_net_commit");
   AGZ_REQUIRE(B >= 1 && B <= max_batch, AGZ_E_INVALID, "agz_net: batch %d exceeds allocated %d", B, max_batch);
@@ -734,6 +763,33 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         hipLaunchKernelGGL(conv3x3_h2w_kernel, dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, a, d_w2_dual[l]);
       } else {
         hipLaunchKernelGGL(conv3x3_h2_kernel, dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, a, d_w2_dual[l]);
+      }
+      rc = AGZ_OK;
+    }
+    else if (split_ok && compute_mode == AGZ_COMPUTE_WINO) {
+      // Winograd F(4x4,3x3): boards in chunks (scratch V + M: 2.8 MB per 19x19 board at K=256)
+      AGZ_REQUIRE((int)d_u3_dual.size() == conf.SharedLayers && d_u3_dual[l], AGZ_E_STATE, "agz_net: Winograd weights not built");
+      static const int chunk_env = [] { const char* e = getenv("AGZ_WINO_CHUNK"); return e ? atoi(e) : 0; }();  // tuning knob
+      const int tpb = ceil_div(H, 4) * ceil_div(W, 4);
+      // 32-bit byte offsets into V inside the GEMM: 36 * T * Kp * 4 < 4 GiB
+      const int chunk_max = (int)std::min<size_t>((size_t)B, (((size_t)1 << 32) - 1) / ((size_t)36 * tpb * Kp * 4));
+      const int chunk = chunk_env >= 1 ? std::min(chunk_env, chunk_max) : chunk_max;
+      if (chunk > wino_chunk_cap) {
+        AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (d_wV) hipFree(d_wV);
+        if (d_wM) hipFree(d_wM);
+        d_wV = d_wM = nullptr; wino_chunk_cap = 0;
+        AGZ_HIP_TRY(hipMalloc(&d_wV, (size_t)36 * chunk * tpb * Kp * sizeof(float)));
+        AGZ_HIP_TRY(hipMalloc(&d_wM, (size_t)36 * chunk * tpb * 2 * Kp * sizeof(float)));
+        wino_chunk_cap = chunk;
+      }
+      ProfScope ps(ctx, AGZ_PROF_CONV);
+      for (int b0 = 0; b0 < B; b0 += chunk) {
+        WinoArgs wa{};
+        wa.x = cur + (size_t)b0 * Hp * Wp * Kp; wa.y = nxt + (size_t)b0 * Hp * Wp * Kp;
+        wa.V = d_wV; wa.Mb = d_wM; wa.U3 = d_u3_dual[l]; wa.ep = d_ep_dual[l];
+        wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
+        wino_launch(ctx, wa, true);
       }
       rc = AGZ_OK;
     }
@@ -960,6 +1016,8 @@ int agz_net_commit(agz_net* n) {
   for (auto& p : n->d_w2_dual) if (p) hipFree(p);
   n->d_w2_dual.assign(c.SharedLayers, nullptr);
   n->w_unscale.assign(c.SharedLayers, 1.0f);
+  for (auto& p : n->d_u3_dual) if (p) hipFree(p);
+  n->d_u3_dual.clear();
 
   const int half = (n->cfg == 0) ? 64 : 32;  // channels per block tile (BNT/2)
   for (int l = 0; l < c.SharedLayers; l++) {
@@ -1058,16 +1116,57 @@ int agz_net_commit(agz_net* n) {
     (void)A; (void)FCn;
   }
   n->committed = true;
+  if (n->compute_mode == AGZ_COMPUTE_WINO && n->cfg == 0) return n->build_wino_weights();
   return AGZ_OK;
+}
+
+int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, int W, int C, int N, float* V, float* M) {
+  AGZ_REQUIRE(ctx && x && w && V && M, AGZ_E_INVALID, "agz_wino_stages: NULL argument");
+  AGZ_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 16 && C % 16 == 0 && N >= 1, AGZ_E_INVALID, "agz_wino_stages: bad shape");
+  AGZ_HIP_TRY(hipSetDevice(ctx->device));
+  const int Hp = H + 2, Wp = W + 2;
+  std::vector<float> xp((size_t)B * Hp * Wp * C, 0.f);
+  for (int b = 0; b < B; b++) for (int h = 0; h < H; h++)
+    memcpy(&xp[(((size_t)b * Hp + h + 1) * Wp + 1) * C], &x[((size_t)b * H + h) * W * C], (size_t)W * C * sizeof(float));
+  std::vector<unsigned short> u3;
+  agz::wino_build_u3(u3, N, C, [&](int n, int ci, int tap) -> double { return (double)w[((size_t)n * C + ci) * 9 + tap]; });
+  agz::WinoArgs a{};
+  a.B = B; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.C = C; a.Cout_p = N; a.Ntot = N;
+  const size_t T = (size_t)B * agz::ceil_div(H, 4) * agz::ceil_div(W, 4);
+  AGZ_REQUIRE((size_t)36 * T * C * 4 < ((size_t)1 << 32), AGZ_E_UNSUPPORTED, "agz_wino_stages: V above 4 GiB");
+  float *dx = nullptr, *dV = nullptr, *dM = nullptr;
+  unsigned short* dU = nullptr;
+  int rc = AGZ_OK;
+  if (hipMalloc(&dx, xp.size() * 4) != hipSuccess || hipMalloc(&dV, (size_t)36 * T * C * 4) != hipSuccess ||
+      hipMalloc(&dM, (size_t)36 * T * N * 4) != hipSuccess || hipMalloc(&dU, u3.size() * 2) != hipSuccess) {
+    agz::set_error("agz_wino_stages: out of device memory");
+    rc = AGZ_E_NOMEM;
+  } else {
+    hipStream_t s = ctx->stream;
+    bool ok = hipMemcpyAsync(dx, xp.data(), xp.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(dU, u3.data(), u3.size() * 2, hipMemcpyHostToDevice, s) == hipSuccess;
+    a.x = dx; a.V = dV; a.U3 = dU; a.Mb = dM;
+    if (ok) agz::wino_launch(ctx, a, false);
+    ok = ok && hipGetLastError() == hipSuccess &&
+         hipMemcpyAsync(V, dV, (size_t)36 * T * C * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+         hipMemcpyAsync(M, dM, (size_t)36 * T * N * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok) { agz::set_error("agz_wino_stages: HIP failure: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_E_HIP; }
+  }
+  if (dx) hipFree(dx);
+  if (dV) hipFree(dV);
+  if (dM) hipFree(dM);
+  if (dU) hipFree(dU);
+  return rc;
 }
 
 int agz_net_set_compute_mode(agz_net* n, int mode) {
   AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_compute_mode: NULL net");
   const int base = mode & ~AGZ_COMPUTE_FORCE;
-  AGZ_REQUIRE(base == AGZ_COMPUTE_F32_MFMA || base == AGZ_COMPUTE_BF16X3 || base == AGZ_COMPUTE_FP16X2, AGZ_E_INVALID,
-              "agz_net_set_compute_mode: unknown mode %d", mode);
+  AGZ_REQUIRE(base == AGZ_COMPUTE_F32_MFMA || base == AGZ_COMPUTE_BF16X3 || base == AGZ_COMPUTE_FP16X2 || base == AGZ_COMPUTE_WINO,
+              AGZ_E_INVALID, "agz_net_set_compute_mode: unknown mode %d", mode);
   n->compute_mode = base;
   n->compute_force = (mode & AGZ_COMPUTE_FORCE) != 0;
+  if (base == AGZ_COMPUTE_WINO && n->committed && n->cfg == 0 && n->d_u3_dual.empty()) return n->build_wino_weights();
   return AGZ_OK;
 }
 

@@ -104,6 +104,7 @@ const (
 	ComputeF32MFMA = C.AGZ_COMPUTE_F32_MFMA
 	ComputeBF16X3  = C.AGZ_COMPUTE_BF16X3
 	ComputeFP16X2  = C.AGZ_COMPUTE_FP16X2 // opt-in: range-managed 2-way fp16 split, 3 MFMAs per product
+	ComputeWino    = C.AGZ_COMPUTE_WINO   // opt-in: Winograd F(4x4,3x3) with bf16x3 products, ~1.9x BF16X3 at self-play batch sizes
 )
 
 func (n *Net) Close() error { defer n.ctx.enter()(); C.agz_net_destroy(n.h); n.h = nil; return nil }

@@ -66,7 +66,10 @@ void* agz_ctx_stream(agz_ctx* ctx);
 #define AGZ_PROF_EXPAND 3  /* MCTS expand/backup */
 #define AGZ_PROF_MOVE 4    /* root update / best move / apply */
 #define AGZ_PROF_CONV_INIT 5 /* the single F->K input conv */
-#define AGZ_PROF_NCLASS 6
+#define AGZ_PROF_WINO_IN 6   /* AGZ_COMPUTE_WINO: input transform; these three nest inside AGZ_PROF_CONV (the whole block) */
+#define AGZ_PROF_WINO_GEMM 7 /* the 36 transform-domain GEMMs (the dominant kernel of that mode) */
+#define AGZ_PROF_WINO_OUT 8  /* output transform + block epilogue */
+#define AGZ_PROF_NCLASS 9
 int agz_ctx_prof_enable(agz_ctx* ctx, int enable);
 int agz_ctx_prof_read(agz_ctx* ctx, int klass, int64_t* launches, double* total_ms);
 
@@ -138,8 +141,15 @@ int agz_net_set_latency_mode(agz_net* net, int on);
 #define AGZ_COMPUTE_F32_MFMA 0
 #define AGZ_COMPUTE_BF16X3 1
 #define AGZ_COMPUTE_FP16X2 2
+#define AGZ_COMPUTE_WINO 3 /* Winograd F(4x4,3x3): transforms in fp32, the 36 transform-domain GEMMs with BF16X3 products — 3.6x
+                            * fewer matrix instructions on 19x19; rounding error ~5x a direct fp32 convolution's (still inside
+                            * the stated tolerance); opt-in, same shape conditions as the split modes */
 #define AGZ_COMPUTE_FORCE 0x100 /* OR-ed in: take the split kernel even below the chip-filling threshold (tests) */
 int agz_net_set_compute_mode(agz_net* net, int mode);
+/* Diagnostics (tests): the first two stages of the Winograd path on host data.  x [B][H][W][C] (NHWC, C % 16 == 0),
+ * w [N][C][3][3]  ->  V [36][T][C] = Bt d B of every 6x6 input tile, M [36][T][N] = V[pos] * (G g Gt)[pos],
+ * T = B * ceil(H/4) * ceil(W/4) tiles in (board, tile row, tile column) order, pos = 6 * xi + nu. */
+int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, int W, int C, int N, float* V, float* M);
 /* Checkpoint of the learnables in Model() order (+ BN statistics).  The reference gob-encodes G.Values
  * (AZ.Save / Dual.GobEncode, agogo.go:175-209, dualnet/dual.go:180-206); gob is Go-only, so this is a documented
  * flat format: "AGZNET01", agz_net_conf, n_params, then per parameter {uint64 n, float32[n]}, then per BN op

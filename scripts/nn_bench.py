@@ -19,6 +19,7 @@ ap.add_argument("--size", type=int, default=19)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--x3", action="store_true")
 ap.add_argument("--h2", action="store_true", help="AGZ_COMPUTE_FP16X2")
+ap.add_argument("--wino", action="store_true", help="AGZ_COMPUTE_WINO (AGZ_WINO_CHUNK=n in the environment: boards per chunk)")
 ap.add_argument("--zero", action="store_true", help="all-zero weights (DVFS probe: same instruction stream, low toggle power)")
 args = ap.parse_args()
 ctx = A.Ctx(0)
@@ -31,6 +32,8 @@ if args.x3:
     net.set_compute_mode(A.capi.COMPUTE_BF16X3)
 if args.h2:
     net.set_compute_mode(A.capi.COMPUTE_FP16X2)
+if args.wino:
+    net.set_compute_mode(A.capi.COMPUTE_WINO)
 x = torch.randint(-1, 2, (args.B, 18, S, S), device="cuda").float()
 pol = torch.empty((args.B, S * S + 1), device="cuda")
 val = torch.empty((args.B,), device="cuda")
@@ -47,9 +50,15 @@ t1 = time.perf_counter()
 ctx.prof_enable(False)
 n_conv, ms_conv = ctx.prof_read(A.capi.PROF_CONV)
 n_head, ms_head = ctx.prof_read(A.capi.PROF_HEADS)
+wino = {}
+if args.wino:
+    for nm, k in (("in", A.capi.PROF_WINO_IN), ("gemm", A.capi.PROF_WINO_GEMM), ("out", A.capi.PROF_WINO_OUT)):
+        n_, ms_ = ctx.prof_read(k)
+        wino[nm + "_ms_avg"] = ms_ / max(n_, 1)
+        wino[nm + "_launches"] = n_
 flops = net.flops_per_eval() * args.B
 dt = (t1 - t0) / args.iters
 print(json.dumps({"B": args.B, "K": args.K, "L": args.L, "ms_per_pass": dt * 1e3, "evals_per_s": args.B / dt,
                   "tflops": flops / dt / 1e12, "frac_fp32_peak": flops / dt / 157.3e12,
                   "conv_launches": n_conv, "conv_ms_avg": ms_conv / max(n_conv, 1), "heads_ms_avg": ms_head / max(n_head, 1),
-                  "policy_sum": float(pol.sum().item()), "value_mean": float(val.mean().item())}))
+                  "wino": wino, "policy_sum": float(pol.sum().item()), "value_mean": float(val.mean().item())}))

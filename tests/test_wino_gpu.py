@@ -1,0 +1,115 @@
+"""GPU: the Winograd F(4x4,3x3) path (AGZ_COMPUTE_WINO, agogo_amd/csrc/conv_wino.hpp).  Stage by stage against numpy (input
+transform Bt d B, the 36 transform-domain GEMMs), then whole networks against the oracle and the fp32-MFMA path with the
+same tolerance every other arithmetic mode meets."""
+import numpy as np
+import pytest
+
+import agogo_amd as A
+from test_net_gpu import make_pair, rand_planes, POL_ATOL, POL_RTOL, VAL_ATOL
+
+pytestmark = pytest.mark.gpu
+
+BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+               [0, 4, 0, -5, 0, 1]], np.float64)
+G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+              [0, 0, 1]], np.float64)
+AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], np.float64)
+
+
+def numpy_stages(x, w):
+    """x [B,H,W,C], w [N,C,3,3] (float64 arithmetic) -> V [36,T,C], M [36,T,N], y [B,H,W,N] (At M A, cropped)"""
+    B, H, W, C = x.shape
+    N = w.shape[0]
+    nty, ntx = (H + 3) // 4, (W + 3) // 4
+    xp = np.zeros((B, 4 * nty + 2, 4 * ntx + 2, C))
+    xp[:, 1:H + 1, 1:W + 1] = x
+    U = np.einsum("ai,ncij,bj->abnc", G, w.astype(np.float64), G).astype(np.float32).astype(np.float64)   # rounded once, like commit
+    V = np.zeros((36, B * nty * ntx, C))
+    t = 0
+    for b in range(B):
+        for ty in range(nty):
+            for tx in range(ntx):
+                d = xp[b, 4 * ty:4 * ty + 6, 4 * tx:4 * tx + 6]
+                V[:, t] = np.einsum("ai,ijc,bj->abc", BT, d, BT).reshape(36, C)
+                t += 1
+    M = np.einsum("ptc,pnc->ptn", V, U.reshape(36, N, C))
+    Y = np.einsum("ka,abtn,lb->tkln", AT, M.reshape(6, 6, -1, N), AT)
+    y = np.zeros((B, 4 * nty, 4 * ntx, N))
+    t = 0
+    for b in range(B):
+        for ty in range(nty):
+            for tx in range(ntx):
+                y[b, 4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4] = Y[t]
+                t += 1
+    return V, M, y[:, :H, :W]
+
+
+def direct_conv(x, w):
+    B, H, W, C = x.shape
+    xp = np.zeros((B, H + 2, W + 2, C))
+    xp[:, 1:-1, 1:-1] = x
+    y = np.zeros((B, H, W, w.shape[0]))
+    for ky in range(3):
+        for kx in range(3):
+            y += np.einsum("bhwc,nc->bhwn", xp[:, ky:ky + H, kx:kx + W], w[:, :, ky, kx].astype(np.float64))
+    return y
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 7, 5, 16, 40), (3, 19, 19, 64, 128), (1, 4, 4, 32, 130), (5, 9, 9, 48, 256)])
+def test_stages_match_numpy(ctx, B, H, W, C, N):
+    rng = np.random.default_rng(B * 1000 + C)
+    x = np.maximum(rng.normal(0, 1, (B, H, W, C)), 0).astype(np.float32)
+    w = (rng.uniform(-1, 1, (N, C, 3, 3)) * np.sqrt(6 / (9 * C + 9 * N))).astype(np.float32)
+    V, M = A.wino_stages(ctx, x, w)
+    Vn, Mn, yn = numpy_stages(x.astype(np.float64), w)
+    # the numpy restatement itself: At M A equals the direct convolution
+    np.testing.assert_allclose(yn, direct_conv(x.astype(np.float64), w), atol=1e-4 * np.abs(yn).max())
+    np.testing.assert_allclose(V, Vn, atol=2e-6 * np.abs(Vn).max(), rtol=0)          # small-integer transform in fp32
+    np.testing.assert_allclose(M, Mn, atol=4e-6 * np.abs(Mn).max(), rtol=0)          # fp32-grade products, fp32 accumulation over C
+
+
+@pytest.mark.parametrize("K,L,FC,W,H,F,Aspace,B,bn_mode", [
+    (64, 2, 128, 9, 9, 18, 82, 70, 0),      # partial last row tile
+    (128, 2, 64, 9, 9, 18, 82, 33, 2),
+    (256, 2, 128, 19, 19, 18, 362, 12, 2),  # BASELINE width and board: 5x5 tiles, the last tile row/column hangs over the edge
+    (64, 5, 64, 9, 9, 18, 82, 64, 1),       # deeper tower, running-stats BN
+    (192, 1, 64, 7, 6, 2, 8, 37, 2),        # K=192, 6x7 board (2x2 tiles, both ragged)
+    (128, 1, 32, 5, 5, 2, 26, 90, 2),       # 5x5 board
+])
+def test_wino_networks_match_oracle_and_f32(ctx, K, L, FC, W, H, F, Aspace, B, bn_mode):
+    onet, gnet = make_pair(ctx, K, L, FC, W, H, F, Aspace, bn_mode)
+    x = rand_planes(B, F, H, W, seed=K + B)
+    pol_f, val_f = gnet.infer(x)
+    gnet.set_compute_mode(A.capi.COMPUTE_WINO | A.capi.COMPUTE_FORCE)
+    pol_g, val_g = gnet.infer(x)
+    assert not np.array_equal(pol_g, pol_f)          # really a different arithmetic path
+    idx = [0, B // 2, B - 1]
+    pol_o, val_o = onet.infer(x[idx])
+    np.testing.assert_allclose(pol_g[idx], pol_o, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(val_g[idx], val_o, atol=VAL_ATOL)
+    np.testing.assert_allclose(pol_g, pol_f, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(val_g, val_f, atol=VAL_ATOL)
+    print("wino max |dpol| vs f32: %.3e  vs oracle: %.3e   f32 vs oracle: %.3e" % (
+        np.abs(pol_g - pol_f).max(), np.abs(pol_g[idx] - pol_o).max(), np.abs(pol_f[idx] - pol_o).max()))
+
+
+def test_wino_recommit_and_mode_round_trip(ctx):
+    """weights are rebuilt on commit; switching modes back and forth keeps every mode's own result"""
+    onet, gnet = make_pair(ctx, 64, 1, 32, 9, 9, 18, 82, 2)
+    x = rand_planes(24, 18, 9, 9, seed=4)
+    gnet.set_compute_mode(A.capi.COMPUTE_WINO | A.capi.COMPUTE_FORCE)
+    p1, v1 = gnet.infer(x)
+    gnet.set_compute_mode(A.capi.COMPUTE_F32_MFMA)
+    pf, vf = gnet.infer(x)
+    gnet.set_compute_mode(A.capi.COMPUTE_WINO | A.capi.COMPUTE_FORCE)
+    p2, v2 = gnet.infer(x)
+    np.testing.assert_array_equal(p1, p2)
+    np.testing.assert_array_equal(v1, v2)
+    w = gnet.get_param(3)
+    gnet.set_param(3, (w * 0.5).astype(np.float32))     # first dual block, branch a filter
+    gnet.commit()
+    p3, _ = gnet.infer(x)
+    gnet.set_compute_mode(A.capi.COMPUTE_F32_MFMA)
+    pf3, _ = gnet.infer(x)
+    assert not np.array_equal(p3, p1)
+    np.testing.assert_allclose(p3, pf3, atol=POL_ATOL, rtol=POL_RTOL)
