@@ -37,7 +37,8 @@ BF16_MFMA_PEAK_TFLOPS = 2516.6  # same guide: v_mfma_f32_32x32x16_bf16 dense (25
 BF16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 # fp16x2 formulation (conv_h2.hpp): 3 fp16 MFMAs per product (fp16 dense peak = bf16 dense peak)
 FP16X2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
-MODES = {"f32": capi.COMPUTE_F32_MFMA, "bf16x3": capi.COMPUTE_BF16X3, "fp16x2": capi.COMPUTE_FP16X2}
+MODES = {"f32": capi.COMPUTE_F32_MFMA, "bf16x3": capi.COMPUTE_BF16X3, "fp16x2": capi.COMPUTE_FP16X2, "wino": capi.COMPUTE_WINO}
+HBM_PEAK_GBS = 8000.0          # same guide: HBM3E ~8 TB/s
 
 
 def standard_bn_init(net):
@@ -136,10 +137,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-games-leg", action="store_true", help="skip the measured games/s leg (config #2)")
     ap.add_argument("--two-nets", action="store_true", help="agents A and B hold different networks")
-    ap.add_argument("--compute", choices=["bf16x3", "f32", "fp16x2"], default="bf16x3",
-                    help="dual-block conv arithmetic: bf16x3 = exact 3-way bf16 split on the bf16 matrix pipe (fp32-grade, "
-                         "same parity tolerance), f32 = v_mfma_f32_32x32x2_f32, fp16x2 = range-managed 2-way fp16 split "
-                         "(3 MFMAs per product; opt-in fast mode)")
+    ap.add_argument("--compute", choices=["wino", "bf16x3", "f32", "fp16x2"], default="wino",
+                    help="dual-block conv arithmetic: wino = Winograd F(4x4,3x3), fp32 transforms + bf16x3 products in the "
+                         "transform domain (3.6x fewer matrix instructions; same parity tolerance), bf16x3 = direct conv, exact "
+                         "3-way bf16 split on the bf16 matrix pipe (fp32-grade), f32 = v_mfma_f32_32x32x2_f32, fp16x2 = "
+                         "range-managed 2-way fp16 split (3 MFMAs per product; opt-in fast mode)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the short comparison legs in the other compute modes")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="debug: all ranks use GPU 0 and gloo collectives (exercises the N>1 code path on a 1-GPU box)")
@@ -215,14 +217,15 @@ def main():
 
     prof = {}
     for name, k in (("conv_dual", capi.PROF_CONV), ("conv_init", capi.PROF_CONV_INIT), ("heads", capi.PROF_HEADS),
-                    ("select", capi.PROF_SELECT), ("expand", capi.PROF_EXPAND), ("move", capi.PROF_MOVE)):
+                    ("select", capi.PROF_SELECT), ("expand", capi.PROF_EXPAND), ("move", capi.PROF_MOVE),
+                    ("wino_in", capi.PROF_WINO_IN), ("wino_gemm", capi.PROF_WINO_GEMM), ("wino_out", capi.PROF_WINO_OUT)):
         n, ms = ctx.prof_read(k)
         prof[name] = {"launches": n, "avg_ms": (ms / n) if n else None, "total_ms": ms}
 
     # short comparison legs in the other compute modes (same arena, the games simply continue)
     legs = {}
     if world == 1 and not args.no_f32_leg:
-        for mode in ("f32", "bf16x3", "fp16x2"):
+        for mode in ("f32", "bf16x3", "fp16x2", "wino"):
             if mode == args.compute:
                 continue
             for n_ in nets:
@@ -269,11 +272,34 @@ def main():
         conv_flops_launch = 2.0 * (G * hw) * (2 * K) * (9 * K)  # algorithmic FLOPs of one dual-block launch
         conv_ms = prof["conv_dual"]["avg_ms"]
         achieved = conv_flops_launch / (conv_ms * 1e-3) / 1e12 if conv_ms else None
-        x3 = args.compute == "bf16x3"
-        peaks = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16X3_PEAK_TFLOPS, "fp16x2": FP16X2_PEAK_TFLOPS}
+        peaks = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16X3_PEAK_TFLOPS, "fp16x2": FP16X2_PEAK_TFLOPS, "wino": BF16X3_PEAK_TFLOPS}
         peak = peaks[args.compute]
+        wino_detail = None
+        flops_launch, launch_ms, n_launch = conv_flops_launch, conv_ms, prof["conv_dual"]["launches"]
+        if args.compute == "wino" and prof["wino_gemm"]["avg_ms"]:
+            # dominant kernel of this mode: the 36 transform-domain GEMMs of one block (its own FLOPs, not the direct conv's)
+            tiles = G * ((S + 3) // 4) ** 2
+            flops_launch = 2.0 * 36 * tiles * K * (2 * K)
+            launch_ms, n_launch = prof["wino_gemm"]["avg_ms"], prof["wino_gemm"]["launches"]
+            achieved = flops_launch / (launch_ms * 1e-3) / 1e12
+            in_bytes = 4.0 * (G * hw * K + 36 * tiles * K)            # x read once + V written
+            gemm_bytes = 4.0 * (36 * tiles * K + 36 * tiles * 2 * K)  # V read once + M written (weights stay in L2)
+            out_bytes = 4.0 * (36 * tiles * 2 * K + G * hw * K)       # M read + y written
+            def gbs(b, ms):
+                return (b / (ms * 1e-3) / 1e9) if ms else None
+            wino_detail = {
+                "block_avg_ms": conv_ms, "block_direct_equivalent_tflops": conv_flops_launch / (conv_ms * 1e-3) / 1e12 if conv_ms else None,
+                "block_note": "one dual block = input transform + 36 GEMMs + output transform/epilogue; direct-equivalent = the "
+                              "FLOPs a direct 3x3 convolution would need for the same result (3.61x the GEMM FLOPs on 19x19)",
+                "wino_in": {"avg_ms": prof["wino_in"]["avg_ms"], "bound": "hbm", "algorithmic_bytes": in_bytes,
+                            "achieved_GBs": gbs(in_bytes, prof["wino_in"]["avg_ms"]), "peak_GBs": HBM_PEAK_GBS},
+                "wino_gemm": {"avg_ms": launch_ms, "bound": "mfma", "flops": flops_launch, "algorithmic_bytes": gemm_bytes,
+                              "achieved_GBs": gbs(gemm_bytes, launch_ms)},
+                "wino_out": {"avg_ms": prof["wino_out"]["avg_ms"], "bound": "hbm", "algorithmic_bytes": out_bytes,
+                             "achieved_GBs": gbs(out_bytes, prof["wino_out"]["avg_ms"]), "peak_GBs": HBM_PEAK_GBS}}
         traffic = None
-        pmc_name = {"f32": "pmc_conv_dual.json", "bf16x3": "pmc_conv_x3.json", "fp16x2": "pmc_conv_h2.json"}[args.compute]
+        pmc_name = {"f32": "pmc_conv_dual.json", "bf16x3": "pmc_conv_x3.json", "fp16x2": "pmc_conv_h2.json",
+                    "wino": "pmc_wino_gemm.json"}[args.compute]
         pmc_path = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc_path) and (S, K, L, G) == (19, 256, 20, 512):  # the PMC pass was taken on this exact shape
             try:
@@ -283,20 +309,28 @@ def main():
         for mode, leg in legs.items():
             if leg.get("conv_dual_avg_ms"):
                 leg["conv_dual_tflops"] = conv_flops_launch / (leg["conv_dual_avg_ms"] * 1e-3) / 1e12
-                leg["frac_of_its_roofline"] = leg["conv_dual_tflops"] / peaks[mode]
-                leg["roofline_peak_tflops"] = peaks[mode]
+                if mode == "wino":
+                    leg["note"] = "direct-equivalent FLOPs per block time (the mode executes 3.61x fewer)"
+                else:
+                    leg["frac_of_its_roofline"] = leg["conv_dual_tflops"] / peaks[mode]
+                    leg["roofline_peak_tflops"] = peaks[mode]
         dtypes = {"f32": "f32",
                   "bf16x3": "f32 (bf16x3 split: each fp32 operand = 3 exact bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate)",
-                  "fp16x2": "f32 (fp16x2 split: power-of-two range scaling, 2 fp16 pieces = 23 significand bits, 3 fp16 MFMAs per product, fp32 accumulate)"}
+                  "fp16x2": "f32 (fp16x2 split: power-of-two range scaling, 2 fp16 pieces = 23 significand bits, 3 fp16 MFMAs per product, fp32 accumulate)",
+                  "wino": "f32 (Winograd F(4x4,3x3): fp32 transforms; transform-domain products as bf16x3 = 3 exact bf16 pieces per fp32 operand, 6 bf16 MFMAs per product, fp32 accumulate)"}
         kernels = {"f32": "conv3x3_mfma_kernel<2,2,2,DUAL> (fused dual-branch block)",
                    "bf16x3": "conv3x3_x3_kernel<DUAL> (fused dual-branch block, bf16x3)",
-                   "fp16x2": "conv3x3_h2w_kernel (fused dual-branch block, fp16x2, 128x256 tile)"}
+                   "fp16x2": "conv3x3_h2w_kernel (fused dual-branch block, fp16x2, 128x256 tile)",
+                   "wino": "wino_gemm_kernel (36 transform-domain GEMMs of one dual block, bf16x3 products; 0.70 of the block's 1.09 ms)"}
         notes = {"f32": "dense fp32 MFMA peak",
                  "bf16x3": ("algorithmic fp32-grade FLOPs against the dense bf16 MFMA peak / 6 (six bf16 MFMAs per product); the same "
                             "FLOPs are %.2fx the fp32-MFMA peak of 157.3; measured bare-MFMA ceiling under the power cap on random "
                             "rotating operands: 1772 TFLOP/s bf16 = 295 in these units (DESIGN.md 4b)" % ((achieved or 0) / FP32_MFMA_PEAK_TFLOPS)),
                  "fp16x2": ("algorithmic FLOPs against the dense fp16 MFMA peak / 3 (three fp16 MFMAs per product); %.2fx the "
-                            "fp32-MFMA peak (DESIGN.md 4c)" % ((achieved or 0) / FP32_MFMA_PEAK_TFLOPS))}
+                            "fp32-MFMA peak (DESIGN.md 4c)" % ((achieved or 0) / FP32_MFMA_PEAK_TFLOPS)),
+                 "wino": ("FLOPs of the transform-domain GEMMs (what this formulation executes) against the dense bf16 MFMA peak / 6; "
+                          "the block as a whole delivers the direct convolution's result at extra.wino.block_direct_equivalent_tflops "
+                          "(DESIGN.md 4d); the two transform kernels are HBM-bound, see extra.wino")}
         out = {
             "metric": "mcts_sims_per_sec", "value": sims_sum / t_max, "unit": "sims/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
@@ -312,8 +346,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic,
                          "kernel": kernels[args.compute], "peak_note": notes[args.compute],
-                         "flops_per_launch": conv_flops_launch, "avg_launch_ms": conv_ms,
-                         "launches": prof["conv_dual"]["launches"]},
+                         "flops_per_launch": flops_launch, "avg_launch_ms": launch_ms,
+                         "launches": n_launch},
             "extra": {"nn_evals_per_s": evals_sum / t_max, "iterations_per_s": iters_sum / t_max,
                       "moves_per_s": sims_sum / t_max / args.budget,
                       "games_per_s_est": sims_sum / t_max / args.budget / (2 * hw),
@@ -321,7 +355,7 @@ def main():
                       "end_to_end_tflops": evals_sum * flops_eval / t_max / 1e12,
                       "end_to_end_frac_of_fp32_peak": evals_sum * flops_eval / t_max / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
                       "kernel_classes": prof, "examples_allgather_ms": gather_ms, "compute": args.compute,
-                      "other_compute_modes": legs,
+                      "other_compute_modes": legs, "wino": wino_detail,
                       "tree_full": st1["tree_full"]},
         }
         if world == 1 and not args.no_games_leg:
