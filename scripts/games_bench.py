@@ -17,9 +17,9 @@ from agogo_amd import capi
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", choices=["c4", "go9"], default="go9")
 ap.add_argument("--games", type=int, default=0, help="games to finish (default: the number of concurrent games)")
-ap.add_argument("--compute", choices=["f32", "bf16x3", "fp16x2"], default="bf16x3")
+ap.add_argument("--compute", choices=["f32", "bf16x3", "fp16x2", "wino"], default="bf16x3")
 args = ap.parse_args()
-MODES = {"f32": capi.COMPUTE_F32_MFMA, "bf16x3": capi.COMPUTE_BF16X3, "fp16x2": capi.COMPUTE_FP16X2}
+MODES = {"f32": capi.COMPUTE_F32_MFMA, "bf16x3": capi.COMPUTE_BF16X3, "fp16x2": capi.COMPUTE_FP16X2, "wino": capi.COMPUTE_WINO}
 ctx = A.Ctx(0)
 if args.config == "c4":
     K, L, G, sims = 64, 6, 256, 400
