@@ -200,7 +200,7 @@ struct Config {
   int MaxExamples = 0;
   int Encoder = AGZ_ENC_TWOPLANE;
   bool AugmentRotate = false;  // Augmenter (datatypes.go:24): the RotateBoard-based rotation augmenter, or none
-  int ComputeMode = AGZ_COMPUTE_F32_MFMA;  // build extension: AGZ_COMPUTE_BF16X3 for self-play inference and training convolutions
+  int ComputeMode = AGZ_COMPUTE_F32_MFMA;  // build extension: AGZ_COMPUTE_BF16X3 (inference + training convolutions) or AGZ_COMPUTE_WINO (inference; training then uses BF16X3)
 };
 struct GameSpec { int kind, m, n, k; float komi; };
 
@@ -231,7 +231,7 @@ struct AZ {
       A->SwitchToInference(*infA); B->SwitchToInference(*infB);           // setupSelfPlay, agogo.go:75-90
       agz::check(agz_net_set_compute_mode(infA->h, conf.ComputeMode), "compute mode");
       agz::check(agz_net_set_compute_mode(infB->h, conf.ComputeMode), "compute mode");
-      if (conf.ComputeMode == AGZ_COMPUTE_BF16X3) B->SetComputeMode(AGZ_COMPUTE_BF16X3);
+      if (conf.ComputeMode == AGZ_COMPUTE_BF16X3 || conf.ComputeMode == AGZ_COMPUTE_WINO) B->SetComputeMode(AGZ_COMPUTE_BF16X3);
       Examples ex(ctx, conf.NNConf.Features, conf.NNConf.Height, conf.NNConf.Width, conf.NNConf.ActionSpace);
       {
         Arena sp(ctx, game.kind, game.m, game.n, game.k, game.komi, conf.Encoder, conf.MCTSConf, episodes, seed + 1000 * epoch);
