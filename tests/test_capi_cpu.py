@@ -109,3 +109,19 @@ int main(void) {
         assert code == "0"
     else:
         assert int(code) < 0 and "no CPU fallback" in msg
+
+
+def test_go_shim_only_references_declared_symbols():
+    """go/agzhip cannot be compiled in this image (no Go toolchain): at least every C.agz_* / C.AGZ_* it uses must exist in
+    include/agz.h, and its braces must balance."""
+    src = open(os.path.join(ROOT, "go", "agzhip", "agzhip.go")).read()
+    hdr = open(os.path.join(ROOT, "include", "agz.h")).read()
+    code = re.sub(r"//[^\n]*", "", src)
+    code = re.sub(r"/\*.*?\*/", "", code, flags=re.S)
+    code = re.sub(r'"(\\.|[^"\\])*"', '""', code)
+    for a, b in ("{}", "()", "[]"):
+        assert code.count(a) == code.count(b), (a, b)
+    used = set(re.findall(r"C\.(agz_\w+|AGZ_\w+)", src))
+    assert len(used) > 30
+    missing = sorted(u for u in used if not re.search(r"\b%s\b" % re.escape(u), hdr))
+    assert not missing, missing
