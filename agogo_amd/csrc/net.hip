@@ -748,7 +748,44 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   // K2: SharedLayers x fused dual-branch block
   float* cur = d_actA;
   float* nxt = d_actB;
-  for (int l = 0; l < conf.SharedLayers; l++) {
+  bool tower_done = false;
+  {
+    // Winograd tower with fused block boundaries (AGZ_WINO_FUSE=1, tuning knob): input transform once, then per block
+    // GEMMs + [output transform of block l | input transform of block l+1] in one kernel, the activation staying on chip
+    static const int fuse_env = [] { const char* e = getenv("AGZ_WINO_FUSE"); return e ? atoi(e) : 0; }();
+    const int tpb = ceil_div(H, 4) * ceil_div(W, 4);
+    const size_t v_bytes = (size_t)36 * B * tpb * Kp * 4;
+    if (fuse_env && split_ok && compute_mode == AGZ_COMPUTE_WINO && v_bytes < ((size_t)1 << 32) && Kp % WINO_CG == 0 &&
+        (size_t)Hp * Wp * WINO_CG * sizeof(float) <= 64 * 1024) {
+      AGZ_REQUIRE((int)d_u3_dual.size() == conf.SharedLayers, AGZ_E_STATE, "agz_net: Winograd weights not built");
+      if (B > wino_chunk_cap) {
+        AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (d_wV) hipFree(d_wV);
+        if (d_wM) hipFree(d_wM);
+        d_wV = d_wM = nullptr; wino_chunk_cap = 0;
+        AGZ_HIP_TRY(hipMalloc(&d_wV, (size_t)36 * B * tpb * Kp * sizeof(float)));
+        AGZ_HIP_TRY(hipMalloc(&d_wM, (size_t)36 * B * tpb * 2 * Kp * sizeof(float)));
+        wino_chunk_cap = B;
+      }
+      WinoArgs wa{};
+      wa.V = d_wV; wa.Mb = d_wM;
+      wa.B = B; wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
+      for (int l = 0; l < conf.SharedLayers; l++) {
+        ProfScope ps(ctx, AGZ_PROF_CONV);
+        wa.U3 = d_u3_dual[l];
+        if (l == 0) { wa.x = cur; wino_launch(ctx, wa, WINO_IN | WINO_GEMM); }
+        else { wa.ep = d_ep_dual[l - 1]; wa.y = nullptr; wino_launch(ctx, wa, WINO_MID | WINO_GEMM); }
+      }
+      {
+        ProfScope ps(ctx, AGZ_PROF_CONV);
+        wa.ep = d_ep_dual[conf.SharedLayers - 1]; wa.y = nxt;
+        wino_launch(ctx, wa, WINO_OUT);
+      }
+      cur = nxt;
+      tower_done = true;
+    }
+  }
+  for (int l = 0; !tower_done && l < conf.SharedLayers; l++) {
     a.x = cur; a.w = d_w_dual[l]; a.ep = d_ep_dual[l]; a.y = nxt;
     a.Cin_p = Kp; a.Cout_p = Kp; a.Ntot = 2 * Kp;
     if (use_h2) {
@@ -789,7 +826,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         wa.x = cur + (size_t)b0 * Hp * Wp * Kp; wa.y = nxt + (size_t)b0 * Hp * Wp * Kp;
         wa.V = d_wV; wa.Mb = d_wM; wa.U3 = d_u3_dual[l]; wa.ep = d_ep_dual[l];
         wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
-        wino_launch(ctx, wa, true);
+        wino_launch(ctx, wa, WINO_IN | WINO_GEMM | WINO_OUT);
       }
       rc = AGZ_OK;
     }
@@ -1146,7 +1183,7 @@ int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, 
     bool ok = hipMemcpyAsync(dx, xp.data(), xp.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(dU, u3.data(), u3.size() * 2, hipMemcpyHostToDevice, s) == hipSuccess;
     a.x = dx; a.V = dV; a.U3 = dU; a.Mb = dM;
-    if (ok) agz::wino_launch(ctx, a, false);
+    if (ok) agz::wino_launch(ctx, a, agz::WINO_IN | agz::WINO_GEMM);
     ok = ok && hipGetLastError() == hipSuccess &&
          hipMemcpyAsync(V, dV, (size_t)36 * T * C * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
          hipMemcpyAsync(M, dM, (size_t)36 * T * N * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
