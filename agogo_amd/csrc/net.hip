@@ -683,6 +683,8 @@ int agz::conv3x3_raw_x3(agz_ctx* ctx, const float* x, const unsigned short* w3, 
 // Winograd-domain weights of every dual block (conv_wino.hpp): columns [0,Kp) branch a, [Kp,2Kp) branch b, natural order
 int agz_net::build_wino_weights() {
   AGZ_REQUIRE(cfg == 0, AGZ_E_UNSUPPORTED, "agz_net: the Winograd path needs K a multiple of 64");
+  // wino_gemm_kernel addresses the weights of one block with 32-bit byte offsets
+  AGZ_REQUIRE((size_t)36 * (Kp / 16) * 3 * (2 * Kp) * 32 < ((size_t)1 << 32), AGZ_E_UNSUPPORTED, "agz_net: K %d too wide for the Winograd weight image", conf.K);
   AGZ_HIP_TRY(hipSetDevice(ctx->device));
   for (auto& p : d_u3_dual) if (p) hipFree(p);
   d_u3_dual.assign(conf.SharedLayers, nullptr);
