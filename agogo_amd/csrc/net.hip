@@ -735,6 +735,14 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   const bool split_ok = cfg == 0 && !latency && (!half_dual || compute_force) && conf.SharedLayers > 0 &&
                         (size_t)B * Hp * Wp * Kp * sizeof(float) < ((size_t)1 << 32);
   const bool use_h2 = split_ok && compute_mode == AGZ_COMPUTE_FP16X2;
+  // Winograd in the latency regime (AGZ_WINO_LATENCY_TILES=<min tiles>, tuning knob): a round of 8-16 lanes of one tree is
+  // 200-400 tiles = 2-4 row tiles x 4 column tiles x 36 positions — a few hundred workgroups of 16 K steps, where the
+  // split-K fp32 path runs 9 x fewer-but-longer workgroups plus a reduction kernel.  The init conv and the heads keep
+  // their latency-regime kernels.
+  static const int wino_lat_tiles = [] { const char* e = getenv("AGZ_WINO_LATENCY_TILES"); return e ? atoi(e) : 0; }();
+  const bool wino_lat = latency && cfg == 0 && conf.SharedLayers > 0 && wino_lat_tiles > 0 &&
+                        B * ceil_div(H, 4) * ceil_div(W, 4) >= wino_lat_tiles;
+  const bool wino_ok = (split_ok || wino_lat) && compute_mode == AGZ_COMPUTE_WINO;
   if (use_h2 && (size_t)B > amax_cap) {
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (d_amax) hipFree(d_amax);
@@ -757,7 +765,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     static const int fuse_env = [] { const char* e = getenv("AGZ_WINO_FUSE"); return e ? atoi(e) : 0; }();
     const int tpb = ceil_div(H, 4) * ceil_div(W, 4);
     const size_t v_bytes = (size_t)36 * B * tpb * Kp * 4;
-    if (fuse_env && split_ok && compute_mode == AGZ_COMPUTE_WINO && v_bytes < ((size_t)1 << 32) && Kp % WINO_CG == 0 &&
+    if (fuse_env && wino_ok && v_bytes < ((size_t)1 << 32) && Kp % WINO_CG == 0 &&
         (size_t)Hp * Wp * WINO_CG * sizeof(float) <= 64 * 1024) {
       AGZ_REQUIRE((int)d_u3_dual.size() == conf.SharedLayers, AGZ_E_STATE, "agz_net: Winograd weights not built");
       if (B > wino_chunk_cap) {
@@ -805,7 +813,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       }
       rc = AGZ_OK;
     }
-    else if (split_ok && compute_mode == AGZ_COMPUTE_WINO) {
+    else if (wino_ok) {
       // Winograd F(4x4,3x3): boards in chunks (scratch V + M: 2.8 MB per 19x19 board at K=256)
       AGZ_REQUIRE((int)d_u3_dual.size() == conf.SharedLayers && d_u3_dual[l], AGZ_E_STATE, "agz_net: Winograd weights not built");
       static const int chunk_env = [] { const char* e = getenv("AGZ_WINO_CHUNK"); return e ? atoi(e) : 0; }();  // tuning knob
