@@ -486,7 +486,8 @@ static void wino_launch(agz_ctx* ctx, WinoArgs& a, int stages) {
     static const int stream_wgs = [] { const char* e = getenv("AGZ_WINO_STREAM"); return e ? atoi(e) : 0; }();   // tuning knob: workgroups per CU
     const int nblk = 36 * a.n_mtiles * a.n_ntiles;
     if (stream_wgs > 0 && ((a.C >> 4) & 1) == 0)
-      hipLaunchKernelGGL(wino_gemm_stream_kernel, dim3(std::min(nblk, stream_wgs * ctx->num_cus)), dim3(256), 0, ctx->stream, a);
+      // (at least 8 workgroups when there are 8 tiles: every XCD range needs an owner)
+      hipLaunchKernelGGL(wino_gemm_stream_kernel, dim3(std::min(nblk, std::max(8, stream_wgs * ctx->num_cus))), dim3(256), 0, ctx->stream, a);
     else
       hipLaunchKernelGGL(wino_gemm_kernel, dim3(nblk), dim3(256), 0, ctx->stream, a);
   }
