@@ -734,6 +734,13 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   // (the split kernels use 32-bit BYTE offsets: activation tensor below 4 GiB)
   const bool split_ok = cfg == 0 && !latency && (!half_dual || compute_force) && conf.SharedLayers > 0 &&
                         (size_t)B * Hp * Wp * Kp * sizeof(float) < ((size_t)1 << 32);
+  // AGZ_COMPUTE_AUTO: the measured per-shape choice (19x19 K=256: Winograd 1.07 vs bf16x3 2.03 ms per block; 9x9 K=128: bf16x3
+  // 13.4 vs Winograd 12.6 games/s; shapes below the chip-filling threshold: fp32 kernels)
+  int compute_mode = this->compute_mode;
+  if (compute_mode == AGZ_COMPUTE_AUTO) {
+    const int cover = ceil_div(H, 4) * 4 * ceil_div(W, 4) * 4;
+    compute_mode = (Kp >= 192 && cover * 4 <= HW * 5) ? AGZ_COMPUTE_WINO : AGZ_COMPUTE_BF16X3;
+  }
   const bool use_h2 = split_ok && compute_mode == AGZ_COMPUTE_FP16X2;
   // Winograd in the latency regime (AGZ_WINO_LATENCY_TILES=<min tiles>, tuning knob): a round of 8-16 lanes of one tree is
   // 200-400 tiles = 2-4 row tiles x 4 column tiles x 36 positions — a few hundred workgroups of 16 K steps, where the
@@ -1163,7 +1170,7 @@ int agz_net_commit(agz_net* n) {
     (void)A; (void)FCn;
   }
   n->committed = true;
-  if (n->compute_mode == AGZ_COMPUTE_WINO && n->cfg == 0) return n->build_wino_weights();
+  if ((n->compute_mode == AGZ_COMPUTE_WINO || n->compute_mode == AGZ_COMPUTE_AUTO) && n->cfg == 0) return n->build_wino_weights();
   return AGZ_OK;
 }
 
@@ -1209,11 +1216,11 @@ int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, 
 int agz_net_set_compute_mode(agz_net* n, int mode) {
   AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_compute_mode: NULL net");
   const int base = mode & ~AGZ_COMPUTE_FORCE;
-  AGZ_REQUIRE(base == AGZ_COMPUTE_F32_MFMA || base == AGZ_COMPUTE_BF16X3 || base == AGZ_COMPUTE_FP16X2 || base == AGZ_COMPUTE_WINO,
+  AGZ_REQUIRE(base == AGZ_COMPUTE_F32_MFMA || base == AGZ_COMPUTE_BF16X3 || base == AGZ_COMPUTE_FP16X2 || base == AGZ_COMPUTE_WINO || base == AGZ_COMPUTE_AUTO,
               AGZ_E_INVALID, "agz_net_set_compute_mode: unknown mode %d", mode);
   n->compute_mode = base;
   n->compute_force = (mode & AGZ_COMPUTE_FORCE) != 0;
-  if (base == AGZ_COMPUTE_WINO && n->committed && n->cfg == 0 && n->d_u3_dual.empty()) return n->build_wino_weights();
+  if ((base == AGZ_COMPUTE_WINO || base == AGZ_COMPUTE_AUTO) && n->committed && n->cfg == 0 && n->d_u3_dual.empty()) return n->build_wino_weights();
   return AGZ_OK;
 }
 
