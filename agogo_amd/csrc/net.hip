@@ -683,6 +683,8 @@ int agz::conv3x3_raw_x3(agz_ctx* ctx, const float* x, const unsigned short* w3, 
 // Winograd-domain weights of every dual block (conv_wino.hpp): columns [0,Kp) branch a, [Kp,2Kp) branch b, natural order
 int agz_net::build_wino_weights() {
   AGZ_REQUIRE(cfg == 0, AGZ_E_UNSUPPORTED, "agz_net: the Winograd path needs K a multiple of 64");
+  // wino_gemm_kernel addresses the weights of one block with 32-bit byte offsets
+  AGZ_REQUIRE((size_t)36 * (Kp / 16) * 3 * (2 * Kp) * 32 < ((size_t)1 << 32), AGZ_E_UNSUPPORTED, "agz_net: K %d too wide for the Winograd weight image", conf.K);
   AGZ_HIP_TRY(hipSetDevice(ctx->device));
   for (auto& p : d_u3_dual) if (p) hipFree(p);
   d_u3_dual.assign(conf.SharedLayers, nullptr);
@@ -732,7 +734,22 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   // (the split kernels use 32-bit BYTE offsets: activation tensor below 4 GiB)
   const bool split_ok = cfg == 0 && !latency && (!half_dual || compute_force) && conf.SharedLayers > 0 &&
                         (size_t)B * Hp * Wp * Kp * sizeof(float) < ((size_t)1 << 32);
+  // AGZ_COMPUTE_AUTO: the measured per-shape choice (19x19 K=256: Winograd 1.07 vs bf16x3 2.03 ms per block; 9x9 K=128: bf16x3
+  // 13.4 vs Winograd 12.6 games/s; shapes below the chip-filling threshold: fp32 kernels)
+  int compute_mode = this->compute_mode;
+  if (compute_mode == AGZ_COMPUTE_AUTO) {
+    const int cover = ceil_div(H, 4) * 4 * ceil_div(W, 4) * 4;
+    compute_mode = (Kp >= 192 && cover * 4 <= HW * 5) ? AGZ_COMPUTE_WINO : AGZ_COMPUTE_BF16X3;
+  }
   const bool use_h2 = split_ok && compute_mode == AGZ_COMPUTE_FP16X2;
+  // Winograd in the latency regime (AGZ_WINO_LATENCY_TILES=<min tiles>, tuning knob): a round of 8-16 lanes of one tree is
+  // 200-400 tiles = 2-4 row tiles x 4 column tiles x 36 positions — a few hundred workgroups of 16 K steps, where the
+  // split-K fp32 path runs 9 x fewer-but-longer workgroups plus a reduction kernel.  The init conv and the heads keep
+  // their latency-regime kernels.
+  static const int wino_lat_tiles = [] { const char* e = getenv("AGZ_WINO_LATENCY_TILES"); return e ? atoi(e) : 0; }();
+  const bool wino_lat = latency && cfg == 0 && conf.SharedLayers > 0 && wino_lat_tiles > 0 &&
+                        B * ceil_div(H, 4) * ceil_div(W, 4) >= wino_lat_tiles;
+  const bool wino_ok = (split_ok || wino_lat) && compute_mode == AGZ_COMPUTE_WINO;
   if (use_h2 && (size_t)B > amax_cap) {
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (d_amax) hipFree(d_amax);
@@ -748,7 +765,44 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   // K2: SharedLayers x fused dual-branch block
   float* cur = d_actA;
   float* nxt = d_actB;
-  for (int l = 0; l < conf.SharedLayers; l++) {
+  bool tower_done = false;
+  {
+    // Winograd tower with fused block boundaries (AGZ_WINO_FUSE=1, tuning knob): input transform once, then per block
+    // GEMMs + [output transform of block l | input transform of block l+1] in one kernel, the activation staying on chip
+    static const int fuse_env = [] { const char* e = getenv("AGZ_WINO_FUSE"); return e ? atoi(e) : 0; }();
+    const int tpb = ceil_div(H, 4) * ceil_div(W, 4);
+    const size_t v_bytes = (size_t)36 * B * tpb * Kp * 4;
+    if (fuse_env && wino_ok && v_bytes < ((size_t)1 << 32) && Kp % WINO_CG == 0 &&
+        (size_t)Hp * Wp * WINO_CG * sizeof(float) <= 64 * 1024) {
+      AGZ_REQUIRE((int)d_u3_dual.size() == conf.SharedLayers, AGZ_E_STATE, "agz_net: Winograd weights not built");
+      if (B > wino_chunk_cap) {
+        AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (d_wV) hipFree(d_wV);
+        if (d_wM) hipFree(d_wM);
+        d_wV = d_wM = nullptr; wino_chunk_cap = 0;
+        AGZ_HIP_TRY(hipMalloc(&d_wV, (size_t)36 * B * tpb * Kp * sizeof(float)));
+        AGZ_HIP_TRY(hipMalloc(&d_wM, (size_t)36 * B * tpb * 2 * Kp * sizeof(float)));
+        wino_chunk_cap = B;
+      }
+      WinoArgs wa{};
+      wa.V = d_wV; wa.Mb = d_wM;
+      wa.B = B; wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
+      for (int l = 0; l < conf.SharedLayers; l++) {
+        ProfScope ps(ctx, AGZ_PROF_CONV);
+        wa.U3 = d_u3_dual[l];
+        if (l == 0) { wa.x = cur; wino_launch(ctx, wa, WINO_IN | WINO_GEMM); }
+        else { wa.ep = d_ep_dual[l - 1]; wa.y = nullptr; wino_launch(ctx, wa, WINO_MID | WINO_GEMM); }
+      }
+      {
+        ProfScope ps(ctx, AGZ_PROF_CONV);
+        wa.ep = d_ep_dual[conf.SharedLayers - 1]; wa.y = nxt;
+        wino_launch(ctx, wa, WINO_OUT);
+      }
+      cur = nxt;
+      tower_done = true;
+    }
+  }
+  for (int l = 0; !tower_done && l < conf.SharedLayers; l++) {
     a.x = cur; a.w = d_w_dual[l]; a.ep = d_ep_dual[l]; a.y = nxt;
     a.Cin_p = Kp; a.Cout_p = Kp; a.Ntot = 2 * Kp;
     if (use_h2) {
@@ -766,7 +820,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       }
       rc = AGZ_OK;
     }
-    else if (split_ok && compute_mode == AGZ_COMPUTE_WINO) {
+    else if (wino_ok) {
       // Winograd F(4x4,3x3): boards in chunks (scratch V + M: 2.8 MB per 19x19 board at K=256)
       AGZ_REQUIRE((int)d_u3_dual.size() == conf.SharedLayers && d_u3_dual[l], AGZ_E_STATE, "agz_net: Winograd weights not built");
       static const int chunk_env = [] { const char* e = getenv("AGZ_WINO_CHUNK"); return e ? atoi(e) : 0; }();  // tuning knob
@@ -789,7 +843,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         wa.x = cur + (size_t)b0 * Hp * Wp * Kp; wa.y = nxt + (size_t)b0 * Hp * Wp * Kp;
         wa.V = d_wV; wa.Mb = d_wM; wa.U3 = d_u3_dual[l]; wa.ep = d_ep_dual[l];
         wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
-        wino_launch(ctx, wa, true);
+        wino_launch(ctx, wa, WINO_IN | WINO_GEMM | WINO_OUT);
       }
       rc = AGZ_OK;
     }
@@ -1116,7 +1170,7 @@ int agz_net_commit(agz_net* n) {
     (void)A; (void)FCn;
   }
   n->committed = true;
-  if (n->compute_mode == AGZ_COMPUTE_WINO && n->cfg == 0) return n->build_wino_weights();
+  if ((n->compute_mode == AGZ_COMPUTE_WINO || n->compute_mode == AGZ_COMPUTE_AUTO) && n->cfg == 0) return n->build_wino_weights();
   return AGZ_OK;
 }
 
@@ -1146,7 +1200,7 @@ int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, 
     bool ok = hipMemcpyAsync(dx, xp.data(), xp.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(dU, u3.data(), u3.size() * 2, hipMemcpyHostToDevice, s) == hipSuccess;
     a.x = dx; a.V = dV; a.U3 = dU; a.Mb = dM;
-    if (ok) agz::wino_launch(ctx, a, false);
+    if (ok) agz::wino_launch(ctx, a, agz::WINO_IN | agz::WINO_GEMM);
     ok = ok && hipGetLastError() == hipSuccess &&
          hipMemcpyAsync(V, dV, (size_t)36 * T * C * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
          hipMemcpyAsync(M, dM, (size_t)36 * T * N * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
@@ -1162,11 +1216,11 @@ int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, 
 int agz_net_set_compute_mode(agz_net* n, int mode) {
   AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_compute_mode: NULL net");
   const int base = mode & ~AGZ_COMPUTE_FORCE;
-  AGZ_REQUIRE(base == AGZ_COMPUTE_F32_MFMA || base == AGZ_COMPUTE_BF16X3 || base == AGZ_COMPUTE_FP16X2 || base == AGZ_COMPUTE_WINO,
+  AGZ_REQUIRE(base == AGZ_COMPUTE_F32_MFMA || base == AGZ_COMPUTE_BF16X3 || base == AGZ_COMPUTE_FP16X2 || base == AGZ_COMPUTE_WINO || base == AGZ_COMPUTE_AUTO,
               AGZ_E_INVALID, "agz_net_set_compute_mode: unknown mode %d", mode);
   n->compute_mode = base;
   n->compute_force = (mode & AGZ_COMPUTE_FORCE) != 0;
-  if (base == AGZ_COMPUTE_WINO && n->committed && n->cfg == 0 && n->d_u3_dual.empty()) return n->build_wino_weights();
+  if ((base == AGZ_COMPUTE_WINO || base == AGZ_COMPUTE_AUTO) && n->committed && n->cfg == 0 && n->d_u3_dual.empty()) return n->build_wino_weights();
   return AGZ_OK;
 }
 

@@ -144,6 +144,8 @@ int agz_net_set_latency_mode(agz_net* net, int on);
 #define AGZ_COMPUTE_WINO 3 /* Winograd F(4x4,3x3): transforms in fp32, the 36 transform-domain GEMMs with BF16X3 products — 3.6x
                             * fewer matrix instructions on 19x19; rounding error ~5x a direct fp32 convolution's (still inside
                             * the stated tolerance); opt-in, same shape conditions as the split modes */
+#define AGZ_COMPUTE_AUTO 4 /* per forward: Winograd where it measured fastest (K >= 192 and the 4x4 tiles overhang the board by at most
+                            * 25 %), else BF16X3 where the split kernels apply, else F32_MFMA */
 #define AGZ_COMPUTE_FORCE 0x100 /* OR-ed in: take the split kernel even below the chip-filling threshold (tests) */
 int agz_net_set_compute_mode(agz_net* net, int mode);
 /* Diagnostics (tests): the first two stages of the Winograd path on host data.  x [B][H][W][C] (NHWC, C % 16 == 0),

@@ -25,6 +25,7 @@ ap.add_argument("--sims", type=int, default=1600)
 ap.add_argument("--moves", type=int, default=12)
 ap.add_argument("--games", type=int, default=1)
 ap.add_argument("--lanes", type=int, default=1, help="agz_arena_set_parallel: simulations per tree and round")
+ap.add_argument("--compute", choices=["f32", "wino"], default="f32", help="wino: AGZ_COMPUTE_WINO (with AGZ_WINO_LATENCY_TILES=<n> in the environment it also serves small lane rounds)")
 args = ap.parse_args()
 
 ctx = A.Ctx(0)
@@ -32,6 +33,8 @@ S = args.size
 net = A.Net(ctx, args.K, args.L, 2 * args.K, S, S, 18, S * S + 1, BatchSize=args.games, bn_mode=capi.BN_IDENTITY)
 net.init_random(1337)
 net.commit()
+if args.compute == "wino":
+    net.set_compute_mode(capi.COMPUTE_WINO)
 arena = A.Arena(ctx, capi.GAME_WQ, S, S, komi=7.5, encoder=capi.ENC_WQ, n_games=args.games, seed=7, Budget=args.sims,
                 max_moves=S * S * 2)
 arena.set_inferencer(0, capi.INF_NET, net)

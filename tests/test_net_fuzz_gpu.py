@@ -38,3 +38,30 @@ def test_random_network_shape(ctx, seed):
     np.testing.assert_allclose(pol_g.sum(axis=1), 1.0, atol=1e-5)
     np.testing.assert_allclose(pol_g, pol_o, atol=POL_ATOL, rtol=POL_RTOL, err_msg=str((K, L, FC, W, H, F, Aspace, bn_mode, B, mode)))
     np.testing.assert_allclose(val_g, val_o, atol=VAL_ATOL)
+
+
+@pytest.mark.parametrize("seed", fuzz_seeds(16))
+def test_random_network_shape_winograd(ctx, seed):
+    """the same family in AGZ_COMPUTE_WINO (forced below the chip-filling threshold): K a multiple of 64, boards from 3x3 (one ragged
+    tile) to 13x13, batches on both sides of the latency regime (which keeps its own kernels unless AGZ_WINO_LATENCY_TILES is set)"""
+    rng = np.random.default_rng(2500 + seed)
+    K = int(rng.choice([64, 128, 192]))
+    L = int(rng.integers(1, 4))
+    FC = int(rng.choice([2, 7, 16, 33, 64]))
+    H, W = int(rng.integers(3, 14)), int(rng.integers(3, 14))
+    F = int(rng.choice([1, 2, 3, 18]))
+    Aspace = min(max(int(rng.choice([3, H * W + 1, W + 1])), 3), 512)
+    bn_mode = int(rng.integers(0, 3))
+    B = int(rng.choice([3, 9, 33, 70]))
+    onet, gnet = make_pair(ctx, K, L, FC, W, H, F, Aspace, bn_mode, seed=seed + 11)
+    gnet.set_compute_mode(capi.COMPUTE_WINO | capi.COMPUTE_FORCE)
+    if rng.integers(0, 2):
+        gnet.set_latency_mode(False)
+    x = rand_planes(B, F, H, W, seed=seed)
+    pol_g, val_g = gnet.infer(x)
+    idx = sorted(set([0, B // 2, B - 1]))
+    pol_o, val_o = onet.infer(x[idx])
+    assert np.all(np.isfinite(pol_g)) and np.all(np.isfinite(val_g))
+    np.testing.assert_allclose(pol_g.sum(axis=1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(pol_g[idx], pol_o, atol=POL_ATOL, rtol=POL_RTOL, err_msg=str((K, L, FC, W, H, F, Aspace, bn_mode, B)))
+    np.testing.assert_allclose(val_g[idx], val_o, atol=VAL_ATOL)

@@ -113,3 +113,31 @@ def test_wino_recommit_and_mode_round_trip(ctx):
     pf3, _ = gnet.infer(x)
     assert not np.array_equal(p3, p1)
     np.testing.assert_allclose(p3, pf3, atol=POL_ATOL, rtol=POL_RTOL)
+
+
+def test_wino_board_chunks_in_a_subprocess():
+    """AGZ_WINO_CHUNK (read once per process) forces the chunked schedule that otherwise only starts above ~4660 boards:
+    same results as one launch over the whole batch, bitwise (tiles are independent GEMM rows)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, os, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import agogo_amd as A
+from test_net_gpu import make_pair, rand_planes
+ctx = A.Ctx(0)
+onet, gnet = make_pair(ctx, 64, 2, 32, 9, 9, 18, 82, 2)
+gnet.set_compute_mode(A.capi.COMPUTE_WINO | A.capi.COMPUTE_FORCE)
+pol, val = gnet.infer(rand_planes(37, 18, 9, 9, seed=11))
+np.save(sys.argv[1], np.concatenate([pol.ravel(), val.ravel()]))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for chunk in ("0", "8"):
+        path = os.path.join(root, "gpurun_out", "wino_chunk_%s.npy" % chunk)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        env = dict(os.environ, AGZ_WINO_CHUNK=chunk)
+        subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env=env, timeout=120)
+        outs.append(np.load(path))
+    np.testing.assert_array_equal(outs[0], outs[1])
