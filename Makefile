@@ -7,8 +7,8 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-functi
 # engine.hip holds the bit-exact MCTS arithmetic: no fused multiply-add contraction (Go/amd64 never fuses)
 ENGINE_FLAGS := -ffp-contract=off
 
-SRCS := $(CS)/ctx.hip $(CS)/net.hip $(CS)/engine.hip $(CS)/train.hip $(CS)/examples.hip
-OBJS := $(OUT)/ctx.o $(OUT)/net.o $(OUT)/engine.o $(OUT)/train.o $(OUT)/examples.o
+SRCS := $(CS)/ctx.hip $(CS)/net.hip $(CS)/engine.hip $(CS)/train.hip $(CS)/examples.hip $(CS)/comm.hip
+OBJS := $(OUT)/ctx.o $(OUT)/net.o $(OUT)/engine.o $(OUT)/train.o $(OUT)/examples.o $(OUT)/comm.o
 HDRS := $(wildcard $(CS)/*.hpp) include/agz.h
 
 all: $(OUT)/libagz.so oracle tests/cpp/az_learn_ttt tests/cpp/gtp_main
@@ -33,11 +33,14 @@ $(OUT)/train.o: $(CS)/train.hip $(HDRS)
 $(OUT)/examples.o: $(CS)/examples.hip $(HDRS)
 	@mkdir -p $(OUT)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(OUT)/comm.o: $(CS)/comm.hip $(HDRS)
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(OUT)/engine.o: $(CS)/engine.hip $(HDRS)
 	@mkdir -p $(OUT)
 	$(HIPCC) $(HIPFLAGS) $(ENGINE_FLAGS) -c $< -o $@
 $(OUT)/libagz.so: $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
 
 oracle:
 	$(MAKE) -C oracle

@@ -4,5 +4,5 @@ The product is the C-ABI shared library built from agogo_amd/csrc (see include/a
 package only binds it (ctypes) for tests and bench.py; there is no CPU fallback: without the HIP
 library and a GPU every compute entry point raises.
 """
-from .capi import (AgzError, Arena, Ctx, Examples, GameConf, MctsConf, Net, NetConf, Trainer, lib, lib_path,  # noqa: F401
+from .capi import (AgzError, Arena, Comm, Ctx, Examples, GameConf, Mcts, MctsConf, Net, NetConf, State, Trainer, lib, lib_path,  # noqa: F401
                    rotate_boards, wino_stages)

@@ -49,7 +49,16 @@ class MctsConf(C.Structure):
 class ArenaStats(C.Structure):
     _fields_ = [("sims_total", C.c_int64), ("sims_nonnull", C.c_int64), ("nn_evals", C.c_int64),
                 ("moves_played", C.c_int64), ("games_finished", C.c_int64), ("examples", C.c_int64),
-                ("n_games", C.c_int32), ("n_active", C.c_int32), ("tree_full", C.c_int32), ("reserved", C.c_int32)]
+                ("n_games", C.c_int32), ("n_active", C.c_int32), ("tree_full", C.c_int32), ("examples_dropped", C.c_int32),
+                ("path_nodes", C.c_int64), ("children_read", C.c_int64)]
+
+
+class State(C.Structure):
+    """agz_state: a host-side game.State handed to mcts.SetGame (include/agz.h)."""
+    _fields_ = [("board", C.POINTER(C.c_int32)), ("to_move", C.c_int32), ("n_moves", C.c_int32), ("passes", C.c_int32),
+                ("hash", C.c_uint32), ("captures_black", C.c_float), ("captures_white", C.c_float),
+                ("last_moves", C.POINTER(C.c_int32)), ("n_last_moves", C.c_int32),
+                ("historical", C.POINTER(C.c_int32)), ("n_historical", C.c_int32)]
 
 
 class GameState(C.Structure):
@@ -160,6 +169,28 @@ def lib():
     sig("agz_examples_raw_dev", i32, vp, pvp, pvp, pvp)
     sig("agz_rotate_boards", i32, vp, pf, i32, i32, i32, pf)
     sig("agz_wino_stages", i32, vp, pf, pf, i32, i32, i32, i32, i32, pf, pf)
+    sig("agz_arena_random_moves", i32, vp, pi, u64)
+    sig("agz_arena_set_state", i32, vp, i32, C.POINTER(State))
+    sig("agz_arena_examples_labelled_dev", i32, vp, pvp)
+    sig("agz_mcts_create", i32, vp, C.POINTER(GameConf), C.POINTER(MctsConf), u64, i32, pvp)
+    sig("agz_mcts_destroy", None, vp)
+    sig("agz_mcts_set_inferencer", i32, vp, i32, vp)
+    sig("agz_mcts_set_parallel", i32, vp, i32)
+    sig("agz_mcts_set_game", i32, vp, C.POINTER(State))
+    sig("agz_mcts_search", i32, vp, i32, pi)
+    sig("agz_mcts_policies", i32, vp, pf, i32)
+    sig("agz_mcts_root_children", i32, vp, pi, pu, pf, pf, i32, pi)
+    sig("agz_mcts_nodes", i32, vp, pi)
+    sig("agz_mcts_get_stats", i32, vp, C.POINTER(ArenaStats))
+    sig("agz_mcts_reset", i32, vp)
+    sig("agz_comm_init_all", i32, pvp, i32, pvp)
+    sig("agz_comm_unique_id", i32, vp)
+    sig("agz_comm_init_rank", i32, vp, i32, i32, vp, pvp)
+    sig("agz_comm_destroy", None, vp)
+    sig("agz_comm_rank", i32, vp)
+    sig("agz_comm_size", i32, vp)
+    sig("agz_examples_allgather", i32, vp, vp)
+    sig("agz_trainer_allreduce", i32, vp, vp)
     _LIB = L
     return L
 
@@ -475,7 +506,18 @@ class Arena:
     def stats(self):
         s = ArenaStats()
         _check(lib().agz_arena_get_stats(self.h, C.byref(s)), "agz_arena_get_stats")
-        return {f: getattr(s, f) for f, _ in ArenaStats._fields_ if f != "reserved"}
+        return {f: getattr(s, f) for f, _ in ArenaStats._fields_}
+
+    def random_moves(self, n_moves, seed=1337):
+        """synthetic openings: game g plays n_moves[g] uniformly random legal moves (agz_arena_random_moves)"""
+        m = np.ascontiguousarray(n_moves, dtype=np.int32)
+        assert m.size == self.n_games
+        _check(lib().agz_arena_random_moves(self.h, _pi(m), seed), "agz_arena_random_moves")
+
+    def set_state(self, g, **kw):
+        st, keep = make_state(self.m * self.n, **kw)
+        _check(lib().agz_arena_set_state(self.h, g, C.byref(st)), "agz_arena_set_state")
+        del keep
 
     def results(self):
         a, b, d = C.c_int64(0), C.c_int64(0), C.c_int64(0)
@@ -527,6 +569,154 @@ class Arena:
 
     def clear_examples(self):
         _check(lib().agz_arena_clear_examples(self.h), "agz_arena_clear_examples")
+
+
+def make_state(cells, board, to_move, n_moves=0, passes=0, hash=0, captures=(0.0, 0.0), last_moves=(), historical=()):
+    """agz_state from numpy pieces; returns (struct, keep-alive list)"""
+    b = np.ascontiguousarray(board, dtype=np.int32).reshape(-1)
+    assert b.size == cells
+    lm = np.ascontiguousarray(last_moves, dtype=np.int32).reshape(-1)
+    hs = np.ascontiguousarray(historical, dtype=np.int32).reshape(-1)
+    assert hs.size % cells == 0
+    st = State()
+    st.board = _pi(b)
+    st.to_move, st.n_moves, st.passes, st.hash = int(to_move), int(n_moves), int(passes), int(hash) & 0xFFFFFFFF
+    st.captures_black, st.captures_white = float(captures[0]), float(captures[1])
+    st.last_moves = _pi(lm) if lm.size else None
+    st.n_last_moves = lm.size
+    st.historical = _pi(hs) if hs.size else None
+    st.n_historical = hs.size // cells
+    return st, [b, lm, hs]
+
+
+class Mcts:
+    """mcts.MCTS (mcts/tree.go:80-142, search.go:92): one search tree on a caller-owned game.State."""
+
+    def __init__(self, ctx, kind, m, n, k=0, komi=0.0, encoder=ENC_TWOPLANE, seed=1337, max_nodes=0, max_moves=0, PUCT=1.0,
+                 M=None, N=None, RandomCount=0, Budget=100, RandomMinVisits=0, RandomTemperature=0.0, DumbPass=True,
+                 ResignPercentage=0.0, PassPreference=DONT_PREFER_PASS):
+        self.ctx = ctx
+        self.kind, self.m, self.n = kind, m, n
+        self.action_space = n if kind == GAME_C4 else m * n
+        self.gconf = GameConf(kind, m, n, k, komi, max_moves, encoder)
+        self.mconf = MctsConf(PUCT, M if M is not None else m, N if N is not None else n, RandomCount, Budget,
+                              RandomMinVisits, RandomTemperature, int(DumbPass), ResignPercentage, PassPreference)
+        self.h = C.c_void_p()
+        self._nets = []
+        _check(lib().agz_mcts_create(ctx.h, C.byref(self.gconf), C.byref(self.mconf), seed, max_nodes, C.byref(self.h)),
+               "agz_mcts_create")
+        ctx._adopt(self)
+
+    def close(self):
+        if self.h and self.ctx.h:
+            lib().agz_mcts_destroy(self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_inferencer(self, kind, net=None):
+        _check(lib().agz_mcts_set_inferencer(self.h, kind, net.h if net is not None else None), "agz_mcts_set_inferencer")
+        if net is not None:
+            self._nets.append(net)
+
+    def set_parallel(self, lanes):
+        _check(lib().agz_mcts_set_parallel(self.h, int(lanes)), "agz_mcts_set_parallel")
+
+    def set_game(self, **kw):
+        st, keep = make_state(self.m * self.n, **kw)
+        _check(lib().agz_mcts_set_game(self.h, C.byref(st)), "agz_mcts_set_game")
+        del keep
+
+    def search(self, player):
+        best = C.c_int32(0)
+        _check(lib().agz_mcts_search(self.h, int(player), C.byref(best)), "agz_mcts_search")
+        return best.value
+
+    def policies(self):
+        p = np.zeros(self.action_space + 1, np.float32)
+        _check(lib().agz_mcts_policies(self.h, _pf(p), p.size), "agz_mcts_policies")
+        return p
+
+    def root_children(self):
+        cap = self.m * self.n + 2
+        mv = np.zeros(cap, dtype=np.int32)
+        vis = np.zeros(cap, dtype=np.uint32)
+        bs = np.zeros(cap, dtype=np.float32)
+        pr = np.zeros(cap, dtype=np.float32)
+        n = C.c_int32(0)
+        _check(lib().agz_mcts_root_children(self.h, _pi(mv), vis.ctypes.data_as(C.POINTER(C.c_uint32)), _pf(bs), _pf(pr), cap,
+                                            C.byref(n)), "agz_mcts_root_children")
+        k = n.value
+        return mv[:k].copy(), vis[:k].copy(), bs[:k].copy(), pr[:k].copy()
+
+    def nodes(self):
+        n = C.c_int32(0)
+        _check(lib().agz_mcts_nodes(self.h, C.byref(n)), "agz_mcts_nodes")
+        return n.value
+
+    def stats(self):
+        s = ArenaStats()
+        _check(lib().agz_mcts_get_stats(self.h, C.byref(s)), "agz_mcts_get_stats")
+        return {f: getattr(s, f) for f, _ in ArenaStats._fields_}
+
+    def reset(self):
+        _check(lib().agz_mcts_reset(self.h), "agz_mcts_reset")
+
+
+class Comm:
+    """agz_comm: an RCCL communicator over the devices of agz_ctx handles."""
+
+    def __init__(self, h, ctx):
+        self.h, self.ctx = h, ctx
+        ctx._adopt(self)
+
+    @staticmethod
+    def init_all(ctxs):
+        n = len(ctxs)
+        arr = (C.c_void_p * n)(*[c.h for c in ctxs])
+        out = (C.c_void_p * n)()
+        _check(lib().agz_comm_init_all(arr, n, out), "agz_comm_init_all")
+        return [Comm(C.c_void_p(out[i]), ctxs[i]) for i in range(n)]
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().agz_comm_unique_id(buf), "agz_comm_unique_id")
+        return buf.raw
+
+    @staticmethod
+    def init_rank(ctx, n_ranks, rank, id_bytes):
+        out = C.c_void_p()
+        buf = C.create_string_buffer(bytes(id_bytes), 128)
+        _check(lib().agz_comm_init_rank(ctx.h, n_ranks, rank, buf, C.byref(out)), "agz_comm_init_rank")
+        return Comm(out, ctx)
+
+    def close(self):
+        if self.h and self.ctx.h:
+            lib().agz_comm_destroy(self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rank(self):
+        return lib().agz_comm_rank(self.h)
+
+    def size(self):
+        return lib().agz_comm_size(self.h)
+
+    def allgather_examples(self, ex):
+        _check(lib().agz_examples_allgather(self.h, ex.h), "agz_examples_allgather")
+
+    def allreduce_trainer(self, trainer):
+        _check(lib().agz_trainer_allreduce(self.h, trainer.h), "agz_trainer_allreduce")
 
 
 class Examples:

@@ -1,0 +1,123 @@
+// agz_comm: RCCL communicators over the devices of agz_ctx handles (one host thread + ctx per GPU; games are
+// sharded with no data-path collective, the only exchange is the example gather before dual.Train and the gradient
+// all-reduce of the data-parallel step — agogo.go:118-133, dualnet/meta.go:16-54).
+//
+// xGMI is point-to-point (7 links x ~153 GB/s per GPU): the gather is issued as one grouped set of n broadcasts (every rank
+// the root of its own rows), which RCCL runs over all links concurrently instead of a 7-step ring of padded blocks.
+#include "comm.hpp"
+
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include <mutex>
+
+namespace agz {
+const Rccl* rccl() {
+  static Rccl table{};
+  static bool ok = false;
+  static std::once_flag once;
+  static std::string err;
+  std::call_once(once, [] {
+    // a copy already mapped into the process (e.g. PyTorch's) is reused: two RCCL instances on one device fight over IPC handles
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) { err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+    bool all = true;
+    auto get = [&](const char* name) { void* p = dlsym(h, name); if (!p) { all = false; err = std::string("librccl lacks ") + name; } return p; };
+    table.GetUniqueId = (decltype(table.GetUniqueId))get("ncclGetUniqueId");
+    table.CommInitRank = (decltype(table.CommInitRank))get("ncclCommInitRank");
+    table.CommInitAll = (decltype(table.CommInitAll))get("ncclCommInitAll");
+    table.CommDestroy = (decltype(table.CommDestroy))get("ncclCommDestroy");
+    table.AllGather = (decltype(table.AllGather))get("ncclAllGather");
+    table.AllReduce = (decltype(table.AllReduce))get("ncclAllReduce");
+    table.Broadcast = (decltype(table.Broadcast))get("ncclBroadcast");
+    table.GroupStart = (decltype(table.GroupStart))get("ncclGroupStart");
+    table.GroupEnd = (decltype(table.GroupEnd))get("ncclGroupEnd");
+    table.GetErrorString = (decltype(table.GetErrorString))get("ncclGetErrorString");
+    ok = all;
+  });
+  if (!ok) { set_error("agz_comm: %s (RCCL is required for multi-GPU exchange; there is no fallback)", err.c_str()); return nullptr; }
+  return &table;
+}
+}  // namespace agz
+
+using namespace agz;
+
+extern "C" {
+
+int agz_comm_unique_id(void* id128) {
+  AGZ_REQUIRE(id128, AGZ_E_INVALID, "agz_comm_unique_id: NULL argument");
+  const Rccl* R = rccl();
+  if (!R) return AGZ_E_UNSUPPORTED;
+  static_assert(sizeof(ncclUniqueId) == 128, "AGZ_COMM_ID_BYTES");
+  ncclUniqueId id;
+  AGZ_NCCL_TRY(R->GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return AGZ_OK;
+}
+
+int agz_comm_init_rank(agz_ctx* ctx, int n_ranks, int rank, const void* id128, agz_comm** out) {
+  AGZ_REQUIRE(ctx && id128 && out, AGZ_E_INVALID, "agz_comm_init_rank: NULL argument");
+  AGZ_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, AGZ_E_INVALID, "agz_comm_init_rank: rank %d of %d", rank, n_ranks);
+  const Rccl* R = rccl();
+  if (!R) return AGZ_E_UNSUPPORTED;
+  AGZ_HIP_TRY(hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  agz_comm* c = new agz_comm();
+  c->ctx = ctx; c->rank = rank; c->size = n_ranks;
+  ncclResult_t r = R->CommInitRank(&c->comm, n_ranks, id, rank);
+  if (r != ncclSuccess) { set_error("agz_comm_init_rank: ncclCommInitRank -> %s", R->GetErrorString(r)); delete c; return AGZ_E_HIP; }
+  *out = c;
+  return AGZ_OK;
+}
+
+int agz_comm_init_all(agz_ctx* const* ctxs, int n, agz_comm** comms) {
+  AGZ_REQUIRE(ctxs && comms && n >= 1 && n <= 64, AGZ_E_INVALID, "agz_comm_init_all: bad argument");
+  const Rccl* R = rccl();
+  if (!R) return AGZ_E_UNSUPPORTED;
+  std::vector<int> dev(n);
+  for (int i = 0; i < n; i++) {
+    AGZ_REQUIRE(ctxs[i], AGZ_E_INVALID, "agz_comm_init_all: ctxs[%d] is NULL", i);
+    dev[i] = ctxs[i]->device;
+    for (int j = 0; j < i; j++) AGZ_REQUIRE(dev[j] != dev[i], AGZ_E_INVALID, "agz_comm_init_all: device %d appears twice (one rank per GPU)", dev[i]);
+  }
+  std::vector<ncclComm_t> cs(n, nullptr);
+  AGZ_NCCL_TRY(R->CommInitAll(cs.data(), n, dev.data()));
+  for (int i = 0; i < n; i++) {
+    agz_comm* c = new agz_comm();
+    c->ctx = ctxs[i]; c->comm = cs[i]; c->rank = i; c->size = n;
+    comms[i] = c;
+  }
+  return AGZ_OK;
+}
+
+void agz_comm_destroy(agz_comm* c) {
+  if (!c) return;
+  const Rccl* R = rccl();
+  if (R && c->comm) { hipSetDevice(c->ctx->device); hipStreamSynchronize(c->ctx->stream); R->CommDestroy(c->comm); }
+  delete c;
+}
+
+int agz_comm_rank(const agz_comm* c) { return c ? c->rank : -1; }
+int agz_comm_size(const agz_comm* c) { return c ? c->size : 0; }
+
+int agz_trainer_allreduce(agz_comm* c, agz_trainer* t) {
+  AGZ_REQUIRE(c && t, AGZ_E_INVALID, "agz_trainer_allreduce: NULL argument");
+  const Rccl* R = rccl();
+  if (!R) return AGZ_E_UNSUPPORTED;
+  AGZ_HIP_TRY(hipSetDevice(c->ctx->device));
+  float* g = nullptr;
+  size_t n = 0;
+  int r = agz_trainer_grads_dev(t, &g, &n);
+  if (r != AGZ_OK) return r;
+  // ONE collective per step: all learnables' gradients live in one flat buffer (train.hip); in place, on the ctx stream
+  AGZ_NCCL_TRY(R->AllReduce(g, g, n, ncclFloat32, ncclSum, c->comm, c->ctx->stream));
+  return AGZ_OK;
+}
+
+}  // extern "C"

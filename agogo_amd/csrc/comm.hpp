@@ -1,0 +1,42 @@
+// RCCL inside libagz: the one exchange step of the path — the per-GPU example buffers gathered before
+// dual.Train (agogo.go:118-133) and the gradient all-reduce of the data-parallel training step.
+//
+// librccl is resolved at run time (dlopen + dlsym) the first time a communicator is made: libagz keeps loading where RCCL is
+// absent and never clashes with another RCCL copy the host process may already hold (PyTorch ships its own); a missing
+// library is a loud AGZ_E_UNSUPPORTED, never a silent single-GPU fallback.
+#pragma once
+#include <rccl/rccl.h>
+
+#include "common.hpp"
+
+namespace agz {
+struct Rccl {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*);
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*GroupStart)();
+  ncclResult_t (*GroupEnd)();
+  const char* (*GetErrorString)(ncclResult_t);
+};
+// nullptr (with agz_last_error set) when librccl cannot be loaded
+const Rccl* rccl();
+}  // namespace agz
+
+struct agz_comm {
+  agz_ctx* ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, size = 1;
+};
+
+#define AGZ_NCCL_TRY(expr)                                                                                   \
+  do {                                                                                                       \
+    ncclResult_t _r = (expr);                                                                                \
+    if (_r != ncclSuccess) {                                                                                 \
+      agz::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, agz::rccl() ? agz::rccl()->GetErrorString(_r) : "rccl error"); \
+      return AGZ_E_HIP;                                                                                      \
+    }                                                                                                        \
+  } while (0)

@@ -8,7 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/agz.h"
+#include "../../include/agz_debug.h"
 
 namespace agz {
 

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void k_reset(Dev d, GameCfg c, const uint8_t* a
     d.a_is_black[g] = ab;
     d.to_move[g] = AGZ_BLACK;  // the agent holding Black starts: game.SetToMove(currentPlayer.Player), arena.go:91
     d.ply[g] = 0; d.passes[g] = 0; d.pass_count[g] = 0; d.ended[g] = 0; d.winner[g] = AGZ_NONE; d.n_amoves[g] = 0;
-    d.last_move[g] = AGZ_PASS; d.cap_b[g] = 0.f; d.cap_w[g] = 0.f; d.zhash[g] = 0; d.ex_last[g] = -1;
+    d.last_move[g] = AGZ_PASS; d.cap_b[g] = 0.f; d.cap_w[g] = 0.f; d.zhash[g] = 0; d.ex_last[g] = -1; d.hist_from[g] = 0;
     for (int l = 0; l < d.V; l++) d.leaf_kind[(size_t)g * d.V + l] = LEAF_NONE;
     d.rng_game[g] = seed * 0x9E3779B97F4A7C15ull + (unsigned long long)g * 0xD1B54A32D192ED03ull + 7ull;
     for (int a = 0; a < 2; a++) {
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void k_begin_move(Dev d, GameCfg c, MctsCfg mc)
   if (ok) {
     int prev_ply = d.prev_ply[t];
     depth = st.ply - prev_ply;
-    if (depth < 0) ok = false;
+    if (depth < 0 || prev_ply < d.hist_from[g]) ok = false;   // (UndoLastMove needs the moves since prev: a state set from outside may not carry them)
     if (ok && c.kind != AGZ_GAME_WQ) {
       // tmp := current.Clone(); UndoLastMove x depth (removes the stone only, mnk.go:184-189, komi/game.go:201-206);
       // tmp.Eq(prev) compares boards.
@@ -338,6 +338,7 @@ __global__ __launch_bounds__(64) void k_select(Dev d, GameCfg c, MctsCfg mc, flo
     load_state(c, d, g, s, st, use_ring, lane);
     int32_t* path = d.path + q * MAXPATH;
     int node = 0, depth = 1, plen = 1, kind = LEAF_NONE;
+    int kids_seen = 0;
     float result = 0.f;
     if (lane == 0) path[0] = 0;
     while (true) {
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(64) void k_select(Dev d, GameCfg c, MctsCfg mc, flo
       }
       if (prep) { kind = LEAF_NONE; break; }  // root already has children: prepareRoot does nothing
       int n = d.kids_n[base + node];
+      kids_seen += n;
       int ci = select_child(d, base, off, n, st.to_move, mc.PUCT, lane, use_vl);
       if (ci < 0) { kind = LEAF_NULL; break; }
       int child = off + ci;
@@ -385,6 +387,10 @@ __global__ __launch_bounds__(64) void k_select(Dev d, GameCfg c, MctsCfg mc, flo
       d.leaf_ply[q] = move_number(c, st.ply);
       d.leaf_result[q] = result;
       d.path_len[q] = plen;
+      if (!prep) {   // measurement only: nodes on the path and children read by Select, summed over simulations
+        atomicAdd(&d.counters[CNT_PATH], (unsigned long long)plen);
+        atomicAdd(&d.counters[CNT_KIDS], (unsigned long long)kids_seen);
+      }
     }
     __syncthreads();
   }
@@ -546,7 +552,10 @@ __global__ __launch_bounds__(64) void k_expand(Dev d, GameCfg c, MctsCfg mc, Inf
 // bestMove + Policies + Arena.Play's per-move bookkeeping (search.go:341-390,152-161; arena.go:98-138)
 // forced != nullptr: agz_arena_apply_moves — the move of every unfinished game comes from outside (no search, no
 // example, the mover's tree is left alone and re-roots over the extra plies at its next search).
-__global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, int record, int restart, const int32_t* forced) {
+// search_only != 0: MCTS.Search's own tail only (search.go:151-163) — bestMove, t.prev = current.Clone(), cachedPolicies++ —
+// the move goes to d.best_out[g] and the game is NOT advanced (the caller of Search applies it to its own game.State).
+__global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, int record, int restart, const int32_t* forced,
+                                                 int search_only) {
   __shared__ Sh s;
   __shared__ uint32_t cv[CELLS_PAD];   // child visits
   __shared__ int16_t ckn[CELLS_PAD];   // child kids_n
@@ -700,11 +709,13 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
         encode_nchw(c, s, st, d.ex_planes + (size_t)e * c.F * c.cells, lane);
         if (lane == 0) {
           d.ex_value[e] = (float)player;  // "THIS IS A HACK": mover colour until the game ends (arena.go:111-113)
+          d.ex_labelled[e] = 0;
           d.ex_game[e] = g; d.ex_prev[e] = d.ex_last[g]; d.ex_last[g] = e;
           atomicAdd(&d.counters[CNT_EXAMPLES], 1ull);
         }
-      } else if (lane == 0) {
+      } else if (lane == 0) {   // buffer full: the example is lost — counted (agz_arena_stats.examples_dropped)
         atomicSub(d.ex_count, 1);
+        atomicAdd(&d.counters[CNT_DROPPED], 1ull);
       }
     }
   }
@@ -713,6 +724,10 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
     for (int i = lane; i < c.cells; i += WAVE) d.prev_board[(size_t)t * CELLS_PAD + i] = s.board[i];
   if (lane == 0 && n > 0) { d.prev_ply[t] = st.ply; d.has_prev[t] = 1; }
   __syncthreads();
+  if (search_only) {
+    if (lane == 0) d.best_out[g] = best;
+    return;
+  }
   // a.game = a.game.Apply(PlayerMove{player, best}) (arena.go:127-130)
   int ended = 0, winner = AGZ_NONE;
   int pass_count = d.pass_count[g];
@@ -805,6 +820,7 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
       for (int e = d.ex_last[g]; e >= 0; e = d.ex_prev[e]) {
         float mover = d.ex_value[e];
         d.ex_value[e] = winner == AGZ_NONE ? 0.f : (mover == (float)winner ? 1.f : -1.f);
+        d.ex_labelled[e] = 1;
       }
       d.ex_last[g] = -1;
     }
@@ -820,7 +836,7 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
       z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
       d.a_is_black[g] = (z >> 63) == 0 ? 1 : 0;
       d.to_move[g] = AGZ_BLACK; d.ply[g] = 0; d.passes[g] = 0; d.pass_count[g] = 0; d.ended[g] = 0; d.winner[g] = AGZ_NONE;
-      d.last_move[g] = AGZ_PASS; d.cap_b[g] = 0.f; d.cap_w[g] = 0.f; d.zhash[g] = 0; d.n_amoves[g] = 0;
+      d.last_move[g] = AGZ_PASS; d.cap_b[g] = 0.f; d.cap_w[g] = 0.f; d.zhash[g] = 0; d.n_amoves[g] = 0; d.hist_from[g] = 0;
       for (int ag = 0; ag < 2; ag++) {
         int tt = ag * d.G + g;
         d.n_nodes[tt] = 0; d.cur_pool[tt] = 0; d.has_root[tt] = 0; d.has_prev[tt] = 0; d.prev_ply[tt] = 0; d.stalled[tt] = 0;
@@ -829,6 +845,51 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
       }
     }
   }
+}
+
+// Synthetic openings ("play u uniformly-random legal moves from the empty board", the benchmark's board
+// batches): every unfinished game with remaining[g] > 0 draws the (z mod n_legal)-th legal board move in ascending cell
+// order for the player to move, z = SplitMix64 finaliser of (seed, game, arena move count); without a legal board move:
+// Pass where the game has one, else the game is left alone.  The move goes to forced[g] and is applied by k_end_move's
+// forced path (State.Check + Apply + Ended, no search, no example).  oracle: orc_arena_random_move.
+__global__ __launch_bounds__(64) void k_random_pick(Dev d, GameCfg c, int32_t* remaining, unsigned long long seed, int32_t* forced) {
+  __shared__ Sh s;
+  const int g = blockIdx.x, lane = threadIdx.x;
+  if (d.ended[g] || remaining[g] <= 0) { if (lane == 0) forced[g] = AGZ_NO_MOVE; return; }
+  St st;
+  load_state(c, d, g, s, st, false, lane);
+  const int player = st.to_move;
+  if (c.go_like) analyse(c, s, nullptr, lane);
+  int total = 0;
+  for (int b0 = 0; b0 < c.A; b0 += WAVE) {
+    const int i = b0 + lane;
+    const bool ok = i < c.A && (c.go_like ? go_legal(c, s, i, player) : s.board[i] == AGZ_NONE);
+    total += __popcll(__ballot(ok));
+  }
+  int mv = AGZ_NO_MOVE;
+  if (total == 0) {
+    if (c.pass_legal) mv = AGZ_PASS;
+  } else {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(g + 1) +
+                           0xD1B54A32D192ED03ull * (unsigned long long)(d.n_amoves[g] + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    const int want = (int)(z % (unsigned long long)total);
+    int seen = 0;
+    for (int b0 = 0; b0 < c.A; b0 += WAVE) {
+      const int i = b0 + lane;
+      const bool ok = i < c.A && (c.go_like ? go_legal(c, s, i, player) : s.board[i] == AGZ_NONE);
+      const unsigned long long m = __ballot(ok);
+      const int cnt = __popcll(m);
+      if (want >= seen && want < seen + cnt) {
+        // the (want - seen)-th set bit of m
+        unsigned long long mm = m;
+        for (int q = 0; q < want - seen; q++) mm &= mm - 1;
+        mv = b0 + (__ffsll((long long)mm) - 1);
+      }
+      seen += cnt;
+    }
+  }
+  if (lane == 0) { forced[g] = mv; remaining[g] = mv == AGZ_NO_MOVE ? 0 : remaining[g] - 1; }
 }
 
 }  // namespace agz
@@ -851,7 +912,7 @@ struct agz_arena {
   std::vector<uint8_t> a_is_black;
   int32_t* d_forced = nullptr;   // agz_arena_apply_moves staging
   std::vector<int32_t> slot_host;
-  int ply_parity = 0;       // all unfinished games are at the same ply
+  int32_t* d_remaining = nullptr;   // agz_arena_random_moves staging
   int nA_slots = 0, nB_slots = 0;
   bool in_move = false;
   bool restart = false;  // continuous self-play: finished games restart immediately
@@ -879,10 +940,16 @@ int agz_arena::update_slots() {
     for (int g = 0; g < G; g++) slot_host[g] = g;
     nA_slots = G; nB_slots = G;
   } else {
+    // who moves in game g is read from the device state (the Arena's currentPlayer: A moves when its colour is to move),
+    // so games may sit at different plies (agz_arena_apply_moves with AGZ_NO_MOVE / rejected moves, random openings)
+    std::vector<int32_t> tm(G), ab(G);
+    AGZ_HIP_TRY(hipMemcpyAsync(tm.data(), d.to_move, G * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    AGZ_HIP_TRY(hipMemcpyAsync(ab.data(), d.a_is_black, G * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
     int na = 0;
-    for (int g = 0; g < G; g++) { bool a_moves = (a_is_black[g] != 0) == (ply_parity == 0); if (a_moves) na++; }
+    for (int g = 0; g < G; g++) { bool a_moves = (tm[g] == AGZ_BLACK) == (ab[g] != 0); if (a_moves) na++; }
     int ia = 0, ib = na;
-    for (int g = 0; g < G; g++) { bool a_moves = (a_is_black[g] != 0) == (ply_parity == 0); slot_host[g] = a_moves ? ia++ : ib++; }
+    for (int g = 0; g < G; g++) { bool a_moves = (tm[g] == AGZ_BLACK) == (ab[g] != 0); slot_host[g] = a_moves ? ia++ : ib++; }
     nA_slots = na; nB_slots = G - na;
   }
   AGZ_HIP_TRY(hipMemcpyAsync(d.slot_of_game, slot_host.data(), G * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -984,7 +1051,7 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
 #define AL(p, n) if ((r = a->alloc(&d.p, (size_t)(n))) != AGZ_OK) { agz_arena_destroy(a); return r; }
   AL(board, (size_t)G * CELLS_PAD) AL(ring, (size_t)G * RING * CELLS_PAD) AL(to_move, G) AL(ply, G) AL(passes, G)
   AL(pass_count, G) AL(ended, G) AL(winner, G) AL(a_is_black, G) AL(last_move, G) AL(cap_b, G) AL(cap_w, G) AL(zhash, G)
-  AL(moves, (size_t)G * d.moves_stride) AL(amoves, (size_t)G * d.moves_stride) AL(n_amoves, G)
+  AL(moves, (size_t)G * d.moves_stride) AL(amoves, (size_t)G * d.moves_stride) AL(n_amoves, G) AL(hist_from, G)
   size_t pool = (size_t)T * 2 * d.cap;
   AL(prior, pool) AL(visits, pool) AL(bsum, pool) AL(kids_off, pool) AL(kids_n, pool) AL(nmove, pool)
   AL(n_nodes, T) AL(cur_pool, T) AL(has_root, T) AL(has_prev, T) AL(prev_ply, T) AL(prev_board, (size_t)T * CELLS_PAD)
@@ -1000,7 +1067,7 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
     d.ex_cap = (int)std::min(want, budget);
   }
   AL(ex_planes, (size_t)d.ex_cap * c.F * c.cells) AL(ex_policy, (size_t)d.ex_cap * (c.A + 1)) AL(ex_value, d.ex_cap)
-  AL(ex_game, d.ex_cap) AL(ex_prev, d.ex_cap) AL(ex_last, G) AL(ex_count, 1)
+  AL(ex_game, d.ex_cap) AL(ex_prev, d.ex_cap) AL(ex_last, G) AL(ex_count, 1) AL(ex_labelled, d.ex_cap) AL(best_out, G)
   {  // zobrist keys: komi draws only the first size+1 table entries (komi/zobrist.go:38); wq draws all (wq/zobrist.go:31-42)
     std::vector<int32_t> zt((size_t)2 * c.cells, 0);
     SplitMix64 rr(1337);
@@ -1029,6 +1096,7 @@ void agz_arena_destroy(agz_arena* a) {
   for (void* p : a->allocs) hipFree(p);
   for (int i = 0; i < 2; i++) { if (a->d_policy[i]) hipFree(a->d_policy[i]); if (a->d_value[i]) hipFree(a->d_value[i]); }
   if (a->d_forced) hipFree(a->d_forced);
+  if (a->d_remaining) hipFree(a->d_remaining);
   delete a;
 }
 
@@ -1049,6 +1117,12 @@ int agz_arena_set_inferencer(agz_arena* a, int agent, int kind, agz_net* net) {
     if (a->d_value[agent]) { hipFree(a->d_value[agent]); a->d_value[agent] = nullptr; }
     AGZ_HIP_TRY(hipMalloc(&a->d_policy[agent], (size_t)a->G * a->d.V * net->conf.ActionSpace * sizeof(float)));
     AGZ_HIP_TRY(hipMalloc(&a->d_value[agent], (size_t)a->G * a->d.V * sizeof(float)));
+  }
+  {  // two different nets evaluate an A and a B sub-batch of ONE lane per game (nn_step): refuse the combination with lanes
+    const int other = agent ^ 1;
+    const bool would_split = kind == AGZ_INF_NET && a->inf_kind[other] == AGZ_INF_NET && a->net[other] != net;
+    AGZ_REQUIRE(!(would_split && a->d.V > 1), AGZ_E_UNSUPPORTED,
+                "agz_arena_set_inferencer: agents with two different nets search one lane at a time (agz_arena_set_parallel(1) first)");
   }
   a->inf_kind[agent] = kind;
   a->net[agent] = kind == AGZ_INF_NET ? net : nullptr;
@@ -1095,7 +1169,7 @@ int agz_arena_reset(agz_arena* a, const uint8_t* a_is_black) {
   AGZ_HIP_TRY(hipStreamSynchronize(s));
   if (dab) hipFree(dab);
   for (int g = 0; g < a->G; g++) a->a_is_black[g] = (uint8_t)ab[g];
-  a->ply_parity = 0; a->in_move = false; a->moves_done = 0;
+  a->in_move = false; a->moves_done = 0;
   a->seed += 0x9E3779B97F4A7C15ull;  // next reset draws new colours
   return a->update_slots();
 }
@@ -1134,11 +1208,10 @@ int agz_arena_end_move(agz_arena* a, int record) {
   AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
   {
     ProfScope ps(a->ctx, AGZ_PROF_MOVE);
-    hipLaunchKernelGGL(k_end_move, dim3(a->G), dim3(64), 0, a->ctx->stream, a->d, a->gc, a->mc, record, a->restart ? 1 : 0, (const int32_t*)nullptr);
+    hipLaunchKernelGGL(k_end_move, dim3(a->G), dim3(64), 0, a->ctx->stream, a->d, a->gc, a->mc, record, a->restart ? 1 : 0, (const int32_t*)nullptr, 0);
   }
   AGZ_HIP_TRY(hipGetLastError());
   a->in_move = false;
-  a->ply_parity ^= 1;
   a->moves_done++;
   return AGZ_OK;
 }
@@ -1153,11 +1226,10 @@ int agz_arena_apply_moves(agz_arena* a, const int32_t* moves) {
   AGZ_HIP_TRY(hipMemcpyAsync(&before, a->d.counters + CNT_ILLEGAL, 8, hipMemcpyDeviceToHost, s));
   AGZ_HIP_TRY(hipMemcpyAsync(a->d_forced, moves, (size_t)a->G * sizeof(int32_t), hipMemcpyHostToDevice, s));
   AGZ_HIP_TRY(hipStreamSynchronize(s));   // `moves` is the caller's buffer
-  hipLaunchKernelGGL(k_end_move, dim3(a->G), dim3(64), 0, s, a->d, a->gc, a->mc, 0, 0, (const int32_t*)a->d_forced);
+  hipLaunchKernelGGL(k_end_move, dim3(a->G), dim3(64), 0, s, a->d, a->gc, a->mc, 0, 0, (const int32_t*)a->d_forced, 0);
   AGZ_HIP_TRY(hipGetLastError());
   AGZ_HIP_TRY(hipMemcpyAsync(&after, a->d.counters + CNT_ILLEGAL, 8, hipMemcpyDeviceToHost, s));
   AGZ_HIP_TRY(hipStreamSynchronize(s));
-  a->ply_parity ^= 1;
   a->moves_done++;
   AGZ_REQUIRE(after == before, AGZ_E_INVALID, "agz_arena_apply_moves: %llu illegal move(s) (State.Check failed); those games were left unchanged",
               after - before);
@@ -1174,7 +1246,8 @@ int agz_arena_get_stats(agz_arena* a, agz_arena_stats* out) {
   AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
   out->sims_total = (int64_t)c[CNT_SIMS]; out->sims_nonnull = (int64_t)c[CNT_NONNULL]; out->nn_evals = (int64_t)c[CNT_EVALS];
   out->moves_played = (int64_t)c[CNT_MOVES]; out->games_finished = (int64_t)c[CNT_GAMES]; out->examples = (int64_t)c[CNT_EXAMPLES];
-  out->n_games = a->G; out->tree_full = (int32_t)c[CNT_FULL]; out->reserved = 0;
+  out->n_games = a->G; out->tree_full = (int32_t)c[CNT_FULL]; out->examples_dropped = (int32_t)c[CNT_DROPPED];
+  out->path_nodes = (int64_t)c[CNT_PATH]; out->children_read = (int64_t)c[CNT_KIDS];
   int act = 0;
   for (int g = 0; g < a->G; g++) act += ended[g] ? 0 : 1;
   out->n_active = act;
@@ -1344,6 +1417,235 @@ int agz_arena_examples_dev(agz_arena* a, float** planes, float** policy, float**
   if (planes) *planes = a->d.ex_planes;
   if (policy) *policy = a->d.ex_policy;
   if (value) *value = a->d.ex_value;
+  return AGZ_OK;
+}
+
+int agz_arena_examples_labelled_dev(agz_arena* a, const uint8_t** labelled) {
+  AGZ_REQUIRE(a && labelled, AGZ_E_INVALID, "bad argument");
+  *labelled = a->d.ex_labelled;
+  return AGZ_OK;
+}
+
+int agz_arena_random_moves(agz_arena* a, const int32_t* n_moves, uint64_t seed) {
+  AGZ_REQUIRE(a && n_moves, AGZ_E_INVALID, "agz_arena_random_moves: NULL argument");
+  AGZ_REQUIRE(!a->in_move, AGZ_E_STATE, "agz_arena_random_moves: a search is in progress");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  hipStream_t s = a->ctx->stream;
+  if (!a->d_forced) AGZ_HIP_TRY(hipMalloc(&a->d_forced, (size_t)a->G * sizeof(int32_t)));
+  if (!a->d_remaining) AGZ_HIP_TRY(hipMalloc(&a->d_remaining, (size_t)a->G * sizeof(int32_t)));
+  int most = 0;
+  for (int g = 0; g < a->G; g++) {
+    AGZ_REQUIRE(n_moves[g] >= 0, AGZ_E_INVALID, "agz_arena_random_moves: n_moves[%d] = %d", g, n_moves[g]);
+    most = std::max(most, n_moves[g]);
+  }
+  AGZ_HIP_TRY(hipMemcpyAsync(a->d_remaining, n_moves, (size_t)a->G * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));   // `n_moves` is the caller's buffer
+  for (int i = 0; i < most; i++) {
+    hipLaunchKernelGGL(k_random_pick, dim3(a->G), dim3(64), 0, s, a->d, a->gc, a->d_remaining, (unsigned long long)seed, a->d_forced);
+    hipLaunchKernelGGL(k_end_move, dim3(a->G), dim3(64), 0, s, a->d, a->gc, a->mc, 0, 0, (const int32_t*)a->d_forced, 0);
+  }
+  AGZ_HIP_TRY(hipGetLastError());
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  a->moves_done += most;
+  return AGZ_OK;
+}
+
+// ---- game.State of one game written from the host: what SetGame hands to a tree (tree.go:120-124) ------------------------
+int agz_arena_set_state(agz_arena* a, int g, const agz_state* st) {
+  AGZ_REQUIRE(a && st && g >= 0 && g < a->G, AGZ_E_INVALID, "agz_arena_set_state: bad argument");
+  AGZ_REQUIRE(!a->in_move, AGZ_E_STATE, "agz_arena_set_state: a search is in progress");
+  AGZ_REQUIRE(st->board, AGZ_E_INVALID, "agz_arena_set_state: board is NULL");
+  const GameCfg& c = a->gc;
+  Dev& d = a->d;
+  AGZ_REQUIRE(st->to_move == AGZ_BLACK || st->to_move == AGZ_WHITE, AGZ_E_INVALID, "agz_arena_set_state: to_move %d", st->to_move);
+  AGZ_REQUIRE(st->n_moves >= 0 && st->n_moves <= c.max_moves, AGZ_E_INVALID, "agz_arena_set_state: n_moves %d outside [0, max_moves %d]", st->n_moves, c.max_moves);
+  AGZ_REQUIRE(st->n_last_moves >= 0 && st->n_last_moves <= st->n_moves && (st->n_last_moves == 0 || st->last_moves), AGZ_E_INVALID, "agz_arena_set_state: bad last_moves");
+  AGZ_REQUIRE(st->n_historical >= 0 && st->n_historical <= RING && (st->n_historical == 0 || st->historical), AGZ_E_INVALID, "agz_arena_set_state: n_historical %d outside [0, %d]", st->n_historical, RING);
+  AGZ_REQUIRE(st->n_historical <= st->n_moves, AGZ_E_INVALID, "agz_arena_set_state: more historical boards than moves");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  hipStream_t s = a->ctx->stream;
+  std::vector<int8_t> b(CELLS_PAD, 0), ring((size_t)RING * CELLS_PAD, 0);
+  for (int i = 0; i < c.cells; i++) {
+    AGZ_REQUIRE(st->board[i] >= 0 && st->board[i] <= 2, AGZ_E_INVALID, "agz_arena_set_state: board[%d] = %d", i, st->board[i]);
+    b[i] = (int8_t)st->board[i];
+  }
+  const int ply = st->n_moves;
+  // ring slot j % RING holds the board after move j (komi's post-move `historical`, DESIGN.md wq): the last n_historical boards
+  for (int q = 0; q < st->n_historical; q++) {
+    const int j = ply - st->n_historical + 1 + q;   // board after move j, oldest first
+    for (int i = 0; i < c.cells; i++) ring[(size_t)(j % RING) * CELLS_PAD + i] = (int8_t)st->historical[(size_t)q * c.cells + i];
+  }
+  std::vector<int16_t> mv(d.moves_stride, 0);
+  for (int q = 0; q < st->n_last_moves; q++) mv[ply - st->n_last_moves + q] = (int16_t)st->last_moves[q];
+  const int32_t last = st->n_last_moves > 0 ? st->last_moves[st->n_last_moves - 1] : AGZ_PASS;   // LastMove() of an empty history is Pass
+  int32_t pc = 0;   // the arena's consecutive-pass count (arena.go:99-103)
+  for (int q = st->n_last_moves - 1; q >= 0 && st->last_moves[q] == AGZ_PASS; q--) pc++;
+  const int32_t i32[7] = {st->to_move, ply, st->passes, pc, 0, AGZ_NONE, last};
+  int32_t* dst[7] = {d.to_move, d.ply, d.passes, d.pass_count, d.ended, d.winner, d.last_move};
+  AGZ_HIP_TRY(hipMemcpyAsync(d.board + (size_t)g * CELLS_PAD, b.data(), CELLS_PAD, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(d.ring + (size_t)g * RING * CELLS_PAD, ring.data(), ring.size(), hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(d.moves + (size_t)g * d.moves_stride, mv.data(), mv.size() * sizeof(int16_t), hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(d.amoves + (size_t)g * d.moves_stride, mv.data(), mv.size() * sizeof(int16_t), hipMemcpyHostToDevice, s));
+  for (int i = 0; i < 7; i++) AGZ_HIP_TRY(hipMemcpyAsync(dst[i] + g, &i32[i], 4, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(d.n_amoves + g, &ply, 4, hipMemcpyHostToDevice, s));
+  const int32_t hist_from = ply - st->n_last_moves;
+  AGZ_HIP_TRY(hipMemcpyAsync(d.hist_from + g, &hist_from, 4, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(d.cap_b + g, &st->captures_black, 4, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(d.cap_w + g, &st->captures_white, 4, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(d.zhash + g, &st->hash, 4, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));   // the staging vectors and *st are the caller's / locals
+  return AGZ_OK;
+}
+
+}  // extern "C"
+
+// ---- mcts.MCTS as a single-tree handle (mcts/tree.go:80-142, mcts/search.go:92-164): a one-game arena whose agent A owns THE tree ----
+struct agz_mcts {
+  agz_arena* arena = nullptr;
+  bool have_game = false;
+};
+
+namespace agz {
+// Policies (tree.go:128-142) of the game currently set: counts of cachedPolicies[{hash, a}] for a in [0, A], normalised (NaN when none)
+__global__ __launch_bounds__(64) void k_policies(Dev d, GameCfg c, int t, float* out) {
+  __shared__ int8_t board[CELLS_PAD];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < c.cells; i += WAVE) board[i] = d.board[i];   // game 0
+  __syncthreads();
+  const uint32_t hash = c.go_like ? d.zhash[0] : fnv_board(c, board);
+  const int pcn = d.pc_n[t];
+  float tot = 0.f;
+  for (int q = 0; q < pcn; q++) {
+    const int mv = d.pc_move[(size_t)t * d.moves_stride + q];
+    if (d.pc_hash[(size_t)t * d.moves_stride + q] == hash && mv >= 0 && mv <= c.A) tot += 1.f;
+  }
+  for (int a = lane; a <= c.A; a += WAVE) {
+    float cnt = 0.f;
+    for (int q = 0; q < pcn; q++)
+      if (d.pc_hash[(size_t)t * d.moves_stride + q] == hash && d.pc_move[(size_t)t * d.moves_stride + q] == a) cnt += 1.f;
+    out[a] = __fdiv_rn(cnt, tot);   // 0/0 = NaN, as the reference's retVal[i] /= sum
+  }
+}
+}  // namespace agz
+
+extern "C" {
+
+int agz_mcts_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_conf* conf, uint64_t seed, int max_nodes, agz_mcts** out) {
+  AGZ_REQUIRE(out, AGZ_E_INVALID, "agz_mcts_create: NULL argument");
+  agz_arena* ar = nullptr;
+  int r = agz_arena_create(ctx, game, conf, 1, seed, max_nodes, &ar);
+  if (r != AGZ_OK) return r;
+  agz_mcts* m = new agz_mcts();
+  m->arena = ar;
+  *out = m;
+  return AGZ_OK;
+}
+
+void agz_mcts_destroy(agz_mcts* m) {
+  if (!m) return;
+  agz_arena_destroy(m->arena);
+  delete m;
+}
+
+int agz_mcts_set_inferencer(agz_mcts* m, int kind, agz_net* net) {
+  AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
+  int r = agz_arena_set_inferencer(m->arena, 0, kind, net);
+  if (r != AGZ_OK) return r;
+  return agz_arena_set_inferencer(m->arena, 1, kind, net);   // agent B's tree is never searched; same inferencer keeps one NN batch
+}
+
+int agz_mcts_set_parallel(agz_mcts* m, int lanes) {
+  AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
+  return agz_arena_set_parallel(m->arena, lanes);
+}
+
+int agz_mcts_set_game(agz_mcts* m, const agz_state* st) {
+  AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
+  int r = agz_arena_set_state(m->arena, 0, st);
+  if (r == AGZ_OK) m->have_game = true;
+  return r;
+}
+
+int agz_mcts_search(agz_mcts* m, int player, int32_t* best) {
+  AGZ_REQUIRE(m && best, AGZ_E_INVALID, "agz_mcts_search: NULL argument");
+  AGZ_REQUIRE(player == AGZ_BLACK || player == AGZ_WHITE, AGZ_E_INVALID, "agz_mcts_search: player %d", player);
+  agz_arena* a = m->arena;
+  AGZ_REQUIRE(!a->in_move, AGZ_E_STATE, "agz_mcts_search: a search is in progress");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  hipStream_t s = a->ctx->stream;
+  // t.current.SetToMove(player) (search.go:95); the tree of this handle is agent A's: A holds the colour that searches
+  const int32_t tm = player, ab = player == AGZ_BLACK ? 1 : 0, zero = 0;
+  AGZ_HIP_TRY(hipMemcpyAsync(a->d.to_move, &tm, 4, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(a->d.a_is_black, &ab, 4, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(a->d.ended, &zero, 4, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  a->a_is_black[0] = (uint8_t)ab;
+  int r = agz_arena_begin_move(a);
+  if (r != AGZ_OK) return r;
+  r = agz_arena_simulate(a, a->mc.Budget);
+  if (r != AGZ_OK) { a->in_move = false; return r; }
+  {
+    ProfScope ps(a->ctx, AGZ_PROF_MOVE);
+    hipLaunchKernelGGL(k_end_move, dim3(1), dim3(64), 0, s, a->d, a->gc, a->mc, 0, 0, (const int32_t*)nullptr, 1);
+  }
+  a->in_move = false;
+  AGZ_HIP_TRY(hipGetLastError());
+  int32_t out[2] = {0, 0};
+  unsigned long long full = 0;
+  AGZ_HIP_TRY(hipMemcpyAsync(&out[0], a->d.best_out, 4, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(&full, a->d.counters + CNT_FULL, 8, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  *best = out[0];
+  AGZ_REQUIRE(full == 0, AGZ_E_TREE_FULL, "agz_mcts_search: the node pool overflowed (max_nodes too small); the move is the best of the truncated search");
+  return AGZ_OK;
+}
+
+int agz_mcts_policies(agz_mcts* m, float* policy, int cap) {
+  AGZ_REQUIRE(m && policy, AGZ_E_INVALID, "agz_mcts_policies: NULL argument");
+  agz_arena* a = m->arena;
+  const int n = a->gc.A + 1;
+  AGZ_REQUIRE(cap >= n, AGZ_E_INVALID, "agz_mcts_policies: buffer of %d floats, need %d", cap, n);
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  hipStream_t s = a->ctx->stream;
+  float* dp = nullptr;
+  AGZ_HIP_TRY(hipMalloc(&dp, (size_t)n * sizeof(float)));
+  hipLaunchKernelGGL(k_policies, dim3(1), dim3(64), 0, s, a->d, a->gc, 0, dp);
+  hipError_t e = hipMemcpyAsync(policy, dp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(dp);
+  AGZ_HIP_TRY(e);
+  return AGZ_OK;
+}
+
+int agz_mcts_root_children(agz_mcts* m, int32_t* moves, uint32_t* visits, float* black_scores, float* priors, int cap, int* n) {
+  AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
+  return agz_arena_root_children(m->arena, 0, 0, moves, visits, black_scores, priors, cap, n);
+}
+
+int agz_mcts_nodes(agz_mcts* m, int* n_nodes) {
+  AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
+  return agz_arena_tree_nodes(m->arena, 0, 0, n_nodes);
+}
+
+int agz_mcts_get_stats(agz_mcts* m, agz_arena_stats* out) {
+  AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
+  return agz_arena_get_stats(m->arena, out);
+}
+
+int agz_mcts_reset(agz_mcts* m) {
+  AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
+  agz_arena* a = m->arena;
+  AGZ_REQUIRE(!a->in_move, AGZ_E_STATE, "agz_mcts_reset: a search is in progress");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  hipStream_t s = a->ctx->stream;
+  const int32_t zero = 0;
+  for (int t = 0; t < 2; t++) {
+    int32_t* f[7] = {a->d.n_nodes, a->d.cur_pool, a->d.has_root, a->d.has_prev, a->d.prev_ply, a->d.stalled, a->d.pc_n};
+    for (int i = 0; i < 7; i++) AGZ_HIP_TRY(hipMemcpyAsync(f[i] + t, &zero, 4, hipMemcpyHostToDevice, s));
+    AGZ_HIP_TRY(hipMemcpyAsync(a->d.overflow + t, &zero, 4, hipMemcpyHostToDevice, s));
+  }
+  AGZ_HIP_TRY(hipMemsetAsync(a->d.counters, 0, CNT_N * sizeof(unsigned long long), s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
   return AGZ_OK;
 }
 

@@ -71,6 +71,7 @@ struct Dev {
   int16_t* amoves;        // [G][max_moves + 4]   the ARENA's move list: every `best`, including a Resign and a Pass the game
                           //                      ignored (mnk/komi Apply of a pass is a no-op) — arena.go:125, agz_arena_get_history
   int32_t* n_amoves;      // [G]
+  int32_t* hist_from;     // [G] earliest ply whose move is known in `moves` (0 for games played here; agz_arena_set_state may know fewer)
   const int32_t* ztable;  // [2*cells] zobrist keys
   // ---- trees
   float* prior;           // [T][2][cap]   P(s,a)  (Node.score)
@@ -112,13 +113,15 @@ struct Dev {
   int32_t* ex_game;       // [ex_cap]
   int32_t* ex_prev;       // [ex_cap] previous example of the same game (-1 terminates)
   int32_t* ex_last;       // [G]
+  uint8_t* ex_labelled;   // [ex_cap] 1 once the game of this example has ended and Value holds +1/-1/0 (arena.go:146-155)
   int32_t* ex_count;      // [1]
+  int32_t* best_out;      // [G] result of a search-only end of move (agz_mcts_search: Search does not Apply, search.go:151-163)
   int ex_cap;
   int moves_stride;       // max_moves + 4
 };
 
 enum { CNT_SIMS = 0, CNT_NONNULL = 1, CNT_EVALS = 2, CNT_MOVES = 3, CNT_GAMES = 4, CNT_EXAMPLES = 5, CNT_FULL = 6, CNT_A_WINS = 7, CNT_B_WINS = 8,
-       CNT_DRAWS = 9, CNT_ILLEGAL = 10, CNT_N = 12 };
+       CNT_DRAWS = 9, CNT_ILLEGAL = 10, CNT_DROPPED = 11, CNT_PATH = 12, CNT_KIDS = 13, CNT_N = 16 };
 
 // per-agent inferencer description passed to the expand kernel
 struct InfDesc {

@@ -8,7 +8,7 @@
 #include <algorithm>
 #include <numeric>
 
-#include "common.hpp"
+#include "comm.hpp"
 
 namespace agz {
 
@@ -168,10 +168,20 @@ int agz_examples_append_arena(agz_examples* e, agz_arena* arena) {
   std::vector<int32_t> game(cnt);
   r = agz_arena_get_examples(arena, nullptr, nullptr, nullptr, game.data(), cnt, &cnt);
   if (r != AGZ_OK) return r;
-  std::vector<int32_t> order(cnt);
-  std::iota(order.begin(), order.end(), 0);
+  // only examples of FINISHED games carry a training target: SelfPlay returns after the game has ended and been labelled
+  // (arena.go:140-155); rows of games still running (agz_arena_selfplay stopped at its target, agz_arena_play(n_moves > 0))
+  // hold the raw mover colour and stay in the arena until their game ends
+  const uint8_t* lab_dev = nullptr;
+  r = agz_arena_examples_labelled_dev(arena, &lab_dev);
+  if (r != AGZ_OK) return r;
+  std::vector<uint8_t> lab(cnt);
+  AGZ_HIP_TRY(hipMemcpy(lab.data(), lab_dev, (size_t)cnt, hipMemcpyDeviceToHost));
+  std::vector<int32_t> order;
+  order.reserve(cnt);
+  for (int i = 0; i < cnt; i++) if (lab[i]) order.push_back(i);
+  if (order.empty()) return AGZ_OK;
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return game[a] < game[b]; });
-  return e->append(p, q, v, (size_t)cnt, &order);
+  return e->append(p, q, v, order.size(), &order);
 }
 
 int agz_examples_append_dev(agz_examples* e, const float* planes_dev, const float* policy_dev, const float* value_dev, int64_t n) {
@@ -192,6 +202,63 @@ int agz_examples_append_host(agz_examples* e, const float* planes, const float* 
   AGZ_HIP_TRY(hipMemcpyAsync(e->value + e->n, value, (size_t)n * 4, hipMemcpyHostToDevice, s));
   AGZ_HIP_TRY(hipStreamSynchronize(s));
   e->n += (size_t)n;
+  return AGZ_OK;
+}
+
+// The exchange step of the path (agogo.go:118-133 runs on the union of all self-play examples): every rank
+// contributes the rows its store holds; afterwards every rank's store holds the rows of rank 0, 1, ... in that order.
+// Counts are exchanged first (one 8-byte all-gather), then n broadcasts — rank r the root of its own rows, received straight
+// into their final position in a new store — are issued as ONE group: no padding, no staging copy, all xGMI links busy at once.
+int agz_examples_allgather(agz_comm* c, agz_examples* e) {
+  AGZ_REQUIRE(c && e, AGZ_E_INVALID, "agz_examples_allgather: NULL argument");
+  AGZ_REQUIRE(c->ctx == e->ctx, AGZ_E_INVALID, "agz_examples_allgather: the communicator and the example set belong to different contexts");
+  const agz::Rccl* R = agz::rccl();
+  if (!R) return AGZ_E_UNSUPPORTED;
+  AGZ_HIP_TRY(hipSetDevice(e->ctx->device));
+  hipStream_t s = e->ctx->stream;
+  const int n = c->size;
+  unsigned long long* d_cnt = nullptr;
+  AGZ_HIP_TRY(hipMalloc(&d_cnt, (size_t)(n + 1) * 8));
+  std::vector<unsigned long long> cnt(n, 0);
+  const unsigned long long mine = (unsigned long long)e->n;
+  hipError_t he = hipMemcpyAsync(d_cnt + n, &mine, 8, hipMemcpyHostToDevice, s);
+  ncclResult_t nr = he == hipSuccess ? R->AllGather(d_cnt + n, d_cnt, 1, ncclUint64, c->comm, s) : ncclSuccess;
+  if (he == hipSuccess && nr == ncclSuccess) he = hipMemcpyAsync(cnt.data(), d_cnt, (size_t)n * 8, hipMemcpyDeviceToHost, s);
+  if (he == hipSuccess && nr == ncclSuccess) he = hipStreamSynchronize(s);
+  hipFree(d_cnt);
+  AGZ_REQUIRE(nr == ncclSuccess, AGZ_E_HIP, "agz_examples_allgather: count exchange -> %s", R->GetErrorString(nr));
+  AGZ_HIP_TRY(he);
+  size_t total = 0;
+  for (int r = 0; r < n; r++) total += (size_t)cnt[r];
+  if (n == 1 || total == 0) return AGZ_OK;          // one rank: the store already is the union
+  float *p = nullptr, *q = nullptr, *v = nullptr;
+  if (hipMalloc(&p, total * e->xs * 4) != hipSuccess || hipMalloc(&q, total * e->A1 * 4) != hipSuccess || hipMalloc(&v, total * 4) != hipSuccess) {
+    hipFree(p); hipFree(q); hipFree(v);
+    agz::set_error("agz_examples_allgather: out of device memory for %zu gathered examples", total);
+    return AGZ_E_NOMEM;
+  }
+  nr = R->GroupStart();
+  size_t off = 0;
+  for (int r = 0; r < n && nr == ncclSuccess; r++) {
+    const size_t k = (size_t)cnt[r];
+    if (k) {
+      const bool root = r == c->rank;
+      nr = R->Broadcast(root ? e->planes : p + off * e->xs, p + off * e->xs, k * e->xs, ncclFloat32, r, c->comm, s);
+      if (nr == ncclSuccess) nr = R->Broadcast(root ? e->policy : q + off * e->A1, q + off * e->A1, k * (size_t)e->A1, ncclFloat32, r, c->comm, s);
+      if (nr == ncclSuccess) nr = R->Broadcast(root ? e->value : v + off, v + off, k, ncclFloat32, r, c->comm, s);
+    }
+    off += k;
+  }
+  ncclResult_t ge = R->GroupEnd();
+  if (nr == ncclSuccess) nr = ge;
+  he = hipStreamSynchronize(s);
+  if (nr != ncclSuccess || he != hipSuccess) {
+    hipFree(p); hipFree(q); hipFree(v);
+    AGZ_REQUIRE(nr == ncclSuccess, AGZ_E_HIP, "agz_examples_allgather: broadcast group -> %s", R->GetErrorString(nr));
+    AGZ_HIP_TRY(he);
+  }
+  hipFree(e->planes); hipFree(e->policy); hipFree(e->value);
+  e->planes = p; e->policy = q; e->value = v; e->n = total; e->cap = total;
   return AGZ_OK;
 }
 

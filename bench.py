@@ -13,6 +13,12 @@ One STEP = one simulation for every game on the GPU: PUCT descent + Apply in eac
 ONE batched 512-leaf pass through the conv tower and heads, expansion + backup (k_expand).  Every
 `Budget` steps the move is finished (bestMove, Apply, tree re-root) and the next one prepared — inside the
 timed region.  value = non-null simulations (search.go:175-178) completed by all ranks / max-over-ranks time.
+
+Steady state: before anything is timed every game gets its OWN position — u ~ U[0, floor(0.6*H*W)] uniformly
+random legal moves (agz_arena_random_moves, deterministic per slot) — one whole move is searched (its wall time
+is the measured 19x19 moves/s in `extra`), and the next move's tree is grown to Budget - warmup - steps/2 simulations, so the
+timed steps run on deep trees and straddle a move boundary: end_move (bestMove, example record, Apply, Ended) and begin_move
+(tree re-root, prepareRoot) of all games are inside the timed region.
 """
 import argparse
 import json
@@ -52,11 +58,11 @@ def standard_bn_init(net):
             net.set_param(i, np.zeros(n, np.float32))
 
 
-def cpu_baseline(size, K, L, budget_s=10.0, max_threads=32):
+def cpu_baseline(size, K, L, budget_s=12.0, max_threads=64):
     """The oracle (CPU restatement of the reference algorithm: per-leaf inference, sequential pipeline) timed on the box's
     host cores, on a bounded sample of the same workload: T threads (one independent 19x19 game each, the way the
-    reference would use its cores: SURVEY 8(d)), one move of a few simulations per game.  The oracle calls run outside the
-    GIL (ctypes), so the threads are real."""
+    reference would use its cores: SURVEY 8(d)), each from its own random mid-game opening (the same generator as the GPU
+    leg), one move of a few simulations per game.  The oracle calls run outside the GIL (ctypes), so the threads are real."""
     import threading
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -74,13 +80,16 @@ def cpu_baseline(size, K, L, budget_s=10.0, max_threads=32):
     net.infer(x)
     t_eval = time.perf_counter() - t0
     sims = int(max(2, min(64, budget_s / max(t_eval, 1e-3) - 1)))
-    T = max(1, min(max_threads, os.cpu_count() or 1))
+    T = max(1, min(max_threads, (os.cpu_count() or 2) // 2))
     arenas = []
+    rng = np.random.default_rng(1337)
     for g in range(T):
         ar = O.Arena(O.WQ, size, size, komi=7.5, enc=O.ENC_WQ, Budget=sims, seed=1337 + g)
         ar.set_inferencer(0, O.INF_NET, net)     # the net is read-only during inference
         ar.set_inferencer(1, O.INF_NET, net)
         ar.begin(g % 2)
+        for _ in range(int(rng.integers(0, int(0.6 * size * size) + 1))):
+            ar.random_move(1337, g)
         arenas.append(ar)
     threads = [threading.Thread(target=ar.step, args=(True,)) for ar in arenas]
     t0 = time.perf_counter()
@@ -89,12 +98,12 @@ def cpu_baseline(size, K, L, budget_s=10.0, max_threads=32):
     for th in threads:
         th.join()
     dt = time.perf_counter() - t0
-    stats = [ar.tree_stats(0 if g % 2 == 1 else 1) for g, ar in enumerate(arenas)]   # the agent holding Black searched
-    playouts = sum(st["playouts"] for st in stats)
-    evals = sum(st["nn_evals"] for st in stats)
+    stats = [[ar.tree_stats(a) for a in (0, 1)] for ar in arenas]   # exactly one of the two agents searched
+    playouts = sum(st["playouts"] for pair in stats for st in pair)
+    evals = sum(st["nn_evals"] for pair in stats for st in pair)
     return {"value": playouts / dt, "unit": "sims/s", "cores": T, "kind": "port",
-            "sample": "oracle (C++ restatement, per-leaf inference): %d threads x (1 game, 1 move, %d sims + root eval) = %d evals "
-                      "in %.1f s on %d of the box's %d host cores" % (T, sims, evals, dt, T, os.cpu_count() or 0),
+            "sample": "oracle (C++ restatement, per-leaf inference): %d threads x (1 game from a random mid-game opening, 1 move, %d sims "
+                      "+ root eval) = %d evals in %.1f s on %d of the box's %d host cores" % (T, sims, evals, dt, T, os.cpu_count() or 0),
             "evals_per_s": evals / dt, "per_core_sims_per_s": playouts / dt / T}
 
 
@@ -124,6 +133,69 @@ def games_leg(ctx, compute="bf16x3"):
     return out
 
 
+def go9_leg(ctx, compute="bf16x3"):
+    """Measured games/s on BASELINE config #3: 9x9 Go (wq), K=128, 10 blocks, 512 concurrent games, 400 sims/move,
+    continuous self-play until 512 complete games have finished (bf16x3: the measured-fastest arithmetic on this shape)."""
+    K, L, G, sims = 128, 10, 512, 400
+    net = A.Net(ctx, K, L, 2 * K, 9, 9, 18, 82, bn_mode=capi.BN_IDENTITY)
+    net.init_random(1337)
+    standard_bn_init(net)
+    net.commit()
+    net.set_compute_mode(MODES[compute])
+    arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337, Budget=sims)
+    arena.set_inferencer(0, capi.INF_NET, net)
+    arena.set_inferencer(1, capi.INF_NET, net)
+    arena.reset()
+    ctx.sync()
+    t0 = time.perf_counter()
+    arena.selfplay(G, record=True)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    st = arena.stats()
+    out = {"workload": "config #3: 9x9 Go (wq, komi 7.5), K=128, 10 blocks, 512 concurrent games, 400 sims/move, continuous self-play, "
+                       "complete games", "compute": compute,
+           "games_finished": st["games_finished"], "seconds": dt, "games_per_s": st["games_finished"] / dt,
+           "sims_per_s": st["sims_nonnull"] / dt, "moves_per_s": st["moves_played"] / dt,
+           "moves_per_game": st["moves_played"] / max(st["games_finished"], 1), "examples": st["examples"],
+           "examples_dropped": st["examples_dropped"], "tree_full": st["tree_full"]}
+    arena.close()
+    net.close()
+    return out
+
+
+def latency_leg(ctx, lanes_list=(1, 16), moves=3, sims=1600):
+    """BASELINE config #5 (tournament Agent.Search): 19x19, K=256, 40 blocks, 1600 sims/move, ONE tree through the single-tree
+    boundary's engine; p50 wall time of a move (begin_move + simulate(Budget) + end_move + sync) on a short sample, sequential
+    search (lanes 1, the declared semantics) and in lane rounds."""
+    S, K, L = 19, 256, 40
+    net = A.Net(ctx, K, L, 2 * K, S, S, 18, S * S + 1, BatchSize=1, bn_mode=capi.BN_IDENTITY)
+    net.init_random(1337)
+    standard_bn_init(net)
+    net.commit()
+    out = {"workload": "config #5: 19x19 wq Agent.Search, K=256, 40 blocks, %d sims/move, one tree" % sims, "moves_timed": moves}
+    for lanes in lanes_list:
+        arena = A.Arena(ctx, capi.GAME_WQ, S, S, komi=7.5, encoder=capi.ENC_WQ, n_games=1, seed=7, Budget=sims)
+        arena.set_inferencer(0, capi.INF_NET, net)
+        arena.set_inferencer(1, capi.INF_NET, net)
+        arena.set_parallel(lanes)
+        arena.reset()
+        arena.random_moves(np.array([60], np.int32), 1337)
+        lat = []
+        for mv in range(moves + 1):
+            t0 = time.perf_counter()
+            arena.begin_move()
+            arena.simulate(sims)
+            arena.end_move(False)
+            ctx.sync()
+            if mv >= 1:
+                lat.append(time.perf_counter() - t0)
+        out["lanes_%d" % lanes] = {"p50_move_s": float(np.percentile(lat, 50)), "max_move_s": float(np.max(lat)),
+                                   "ms_per_sim": float(np.median(lat)) / sims * 1e3}
+        arena.close()
+    net.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +215,11 @@ def main():
                          "3-way bf16 split on the bf16 matrix pipe (fp32-grade), f32 = v_mfma_f32_32x32x2_f32, fp16x2 = "
                          "range-managed 2-way fp16 split (3 MFMAs per product; opt-in fast mode)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the short comparison legs in the other compute modes")
+    ap.add_argument("--empty-boards", action="store_true", help="round-1 workload: all games start from the empty board")
+    ap.add_argument("--no-pregrow", action="store_true",
+                    help="skip the untimed whole move and the tree pre-growth (the timed steps then run on the first simulations of a move)")
+    ap.add_argument("--no-latency-leg", action="store_true", help="skip the configs[4] single-tree move-latency sample")
+    ap.add_argument("--no-go9-leg", action="store_true", help="skip the measured 9x9 games/s leg (configs[2])")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="debug: all ranks use GPU 0 and gloo collectives (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -172,6 +249,12 @@ def main():
     arena.set_inferencer(0, capi.INF_NET, nets[0])
     arena.set_inferencer(1, capi.INF_NET, nets[-1])
     arena.reset()
+    # every game on its own position: u ~ U[0, floor(0.6*H*W)] random legal moves, deterministic per (rank, slot)
+    open_rng = np.random.default_rng(1337 + rank)
+    n_open = open_rng.integers(0, int(0.6 * S * S) + 1, size=G).astype(np.int32)
+    if args.empty_boards:
+        n_open[:] = 0
+    arena.random_moves(n_open, 1337 + 7919 * rank)
 
     sims_in_move = [0]
 
@@ -190,6 +273,26 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # (1) one whole move, untimed for `value` but measured: begin_move + Budget simulations + end_move for all games
+    full_move = None
+    if not args.no_pregrow:
+        fence()
+        m0 = arena.stats()
+        g0 = time.perf_counter()
+        for _ in range(args.budget):
+            step()
+        fence()
+        d_move = time.perf_counter() - g0
+        m1 = arena.stats()
+        full_move = {"seconds": d_move, "moves": m1["moves_played"] - m0["moves_played"],
+                     "moves_per_s": (m1["moves_played"] - m0["moves_played"]) / d_move,
+                     "sims_per_s": (m1["sims_nonnull"] - m0["sims_nonnull"]) / d_move,
+                     "note": "one whole move of all %d games from their random openings: begin_move (re-root/prepareRoot) + %d "
+                             "simulations + end_move (bestMove, example, Apply, Ended); measured, not derived" % (G, args.budget)}
+        # (2) grow the next move's trees so that the timed steps straddle the following move boundary
+        pre = max(0, args.budget - args.warmup - args.steps // 2)
+        for _ in range(pre):
+            step()
     for _ in range(args.warmup):
         step()
     fence()
@@ -349,9 +452,19 @@ def main():
                          "flops_per_launch": flops_launch, "avg_launch_ms": launch_ms,
                          "launches": n_launch},
             "extra": {"nn_evals_per_s": evals_sum / t_max, "iterations_per_s": iters_sum / t_max,
-                      "moves_per_s": sims_sum / t_max / args.budget,
-                      "games_per_s_est": sims_sum / t_max / args.budget / (2 * hw),
-                      "games_per_s_note": "moves/s divided by the 2*M*N move cap (random-init nets almost never pass twice)",
+                      "timed_region": {"moves_finished": st1["moves_played"] - st0["moves_played"],
+                                       "move_boundaries": prof["move"]["launches"] // 2,
+                                       "mean_path_nodes": (st1["path_nodes"] - st0["path_nodes"]) / max(1, sims_all),
+                                       "mean_children_per_select": (st1["children_read"] - st0["children_read"]) / max(1, (st1["path_nodes"] - st0["path_nodes"]) - sims_all),
+                                       "opening_moves_mean": float(n_open.mean()), "opening_moves_max": int(n_open.max()),
+                                       "tree_sims_before_timing": (0 if args.no_pregrow else max(0, args.budget - args.warmup - args.steps // 2)) + args.warmup,
+                                       "note": "every game on its own random opening; trees pre-grown so the timed steps cross a move "
+                                               "boundary (end_move + begin_move of all games inside the timed region)"},
+                      "full_move_19x19": full_move,
+                      "games_per_s_19x19": ({"value": full_move["moves_per_s"] / (2 * hw), "moves_per_game": 2 * hw,
+                                             "note": "MEASURED moves/s of a whole move (full_move_19x19) / the 2*M*N move cap: random-init nets "
+                                                     "almost never pass twice, so a game runs to the cap; complete 19x19 games are not played in "
+                                                     "this bench (one game of 722 moves x 800 sims takes ~3.5 h)"} if full_move else None),
                       "end_to_end_tflops": evals_sum * flops_eval / t_max / 1e12,
                       "end_to_end_frac_of_fp32_peak": evals_sum * flops_eval / t_max / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
                       "kernel_classes": prof, "examples_allgather_ms": gather_ms, "compute": args.compute,
@@ -363,6 +476,16 @@ def main():
                 out["extra"]["games_leg"] = games_leg(ctx, args.compute)
             except Exception as e:
                 out["extra"]["games_leg"] = {"error": repr(e)}
+        if world == 1 and not args.no_go9_leg:
+            try:
+                out["extra"]["go9_leg"] = go9_leg(ctx)
+            except Exception as e:
+                out["extra"]["go9_leg"] = {"error": repr(e)}
+        if world == 1 and not args.no_latency_leg:
+            try:
+                out["extra"]["latency_leg"] = latency_leg(ctx)
+            except Exception as e:
+                out["extra"]["latency_leg"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(S, K, L)

@@ -57,22 +57,7 @@ void agz_ctx_destroy(agz_ctx* ctx);
 int agz_ctx_sync(agz_ctx* ctx);
 /* raw hipStream_t the ctx launches on (for callers that want to record their own events) */
 void* agz_ctx_stream(agz_ctx* ctx);
-/* kernel-class timers: HIP events recorded on the ctx stream around every launch of a class.
- * enable=1 starts collecting (and clears), enable=0 stops.  agz_ctx_prof_read syncs and returns
- * the launch count and summed milliseconds of one class. */
-#define AGZ_PROF_CONV 0    /* fused dual-branch 3x3 conv block launches (the dominant kernel) */
-#define AGZ_PROF_HEADS 1   /* policy/value head kernel */
-#define AGZ_PROF_SELECT 2  /* MCTS select/apply/encode */
-#define AGZ_PROF_EXPAND 3  /* MCTS expand/backup */
-#define AGZ_PROF_MOVE 4    /* root update / best move / apply */
-#define AGZ_PROF_CONV_INIT 5 /* the single F->K input conv */
-#define AGZ_PROF_WINO_IN 6   /* AGZ_COMPUTE_WINO: input transform; these three nest inside AGZ_PROF_CONV (the whole block) */
-#define AGZ_PROF_WINO_GEMM 7 /* the 36 transform-domain GEMMs (the dominant kernel of that mode) */
-#define AGZ_PROF_WINO_OUT 8  /* output transform + block epilogue */
-#define AGZ_PROF_NCLASS 9
-int agz_ctx_prof_enable(agz_ctx* ctx, int enable);
-int agz_ctx_prof_read(agz_ctx* ctx, int klass, int64_t* launches, double* total_ms);
-
+/* (kernel-class timers and test diagnostics: include/agz_debug.h — not part of the drop-in surface) */
 /* ---- dual network ------------------------------------------------------------------------- */
 /* Fields 1:1 with dual.Config (dualnet/config.go:4-16); bn_* pin the BatchNorm inference
  * semantics that live in un-vendored gorgonia. */
@@ -148,10 +133,6 @@ int agz_net_set_latency_mode(agz_net* net, int on);
                             * 25 %), else BF16X3 where the split kernels apply, else F32_MFMA */
 #define AGZ_COMPUTE_FORCE 0x100 /* OR-ed in: take the split kernel even below the chip-filling threshold (tests) */
 int agz_net_set_compute_mode(agz_net* net, int mode);
-/* Diagnostics (tests): the first two stages of the Winograd path on host data.  x [B][H][W][C] (NHWC, C % 16 == 0),
- * w [N][C][3][3]  ->  V [36][T][C] = Bt d B of every 6x6 input tile, M [36][T][N] = V[pos] * (G g Gt)[pos],
- * T = B * ceil(H/4) * ceil(W/4) tiles in (board, tile row, tile column) order, pos = 6 * xi + nu. */
-int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, int W, int C, int N, float* V, float* M);
 /* Checkpoint of the learnables in Model() order (+ BN statistics).  The reference gob-encodes G.Values
  * (AZ.Save / Dual.GobEncode, agogo.go:175-209, dualnet/dual.go:180-206); gob is Go-only, so this is a documented
  * flat format: "AGZNET01", agz_net_conf, n_params, then per parameter {uint64 n, float32[n]}, then per BN op
@@ -288,6 +269,28 @@ int agz_arena_end_move(agz_arena* arena, int record);
  * games in lockstep plies: keep all unfinished games at the same ply. */
 #define AGZ_NO_MOVE (-32768)
 int agz_arena_apply_moves(agz_arena* arena, const int32_t* moves);
+/* BUILD EXTENSION — synthetic openings for benchmarks and parity tests ("for each slot play u uniformly-random
+ * legal moves from the empty board"): game g plays n_moves[g] uniformly drawn legal board moves for alternating colours (Pass
+ * only when the mover has no legal board move and the game has a pass), like agz_arena_apply_moves: no search, no example,
+ * trees re-root at their next search.  Deterministic in (seed, g, moves played so far); restated by the oracle. */
+int agz_arena_random_moves(agz_arena* arena, const int32_t* n_moves, uint64_t seed);
+
+/* A game.State as the host holds it (game/state.go:125-156) — what mcts.SetGame / Agent.Search receive (tree.go:120-124,
+ * agent.go:77-80) when the position was NOT reached by playing on the device. */
+typedef struct agz_state {
+  const int32_t* board;       /* [m*n] game.Colour per cell (State.Board()) */
+  int32_t to_move;            /* State.ToMove() */
+  int32_t n_moves;            /* moves applied so far = len(history) (State.MoveNumber(); c4 reports 1 regardless) */
+  int32_t passes;             /* State.Passes(): consecutive passes so far (wq) */
+  uint32_t hash;              /* State.Hash() for komi/wq (the running zobrist hash; mnk/c4 hash the board itself) */
+  float captures_black, captures_white; /* komi: stones captured by each side (State.Score) */
+  const int32_t* last_moves;  /* the most recent n_last_moves moves, oldest first (LastMove()/UndoLastMove() chain): tree reuse */
+  int32_t n_last_moves;       /* replays them (search.go:424-469); with fewer than the plies since the previous Search a fresh root is built */
+  const int32_t* historical;  /* [n_historical][m*n] boards after the last n_historical moves, oldest first (State.Historical): */
+  int32_t n_historical;       /* WQEncoder's history planes (encoding_helper.go:29-68), at most 8 */
+} agz_state;
+/* overwrite game g of an arena with a host-side state (trees are kept: the next search re-roots or starts fresh) */
+int agz_arena_set_state(agz_arena* arena, int g, const agz_state* st);
 
 /* --- observers (all copy into caller buffers) --- */
 typedef struct agz_arena_stats {
@@ -300,7 +303,9 @@ typedef struct agz_arena_stats {
   int32_t n_games;
   int32_t n_active;      /* games not yet ended */
   int32_t tree_full;     /* number of trees that overflowed their pool */
-  int32_t reserved;
+  int32_t examples_dropped; /* examples lost because the arena's example buffer was full (clear or append them earlier) */
+  int64_t path_nodes;    /* measurement: nodes on the selected paths, summed over simulations (mean depth = / sims_total) */
+  int64_t children_read; /* measurement: children Node.Select read, summed over simulations (12 B each, node.go:170-237) */
 } agz_arena_stats;
 int agz_arena_get_stats(agz_arena* arena, agz_arena_stats* out);
 /* Agent statistics since the last reset (Agent.Wins / Loss / Draw, arena.go:156-171; Statistics, statistics.go):
@@ -330,6 +335,36 @@ int agz_arena_get_examples(agz_arena* arena, float* planes, float* policy, float
 int agz_arena_clear_examples(agz_arena* arena);
 /* device pointers of the example buffers (for an RCCL all-gather before dual.Train) */
 int agz_arena_examples_dev(agz_arena* arena, float** planes, float** policy, float** value, int* n);
+/* device flags [n]: 1 = the example's game has ended and Value is the +1/-1/0 label; 0 = still the raw mover colour */
+int agz_arena_examples_labelled_dev(agz_arena* arena, const uint8_t** labelled);
+
+/* ---- mcts.MCTS: ONE search tree on a caller-owned game.State (mcts/tree.go:80-142, mcts/search.go:92-164) ----------------
+ * The drop-in for `mcts.New(game, conf, nn)` behind Agent.Search (agent.go:77-80): the host keeps its game.State, hands the
+ * position over with agz_mcts_set_game and applies the returned move itself.  The tree persists between searches and is
+ * re-rooted (updateRoot, search.go:424-500) when the new position follows from the previous one by agz_state.last_moves. */
+typedef struct agz_mcts agz_mcts;
+/* mcts.New (tree.go:80-103).  max_nodes: node-pool capacity (0 = default from Budget and the action space). */
+int agz_mcts_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_conf* conf, uint64_t seed, int max_nodes, agz_mcts** out);
+void agz_mcts_destroy(agz_mcts* mcts);
+/* the `nn Inferencer` argument of mcts.New (mcts/mcts.go:15-18): AGZ_INF_* (net may be NULL for the synthetic kinds) */
+int agz_mcts_set_inferencer(agz_mcts* mcts, int kind, agz_net* net);
+/* lanes per round (BUILD EXTENSION, see agz_arena_set_parallel) */
+int agz_mcts_set_parallel(agz_mcts* mcts, int lanes);
+/* (*MCTS).SetGame (tree.go:120-124) */
+int agz_mcts_set_game(agz_mcts* mcts, const agz_state* st);
+/* (*MCTS).Search(player) (search.go:92-164): SetToMove(player), updateRoot, prepareRoot, Budget simulations, bestMove,
+ * prev = current.Clone(), cachedPolicies[{hash, best}]++.  The game is NOT advanced.  *best: cell / column, AGZ_PASS, AGZ_RESIGN. */
+int agz_mcts_search(agz_mcts* mcts, int player, int32_t* best);
+/* (*MCTS).Policies(current game) (tree.go:128-142): [ActionSpace+1] floats; NaN when no search of this position is cached */
+int agz_mcts_policies(agz_mcts* mcts, float* policy, int cap);
+/* root children after a search in bestMove's order (the debugging surface of (*MCTS).Children, unsafe_safe.go:15) */
+int agz_mcts_root_children(agz_mcts* mcts, int32_t* moves, uint32_t* visits, float* black_scores, float* priors, int cap, int* n);
+/* (*MCTS).Nodes() (tree.go:126): nodes of the live tree (the reference counts its arena slots, freed ones included) */
+int agz_mcts_nodes(agz_mcts* mcts, int* n_nodes);
+int agz_mcts_get_stats(agz_mcts* mcts, agz_arena_stats* out);
+/* (*MCTS).Reset() (tree.go:249-276) completed to what Arena.Play does with it — Reset then a fresh mcts.New
+ * (arena.go:140-141,175-176; the reference's Reset alone leaves an unusable tree): empty tree, empty policy cache */
+int agz_mcts_reset(agz_mcts* mcts);
 
 /* ---- example sets on device: what sits between AZ.SelfPlay and dual.Train ----------------------
  * []agogo.Example (datatypes.go:41-46) as three device arrays: Board [n, F*H*W], Policy [n, PolicyLen], Value [n].
@@ -364,6 +399,28 @@ int agz_examples_tensors_dev(agz_examples* ex, float** Xs, float** Policies, flo
 int agz_examples_get_tensors(agz_examples* ex, float* Xs, float* Policies, float* Values);
 /* RotateBoard (encoding_helper.go:80-107) on `count` boards of m x n floats (host buffers; runs on the device). */
 int agz_rotate_boards(agz_ctx* ctx, const float* boards, int count, int m, int n, float* out);
+
+/* ---- multi-GPU exchange over RCCL / xGMI -------------------------------------------------------------------
+ * Self-play games shard across GPUs with NO data-path collective (one agz_ctx + arena set per GPU).  The path has exactly
+ * two exchange steps, both around dual.Train: the union of all ranks' examples (agogo.go:110-133: `ex` holds every episode
+ * before shuffleExamples / prepareExamples) and the gradient sum of the data-parallel training step (dualnet/meta.go:33-40).
+ * librccl is loaded on first use; without it these calls fail with AGZ_E_UNSUPPORTED (no single-GPU fallback). */
+typedef struct agz_comm agz_comm;
+#define AGZ_COMM_ID_BYTES 128
+/* one process driving n GPUs (a Go host: one goroutine locked to an OS thread per ctx): ncclCommInitAll over the ctxs' devices;
+ * comms[i] belongs to ctxs[i].  Collective calls on the n communicators must be issued concurrently, one thread per ctx. */
+int agz_comm_init_all(agz_ctx* const* ctxs, int n, agz_comm** comms);
+/* one process per GPU: rank 0 makes the id (agz_comm_unique_id), the host ships its AGZ_COMM_ID_BYTES bytes to the other ranks */
+int agz_comm_unique_id(void* id128);
+int agz_comm_init_rank(agz_ctx* ctx, int n_ranks, int rank, const void* id128, agz_comm** out);
+void agz_comm_destroy(agz_comm* comm);
+int agz_comm_rank(const agz_comm* comm);
+int agz_comm_size(const agz_comm* comm);
+/* every rank's example set becomes the union of all ranks' sets, in rank order (each rank's rows keep their order) */
+int agz_examples_allgather(agz_comm* comm, agz_examples* ex);
+/* sum the flat gradient buffer of the trainer over all ranks (one collective per step, in place, asynchronous on the ctx
+ * stream); follow with agz_trainer_apply(t, lr, 1.0f / agz_comm_size(comm)) */
+int agz_trainer_allreduce(agz_comm* comm, agz_trainer* t);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,38 @@
+/*
+ * agz_debug.h — measurement and test hooks of libagz.so.  NOT part of the drop-in surface (include/agz.h): nothing on the
+ * reference side binds these; bench.py reads the kernel-class timers, the parity tests read single Winograd stages.
+ */
+#ifndef AGZ_DEBUG_H
+#define AGZ_DEBUG_H
+
+#include "agz.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* kernel-class timers: HIP events recorded on the ctx stream around every launch of a class.
+ * enable=1 starts collecting (and clears), enable=0 stops.  agz_ctx_prof_read syncs and returns
+ * the launch count and summed milliseconds of one class. */
+#define AGZ_PROF_CONV 0    /* fused dual-branch 3x3 conv block launches (the dominant kernel) */
+#define AGZ_PROF_HEADS 1   /* policy/value head kernel */
+#define AGZ_PROF_SELECT 2  /* MCTS select/apply/encode */
+#define AGZ_PROF_EXPAND 3  /* MCTS expand/backup */
+#define AGZ_PROF_MOVE 4    /* root update / best move / apply */
+#define AGZ_PROF_CONV_INIT 5 /* the single F->K input conv */
+#define AGZ_PROF_WINO_IN 6   /* AGZ_COMPUTE_WINO: input transform; these three nest inside AGZ_PROF_CONV (the whole block) */
+#define AGZ_PROF_WINO_GEMM 7 /* the 36 transform-domain GEMMs (the dominant kernel of that mode) */
+#define AGZ_PROF_WINO_OUT 8  /* output transform + block epilogue */
+#define AGZ_PROF_NCLASS 9
+int agz_ctx_prof_enable(agz_ctx* ctx, int enable);
+int agz_ctx_prof_read(agz_ctx* ctx, int klass, int64_t* launches, double* total_ms);
+
+/* Diagnostics (tests): the first two stages of the Winograd path on host data.  x [B][H][W][C] (NHWC, C % 16 == 0),
+ * w [N][C][3][3]  ->  V [36][T][C] = Bt d B of every 6x6 input tile, M [36][T][N] = V[pos] * (G g Gt)[pos],
+ * T = B * ceil(H/4) * ceil(W/4) tiles in (board, tile row, tile column) order, pos = 6 * xi + nu. */
+int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, int W, int C, int N, float* V, float* M);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGZ_DEBUG_H */

@@ -310,6 +310,90 @@ int orc_example_root_children(void* h, int32_t* moves, uint32_t* visits, float* 
 int64_t orc_example_nn_evals(void* h) { return ((ExampleBox*)h)->t->nnEvals; }
 
 
+// ---- one mcts.MCTS on a caller-owned game.State: mcts.New / SetGame / Search / Policies / Nodes (tree.go:80-142, search.go:92) ----
+struct MctsBox {
+  std::unique_ptr<Inferencer> inf;
+  std::unique_ptr<MCTS> t;
+  int enc;
+};
+void* orc_mcts_new(void* game, int enc, float PUCT, int M, int N, int RandomCount, int Budget, uint32_t RandomMinVisits,
+                   float RandomTemperature, int DumbPass, float ResignPercentage, int PassPreference, int lanes, int inf_kind,
+                   int policy_len, uint64_t seed) {
+  StatePtr g = *(StatePtr*)game;
+  MCTSConfig c;
+  c.PUCT = PUCT; c.M = M; c.N = N; c.RandomCount = RandomCount; c.Budget = Budget; c.RandomMinVisits = RandomMinVisits;
+  c.RandomTemperature = RandomTemperature; c.DumbPass = DumbPass != 0; c.ResignPercentage = ResignPercentage;
+  c.PassPreference = PassPreference; c.Parallel = lanes < 1 ? 1 : lanes;
+  if (!c.IsValid()) return nullptr;
+  auto* b = new MctsBox();
+  b->enc = enc;
+  int A = g->ActionSpace();
+  switch (inf_kind) {
+    case 2: b->inf.reset(new ScriptNN()); break;
+    case 3: b->inf.reset(new HashNN(policy_len > 0 ? policy_len : A + 1)); break;
+    case 4: b->inf.reset(new UniformNN(policy_len > 0 ? policy_len : 25)); break;
+    default: b->inf.reset(new DummyInferer(A, 0)); break;
+  }
+  b->t.reset(new MCTS(g, c, b->inf.get(), seed));
+  return b;
+}
+void orc_mcts_free(void* h) { delete (MctsBox*)h; }
+void orc_mcts_set_callback(void* h, infer_cb cb, void* user, int policy_len) {
+  MctsBox* b = (MctsBox*)h;
+  b->inf.reset(new CallbackInferencer(cb, user, make_enc(b->enc), policy_len));
+  b->t->nn = b->inf.get();
+}
+// SetGame (tree.go:120-124): the tree searches a CLONE of the caller's state (Agent.Search hands over its own game object,
+// agent.go:77-80; the device copies the state too), so the caller's handle stays untouched by Search's SetToMove
+void orc_mcts_set_game(void* h, void* game) { ((MctsBox*)h)->t->SetGame((*(StatePtr*)game)->Clone()); }
+int orc_mcts_search(void* h, int player) { return ((MctsBox*)h)->t->Search(player); }
+int orc_mcts_policies(void* h, void* game, float* out, int cap) {
+  std::vector<float> p = ((MctsBox*)h)->t->Policies(**(StatePtr*)game);
+  for (size_t i = 0; i < p.size() && (int)i < cap; i++) out[i] = p[i];
+  return (int)p.size();
+}
+int orc_mcts_root_children(void* h, int32_t* moves, uint32_t* visits, float* bscores, float* priors, int cap) {
+  MCTS* t = ((MctsBox*)h)->t.get();
+  if (t->root == nilNode) return 0;
+  const auto& kids = t->children.at(t->root);
+  int n = (int)kids.size();
+  for (int i = 0; i < n && i < cap; i++) {
+    const Node& nd = t->N(kids[i]);
+    moves[i] = nd.move; visits[i] = nd.visits; bscores[i] = nd.blackScores; priors[i] = nd.score;
+  }
+  return n;
+}
+// out: [nnEvals, playouts, lastIter, nodes]
+void orc_mcts_stats(void* h, int64_t* out) {
+  MCTS* t = ((MctsBox*)h)->t.get();
+  out[0] = t->nnEvals; out[1] = t->playouts; out[2] = t->lastIter; out[3] = t->Nodes();
+}
+
+// Synthetic opening ("u uniformly-random legal moves from the empty board"): the arena's player to move plays
+// the (z mod n_legal)-th legal board move in ascending cell order, z = SplitMix64 finaliser of (seed, game index, arena move
+// count); no legal board move: Pass where the game has one, else nothing.  Restated by k_random_pick (engine.hip).
+// returns the move played, or -32768 when none was
+int orc_arena_random_move(void* h, uint64_t seed, int g) {
+  Arena* a = ((ArenaBox*)h)->arena.get();
+  if (a->ended) return -32768;
+  Player pl = a->currentPlayer->player;
+  int A = a->game->ActionSpace();
+  std::vector<int> legal;
+  for (int i = 0; i < A; i++) if (a->game->Check(PlayerMove{pl, (Single)i})) legal.push_back(i);
+  Single mv;
+  if (legal.empty()) {
+    if (!a->game->Check(PlayerMove{pl, Pass})) return -32768;
+    mv = Pass;
+  } else {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(g + 1) + 0xD1B54A32D192ED03ull * (uint64_t)(a->moves.size() + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    mv = (Single)legal[(size_t)(z % (uint64_t)legal.size())];
+  }
+  a->Step(false, &mv);
+  return mv;
+}
+
+
 // ---- dual.Train restatement (oracle/train.hpp) ----
 static DualConfig mkconf(int K, int L, int FC, int BatchSize, int W, int H, int F, int A, float eps) {
   DualConfig c; c.K = K; c.SharedLayers = L; c.FC = FC; c.BatchSize = BatchSize; c.Width = W; c.Height = H; c.Features = F;

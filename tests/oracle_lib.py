@@ -111,6 +111,15 @@ def lib():
     sig("orc_example_turn", i32, vp, pi, pi)
     sig("orc_example_root_children", i32, vp, pi, C.POINTER(C.c_uint32), pf, i32)
     sig("orc_example_nn_evals", i64, vp)
+    sig("orc_arena_random_move", i32, vp, u64, i32)
+    sig("orc_mcts_new", vp, vp, i32, f32, i32, i32, i32, i32, u32, f32, i32, f32, i32, i32, i32, i32, u64)
+    sig("orc_mcts_free", None, vp)
+    sig("orc_mcts_set_callback", None, vp, INFER_CB, vp, i32)
+    sig("orc_mcts_set_game", None, vp, vp)
+    sig("orc_mcts_search", i32, vp, i32)
+    sig("orc_mcts_policies", i32, vp, vp, pf, i32)
+    sig("orc_mcts_root_children", i32, vp, pi, C.POINTER(C.c_uint32), pf, pf, i32)
+    sig("orc_mcts_stats", None, vp, C.POINTER(C.c_int64))
     _LIB = L
     return L
 
@@ -312,6 +321,10 @@ class Arena:
         """externally chosen move for the player to move: 1 continues, 0 game over, -1 illegal (nothing applied)"""
         return lib().orc_arena_apply_move(self.h, int(move))
 
+    def random_move(self, seed, g):
+        """synthetic opening move of game index g (orc_arena_random_move); returns the move or NO_MOVE (-32768)"""
+        return lib().orc_arena_random_move(self.h, seed, g)
+
     def step(self, record=True):
         return bool(lib().orc_arena_step(self.h, int(record)))
 
@@ -361,6 +374,66 @@ class Arena:
             lib().orc_arena_get_example(self.h, i, _pf(B[i]), _pf(P[i]), C.byref(v))
             V[i] = v.value
         return B, P, V
+
+
+class Mcts:
+    """mcts.MCTS on a caller-owned Game (mcts.New / SetGame / Search / Policies, tree.go:80-142, search.go:92)."""
+
+    def __init__(self, game, enc=ENC_TWOPLANE, PUCT=1.0, M=None, N=None, RandomCount=0, Budget=100, RandomMinVisits=0,
+                 RandomTemperature=0.0, DumbPass=True, ResignPercentage=0.0, PassPreference=0, lanes=1, inf=INF_HASH,
+                 policy_len=0, seed=1337):
+        self.game = game
+        self.cells = game.cells
+        self.h = lib().orc_mcts_new(game.h, enc, PUCT, M if M is not None else game.m, N if N is not None else game.n,
+                                    RandomCount, Budget, RandomMinVisits, RandomTemperature, int(DumbPass), ResignPercentage,
+                                    PassPreference, lanes, inf, policy_len, seed)
+        assert self.h
+        self._keep = []
+
+    def __del__(self):
+        try:
+            lib().orc_mcts_free(self.h)
+        except Exception:
+            pass
+
+    def set_callback(self, fn, policy_len):
+        def tramp(planes, n, policy, plen, value, user):
+            x = np.ctypeslib.as_array(planes, shape=(n,)).copy()
+            p, v = fn(x)
+            out = np.ctypeslib.as_array(policy, shape=(plen,))
+            out[:] = np.asarray(p, dtype=np.float32)[:plen]
+            value[0] = float(v)
+
+        cb = INFER_CB(tramp)
+        self._keep.append(cb)
+        lib().orc_mcts_set_callback(self.h, cb, None, policy_len)
+
+    def set_game(self, game):
+        self.game = game
+        lib().orc_mcts_set_game(self.h, game.h)
+
+    def search(self, player):
+        return lib().orc_mcts_search(self.h, int(player))
+
+    def policies(self, game=None):
+        g = game if game is not None else self.game
+        out = np.zeros(self.cells + 2, np.float32)
+        n = lib().orc_mcts_policies(self.h, g.h, _pf(out), out.size)
+        return out[:n].copy()
+
+    def root_children(self):
+        cap = self.cells + 2
+        mv = np.zeros(cap, np.int32)
+        vis = np.zeros(cap, np.uint32)
+        bs = np.zeros(cap, np.float32)
+        pr = np.zeros(cap, np.float32)
+        n = lib().orc_mcts_root_children(self.h, _pi(mv), vis.ctypes.data_as(C.POINTER(C.c_uint32)), _pf(bs), _pf(pr), cap)
+        return mv[:n].copy(), vis[:n].copy(), bs[:n].copy(), pr[:n].copy()
+
+    def stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        lib().orc_mcts_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_int64)))
+        return dict(nn_evals=int(out[0]), playouts=int(out[1]), iters=int(out[2]), nodes=int(out[3]))
 
 
 class ExampleSearch:

@@ -12,10 +12,20 @@ from agogo_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "agz.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(agz_[a-z0-9_]+)\s*\(", src)))
+def declared_symbols(headers=("agz.h", "agz_debug.h")):
+    """every function include/*.h declares (the drop-in surface agz.h and the measurement/test hooks agz_debug.h)"""
+    names = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(agz_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
+
+
+def test_debug_hooks_stay_out_of_the_product_header():
+    prod = declared_symbols(("agz.h",))
+    assert not [n for n in prod if "prof" in n or "wino_stages" in n], "test/measurement hooks belong in agz_debug.h"
+    assert "agz_mcts_search" in prod and "agz_comm_init_all" in prod
 
 
 def test_library_exports_every_declared_symbol():
@@ -41,7 +51,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.NetConf) == 40
     assert C.sizeof(capi.GameConf) == 28
     assert C.sizeof(capi.MctsConf) == 40
-    assert C.sizeof(capi.ArenaStats) == 64
+    assert C.sizeof(capi.ArenaStats) == 80
     assert C.sizeof(capi.GameState) == 40
 
 

@@ -1,0 +1,255 @@
+"""GPU: parity AT the configurations and IN the arithmetic bench.py measures.
+
+(i)   the headline network (19x19, K=256, 20 dual blocks, 512 boards — BASELINE configs[3] per GPU) in every compute mode the
+      bench can select, on mid-game positions (random legal prefixes of 0..216 moves), against the oracle on a sample of
+      boards: same tolerance as every other network test, max |delta| printed;
+(ii)  the engine under that arithmetic at the headline shape: 512 concurrent 19x19 games on their own positions, device trees
+      bit-exact against oracle trees fed the same network outputs;
+(iii) BASELINE configs[4] (tournament Agent.Search: 40 blocks, ONE tree): the batch-1 network against the oracle, and a
+      one-tree search — sequential and in lane rounds of 8 / 16 — bit-exact against the oracle's search.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import agogo_amd as A
+import oracle_lib as O
+from agogo_amd import capi
+from test_net_gpu import POL_ATOL, POL_RTOL, VAL_ATOL
+
+pytestmark = pytest.mark.gpu
+
+S, K, F, ASPACE = 19, 256, 18, 362
+MODES = {"wino": capi.COMPUTE_WINO, "bf16x3": capi.COMPUTE_BF16X3, "fp16x2": capi.COMPUTE_FP16X2, "f32": capi.COMPUTE_F32_MFMA}
+if hasattr(capi, "COMPUTE_WINO_H2"):
+    MODES["wino_h2"] = capi.COMPUTE_WINO_H2
+
+
+def std_net(ctx, L, seed=1337):
+    net = A.Net(ctx, K, L, 2 * K, S, S, F, ASPACE, bn_mode=capi.BN_IDENTITY)
+    net.init_random(seed)
+    for i in range(net.num_params()):
+        name, n = net.param_info(i)
+        if name.endswith("_gamma"):
+            net.set_param(i, np.ones(n, np.float32))
+        elif name.endswith("_beta"):
+            net.set_param(i, np.zeros(n, np.float32))
+    net.commit()
+    return net
+
+
+def oracle_twin(net, L):
+    o = O.Net(K, L, 2 * K, S, S, F, ASPACE, bn_mode=2)
+    for i in range(net.num_params()):
+        o.set_param(i, net.get_param(i))
+    return o
+
+
+def midgame_planes(B, seed=1337, most=216):
+    """WQEncoder planes of B positions: slot b plays u ~ U[0, most] uniformly random legal moves from the empty board
+    (SURVEY 8(d)), through the oracle's game rules"""
+    out = np.zeros((B, F, S, S), np.float32)
+    depth = np.zeros(B, np.int32)
+    for b in range(B):
+        rng = np.random.default_rng(seed + b)
+        u = int(rng.integers(0, most + 1))
+        g = O.Game(O.WQ, S, S, 0, 7.5)
+        player = O.BLACK
+        g.set_to_move(player)
+        for _ in range(u):
+            empt = np.where(g.board() == 0)[0]
+            mv = -1
+            for cand in rng.permutation(empt)[:8]:
+                if g.check(player, int(cand)):
+                    mv = int(cand)
+                    break
+            if mv < 0:
+                break
+            g.apply(player, mv)
+            player = O.WHITE if player == O.BLACK else O.BLACK
+            g.set_to_move(player)
+            depth[b] += 1
+        out[b] = g.encode(O.ENC_WQ).reshape(F, S, S)
+    return out, depth
+
+
+_CACHE = {}
+
+
+def cached_midgame(B):
+    if B not in _CACHE:
+        _CACHE[B] = midgame_planes(B)
+    return _CACHE[B]
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_headline_network_l20_b512_midgame_boards_vs_oracle(ctx, mode):
+    """(i) K=256, L=20, B=512, 19x19 in the measured arithmetic: four boards (an early, two middle, the deepest position)
+    against the oracle, every board of the batch finite and normalised, and the batch agrees with the default fp32-MFMA
+    arithmetic within the same tolerance."""
+    L, B = 20, 512
+    net = std_net(ctx, L)
+    x, depth = cached_midgame(B)
+    assert depth.max() >= 150 and len(np.unique(depth)) > 100
+    p32, v32 = net.infer(x)
+    net.set_compute_mode(MODES[mode])
+    pol, val = net.infer(x)
+    assert np.all(np.isfinite(pol)) and np.all(np.isfinite(val))
+    np.testing.assert_allclose(pol.sum(axis=1), 1.0, atol=2e-5)
+    if mode != "f32":
+        assert not np.array_equal(pol, p32), "the mode under test did not change the arithmetic"
+    np.testing.assert_allclose(pol, p32, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(val, v32, atol=VAL_ATOL)
+    pick = [int(np.argmin(depth)), int(np.argsort(depth)[B // 3]), int(np.argsort(depth)[2 * B // 3]), int(np.argmax(depth))]
+    key = ("oracle", L, tuple(pick))
+    if key not in _CACHE:   # the same net (seed 1337) and boards in every mode: the oracle runs once
+        _CACHE[key] = oracle_twin(net, L).infer(x[pick])
+    po, vo = _CACHE[key]
+    dp, dv = np.abs(pol[pick] - po).max(), np.abs(val[pick] - vo).max()
+    print("\n[headline parity] mode=%s boards=%s (moves played %s): max|dpolicy|=%.3g max|dvalue|=%.3g (tolerance %g + %g*|p|, %g)"
+          % (mode, pick, depth[pick].tolist(), dp, dv, POL_ATOL, POL_RTOL, VAL_ATOL))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "headline_parity.txt"), "a") as f:
+            f.write("mode=%s boards=%s depth=%s max_dpolicy=%.4g max_dvalue=%.4g max_policy=%.4g\n"
+                    % (mode, pick, depth[pick].tolist(), dp, dv, float(po.max())))
+    np.testing.assert_allclose(pol[pick], po, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(val[pick], vo, atol=VAL_ATOL)
+    assert np.abs(pol[pick[0]] - pol[pick[3]]).max() > 1e-6
+    # batch independence of the measured arithmetic: a board evaluated as 512 copies of itself gives the same bits
+    rep, vrep = net.infer(np.repeat(x[pick[2]:pick[2] + 1], B, axis=0))
+    np.testing.assert_array_equal(rep[0], pol[pick[2]])
+    np.testing.assert_array_equal(rep[B - 1], pol[pick[2]])
+    np.testing.assert_array_equal(vrep[7], val[pick[2]])
+    net.close()
+
+
+@pytest.mark.parametrize("mode", ["wino"] + (["wino_h2"] if "wino_h2" in MODES else []))
+def test_headline_engine_512_games_on_their_own_positions_bit_exact(ctx, mode):
+    """(ii) configs[3] per GPU as bench.py runs it: 512 games, each on its own random opening, the measured arithmetic,
+    two searched plies; games 0, 1 and 311 against oracle arenas whose inferencer is the same GPU network evaluated as a
+    512-row batch of the one board (same kernels; the arithmetic is batch independent bit for bit, test above)."""
+    L, G, budget, seed = 20, 512, 12, 1337
+    net = std_net(ctx, L)
+    net.set_compute_mode(MODES[mode])
+    dev = A.Arena(ctx, capi.GAME_WQ, S, S, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=seed, Budget=budget, max_nodes=12000)
+    dev.set_inferencer(0, capi.INF_NET, net)
+    dev.set_inferencer(1, capi.INF_NET, net)
+    ab = np.array([(g % 2) == 0 for g in range(G)], dtype=np.uint8)
+    dev.reset(ab)
+    rng = np.random.default_rng(seed)
+    n_moves = rng.integers(0, 217, size=G).astype(np.int32)
+    n_moves[0], n_moves[1] = 216, 40
+    dev.random_moves(n_moves, seed)
+    assert len({dev.game(g)[0].tobytes() for g in range(0, G, 16)}) == G // 16
+
+    def cb(planes):
+        p, v = net.infer(np.repeat(planes.reshape(1, F, S, S), G, axis=0))
+        return p[0], float(v[0])
+
+    watch = (0, 1, 311)
+    orcs = {}
+    for g in watch:
+        o = O.Arena(O.WQ, S, S, 0, 7.5, enc=O.ENC_WQ, Budget=budget)
+        o.set_callback(0, cb, ASPACE)
+        o.set_callback(1, cb, ASPACE)
+        o.begin(int(ab[g]))
+        for _ in range(int(n_moves[g])):
+            o.random_move(seed, g)
+        np.testing.assert_array_equal(dev.history(g), o.history())
+        orcs[g] = o
+    for ply in range(2):
+        dev.begin_move()
+        dev.simulate(budget)
+        dev.end_move(True)
+        for g, o in orcs.items():
+            _, st0 = o.state()
+            agent = 0 if ((st0["to_move"] == O.BLACK) == bool(ab[g])) else 1
+            o.step(True)
+            omv, ovis, obs, _ = o.root_children(agent)
+            dmv, dvis, dbs, _ = dev.root_children(g, agent)
+            np.testing.assert_array_equal(dmv, omv, err_msg="game %d ply %d" % (g, ply))
+            np.testing.assert_array_equal(dvis, ovis, err_msg="game %d ply %d" % (g, ply))
+            np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+            assert dev.history(g)[-1] == o.history()[-1]
+    st = dev.stats()
+    assert st["tree_full"] == 0 and st["sims_total"] == 2 * G * budget
+    dev.close()
+    net.close()
+
+
+def test_config4_l40_network_batch1_and_lane_batches_vs_oracle(ctx):
+    """(iii-a) BASELINE configs[4] tower (40 blocks): batch 1 (the split-K latency regime), batches 8 and 16 (one lane round)
+    against the oracle on three mid-game boards."""
+    L = 40
+    net = std_net(ctx, L)
+    x, depth = cached_midgame(512)
+    pick = [int(np.argmax(depth)), int(np.argsort(depth)[256]), int(np.argmin(depth))]
+    onet = oracle_twin(net, L)
+    po, vo = onet.infer(x[pick])
+    worst = 0.0
+    for i, b in enumerate(pick):
+        p1, v1 = net.infer(x[b:b + 1])
+        np.testing.assert_allclose(p1[0], po[i], atol=POL_ATOL, rtol=POL_RTOL)
+        np.testing.assert_allclose(v1[0], vo[i], atol=VAL_ATOL)
+        worst = max(worst, float(np.abs(p1[0] - po[i]).max()))
+    for nb in (8, 16):
+        idx = (pick * 6)[:nb]
+        pb, vb = net.infer(x[idx])
+        for r, b in enumerate(idx):
+            i = pick.index(b)
+            np.testing.assert_allclose(pb[r], po[i], atol=POL_ATOL, rtol=POL_RTOL)
+            np.testing.assert_allclose(vb[r], vo[i], atol=VAL_ATOL)
+    print("\n[configs[4] parity] L=40 batch 1/8/16 vs oracle: max|dpolicy| = %.3g" % worst)
+    net.close()
+
+
+@pytest.mark.parametrize("lanes,latency", [(1, True), (8, True), (16, False)])
+def test_config4_one_tree_search_bit_exact_vs_oracle(ctx, lanes, latency):
+    """(iii-b) one tree, 40 blocks, sequential and lane rounds of 8 / 16, from a mid-game position through the single-tree
+    boundary (agz_mcts_*): device tree == oracle tree given the same network outputs.  Batches 1 and 8 both take the latency
+    regime (bit-identical per board); a 16-lane round leaves it, so that case pins one regime for every batch size."""
+    L, budget = 40, 48
+    net = std_net(ctx, L)
+    net.set_latency_mode(latency)
+    g = O.Game(O.WQ, S, S, 0, 7.5)
+    rng = np.random.default_rng(11)
+    player, moves, boards = O.BLACK, [], []
+    g.set_to_move(player)
+    for _ in range(90):
+        empt = np.where(g.board() == 0)[0]
+        mv = next(int(c) for c in rng.permutation(empt) if g.check(player, int(c)))
+        g.apply(player, mv)
+        moves.append(mv)
+        boards.append(g.board())
+        player = O.WHITE if player == O.BLACK else O.BLACK
+        g.set_to_move(player)
+    dev = A.Mcts(ctx, capi.GAME_WQ, S, S, 0, 7.5, encoder=capi.ENC_WQ, Budget=budget)
+    dev.set_inferencer(capi.INF_NET, net)
+    dev.set_parallel(lanes)
+    orc = O.Mcts(g, enc=O.ENC_WQ, Budget=budget, lanes=lanes)
+
+    def cb(planes):
+        p, v = net.infer(planes.reshape(1, F, S, S))
+        return p[0], float(v[0])
+
+    orc.set_callback(cb, ASPACE)
+    for turn in range(2):
+        dev.set_game(board=g.board(), to_move=player, n_moves=len(moves), passes=0, hash=g.hash(), last_moves=moves,
+                     historical=np.array(boards[-8:], np.int32))
+        orc.set_game(g)
+        bd, bo = dev.search(player), orc.search(player)
+        assert bd == bo
+        omv, ovis, obs, _ = orc.root_children()
+        dmv, dvis, dbs, _ = dev.root_children()
+        np.testing.assert_array_equal(dmv, omv)
+        np.testing.assert_array_equal(dvis, ovis)
+        np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+        g.apply(player, bd)
+        moves.append(bd)
+        boards.append(g.board())
+        player = O.WHITE if player == O.BLACK else O.BLACK
+        g.set_to_move(player)
+    dev.close()
+    net.close()

@@ -1,0 +1,201 @@
+"""GPU: the single-tree boundary — agz_mcts_* == mcts.New / SetGame(arbitrary state) / Search(player) / Policies / Reset /
+Nodes (mcts/tree.go:80-142, mcts/search.go:92-164), what Agent.Search(g) calls on a caller-owned game.State
+(agent.go:77-80).  The host (here: the oracle's Game) owns the position; the device tree is bit-exact against the oracle's
+MCTS driven through the same call sequence, including tree reuse across SetGame calls (updateRoot, search.go:424-500)."""
+import numpy as np
+import pytest
+
+import agogo_amd as A
+import oracle_lib as O
+from agogo_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+KINDS = {"mnk": (capi.GAME_MNK, O.MNK), "c4": (capi.GAME_C4, O.C4), "komi": (capi.GAME_KOMI, O.KOMI), "wq": (capi.GAME_WQ, O.WQ)}
+
+
+class Host:
+    """the caller's game.State with what agz_state wants from it: moves so far and the boards after them"""
+
+    def __init__(self, okind, m, n, k, komi):
+        self.g = O.Game(okind, m, n, k, komi)
+        self.g.set_to_move(O.BLACK)
+        self.moves, self.boards = [], []
+        self.caps = [0.0, 0.0]
+
+    def legal(self, player):
+        A_ = self.g.n if self.g.kind == O.C4 else self.g.cells
+        return [i for i in range(A_) if self.g.check(player, i)]
+
+    def apply(self, player, mv):
+        self.g.apply(player, mv)
+        self.moves.append(mv)
+        self.boards.append(self.g.board())
+        self.g.set_to_move(O.WHITE if player == O.BLACK else O.BLACK)
+
+    def state_kw(self, n_last=None, n_hist=8):
+        n = len(self.moves)
+        n_last = n if n_last is None else min(n_last, n)
+        n_hist = min(n_hist, n)
+        return dict(board=self.g.board(), to_move=self.g.to_move(), n_moves=n, passes=max(self.g.passes(), 0), hash=self.g.hash(),
+                    captures=(self.g.score(O.BLACK), self.g.score(O.WHITE)) if self.g.kind == O.KOMI else (0.0, 0.0),
+                    last_moves=self.moves[n - n_last:], historical=np.array(self.boards[n - n_hist:], np.int32))
+
+
+def compare(dev, orc, host, what):
+    omv, ovis, obs, opr = orc.root_children()
+    dmv, dvis, dbs, dpr = dev.root_children()
+    np.testing.assert_array_equal(dmv, omv, err_msg=what)
+    np.testing.assert_array_equal(dvis, ovis, err_msg=what)
+    np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32), err_msg=what)
+    np.testing.assert_array_equal(dpr.view(np.uint32), opr.view(np.uint32), err_msg=what)
+    po, pd = orc.policies(host.g), dev.policies()
+    np.testing.assert_array_equal(np.isnan(pd), np.isnan(po), err_msg=what)
+    np.testing.assert_array_equal(np.nan_to_num(pd), np.nan_to_num(po), err_msg=what)
+
+
+@pytest.mark.parametrize("game,m,n,k,komi,enc,prefix,budget", [
+    ("mnk", 3, 3, 3, 0.0, 0, 2, 40),
+    ("mnk", 5, 5, 4, 0.0, 0, 7, 60),
+    ("c4", 6, 7, 4, 0.0, 0, 9, 48),
+    ("komi", 5, 5, 3, 0.0, 0, 8, 48),
+    ("wq", 5, 5, 0, 0.5, 1, 11, 48),
+    ("wq", 9, 9, 0, 7.5, 1, 30, 64),
+    ("wq", 19, 19, 0, 7.5, 1, 120, 32),
+])
+def test_search_on_an_arbitrary_midgame_state_matches_the_oracle(ctx, game, m, n, k, komi, enc, prefix, budget):
+    dk, ok = KINDS[game]
+    rng = np.random.default_rng(m * 100 + prefix)
+    host = Host(ok, m, n, k, komi)
+    player = O.BLACK
+    for _ in range(prefix):   # a position the device never saw being played
+        if host.g.ended()[0]:
+            break
+        lg = host.legal(player)
+        if not lg:
+            break
+        host.apply(player, int(rng.choice(lg)))
+        player = O.WHITE if player == O.BLACK else O.BLACK
+    if host.g.ended()[0]:
+        pytest.skip("random prefix ended the game")
+    dev = A.Mcts(ctx, dk, m, n, k, komi, encoder=enc, Budget=budget)
+    dev.set_inferencer(capi.INF_HASH)
+    orc = O.Mcts(host.g, enc=enc, Budget=budget, inf=O.INF_HASH)
+    assert np.all(np.isnan(dev.policies()) | (dev.policies() == 0)) or True
+    # three searches with the host applying the chosen move (and an opponent's random reply) in between: SetGame each time
+    for turn in range(3):
+        dev.set_game(**host.state_kw())
+        orc.set_game(host.g)
+        bd, bo = dev.search(player), orc.search(player)
+        assert bd == bo, "turn %d" % turn
+        compare(dev, orc, host, "turn %d" % turn)
+        assert dev.stats()["sims_total"] == (turn + 1) * budget
+        if bd < 0 or not host.g.check(player, bd):
+            break
+        host.apply(player, bd)
+        opp = O.WHITE if player == O.BLACK else O.BLACK
+        if host.g.ended()[0]:
+            break
+        lg = host.legal(opp)
+        if not lg:
+            break
+        host.apply(opp, int(rng.choice(lg)))
+        if host.g.ended()[0]:
+            break
+    assert dev.nodes() > 1
+
+
+def test_tree_reuse_needs_the_moves_since_the_previous_search(ctx):
+    """SetGame with the last moves: the subtree is kept (root visits carry over); without them (UndoLastMove has nothing to
+    undo, search.go:424-469 fails) a fresh root is built — still a valid search, and the oracle agrees on the first case."""
+    host = Host(O.MNK, 5, 5, 4, 0.0)
+    budget = 80
+    dev = A.Mcts(ctx, capi.GAME_MNK, 5, 5, 4, Budget=budget)
+    dev.set_inferencer(capi.INF_HASH)
+    orc = O.Mcts(host.g, Budget=budget, inf=O.INF_HASH)
+    dev.set_game(**host.state_kw())
+    orc.set_game(host.g)
+    b0 = dev.search(O.BLACK)
+    assert b0 == orc.search(O.BLACK)
+    host.apply(O.BLACK, b0)
+    host.apply(O.WHITE, host.legal(O.WHITE)[3])
+    dev.set_game(**host.state_kw())          # both moves known: re-root two plies down
+    orc.set_game(host.g)
+    assert dev.search(O.BLACK) == orc.search(O.BLACK)
+    compare(dev, orc, host, "reused")
+    _, vis_reuse, _, _ = dev.root_children()
+    dev2 = A.Mcts(ctx, capi.GAME_MNK, 5, 5, 4, Budget=budget)
+    dev2.set_inferencer(capi.INF_HASH)
+    h0 = Host(O.MNK, 5, 5, 4, 0.0)
+    dev2.set_game(**h0.state_kw())
+    dev2.search(O.BLACK)
+    dev2.set_game(**host.state_kw(n_last=0))  # same position, history withheld
+    dev2.search(O.BLACK)
+    _, vis_fresh, _, _ = dev2.root_children()
+    assert int(vis_fresh.sum()) - len(vis_fresh) == budget          # fresh root: exactly this search's playouts
+    assert int(vis_reuse.sum()) - len(vis_reuse) >= budget          # reused subtree: at least as many
+
+
+def test_reset_is_a_fresh_tree_and_argument_checks(ctx):
+    host = Host(O.MNK, 3, 3, 3, 0.0)
+    dev = A.Mcts(ctx, capi.GAME_MNK, 3, 3, 3, Budget=30)
+    dev.set_inferencer(capi.INF_HASH)
+    dev.set_game(**host.state_kw())
+    first = dev.search(O.BLACK)
+    kids1 = dev.root_children()
+    assert np.nansum(dev.policies()) == pytest.approx(1.0)
+    dev.reset()
+    assert dev.nodes() == 0 and np.all(np.isnan(dev.policies()))
+    dev.set_game(**host.state_kw())
+    assert dev.search(O.BLACK) == first
+    for a, b in zip(kids1, dev.root_children()):
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(A.AgzError, match="player"):
+        dev.search(0)
+    bad = host.state_kw()
+    bad["to_move"] = 5
+    with pytest.raises(A.AgzError, match="to_move"):
+        dev.set_game(**bad)
+    bad = host.state_kw()
+    bad["board"] = np.full(9, 7, np.int32)
+    with pytest.raises(A.AgzError, match="board"):
+        dev.set_game(**bad)
+
+
+def test_single_tree_search_with_the_hip_network(ctx):
+    """Agent.Search as the tournament uses it: one tree, the dual net as inferencer, a mid-game 9x9 position."""
+    S, K, L, F = 9, 64, 2, 18
+    net = A.Net(ctx, K, L, 2 * K, S, S, F, S * S + 1, bn_mode=capi.BN_IDENTITY)
+    net.init_random(7)
+    for i in range(net.num_params()):
+        name, cnt = net.param_info(i)
+        if name.endswith("_gamma"):
+            net.set_param(i, np.ones(cnt, np.float32))
+        elif name.endswith("_beta"):
+            net.set_param(i, np.zeros(cnt, np.float32))
+    net.commit()
+    net.set_latency_mode(False)
+    host = Host(O.WQ, S, S, 0, 7.5)
+    rng = np.random.default_rng(5)
+    player = O.BLACK
+    for _ in range(24):
+        host.apply(player, int(rng.choice(host.legal(player))))
+        player = O.WHITE if player == O.BLACK else O.BLACK
+    budget = 48
+    dev = A.Mcts(ctx, capi.GAME_WQ, S, S, 0, 7.5, encoder=capi.ENC_WQ, Budget=budget)
+    dev.set_inferencer(capi.INF_NET, net)
+    orc = O.Mcts(host.g, enc=O.ENC_WQ, Budget=budget)
+
+    def cb(planes):
+        p, v = net.infer(planes.reshape(1, F, S, S))
+        return p[0], float(v[0])
+
+    orc.set_callback(cb, S * S + 1)
+    for turn in range(2):
+        dev.set_game(**host.state_kw())
+        orc.set_game(host.g)
+        assert dev.search(player) == orc.search(player)
+        compare(dev, orc, host, "turn %d" % turn)
+        best = dev.root_children()[0][0]
+        host.apply(player, int(best) if best >= 0 else host.legal(player)[0])
+        player = O.WHITE if player == O.BLACK else O.BLACK
