@@ -16,7 +16,7 @@ GAME_MNK, GAME_C4, GAME_KOMI, GAME_WQ = 0, 1, 2, 3
 ENC_TWOPLANE, ENC_WQ = 0, 1
 INF_NET, INF_DUMMY, INF_SCRIPT, INF_HASH, INF_UNIFORM = 0, 1, 2, 3, 4
 BN_DEGENERATE_EPS, BN_RUNNING, BN_IDENTITY = 0, 1, 2
-COMPUTE_F32_MFMA, COMPUTE_BF16X3, COMPUTE_FP16X2, COMPUTE_WINO, COMPUTE_AUTO = 0, 1, 2, 3, 4
+COMPUTE_F32_MFMA, COMPUTE_BF16X3, COMPUTE_FP16X2, COMPUTE_WINO, COMPUTE_AUTO, COMPUTE_WINO_H2 = 0, 1, 2, 3, 4, 5
 COMPUTE_FORCE = 0x100
 PROF_CONV, PROF_HEADS, PROF_SELECT, PROF_EXPAND, PROF_MOVE, PROF_CONV_INIT = 0, 1, 2, 3, 4, 5
 PROF_WINO_IN, PROF_WINO_GEMM, PROF_WINO_OUT = 6, 7, 8

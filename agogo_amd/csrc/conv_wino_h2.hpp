@@ -1,0 +1,463 @@
+// Winograd F(4x4,3x3) dual block with fp16x2 products in the transform domain — AGZ_COMPUTE_WINO_H2.
+//
+// conv_wino.hpp's block spends 0.68 of its 1.07 ms in 36 GEMMs whose bf16x3 products cost six MFMAs each and whose staging
+// splits every fp32 activation into three pieces on the VALU.  Here the transform-domain operands are written ALREADY SPLIT:
+//     V = hi + lo,  hi = RN_fp16(V*s),  lo = RN_fp16(V*s - hi)          (s: a power of two per BOARD, below)
+// by the input-transform kernel — 4 bytes per element, exactly what the fp32 V took — so the GEMM's staging is a pure copy
+// (no VALU), and a product is three fp16 MFMAs (hi*hi, hi*lo, lo*hi; the dropped lo*lo is <= 2^-22 relative): half the
+// matrix instructions of the bf16x3 form, none of its split arithmetic.
+//
+// Range management.  fp16 has 5 exponent bits, so each operand is scaled by a power of two (exact):
+//   weights  U = G g Gt: per layer, max|U| * su in [2^13, 2^14)  — fixed at commit;
+//   V = Bt d B of board b: |V| <= 100 * max|d| (the rows of Bt sum to at most 10 in magnitude), so with amax_b = max |x| over
+//   the board's layer input, s_b = 2^(134 - E(amax_b)) puts every |V*s_b| below 2^15 (fp16 max 65504): overflow is impossible,
+//   and an element hi+lo carries an ABSOLUTE error <= 2^-25 in scaled units, i.e. <= 2^-38 of the largest representable |V| —
+//   far below fp32's own 2^-24 relative rounding of the accumulated sums.  amax_b is a per-board word (one atomicMax per
+//   wave in the producing kernel), so a board's result does not depend on what else is in the batch, bit for bit.
+//   M = V U comes out scaled by s_b*su and is un-scaled (exactly) after the output transform.
+//
+// Kernels per block:   wino_in_h2_kernel (x -> V2, HBM-bound) ; wino_gemm_h2[w]_kernel (MFMA/HBM) ; wino_out_h2_kernel
+// (M -> y + amax of y for the next block, HBM-bound).  Layouts: V2[pos][T][C/32][piece 2][32] fp16 (a row's K range is
+// contiguous: 128 B per 32-channel chunk, hi then lo);  U2[pos][C/32][piece 2][Ntot][32] fp16;  M[pos][T][Ntot] fp32.
+#pragma once
+// (included by net.hip INSIDE namespace agz, after conv_wino.hpp and conv_h2.hpp)
+
+struct WinoH2Args {
+  WinoArgs w;                // geometry, x, V (reinterpreted as the fp16 piece image), Mb, ep, y
+  const _Float16* U2;        // [36][C/32][2][Ntot][32]
+  const unsigned* amax_in;   // [B] max |x| of every board of this block's input (float bits)
+  unsigned* amax_out;        // [B] max of this block's output, accumulated by wino_out_h2_kernel (zeroed by the caller)
+  float w_unscale;           // 1 / su
+};
+
+// s = 2^(134 - E): |V| <= 128 * amax < 2^(E - 119)  =>  |V * s| < 2^15.   inv = 1 / s.
+__device__ __forceinline__ void wino_h2_scales(unsigned amax_bits, float* s, float* inv) {
+  int e = (int)((amax_bits >> 23) & 0xffu);
+  if (amax_bits == 0u) { *s = 1.f; *inv = 1.f; return; }
+  e = e < 30 ? 30 : (e > 230 ? 230 : e);
+  *s = __uint_as_float((unsigned)(261 - e) << 23);
+  *inv = __uint_as_float((unsigned)(e - 7) << 23);
+}
+
+__device__ __forceinline__ unsigned wino_h2_pack(float a, float b, unsigned* lo) {
+  const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+  const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+  *lo = (unsigned)__builtin_bit_cast(unsigned short, la) | ((unsigned)__builtin_bit_cast(unsigned short, lb) << 16);
+  return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+
+// One thread per (tile, channel pair) like wino_in_kernel; the result is scaled by the board's power of two, split, and
+// stored as one 4-byte hi word and one 4-byte lo word (16 lanes fill the 64-byte hi / lo halves of a 32-channel chunk).
+__global__ __launch_bounds__(256) void wino_in_h2_kernel(WinoH2Args h) {
+  const WinoArgs& a = h.w;
+  const int C2 = a.C >> 1;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (size_t)a.T * C2) return;
+  const int c2 = (int)(g % C2);
+  const int t = (int)(g / C2);
+  const int b = t / a.TPB, tt = t - b * a.TPB;
+  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
+  float sb, inv_;
+  wino_h2_scales(h.amax_in[b], &sb, &inv_);
+  const float* xb = a.x + (size_t)b * a.Hp * a.Wp * a.C + 2 * c2;
+  float tmx[6][6], tmy[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const int px = 4 * tx + j;
+    float dx[6], dy[6], ox[6], oy[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const int py = 4 * ty + i;
+      float2 v = make_float2(0.f, 0.f);
+      if (py < a.Hp && px < a.Wp) v = *reinterpret_cast<const float2*>(xb + ((size_t)py * a.Wp + px) * a.C);
+      dx[i] = v.x; dy[i] = v.y;
+    }
+    wino_bt6(dx, ox);
+    wino_bt6(dy, oy);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { tmx[i][j] = ox[i]; tmy[i][j] = oy[i]; }
+  }
+  unsigned* V2 = reinterpret_cast<unsigned*>(a.V);          // 4-byte words: [pos][T][C/32][2][16]
+  const int c = 2 * c2;
+  const size_t word_in_row = (size_t)(c >> 5) * 32 + ((c & 31) >> 1);   // hi word; the lo word sits 16 words further
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float ox[6], oy[6];
+    wino_bt6(tmx[i], ox);
+    wino_bt6(tmy[i], oy);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      unsigned lo;
+      const unsigned hi = wino_h2_pack(ox[j] * sb, oy[j] * sb, &lo);
+      unsigned* row = V2 + ((size_t)(i * 6 + j) * a.T + t) * a.C + word_in_row;
+      row[0] = hi;
+      row[16] = lo;
+    }
+  }
+}
+
+// The 36 GEMMs with fp16x2 products, 128 x 128 tile: conv3x3_h2_kernel's tile / LDS image / single-stage pipeline with a
+// plain K loop over 32-channel chunks; the A operand arrives already split (pure copy into LDS).
+__global__ __launch_bounds__(256, 3) void wino_gemm_h2_kernel(WinoH2Args h) {
+  const WinoArgs& a = h.w;
+  constexpr int PIECE = 128 * 64;
+  constexpr int STAGE = 4 * PIECE;           // A hi, A lo, B hi, B lo
+  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE];
+
+  const int per_pos = a.n_mtiles * a.n_ntiles;
+  const int nblk = 36 * per_pos;
+  const int id = blockIdx.x;
+  int q = nblk >> 3, rr = nblk & 7, xcd = id & 7, slot = id >> 3;
+  int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
+  const int pos = tile / per_pos;
+  const int rem = tile - pos * per_pos;
+  const int m_tile = rem / a.n_ntiles, n_tile = rem - m_tile * a.n_ntiles;
+  const int m0 = m_tile * 128, n0 = n_tile * 128;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int srow = tid >> 1, shalf = tid & 1;
+  int mrow = m0 + srow;
+  if (mrow >= a.T) mrow = a.T - 1;
+  int nrow = n0 + srow;
+  if (nrow >= a.Ntot) nrow = a.Ntot - 1;
+  const int NK = a.C >> 5;
+  const unsigned piece_bytes = (unsigned)a.Ntot * 64u;
+  unsigned xo_ = (unsigned)((((size_t)pos * a.T + mrow) * a.C) * 4) + (unsigned)shalf * 32u;
+  unsigned wo_ = (unsigned)pos * (unsigned)NK * 2u * piece_bytes + (unsigned)nrow * 64u + (unsigned)shalf * 32u;
+  const unsigned s_off0 = h2_lds_off(srow, 2 * shalf), s_off1 = h2_lds_off(srow, 2 * shalf + 1);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  int ra[2], rb[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) ra[i] = (wm * 2 + i) * 32 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < 2; j++) rb[j] = (wn * 2 + j) * 32 + (lane & 31);
+  const int kh = lane >> 5;
+
+  u32x4_t xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3;
+  const char* xbase = reinterpret_cast<const char*>(a.V);
+  const char* wbase = reinterpret_cast<const char*>(h.U2);
+  int f_n = 0;
+#define WH2_GLOAD()                                                                           \
+  xa0 = *reinterpret_cast<const u32x4_t*>(xbase + xo_);                                       \
+  xa1 = *reinterpret_cast<const u32x4_t*>(xbase + xo_ + 16u);                                 \
+  xa2 = *reinterpret_cast<const u32x4_t*>(xbase + xo_ + 64u);                                 \
+  xa3 = *reinterpret_cast<const u32x4_t*>(xbase + xo_ + 80u);                                 \
+  xb0 = *reinterpret_cast<const u32x4_t*>(wbase + wo_);                                       \
+  xb1 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + 16u);                                 \
+  xb2 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + piece_bytes);                         \
+  xb3 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + piece_bytes + 16u);                   \
+  if (f_n + 1 < NK) { f_n++; xo_ += 128u; wo_ += 2u * piece_bytes; }
+#define WH2_STORE()                                                                           \
+  *reinterpret_cast<u32x4_t*>(lds + 0 * PIECE + s_off0) = xa0;                                \
+  *reinterpret_cast<u32x4_t*>(lds + 0 * PIECE + s_off1) = xa1;                                \
+  *reinterpret_cast<u32x4_t*>(lds + 1 * PIECE + s_off0) = xa2;                                \
+  *reinterpret_cast<u32x4_t*>(lds + 1 * PIECE + s_off1) = xa3;                                \
+  *reinterpret_cast<u32x4_t*>(lds + 2 * PIECE + s_off0) = xb0;                                \
+  *reinterpret_cast<u32x4_t*>(lds + 2 * PIECE + s_off1) = xb1;                                \
+  *reinterpret_cast<u32x4_t*>(lds + 3 * PIECE + s_off0) = xb2;                                \
+  *reinterpret_cast<u32x4_t*>(lds + 3 * PIECE + s_off1) = xb3;
+#define WH2_QUAD(PA_, PB_)                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 2; i++)                                               \
+    _Pragma("unroll") for (int j = 0; j < 2; j++)                                             \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[i][PA_], B_[j][PB_], acc[i][j], 0, 0, 0);
+
+  WH2_GLOAD()
+  for (int it = 0; it < NK; it++) {
+    WH2_STORE()
+    __syncthreads();
+    WH2_GLOAD()
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      f16x8_t A_[2][2], B_[2][2];
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) A_[i][p] = *reinterpret_cast<const f16x8_t*>(lds + p * PIECE + h2_lds_off(ra[i], 2 * ks + kh));
+#pragma unroll
+        for (int j = 0; j < 2; j++) B_[j][p] = *reinterpret_cast<const f16x8_t*>(lds + (2 + p) * PIECE + h2_lds_off(rb[j], 2 * ks + kh));
+      }
+      WH2_QUAD(1, 0) WH2_QUAD(0, 1) WH2_QUAD(0, 0)   // small terms first
+    }
+    __syncthreads();
+  }
+#undef WH2_QUAD
+#undef WH2_STORE
+#undef WH2_GLOAD
+
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int m = m0 + row;
+      if (m < a.T) {
+        float* dst = a.Mb + ((size_t)pos * a.T + m) * a.Ntot;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int c = n0 + (wn * 2 + j) * 32 + (lane & 31);
+          if (c < a.Ntot) dst[c] = acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
+// Wide variant: 128 x 256 tile, 64 x 128 per wave (conv3x3_h2w_kernel's shape): half the A re-reads and LDS traffic per MFMA.
+__global__ __launch_bounds__(256, 2) void wino_gemm_h2w_kernel(WinoH2Args h) {
+  const WinoArgs& a = h.w;
+  constexpr int PA = 128 * 64, PB = 256 * 64;
+  constexpr int STAGE = 2 * PA + 2 * PB;          // 48 KB
+  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE];
+
+  const int n_nt = (a.Ntot + 255) / 256;
+  const int per_pos = a.n_mtiles * n_nt;
+  const int nblk = 36 * per_pos;
+  const int id = blockIdx.x;
+  int q = nblk >> 3, rr = nblk & 7, xcd = id & 7, slot = id >> 3;
+  int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
+  const int pos = tile / per_pos;
+  const int rem = tile - pos * per_pos;
+  const int m_tile = rem / n_nt, n_tile = rem - m_tile * n_nt;
+  const int m0 = m_tile * 128, n0 = n_tile * 256;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int srow = tid >> 1, shalf = tid & 1;
+  int mrow = m0 + srow;
+  if (mrow >= a.T) mrow = a.T - 1;
+  int nr0 = n0 + srow, nr1 = n0 + 128 + srow;
+  if (nr0 >= a.Ntot) nr0 = a.Ntot - 1;
+  if (nr1 >= a.Ntot) nr1 = a.Ntot - 1;
+  const int NK = a.C >> 5;
+  const unsigned piece_bytes = (unsigned)a.Ntot * 64u;
+  unsigned xo_ = (unsigned)((((size_t)pos * a.T + mrow) * a.C) * 4) + (unsigned)shalf * 32u;
+  unsigned wo_ = (unsigned)pos * (unsigned)NK * 2u * piece_bytes;
+  const unsigned b_g0 = (unsigned)nr0 * 64u + (unsigned)shalf * 32u, b_g1 = (unsigned)nr1 * 64u + (unsigned)shalf * 32u;
+  const unsigned sa0 = h2_lds_off(srow, 2 * shalf), sa1 = h2_lds_off(srow, 2 * shalf + 1);
+  const unsigned sb0 = h2_lds_off(128 + srow, 2 * shalf), sb1 = h2_lds_off(128 + srow, 2 * shalf + 1);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  int ra[2], rb[4];
+#pragma unroll
+  for (int i = 0; i < 2; i++) ra[i] = (wm * 2 + i) * 32 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < 4; j++) rb[j] = wn * 128 + j * 32 + (lane & 31);
+  const int kh = lane >> 5;
+
+  u32x4_t xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3, xb4, xb5, xb6, xb7;
+  const char* xbase = reinterpret_cast<const char*>(a.V);
+  const char* wbase = reinterpret_cast<const char*>(h.U2);
+  int f_n = 0;
+#define WH2W_GLOAD()                                                                          \
+  xa0 = *reinterpret_cast<const u32x4_t*>(xbase + xo_);                                       \
+  xa1 = *reinterpret_cast<const u32x4_t*>(xbase + xo_ + 16u);                                 \
+  xa2 = *reinterpret_cast<const u32x4_t*>(xbase + xo_ + 64u);                                 \
+  xa3 = *reinterpret_cast<const u32x4_t*>(xbase + xo_ + 80u);                                 \
+  xb0 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + b_g0);                                \
+  xb1 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + b_g0 + 16u);                          \
+  xb2 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + piece_bytes + b_g0);                  \
+  xb3 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + piece_bytes + b_g0 + 16u);            \
+  xb4 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + b_g1);                                \
+  xb5 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + b_g1 + 16u);                          \
+  xb6 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + piece_bytes + b_g1);                  \
+  xb7 = *reinterpret_cast<const u32x4_t*>(wbase + wo_ + piece_bytes + b_g1 + 16u);            \
+  if (f_n + 1 < NK) { f_n++; xo_ += 128u; wo_ += 2u * piece_bytes; }
+#define WH2W_STORE()                                                                          \
+  {                                                                                           \
+    *reinterpret_cast<u32x4_t*>(lds + 0 * PA + sa0) = xa0;                                    \
+    *reinterpret_cast<u32x4_t*>(lds + 0 * PA + sa1) = xa1;                                    \
+    *reinterpret_cast<u32x4_t*>(lds + 1 * PA + sa0) = xa2;                                    \
+    *reinterpret_cast<u32x4_t*>(lds + 1 * PA + sa1) = xa3;                                    \
+    unsigned char* sb_ = lds + 2 * PA;                                                        \
+    *reinterpret_cast<u32x4_t*>(sb_ + 0 * PB + sa0) = xb0;                                    \
+    *reinterpret_cast<u32x4_t*>(sb_ + 0 * PB + sa1) = xb1;                                    \
+    *reinterpret_cast<u32x4_t*>(sb_ + 1 * PB + sa0) = xb2;                                    \
+    *reinterpret_cast<u32x4_t*>(sb_ + 1 * PB + sa1) = xb3;                                    \
+    *reinterpret_cast<u32x4_t*>(sb_ + 0 * PB + sb0) = xb4;                                    \
+    *reinterpret_cast<u32x4_t*>(sb_ + 0 * PB + sb1) = xb5;                                    \
+    *reinterpret_cast<u32x4_t*>(sb_ + 1 * PB + sb0) = xb6;                                    \
+    *reinterpret_cast<u32x4_t*>(sb_ + 1 * PB + sb1) = xb7;                                    \
+  }
+#define WH2W_OCT(PA_, PB_)                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 2; i++)                                               \
+    _Pragma("unroll") for (int j = 0; j < 4; j++)                                             \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[i][PA_], B_[j][PB_], acc[i][j], 0, 0, 0);
+
+  WH2W_GLOAD()
+  for (int it = 0; it < NK; it++) {
+    WH2W_STORE()
+    __syncthreads();
+    WH2W_GLOAD()
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      f16x8_t A_[2][2], B_[4][2];
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) A_[i][p] = *reinterpret_cast<const f16x8_t*>(lds + p * PA + h2_lds_off(ra[i], 2 * ks + kh));
+#pragma unroll
+        for (int j = 0; j < 4; j++) B_[j][p] = *reinterpret_cast<const f16x8_t*>(lds + 2 * PA + p * PB + h2_lds_off(rb[j], 2 * ks + kh));
+      }
+      WH2W_OCT(1, 0) WH2W_OCT(0, 1) WH2W_OCT(0, 0)
+    }
+    __syncthreads();
+  }
+#undef WH2W_OCT
+#undef WH2W_STORE
+#undef WH2W_GLOAD
+
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int m = m0 + row;
+      if (m < a.T) {
+        float* dst = a.Mb + ((size_t)pos * a.T + m) * a.Ntot;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int c = n0 + wn * 128 + j * 32 + (lane & 31);
+          if (c < a.Ntot) dst[c] = acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
+// wino_out_kernel + exact un-scaling + the per-board maximum of the block output (the next block's range).
+__global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
+  const WinoArgs& a = h.w;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = g < (size_t)a.T * a.Cout_p;
+  const size_t gg = live ? g : (size_t)a.T * a.Cout_p - 1;
+  const int c = (int)(gg % a.Cout_p);
+  const int t = (int)(gg / a.Cout_p);
+  const int b = t / a.TPB, tt = t - b * a.TPB;
+  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
+  float s_, unscale;
+  wino_h2_scales(h.amax_in[b], &s_, &unscale);
+  unscale *= h.w_unscale;
+  float Y[2][4][4];
+#pragma unroll
+  for (int br = 0; br < 2; br++) {
+    float tm[4][6];
+#pragma unroll
+    for (int nu = 0; nu < 6; nu++) {
+      float m[6], o[4];
+#pragma unroll
+      for (int xi = 0; xi < 6; xi++) m[xi] = a.Mb[((size_t)(xi * 6 + nu) * a.T + t) * a.Ntot + br * a.Cout_p + c];
+      wino_at4(m, o);
+#pragma unroll
+      for (int k = 0; k < 4; k++) tm[k][nu] = o[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) wino_at4(tm[k], Y[br][k]);
+  }
+  const float4* ep = reinterpret_cast<const float4*>(a.ep);
+  float* yb = a.y + (size_t)b * a.Hp * a.Wp * a.Cout_p + c;
+  float mx = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int hh = 4 * ty + k;
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+      const int ww = 4 * tx + l;
+      if (live && hh < a.H && ww < a.W) {
+        const float4 e = ep[(size_t)(hh * a.W + ww) * a.Cout_p + c];
+        float va = (Y[0][k][l] * unscale) * e.x + e.y;
+        float vb = (Y[1][k][l] * unscale) * e.z + e.w;
+        va = va > 0.f ? va : 0.f;
+        vb = vb > 0.f ? vb : 0.f;
+        float s = va + vb;
+        s = s > 0.f ? s : 0.f;
+        yb[((size_t)(hh + 1) * a.Wp + (ww + 1)) * a.Cout_p] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
+  }
+  // one atomic per wave: the 64 lanes of a wave are 64 channels of ONE tile (Cout_p is a multiple of 64), i.e. one board
+  if (h.amax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(h.amax_out + b, __float_as_uint(mx));
+  }
+}
+
+// Host: the Winograd-domain filter (as wino_build_u3) scaled by a power of two and split into two fp16 pieces:
+// u2[pos][ci/32][piece][n][ci%32]; returns 1/su.
+template <typename Get>
+static float wino_build_u2(std::vector<_Float16>& u2, int Ntot, int C, Get get) {
+  static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+  const int NC = C / 32;
+  std::vector<float> U((size_t)36 * Ntot * C, 0.f);
+  float umax = 0.f;
+  for (int n = 0; n < Ntot; n++)
+    for (int ci = 0; ci < C; ci++) {
+      double g[3][3], tg[6][3];
+      bool any = false;
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { g[i][j] = get(n, ci, i * 3 + j); any = any || g[i][j] != 0.0; }
+      if (!any) continue;
+      for (int xi = 0; xi < 6; xi++) for (int j = 0; j < 3; j++) tg[xi][j] = G[xi][0] * g[0][j] + G[xi][1] * g[1][j] + G[xi][2] * g[2][j];
+      for (int xi = 0; xi < 6; xi++) for (int nu = 0; nu < 6; nu++) {
+        const float v = (float)(tg[xi][0] * G[nu][0] + tg[xi][1] * G[nu][1] + tg[xi][2] * G[nu][2]);   // rounded once to fp32, like u3
+        U[((size_t)(xi * 6 + nu) * Ntot + n) * C + ci] = v;
+        umax = std::max(umax, std::fabs(v));
+      }
+    }
+  int ex = 0;
+  if (umax > 0.f) std::frexp(umax, &ex);
+  const float su = umax > 0.f ? std::ldexp(1.0f, 14 - ex) : 1.0f;
+  u2.assign((size_t)36 * NC * 2 * Ntot * 32, (_Float16)0.f);
+  for (int pos = 0; pos < 36; pos++)
+    for (int n = 0; n < Ntot; n++)
+      for (int ci = 0; ci < C; ci++) {
+        const float xs = U[((size_t)pos * Ntot + n) * C + ci] * su;
+        const _Float16 hi = (_Float16)xs;
+        const _Float16 lo = (_Float16)(xs - (float)hi);
+        const size_t base = ((((size_t)pos * NC + ci / 32) * 2) * Ntot + n) * 32 + (ci % 32);
+        u2[base] = hi;
+        u2[base + (size_t)Ntot * 32] = lo;
+      }
+  return 1.0f / su;
+}
+
+// launches the stages of one block for a chunk of boards (h.w.V / Mb sized by the caller)
+static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide) {
+  WinoArgs& a = h.w;
+  a.nty = ceil_div(a.H, 4); a.ntx = ceil_div(a.W, 4); a.TPB = a.nty * a.ntx; a.T = a.B * a.TPB;
+  a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
+  {
+    ProfScope ps(ctx, AGZ_PROF_WINO_IN);
+    const size_t n_in = (size_t)a.T * (a.C / 2);
+    hipLaunchKernelGGL(wino_in_h2_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, ctx->stream, h);
+  }
+  {
+    ProfScope ps(ctx, AGZ_PROF_WINO_GEMM);
+    if (wide)
+      hipLaunchKernelGGL(wino_gemm_h2w_kernel, dim3(36 * a.n_mtiles * ceil_div(a.Ntot, 256)), dim3(256), 0, ctx->stream, h);
+    else
+      hipLaunchKernelGGL(wino_gemm_h2_kernel, dim3(36 * a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, h);
+  }
+  {
+    ProfScope ps(ctx, AGZ_PROF_WINO_OUT);
+    const size_t n_out = (size_t)a.T * a.Cout_p;
+    hipLaunchKernelGGL(wino_out_h2_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx->stream, h);
+  }
+}

@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 #include "conv_x3.hpp"
 #include "conv_wino.hpp"
 #include "conv_h2.hpp"
+#include "conv_wino_h2.hpp"
 
 
 // device-side weight split for the trainer (weights change every step): one thread per (tap, n, ci)
@@ -577,6 +578,8 @@ void agz_net::free_device() {
   if (d_amax) { hipFree(d_amax); d_amax = nullptr; }
   amax_cap = 0;
   for (auto& p : d_u3_dual) if (p) { hipFree(p); p = nullptr; }
+  for (auto& p : d_u2_dual) if (p) { hipFree(p); p = nullptr; }
+  d_u2_dual.clear();
   f(d_wV); f(d_wM);
   wino_chunk_cap = 0;
   d_w_dual.clear(); d_ep_dual.clear(); d_w3_dual.clear(); d_w2_dual.clear(); d_u3_dual.clear();
@@ -707,6 +710,33 @@ int agz_net::build_wino_weights() {
   return AGZ_OK;
 }
 
+// the same Winograd-domain weights as two fp16 pieces (conv_wino_h2.hpp)
+int agz_net::build_wino_h2_weights() {
+  AGZ_REQUIRE(cfg == 0, AGZ_E_UNSUPPORTED, "agz_net: the Winograd path needs K a multiple of 64");
+  AGZ_REQUIRE((size_t)36 * (Kp / 32) * 2 * (2 * Kp) * 64 < ((size_t)1 << 32), AGZ_E_UNSUPPORTED, "agz_net: K %d too wide for the Winograd weight image", conf.K);
+  AGZ_HIP_TRY(hipSetDevice(ctx->device));
+  for (auto& p : d_u2_dual) if (p) hipFree(p);
+  d_u2_dual.assign(conf.SharedLayers, nullptr);
+  u_unscale.assign(conf.SharedLayers, 1.0f);
+  const int K = conf.K;
+  size_t pi = 3;
+  std::vector<_Float16> u2;
+  for (int l = 0; l < conf.SharedLayers; l++, pi += 6) {
+    const std::vector<float>& wa = params[pi].v;
+    const std::vector<float>& wb = params[pi + 3].v;
+    const int Kp_ = Kp;
+    u_unscale[l] = agz::wino_build_u2(u2, 2 * Kp, Kp, [&](int n, int ci, int tap) -> double {
+      const int o = n < Kp_ ? n : n - Kp_;
+      if (o >= K || ci >= K) return 0.0;
+      return (double)(n < Kp_ ? wa : wb)[((size_t)o * K + ci) * 9 + tap];
+    });
+    AGZ_HIP_TRY(hipMalloc(&d_u2_dual[l], u2.size() * 2));
+    AGZ_HIP_TRY(hipMemcpyAsync(d_u2_dual[l], u2.data(), u2.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return AGZ_OK;
+}
+
 int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   AGZ_REQUIRE(committed, AGZ_E_STATE, "agz_net: infer before agz_net_commit");
   AGZ_REQUIRE(B >= 1 && B <= max_batch, AGZ_E_INVALID, "agz_net: batch %d exceeds allocated %d", B, max_batch);
@@ -750,6 +780,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   const bool wino_lat = latency && cfg == 0 && conf.SharedLayers > 0 && wino_lat_tiles > 0 &&
                         B * ceil_div(H, 4) * ceil_div(W, 4) >= wino_lat_tiles;
   const bool wino_ok = (split_ok || wino_lat) && compute_mode == AGZ_COMPUTE_WINO;
+  const bool wino_h2_ok = split_ok && compute_mode == AGZ_COMPUTE_WINO_H2;
   if (use_h2 && (size_t)B > amax_cap) {
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (d_amax) hipFree(d_amax);
@@ -801,6 +832,48 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       cur = nxt;
       tower_done = true;
     }
+  }
+  if (!tower_done && wino_h2_ok) {
+    // Winograd with fp16x2 transform-domain products (conv_wino_h2.hpp): per-board ranges in d_amax[block][board]
+    AGZ_REQUIRE((int)d_u2_dual.size() == conf.SharedLayers, AGZ_E_STATE, "agz_net: Winograd fp16x2 weights not built");
+    static const int wide_env = [] { const char* e = getenv("AGZ_WINO_H2_WIDE"); return e ? atoi(e) : -1; }();   // tuning knob
+    const bool wide = wide_env >= 0 ? wide_env != 0 : false;
+    const int tpb = ceil_div(H, 4) * ceil_div(W, 4);
+    const int chunk = (int)std::min<size_t>((size_t)B, (((size_t)1 << 32) - 1) / ((size_t)36 * tpb * Kp * 4));
+    if (chunk > wino_chunk_cap) {
+      AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (d_wV) hipFree(d_wV);
+      if (d_wM) hipFree(d_wM);
+      d_wV = d_wM = nullptr; wino_chunk_cap = 0;
+      AGZ_HIP_TRY(hipMalloc(&d_wV, (size_t)36 * chunk * tpb * Kp * sizeof(float)));
+      AGZ_HIP_TRY(hipMalloc(&d_wM, (size_t)36 * chunk * tpb * 2 * Kp * sizeof(float)));
+      wino_chunk_cap = chunk;
+    }
+    const size_t need_amax = (size_t)(conf.SharedLayers + 1) * B;
+    if (need_amax > amax_cap) {
+      AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (d_amax) hipFree(d_amax);
+      d_amax = nullptr; amax_cap = 0;
+      AGZ_HIP_TRY(hipMalloc(&d_amax, need_amax * sizeof(unsigned)));
+      amax_cap = need_amax;
+    }
+    AGZ_HIP_TRY(hipMemsetAsync(d_amax, 0, need_amax * sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, ctx->stream, cur, d_amax, HW, W, Wp, Hp * Wp, Kp);
+    for (int l = 0; l < conf.SharedLayers; l++) {
+      ProfScope ps(ctx, AGZ_PROF_CONV);
+      for (int b0 = 0; b0 < B; b0 += chunk) {
+        WinoH2Args hh{};
+        WinoArgs& wa = hh.w;
+        wa.x = cur + (size_t)b0 * Hp * Wp * Kp; wa.y = nxt + (size_t)b0 * Hp * Wp * Kp;
+        wa.V = d_wV; wa.Mb = d_wM; wa.ep = d_ep_dual[l];
+        wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
+        hh.U2 = d_u2_dual[l]; hh.w_unscale = u_unscale[l];
+        hh.amax_in = d_amax + (size_t)l * B + b0; hh.amax_out = d_amax + (size_t)(l + 1) * B + b0;
+        wino_h2_launch(ctx, hh, wide);
+      }
+      std::swap(cur, nxt);
+    }
+    tower_done = true;
   }
   for (int l = 0; !tower_done && l < conf.SharedLayers; l++) {
     a.x = cur; a.w = d_w_dual[l]; a.ep = d_ep_dual[l]; a.y = nxt;
@@ -1170,7 +1243,10 @@ int agz_net_commit(agz_net* n) {
     (void)A; (void)FCn;
   }
   n->committed = true;
+  for (auto& p : n->d_u2_dual) if (p) hipFree(p);
+  n->d_u2_dual.clear();
   if ((n->compute_mode == AGZ_COMPUTE_WINO || n->compute_mode == AGZ_COMPUTE_AUTO) && n->cfg == 0) return n->build_wino_weights();
+  if (n->compute_mode == AGZ_COMPUTE_WINO_H2 && n->cfg == 0) return n->build_wino_h2_weights();
   return AGZ_OK;
 }
 
@@ -1216,11 +1292,13 @@ int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, 
 int agz_net_set_compute_mode(agz_net* n, int mode) {
   AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_compute_mode: NULL net");
   const int base = mode & ~AGZ_COMPUTE_FORCE;
-  AGZ_REQUIRE(base == AGZ_COMPUTE_F32_MFMA || base == AGZ_COMPUTE_BF16X3 || base == AGZ_COMPUTE_FP16X2 || base == AGZ_COMPUTE_WINO || base == AGZ_COMPUTE_AUTO,
+  AGZ_REQUIRE(base == AGZ_COMPUTE_F32_MFMA || base == AGZ_COMPUTE_BF16X3 || base == AGZ_COMPUTE_FP16X2 || base == AGZ_COMPUTE_WINO || base == AGZ_COMPUTE_AUTO ||
+                  base == AGZ_COMPUTE_WINO_H2,
               AGZ_E_INVALID, "agz_net_set_compute_mode: unknown mode %d", mode);
   n->compute_mode = base;
   n->compute_force = (mode & AGZ_COMPUTE_FORCE) != 0;
   if ((base == AGZ_COMPUTE_WINO || base == AGZ_COMPUTE_AUTO) && n->committed && n->cfg == 0 && n->d_u3_dual.empty()) return n->build_wino_weights();
+  if (base == AGZ_COMPUTE_WINO_H2 && n->committed && n->cfg == 0 && n->d_u2_dual.empty()) return n->build_wino_h2_weights();
   return AGZ_OK;
 }
 

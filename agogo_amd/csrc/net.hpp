@@ -43,11 +43,14 @@ struct agz_net {
   std::vector<_Float16*> d_w2_dual;        // per layer fp16x2 image [Kp/32][9][2][2*Kp][32] (cfg 0 only), conv_h2.hpp
   std::vector<float> w_unscale;            // per layer 2^-eb of the fp16x2 weight scale
   std::vector<unsigned short*> d_u3_dual;  // per layer Winograd-domain bf16x3 image [36][Kp/16][3][2*Kp][16] (AGZ_COMPUTE_WINO), conv_wino.hpp
+  std::vector<_Float16*> d_u2_dual;        // per layer Winograd-domain fp16x2 image [36][Kp/32][2][2*Kp][32] (AGZ_COMPUTE_WINO_H2), conv_wino_h2.hpp
+  std::vector<float> u_unscale;            // per layer 1 / (power-of-two scale of that image)
+  int build_wino_h2_weights();
   float* d_wV = nullptr;                   // Winograd scratch: transformed input [36][T][Kp] and GEMM output [36][T][2*Kp] of one chunk
   float* d_wM = nullptr;
   int wino_chunk_cap = 0;                  // boards the scratch is sized for
   int build_wino_weights();                // (re)builds d_u3_dual from the host parameters; needs cfg == 0
-  unsigned* d_amax = nullptr;              // [B] per-board max |activation| of the layer about to be consumed (fp16x2)
+  unsigned* d_amax = nullptr;              // per-board max |activation|: [B] of the layer about to be consumed (fp16x2), [blocks+1][B] (Winograd fp16x2)
   size_t amax_cap = 0;
   int compute_mode = AGZ_COMPUTE_F32_MFMA;  // agz_net_set_compute_mode
   bool compute_force = false;              // AGZ_COMPUTE_FORCE: split kernels even below the chip-filling threshold

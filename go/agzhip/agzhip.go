@@ -6,6 +6,10 @@
 //
 //	Inferencer    -> agogo.Inferer            (datatypes.go:56-59)   batch-1 path for Agent.Infer
 //	BatchedArena  -> the role of Arena.Play / AZ.SelfPlay (arena.go:80-179, agogo.go:93-97) for N games
+//	MCTS          -> *mcts.MCTS's method set  (mcts/tree.go:80-142, search.go:92): SetGame / Search / Policies / Reset / Nodes
+//	                 on the caller's own game.State — what Agent.Search (agent.go:77-80) drives
+//	Trainer/Train -> dual.Train               (dualnet/meta.go:16-54)
+//	Comm          -> the example gather + gradient sum around dual.Train on n GPUs (agogo.go:118-133) over RCCL
 //
 // Threading: an agz_ctx is not thread-safe; every method locks the OS thread for the duration of the call
 // and serialises on the Ctx mutex (under `-tags cuda` agogo itself runs a single VM, const_cuda.go:5).
@@ -303,6 +307,252 @@ func (a *BatchedArena) Opponent(moves []game.Single) error {
 	}
 	return lastErr(C.agz_arena_apply_moves(a.h, (*C.int32_t)(unsafe.Pointer(&m[0]))))
 }
+
+// ---- mcts.MCTS: one device tree on the caller's own game.State (Agent.Search, agent.go:77-80) -------------------------
+// MCTS has *mcts.MCTS's method set: `agent.MCTS = agzhip.NewMCTS(...)` and Agent.Search keeps reading
+// `a.MCTS.SetGame(g); return a.MCTS.Search(a.Player)`.  The game stays a Go game.State; SetGame ships the position (board,
+// to-move, hash, the moves since the start via LastMove/UndoLastMove on a clone, the last 8 historical boards for WQEncoder).
+type MCTS struct {
+	ctx     *Ctx
+	h       *C.agz_mcts
+	cells   int
+	action  int
+	current game.State
+}
+
+// NewMCTS mirrors mcts.New(game, conf, nn) (tree.go:80-103): kind names the device implementation of g's rules, nn the
+// network (nil: the reference's dummyInferer).
+func NewMCTS(ctx *Ctx, kind GameKind, g game.State, k int, komi float32, encoder int, conf mcts.Config, nn *Net, seed uint64) (*MCTS, error) {
+	defer ctx.enter()()
+	m, n := g.BoardSize()
+	gc := C.agz_game_conf{kind: C.int32_t(kind), m: C.int32_t(m), n: C.int32_t(n), k: C.int32_t(k), komi: C.float(komi), encoder: C.int32_t(encoder)}
+	dumb := 0
+	if conf.DumbPass {
+		dumb = 1
+	}
+	mc := C.agz_mcts_conf{PUCT: C.float(conf.PUCT), M: C.int32_t(conf.M), N: C.int32_t(conf.N), RandomCount: C.int32_t(conf.RandomCount),
+		Budget: C.int32_t(conf.Budget), RandomMinVisits: C.uint32_t(conf.RandomMinVisits), RandomTemperature: C.float(conf.RandomTemperature),
+		DumbPass: C.int32_t(dumb), ResignPercentage: C.float(conf.ResignPercentage), PassPreference: C.int32_t(conf.PassPreference)}
+	t := &MCTS{ctx: ctx, cells: m * n, action: g.ActionSpace(), current: g}
+	if err := lastErr(C.agz_mcts_create(ctx.h, &gc, &mc, C.uint64_t(seed), 0, &t.h)); err != nil {
+		return nil, err
+	}
+	kindInf, h := C.int(C.AGZ_INF_DUMMY), (*C.agz_net)(nil)
+	if nn != nil {
+		kindInf, h = C.int(C.AGZ_INF_NET), nn.h
+	}
+	if err := lastErr(C.agz_mcts_set_inferencer(t.h, kindInf, h)); err != nil {
+		return nil, err
+	}
+	return t, nil
+}
+
+// SetGame (tree.go:120-124).
+func (t *MCTS) SetGame(g game.State) { t.current = g }
+
+// SetParallel: lanes per round (see BatchedArena.SetParallel).
+func (t *MCTS) SetParallel(lanes int) error {
+	defer t.ctx.enter()()
+	return lastErr(C.agz_mcts_set_parallel(t.h, C.int(lanes)))
+}
+
+// ship serialises t.current into an agz_state.
+func (t *MCTS) ship() error {
+	g := t.current
+	board := make([]int32, t.cells)
+	for i, c := range g.Board() {
+		board[i] = int32(c)
+	}
+	// the moves played so far, oldest first: LastMove / UndoLastMove on a clone (what newRootState itself does, search.go:429-440)
+	nMoves := g.MoveNumber()
+	tmp := g.Clone().(game.State)
+	var rev []int32
+	for i := 0; i < nMoves; i++ {
+		lm := tmp.LastMove()
+		if lm.Single.IsPass() && tmp.MoveNumber() == 0 {
+			break
+		}
+		rev = append(rev, int32(lm.Single))
+		tmp.UndoLastMove()
+	}
+	last := make([]int32, len(rev))
+	for i := range rev {
+		last[len(rev)-1-i] = rev[i]
+	}
+	// State.Historical(i): the boards after the last (up to 8) moves, oldest first
+	nh := nMoves
+	if nh > 8 {
+		nh = 8
+	}
+	hist := make([]int32, nh*t.cells)
+	for q := 0; q < nh; q++ {
+		for i, c := range g.Historical(nMoves - nh + q) {
+			hist[q*t.cells+i] = int32(c)
+		}
+	}
+	passes := g.Passes()
+	if passes < 0 {
+		passes = 0
+	}
+	st := C.agz_state{board: (*C.int32_t)(unsafe.Pointer(&board[0])), to_move: C.int32_t(g.ToMove()), n_moves: C.int32_t(nMoves),
+		passes: C.int32_t(passes), hash: C.uint32_t(g.Hash()),
+		captures_black: C.float(g.Score(game.Player(game.Black))), captures_white: C.float(g.Score(game.Player(game.White)))}
+	if len(last) > 0 {
+		st.last_moves, st.n_last_moves = (*C.int32_t)(unsafe.Pointer(&last[0])), C.int32_t(len(last))
+	}
+	if nh > 0 {
+		st.historical, st.n_historical = (*C.int32_t)(unsafe.Pointer(&hist[0])), C.int32_t(nh)
+	}
+	return lastErr(C.agz_mcts_set_game(t.h, &st))
+}
+
+// Search (search.go:92-164).  Like the reference it panics when the search cannot run (Agent.Infer panics on an inferer error,
+// agent.go:66-71).
+func (t *MCTS) Search(player game.Player) game.Single {
+	defer t.ctx.enter()()
+	if err := t.ship(); err != nil {
+		panic(err)
+	}
+	var best C.int32_t
+	if err := lastErr(C.agz_mcts_search(t.h, C.int(player), &best)); err != nil {
+		panic(err)
+	}
+	return game.Single(best)
+}
+
+// Policies (tree.go:128-142) of the game set last.  g is accepted for signature compatibility (Arena.Play passes the game it
+// just searched, arena.go:108).
+func (t *MCTS) Policies(g game.State) []float32 {
+	defer t.ctx.enter()()
+	out := make([]float32, t.action+1)
+	if err := lastErr(C.agz_mcts_policies(t.h, (*C.float)(unsafe.Pointer(&out[0])), C.int(len(out)))); err != nil {
+		panic(err)
+	}
+	return out
+}
+
+// Nodes (tree.go:126).
+func (t *MCTS) Nodes() int {
+	defer t.ctx.enter()()
+	var n C.int
+	C.agz_mcts_nodes(t.h, &n)
+	return int(n)
+}
+
+// Reset (tree.go:249-276), completed to "a fresh tree" (what Arena.Play does next, arena.go:140-141,175-176).
+func (t *MCTS) Reset() { defer t.ctx.enter()(); C.agz_mcts_reset(t.h) }
+
+func (t *MCTS) Close() error { defer t.ctx.enter()(); C.agz_mcts_destroy(t.h); t.h = nil; return nil }
+
+// ---- dual.Train (dualnet/meta.go:16-54) ----------------------------------------------------------------------------------
+// Trainer holds the training graph of a Dual (full batch-shaped learnables in Model() order, train.hip).
+type Trainer struct {
+	ctx *Ctx
+	h   *C.agz_trainer
+	d   *dual.Dual
+}
+
+// NewTrainer copies d's learnables (Model() order, full shapes) to the device.
+func NewTrainer(ctx *Ctx, d *dual.Dual) (*Trainer, error) {
+	defer ctx.enter()()
+	cc := C.agz_net_conf{
+		K: C.int32_t(d.K), SharedLayers: C.int32_t(d.SharedLayers), FC: C.int32_t(d.FC), BatchSize: C.int32_t(d.BatchSize),
+		Width: C.int32_t(d.Width), Height: C.int32_t(d.Height), Features: C.int32_t(d.Features),
+		ActionSpace: C.int32_t(d.ActionSpace), bn_mode: C.AGZ_BN_DEGENERATE_EPS, bn_eps: 1e-5,
+	}
+	t := &Trainer{ctx: ctx, d: d}
+	if err := lastErr(C.agz_trainer_create(ctx.h, &cc, &t.h)); err != nil {
+		return nil, err
+	}
+	for i, node := range d.Model() {
+		data := node.Value().Data().([]float32)
+		if err := lastErr(C.agz_trainer_set_param(t.h, C.int(i), (*C.float)(unsafe.Pointer(&data[0])), C.size_t(len(data)))); err != nil {
+			return nil, err
+		}
+	}
+	return t, nil
+}
+
+// Train is dual.Train(d, Xs, policies, values, batches, iterations) on the device; afterwards the learnables are copied back
+// into d.Model() so the rest of AZ.Learn (SwitchToInference, Save) sees the trained network.  Xs [rows, F, H, W], policies
+// [rows, ActionSpace], values [rows] as flat float32 slices (tensor.Dense.Data()).
+func (t *Trainer) Train(Xs, policies, values []float32, batches, iterations int, seed uint64) error {
+	defer t.ctx.enter()()
+	var cost C.float
+	if err := lastErr(C.agz_train(t.h, (*C.float)(unsafe.Pointer(&Xs[0])), (*C.float)(unsafe.Pointer(&policies[0])),
+		(*C.float)(unsafe.Pointer(&values[0])), C.int(batches), C.int(iterations), C.uint64_t(seed), &cost)); err != nil {
+		return err
+	}
+	for i, node := range t.d.Model() {
+		data := node.Value().Data().([]float32)
+		if err := lastErr(C.agz_trainer_get_param(t.h, C.int(i), (*C.float)(unsafe.Pointer(&data[0])), C.size_t(len(data)))); err != nil {
+			return err
+		}
+	}
+	return nil
+}
+
+// TrainDev is dual.Train over the tensors an Examples set prepared on the device (no host copy of the examples).
+func (t *Trainer) TrainDev(ex *Examples, iterations int, seed uint64) error {
+	defer t.ctx.enter()()
+	var xs, pi, v *C.float
+	var rows C.int64_t
+	var batches C.int
+	if err := lastErr(C.agz_examples_tensors_dev(ex.h, &xs, &pi, &v, &rows, &batches)); err != nil {
+		return err
+	}
+	var cost C.float
+	return lastErr(C.agz_train_dev(t.h, xs, pi, v, batches, C.int(iterations), C.uint64_t(seed), &cost))
+}
+
+// Export is dual.Infer's copy loop (meta.go:141-146): row 0 of every learnable into an inference Net.
+func (t *Trainer) Export(n *Net) error { defer t.ctx.enter()(); return lastErr(C.agz_trainer_export(t.h, n.h)) }
+
+func (t *Trainer) Close() error { defer t.ctx.enter()(); C.agz_trainer_destroy(t.h); t.h = nil; return nil }
+
+// ---- n GPUs: games shard with no data-path collective; RCCL only around dual.Train (agogo.go:118-133) --------------------
+// Comm is one rank of an RCCL communicator over the devices of n Ctx handles of THIS process.  Collective methods must be
+// called concurrently for all n ranks, one goroutine (locked to its OS thread by enter()) per Ctx.
+type Comm struct {
+	ctx *Ctx
+	h   *C.agz_comm
+}
+
+// NewComms = ncclCommInitAll over the ctxs' devices.
+func NewComms(ctxs []*Ctx) ([]*Comm, error) {
+	n := len(ctxs)
+	hs := make([]*C.agz_ctx, n)
+	for i, c := range ctxs {
+		hs[i] = c.h
+	}
+	out := make([]*C.agz_comm, n)
+	if err := lastErr(C.agz_comm_init_all((**C.agz_ctx)(unsafe.Pointer(&hs[0])), C.int(n), (**C.agz_comm)(unsafe.Pointer(&out[0])))); err != nil {
+		return nil, err
+	}
+	comms := make([]*Comm, n)
+	for i := range comms {
+		comms[i] = &Comm{ctx: ctxs[i], h: out[i]}
+	}
+	return comms, nil
+}
+
+// AllGatherExamples: every rank's set becomes the union of all ranks' self-play examples, in rank order — the `ex` that
+// AZ.Learn shuffles, truncates and tensorises (agogo.go:118-122).
+func (c *Comm) AllGatherExamples(ex *Examples) error {
+	defer c.ctx.enter()()
+	return lastErr(C.agz_examples_allgather(c.h, ex.h))
+}
+
+// AllReduceGradients + the averaged SGD step of one data-parallel training batch.
+func (c *Comm) AllReduceGradients(t *Trainer, lr float32) error {
+	defer c.ctx.enter()()
+	if err := lastErr(C.agz_trainer_allreduce(c.h, t.h)); err != nil {
+		return err
+	}
+	return lastErr(C.agz_trainer_apply(t.h, C.float(lr), C.float(1.0/float32(C.agz_comm_size(c.h)))))
+}
+
+func (c *Comm) Close() error { defer c.ctx.enter()(); C.agz_comm_destroy(c.h); c.h = nil; return nil }
 
 var _ = game.Pass // keep the import: game.Single values cross the ABI as int32 (-1 pass, -2 resign)
 

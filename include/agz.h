@@ -131,6 +131,9 @@ int agz_net_set_latency_mode(agz_net* net, int on);
                             * the stated tolerance); opt-in, same shape conditions as the split modes */
 #define AGZ_COMPUTE_AUTO 4 /* per forward: Winograd where it measured fastest (K >= 192 and the 4x4 tiles overhang the board by at most
                             * 25 %), else BF16X3 where the split kernels apply, else F32_MFMA */
+#define AGZ_COMPUTE_WINO_H2 5 /* Winograd F(4x4,3x3) with FP16X2 products in the transform domain: the input transform writes the
+                            * operand already split into two fp16 pieces (scaled per board by a power of two from a proven bound,
+                            * overflow impossible), three fp16 MFMAs per product — half the matrix instructions of AGZ_COMPUTE_WINO */
 #define AGZ_COMPUTE_FORCE 0x100 /* OR-ed in: take the split kernel even below the chip-filling threshold (tests) */
 int agz_net_set_compute_mode(agz_net* net, int mode);
 /* Checkpoint of the learnables in Model() order (+ BN statistics).  The reference gob-encodes G.Values

@@ -20,6 +20,7 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--x3", action="store_true")
 ap.add_argument("--h2", action="store_true", help="AGZ_COMPUTE_FP16X2")
 ap.add_argument("--wino", action="store_true", help="AGZ_COMPUTE_WINO (AGZ_WINO_CHUNK=n in the environment: boards per chunk)")
+ap.add_argument("--wino-h2", action="store_true", help="AGZ_COMPUTE_WINO_H2 (AGZ_WINO_H2_WIDE=1: 128x256 GEMM tile)")
 ap.add_argument("--zero", action="store_true", help="all-zero weights (DVFS probe: same instruction stream, low toggle power)")
 args = ap.parse_args()
 ctx = A.Ctx(0)
@@ -34,6 +35,8 @@ if args.h2:
     net.set_compute_mode(A.capi.COMPUTE_FP16X2)
 if args.wino:
     net.set_compute_mode(A.capi.COMPUTE_WINO)
+if args.wino_h2:
+    net.set_compute_mode(A.capi.COMPUTE_WINO_H2)
 x = torch.randint(-1, 2, (args.B, 18, S, S), device="cuda").float()
 pol = torch.empty((args.B, S * S + 1), device="cuda")
 val = torch.empty((args.B,), device="cuda")
@@ -51,7 +54,7 @@ ctx.prof_enable(False)
 n_conv, ms_conv = ctx.prof_read(A.capi.PROF_CONV)
 n_head, ms_head = ctx.prof_read(A.capi.PROF_HEADS)
 wino = {}
-if args.wino:
+if args.wino or args.wino_h2:
     for nm, k in (("in", A.capi.PROF_WINO_IN), ("gemm", A.capi.PROF_WINO_GEMM), ("out", A.capi.PROF_WINO_OUT)):
         n_, ms_ = ctx.prof_read(k)
         wino[nm + "_ms_avg"] = ms_ / max(n_, 1)

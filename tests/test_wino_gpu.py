@@ -76,11 +76,12 @@ def test_stages_match_numpy(ctx, B, H, W, C, N):
     (192, 1, 64, 7, 6, 2, 8, 37, 2),        # K=192, 6x7 board (2x2 tiles, both ragged)
     (128, 1, 32, 5, 5, 2, 26, 90, 2),       # 5x5 board
 ])
-def test_wino_networks_match_oracle_and_f32(ctx, K, L, FC, W, H, F, Aspace, B, bn_mode):
+@pytest.mark.parametrize("wmode", [A.capi.COMPUTE_WINO, A.capi.COMPUTE_WINO_H2])
+def test_wino_networks_match_oracle_and_f32(ctx, K, L, FC, W, H, F, Aspace, B, bn_mode, wmode):
     onet, gnet = make_pair(ctx, K, L, FC, W, H, F, Aspace, bn_mode)
     x = rand_planes(B, F, H, W, seed=K + B)
     pol_f, val_f = gnet.infer(x)
-    gnet.set_compute_mode(A.capi.COMPUTE_WINO | A.capi.COMPUTE_FORCE)
+    gnet.set_compute_mode(wmode | A.capi.COMPUTE_FORCE)
     pol_g, val_g = gnet.infer(x)
     assert not np.array_equal(pol_g, pol_f)          # really a different arithmetic path
     idx = [0, B // 2, B - 1]
@@ -89,8 +90,32 @@ def test_wino_networks_match_oracle_and_f32(ctx, K, L, FC, W, H, F, Aspace, B, b
     np.testing.assert_allclose(val_g[idx], val_o, atol=VAL_ATOL)
     np.testing.assert_allclose(pol_g, pol_f, atol=POL_ATOL, rtol=POL_RTOL)
     np.testing.assert_allclose(val_g, val_f, atol=VAL_ATOL)
-    print("wino max |dpol| vs f32: %.3e  vs oracle: %.3e   f32 vs oracle: %.3e" % (
-        np.abs(pol_g - pol_f).max(), np.abs(pol_g[idx] - pol_o).max(), np.abs(pol_f[idx] - pol_o).max()))
+    print("wino[%d] max |dpol| vs f32: %.3e  vs oracle: %.3e   f32 vs oracle: %.3e" % (
+        wmode, np.abs(pol_g - pol_f).max(), np.abs(pol_g[idx] - pol_o).max(), np.abs(pol_f[idx] - pol_o).max()))
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 3e3, 1e6])
+def test_wino_h2_range_management_and_batch_independence(ctx, scale):
+    """fp16x2 in the transform domain: the per-board power-of-two scale comes from a bound (|Bt d B| <= 100 max|d|), so no input
+    magnitude can overflow fp16 — inputs scaled from 1e-6 to 1e6 (the degenerate BatchNorm multiplies by 316 per layer on top)
+    stay finite and inside the tolerance; and a board's result does not depend on its batch neighbours (one loud and one
+    all-zero board next to it), bit for bit."""
+    onet, gnet = make_pair(ctx, 64, 3, 32, 9, 9, 18, 82, 0)
+    x = (rand_planes(40, 18, 9, 9, seed=3) * scale).astype(np.float32)
+    pol_f, val_f = gnet.infer(x)
+    gnet.set_compute_mode(A.capi.COMPUTE_WINO_H2 | A.capi.COMPUTE_FORCE)
+    pol_g, val_g = gnet.infer(x)
+    assert np.all(np.isfinite(pol_g)) and np.all(np.isfinite(val_g))
+    np.testing.assert_allclose(pol_g, pol_f, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(val_g, val_f, atol=VAL_ATOL)
+    y = x.copy()
+    y[1] *= 1000.0
+    y[2] = 0.0
+    pol_h, val_h = gnet.infer(y)
+    np.testing.assert_array_equal(pol_h[0], pol_g[0])
+    np.testing.assert_array_equal(pol_h[3:], pol_g[3:])
+    np.testing.assert_array_equal(val_h[3:], val_g[3:])
+    assert np.all(np.isfinite(pol_h))
 
 
 def test_wino_recommit_and_mode_round_trip(ctx):
