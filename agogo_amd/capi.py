@@ -240,7 +240,17 @@ class Ctx:
     def stream(self):
         return lib().agz_ctx_stream(self.h)
 
-    def prof_enable(self, on=True):
+    def prof_enable(self, on=True, classes=None):
+        """classes: iterable of PROF_* to record (None: all)"""
+        if on and classes is not None:
+            mask = 0
+            for k in classes:
+                mask |= 1 << (k + 1)
+            _check(lib().agz_ctx_prof_enable(self.h, mask), "agz_ctx_prof_enable")
+            return
+        return self._prof_enable_all(on)
+
+    def _prof_enable_all(self, on=True):
         _check(lib().agz_ctx_prof_enable(self.h, int(on)), "agz_ctx_prof_enable")
 
     def prof_read(self, klass):

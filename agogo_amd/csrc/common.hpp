@@ -45,6 +45,7 @@ struct agz_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool prof_on = false;
+  unsigned prof_mask = ~0u;   // classes that record events while prof_on (agz_ctx_prof_enable)
   agz::ProfClass prof[AGZ_PROF_NCLASS];
   int prof_open = 0;   // scopes begun and not yet ended (classes nest: a layer scope around its kernels' scopes)
   int num_cus = 256;
@@ -59,8 +60,9 @@ namespace agz {
 struct ProfScope {
   agz_ctx* c;
   int k;
-  ProfScope(agz_ctx* c_, int k_) : c(c_), k(k_) { if (c->prof_on) c->prof_begin(k); }
-  ~ProfScope() { if (c->prof_on) c->prof_end(k); }
+  bool on;
+  ProfScope(agz_ctx* c_, int k_) : c(c_), k(k_), on(c_->prof_on && ((c_->prof_mask >> k_) & 1u)) { if (on) c->prof_begin(k); }
+  ~ProfScope() { if (on) c->prof_end(k); }
 };
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

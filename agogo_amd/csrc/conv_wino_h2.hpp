@@ -28,6 +28,7 @@ struct WinoH2Args {
   const unsigned* amax_in;   // [B] max |x| of every board of this block's input (float bits)
   unsigned* amax_out;        // [B] max of this block's output, accumulated by wino_out_h2_kernel (zeroed by the caller)
   float w_unscale;           // 1 / su
+  int dbg;                   // AGZ_WINO_H2_DBG (measurement only): 1 = no M stores, 2 = A fetched once per tile, 4 = B fetched once
 };
 
 // s = 2^(134 - E): |V| <= 128 * amax < 2^(E - 119)  =>  |V * s| < 2^15.   inv = 1 / s.
@@ -60,17 +61,27 @@ __global__ __launch_bounds__(256) void wino_in_h2_kernel(WinoH2Args h) {
   float sb, inv_;
   wino_h2_scales(h.amax_in[b], &sb, &inv_);
   const float* xb = a.x + (size_t)b * a.Hp * a.Wp * a.C + 2 * c2;
+  // all 36 loads are issued unconditionally (clamped address, zeroed afterwards): a branch per load keeps only one column of
+  // six in flight (measured 4.2 TB/s of algorithmic bytes with the branches)
+  float2 d[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const int px = 4 * tx + j, pxc = px < a.Wp ? px : a.Wp - 1;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const int py = 4 * ty + i, pyc = py < a.Hp ? py : a.Hp - 1;
+      d[i][j] = *reinterpret_cast<const float2*>(xb + ((size_t)pyc * a.Wp + pxc) * a.C);
+    }
+  }
   float tmx[6][6], tmy[6][6];
 #pragma unroll
   for (int j = 0; j < 6; j++) {
-    const int px = 4 * tx + j;
+    const bool okx = 4 * tx + j < a.Wp;
     float dx[6], dy[6], ox[6], oy[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      const int py = 4 * ty + i;
-      float2 v = make_float2(0.f, 0.f);
-      if (py < a.Hp && px < a.Wp) v = *reinterpret_cast<const float2*>(xb + ((size_t)py * a.Wp + px) * a.C);
-      dx[i] = v.x; dy[i] = v.y;
+      const bool ok = okx && 4 * ty + i < a.Hp;
+      dx[i] = ok ? d[i][j].x : 0.f; dy[i] = ok ? d[i][j].y : 0.f;
     }
     wino_bt6(dx, ox);
     wino_bt6(dy, oy);
@@ -340,6 +351,160 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2w_kernel(WinoH2Args h) {
   }
 }
 
+// Deep-prefetch GEMM for a compile-time K extent (NK 32-channel steps, fully unrolled), tile 128 x (128 * NT).
+//  * The A operand — the only one that comes from HBM, every row a first touch — is fetched PFA steps ahead into rotating
+//    register sets; B (L2-resident) one step ahead.  Every step issues B FIRST and A after it: vmcnt retires in order, so the
+//    wait before the LDS stores is vmcnt(4) — B and the A set that is due have landed, the newest A set stays in flight
+//    (issuing A first forces vmcnt(0) and defeats the prefetch: measured, PFA 1-4 within 5 %).
+//  * Staging map: thread t owns the 16-byte chunk t%4 of rows t/4 + 64*k — eight consecutive lanes write 128 contiguous LDS
+//    bytes (the plain kernels' (row t/2, half t%2) map makes every ds_write_b128 a 2-way bank conflict: SQ_LDS_BANK_CONFLICT
+//    was 1/3 of SQ_LDS_IDX_ACTIVE), and four lanes read 64 contiguous global bytes.
+//  * Full tiles store without per-element bounds branches.
+template <int NK, int PFA, int NT>
+__global__ __launch_bounds__(256, 2) void wino_gemm_h2d_kernel(WinoH2Args h) {
+  const WinoArgs& a = h.w;
+  constexpr int BN = 128 * NT;
+  constexpr int PA = 128 * 64, PB = BN * 64;
+  constexpr int STAGE = 2 * PA + 2 * PB;          // 32 KB (NT 1) / 48 KB (NT 2)
+  constexpr int NJ = 2 * NT;                      // 32-column MFMA tiles per wave
+  constexpr int NBR = 2 * NT;                     // B staging rows per thread
+  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE];
+
+  const int n_nt = (a.Ntot + BN - 1) / BN;
+  const int per_pos = a.n_mtiles * n_nt;
+  const int nblk = 36 * per_pos;
+  const int id = blockIdx.x;
+  int q = nblk >> 3, rr = nblk & 7, xcd = id & 7, slot = id >> 3;
+  int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
+  const int pos = tile / per_pos;
+  const int rem = tile - pos * per_pos;
+  const int m_tile = rem / n_nt, n_tile = rem - m_tile * n_nt;
+  const int m0 = m_tile * 128, n0 = n_tile * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int sr = tid >> 2, sc = tid & 3;          // staging: rows sr + 64 k, 16-byte chunk sc
+  const unsigned piece_bytes = (unsigned)a.Ntot * 64u;
+  unsigned xo[2], so_a[2], wo[NBR], so_b[NBR];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    int m = m0 + sr + 64 * k;
+    if (m >= a.T) m = a.T - 1;
+    xo[k] = (unsigned)((((size_t)pos * a.T + m) * a.C) * 4) + (unsigned)sc * 16u;
+    so_a[k] = h2_lds_off(sr + 64 * k, sc);
+  }
+#pragma unroll
+  for (int k = 0; k < NBR; k++) {
+    int n = n0 + sr + 64 * k;
+    if (n >= a.Ntot) n = a.Ntot - 1;
+    wo[k] = (unsigned)pos * (unsigned)NK * 2u * piece_bytes + (unsigned)n * 64u + (unsigned)sc * 16u;
+    so_b[k] = h2_lds_off(sr + 64 * k, sc);
+  }
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  int ra[2], rb[NJ];
+#pragma unroll
+  for (int i = 0; i < 2; i++) ra[i] = (wm * 2 + i) * 32 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) rb[j] = wn * (64 * NT) + j * 32 + (lane & 31);
+  const int kh = lane >> 5;
+
+  const char* xbase = reinterpret_cast<const char*>(a.V);
+  const char* wbase = reinterpret_cast<const char*>(h.U2);
+  u32x4_t xa[PFA][4];          // [set][row k * 2 + piece]
+  u32x4_t xb[NBR][2];          // [row k][piece]
+  auto load_a = [&](int set, int kk) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      xa[set][2 * k + 0] = *reinterpret_cast<const u32x4_t*>(xbase + xo[k] + (unsigned)kk * 128u);
+      xa[set][2 * k + 1] = *reinterpret_cast<const u32x4_t*>(xbase + xo[k] + (unsigned)kk * 128u + 64u);
+    }
+  };
+  auto load_b = [&](int kk) {
+#pragma unroll
+    for (int k = 0; k < NBR; k++) {
+      xb[k][0] = *reinterpret_cast<const u32x4_t*>(wbase + wo[k] + (unsigned)kk * 2u * piece_bytes);
+      xb[k][1] = *reinterpret_cast<const u32x4_t*>(wbase + wo[k] + (unsigned)kk * 2u * piece_bytes + piece_bytes);
+    }
+  };
+  load_b(0);
+#pragma unroll
+  for (int p = 0; p < PFA; p++) load_a(p, p < NK ? p : NK - 1);
+#pragma unroll
+  for (int it = 0; it < NK; it++) {
+    const int set = it % PFA;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      *reinterpret_cast<u32x4_t*>(lds + 0 * PA + so_a[k]) = xa[set][2 * k + 0];
+      *reinterpret_cast<u32x4_t*>(lds + 1 * PA + so_a[k]) = xa[set][2 * k + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < NBR; k++) {
+      *reinterpret_cast<u32x4_t*>(lds + 2 * PA + 0 * PB + so_b[k]) = xb[k][0];
+      *reinterpret_cast<u32x4_t*>(lds + 2 * PA + 1 * PB + so_b[k]) = xb[k][1];
+    }
+    __syncthreads();
+    if (it + 1 < NK && !(h.dbg & 4)) load_b(it + 1);            // B first: see the header
+    if (it + PFA < NK && !(h.dbg & 2)) load_a(set, it + PFA);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      f16x8_t A_[2][2], B_[NJ][2];
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) A_[i][p] = *reinterpret_cast<const f16x8_t*>(lds + p * PA + h2_lds_off(ra[i], 2 * ks + kh));
+#pragma unroll
+        for (int j = 0; j < NJ; j++) B_[j][p] = *reinterpret_cast<const f16x8_t*>(lds + 2 * PA + p * PB + h2_lds_off(rb[j], 2 * ks + kh));
+      }
+#pragma unroll
+      for (int pp = 0; pp < 3; pp++) {            // small terms first: lo*hi, hi*lo, hi*hi
+        const int pa = pp == 0 ? 1 : 0, pb = pp == 1 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[i][pa], B_[j][pb], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  if ((h.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+  const bool full = m0 + 128 <= a.T && n0 + BN <= a.Ntot;   // uniform
+  float* dst0 = a.Mb + ((size_t)pos * a.T + m0 + wm * 64 + 4 * (lane >> 5)) * a.Ntot + n0 + wn * (64 * NT) + (lane & 31);
+  if (full) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float* d = dst0 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.Ntot;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) d[j * 32] = acc[i][j][r];
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < a.T) {
+          float* d = a.Mb + ((size_t)pos * a.T + m) * a.Ntot;
+#pragma unroll
+          for (int j = 0; j < NJ; j++) {
+            const int c = n0 + wn * (64 * NT) + j * 32 + (lane & 31);
+            if (c < a.Ntot) d[c] = acc[i][j][r];
+          }
+        }
+      }
+  }
+}
+
 // wino_out_kernel + exact un-scaling + the per-board maximum of the block output (the next block's range).
 __global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
   const WinoArgs& a = h.w;
@@ -353,6 +518,21 @@ __global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
   float s_, unscale;
   wino_h2_scales(h.amax_in[b], &s_, &unscale);
   unscale *= h.w_unscale;
+  // the 16 epilogue parameter vectors of this (tile, channel): fetched up front with the M loads (clamped address) — loaded
+  // inside the per-pixel branch each one is a dependent L2 round trip (sixteen of them back to back per thread)
+  float4 E[4][4];
+  {
+    const float4* ep = reinterpret_cast<const float4*>(a.ep);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int hh = 4 * ty + k, hc = hh < a.H ? hh : a.H - 1;
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        const int ww = 4 * tx + l, wc = ww < a.W ? ww : a.W - 1;
+        E[k][l] = ep[(size_t)(hc * a.W + wc) * a.Cout_p + c];
+      }
+    }
+  }
   float Y[2][4][4];
 #pragma unroll
   for (int br = 0; br < 2; br++) {
@@ -369,7 +549,6 @@ __global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
 #pragma unroll
     for (int k = 0; k < 4; k++) wino_at4(tm[k], Y[br][k]);
   }
-  const float4* ep = reinterpret_cast<const float4*>(a.ep);
   float* yb = a.y + (size_t)b * a.Hp * a.Wp * a.Cout_p + c;
   float mx = 0.f;
 #pragma unroll
@@ -378,14 +557,14 @@ __global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
 #pragma unroll
     for (int l = 0; l < 4; l++) {
       const int ww = 4 * tx + l;
+      const float4 e = E[k][l];
+      float va = (Y[0][k][l] * unscale) * e.x + e.y;
+      float vb = (Y[1][k][l] * unscale) * e.z + e.w;
+      va = va > 0.f ? va : 0.f;
+      vb = vb > 0.f ? vb : 0.f;
+      float s = va + vb;
+      s = s > 0.f ? s : 0.f;
       if (live && hh < a.H && ww < a.W) {
-        const float4 e = ep[(size_t)(hh * a.W + ww) * a.Cout_p + c];
-        float va = (Y[0][k][l] * unscale) * e.x + e.y;
-        float vb = (Y[1][k][l] * unscale) * e.z + e.w;
-        va = va > 0.f ? va : 0.f;
-        vb = vb > 0.f ? vb : 0.f;
-        float s = va + vb;
-        s = s > 0.f ? s : 0.f;
         yb[((size_t)(hh + 1) * a.Wp + (ww + 1)) * a.Cout_p] = s;
         mx = fmaxf(mx, s);
       }
@@ -439,7 +618,7 @@ static float wino_build_u2(std::vector<_Float16>& u2, int Ntot, int C, Get get) 
 }
 
 // launches the stages of one block for a chunk of boards (h.w.V / Mb sized by the caller)
-static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide) {
+static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0) {
   WinoArgs& a = h.w;
   a.nty = ceil_div(a.H, 4); a.ntx = ceil_div(a.W, 4); a.TPB = a.nty * a.ntx; a.T = a.B * a.TPB;
   a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
@@ -450,10 +629,28 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide) {
   }
   {
     ProfScope ps(ctx, AGZ_PROF_WINO_GEMM);
-    if (wide)
-      hipLaunchKernelGGL(wino_gemm_h2w_kernel, dim3(36 * a.n_mtiles * ceil_div(a.Ntot, 256)), dim3(256), 0, ctx->stream, h);
-    else
-      hipLaunchKernelGGL(wino_gemm_h2_kernel, dim3(36 * a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, h);
+    const dim3 gw(36 * a.n_mtiles * ceil_div(a.Ntot, 256)), gn(36 * a.n_mtiles * a.n_ntiles);
+    // the unrolled deep-prefetch form is instantiated per K extent (32-channel steps); K = 256 with every prefetch depth (tuning)
+    const int nk = a.C >> 5;
+    bool done = true;
+#define AGZ_H2D(NK_, PF_, NT_, G_) hipLaunchKernelGGL((wino_gemm_h2d_kernel<NK_, PF_, NT_>), G_, dim3(256), 0, ctx->stream, h)
+#define AGZ_H2D_NK(NK_) { if (wide) AGZ_H2D(NK_, 2, 2, gw); else AGZ_H2D(NK_, 2, 1, gn); }
+    if (pfa < 1 || (a.C & 31)) done = false;
+    else if (nk == 8) {
+      if (wide) { if (pfa == 1) AGZ_H2D(8, 1, 2, gw); else if (pfa == 2) AGZ_H2D(8, 2, 2, gw); else if (pfa == 3) AGZ_H2D(8, 3, 2, gw); else AGZ_H2D(8, 4, 2, gw); }
+      else { if (pfa == 1) AGZ_H2D(8, 1, 1, gn); else if (pfa == 2) AGZ_H2D(8, 2, 1, gn); else if (pfa == 3) AGZ_H2D(8, 3, 1, gn); else AGZ_H2D(8, 4, 1, gn); }
+    }
+    else if (nk == 2) AGZ_H2D_NK(2)
+    else if (nk == 4) AGZ_H2D_NK(4)
+    else if (nk == 6) AGZ_H2D_NK(6)
+    else if (nk == 12) AGZ_H2D_NK(12)
+    else if (nk == 16) AGZ_H2D_NK(16)
+    else done = false;
+#undef AGZ_H2D_NK
+#undef AGZ_H2D
+    if (done) {}
+    else if (wide) hipLaunchKernelGGL(wino_gemm_h2w_kernel, gw, dim3(256), 0, ctx->stream, h);
+    else hipLaunchKernelGGL(wino_gemm_h2_kernel, gn, dim3(256), 0, ctx->stream, h);
   }
   {
     ProfScope ps(ctx, AGZ_PROF_WINO_OUT);

@@ -91,6 +91,9 @@ int agz_ctx_prof_enable(agz_ctx* c, int enable) {
   if (enable) {
     AGZ_HIP_TRY(hipStreamSynchronize(c->stream));
     for (auto& p : c->prof) { p.used = 0; p.launches = 0; p.total_ms = 0; }
+    // enable == 1: every class; otherwise bit k+1 selects class k (each recorded launch costs two hipEventRecord calls on the
+    // launching thread: bench.py times only the dominant class inside its timed region)
+    c->prof_mask = enable == 1 ? ~0u : ((unsigned)enable >> 1);
     c->prof_on = true;
   } else {
     c->prof_on = false;

@@ -836,8 +836,12 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   if (!tower_done && wino_h2_ok) {
     // Winograd with fp16x2 transform-domain products (conv_wino_h2.hpp): per-board ranges in d_amax[block][board]
     AGZ_REQUIRE((int)d_u2_dual.size() == conf.SharedLayers, AGZ_E_STATE, "agz_net: Winograd fp16x2 weights not built");
-    static const int wide_env = [] { const char* e = getenv("AGZ_WINO_H2_WIDE"); return e ? atoi(e) : -1; }();   // tuning knob
-    const bool wide = wide_env >= 0 ? wide_env != 0 : false;
+    // GEMM form (measured on G19/B=512, profiles/r02/wino_h2_gemm_variants.log): 128x256 tile with the A operand fetched two
+    // steps ahead 0.385 ms, 128x128 0.40 ms, the plain single-prefetch kernels 0.47-0.50 ms.  Tuning knobs override.
+    static const int wide_env = [] { const char* e = getenv("AGZ_WINO_H2_WIDE"); return e ? atoi(e) : -1; }();
+    static const int pfa_env = [] { const char* e = getenv("AGZ_WINO_H2_PFA"); return e ? atoi(e) : -1; }();
+    const bool wide = wide_env >= 0 ? wide_env != 0 : (2 * Kp) % 256 == 0;
+    const int pfa = pfa_env >= 0 ? pfa_env : 2;
     const int tpb = ceil_div(H, 4) * ceil_div(W, 4);
     const int chunk = (int)std::min<size_t>((size_t)B, (((size_t)1 << 32) - 1) / ((size_t)36 * tpb * Kp * 4));
     if (chunk > wino_chunk_cap) {
@@ -868,8 +872,10 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         wa.V = d_wV; wa.Mb = d_wM; wa.ep = d_ep_dual[l];
         wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
         hh.U2 = d_u2_dual[l]; hh.w_unscale = u_unscale[l];
+        static const int dbg_env = [] { const char* e = getenv("AGZ_WINO_H2_DBG"); return e ? atoi(e) : 0; }();   // measurement knob
+        hh.dbg = dbg_env;
         hh.amax_in = d_amax + (size_t)l * B + b0; hh.amax_out = d_amax + (size_t)(l + 1) * B + b0;
-        wino_h2_launch(ctx, hh, wide);
+        wino_h2_launch(ctx, hh, wide, pfa);
       }
       std::swap(cur, nxt);
     }

@@ -43,7 +43,8 @@ BF16_MFMA_PEAK_TFLOPS = 2516.6  # same guide: v_mfma_f32_32x32x16_bf16 dense (25
 BF16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 # fp16x2 formulation (conv_h2.hpp): 3 fp16 MFMAs per product (fp16 dense peak = bf16 dense peak)
 FP16X2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
-MODES = {"f32": capi.COMPUTE_F32_MFMA, "bf16x3": capi.COMPUTE_BF16X3, "fp16x2": capi.COMPUTE_FP16X2, "wino": capi.COMPUTE_WINO}
+MODES = {"f32": capi.COMPUTE_F32_MFMA, "bf16x3": capi.COMPUTE_BF16X3, "fp16x2": capi.COMPUTE_FP16X2, "wino": capi.COMPUTE_WINO,
+         "wino_h2": capi.COMPUTE_WINO_H2}
 HBM_PEAK_GBS = 8000.0          # same guide: HBM3E ~8 TB/s
 
 
@@ -58,7 +59,7 @@ def standard_bn_init(net):
             net.set_param(i, np.zeros(n, np.float32))
 
 
-def cpu_baseline(size, K, L, budget_s=12.0, max_threads=64):
+def cpu_baseline(size, K, L, budget_s=20.0, max_threads=32):
     """The oracle (CPU restatement of the reference algorithm: per-leaf inference, sequential pipeline) timed on the box's
     host cores, on a bounded sample of the same workload: T threads (one independent 19x19 game each, the way the
     reference would use its cores: SURVEY 8(d)), each from its own random mid-game opening (the same generator as the GPU
@@ -79,8 +80,9 @@ def cpu_baseline(size, K, L, budget_s=12.0, max_threads=64):
     t0 = time.perf_counter()
     net.infer(x)
     t_eval = time.perf_counter() - t0
-    sims = int(max(2, min(64, budget_s / max(t_eval, 1e-3) - 1)))
     T = max(1, min(max_threads, (os.cpu_count() or 2) // 2))
+    # under T concurrent evaluations one evaluation takes ~2.2x its solo time on this class of host (memory bandwidth)
+    sims = int(max(2, min(64, budget_s / max(2.2 * t_eval, 1e-3) - 1)))
     arenas = []
     rng = np.random.default_rng(1337)
     for g in range(T):
@@ -209,9 +211,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-games-leg", action="store_true", help="skip the measured games/s leg (config #2)")
     ap.add_argument("--two-nets", action="store_true", help="agents A and B hold different networks")
-    ap.add_argument("--compute", choices=["wino", "bf16x3", "f32", "fp16x2"], default="wino",
-                    help="dual-block conv arithmetic: wino = Winograd F(4x4,3x3), fp32 transforms + bf16x3 products in the "
-                         "transform domain (3.6x fewer matrix instructions; same parity tolerance), bf16x3 = direct conv, exact "
+    ap.add_argument("--compute", choices=["wino_h2", "wino", "bf16x3", "f32", "fp16x2"], default="wino_h2",
+                    help="dual-block conv arithmetic: wino_h2 = Winograd F(4x4,3x3), fp32 transforms, the transform-domain operand "
+                         "written pre-split into two fp16 pieces (per-board power-of-two range from a proven bound), 3 fp16 MFMAs per "
+                         "product; wino = the same with bf16x3 products (6 MFMAs per product); bf16x3 = direct conv, exact "
                          "3-way bf16 split on the bf16 matrix pipe (fp32-grade), f32 = v_mfma_f32_32x32x2_f32, fp16x2 = "
                          "range-managed 2-way fp16 split (3 MFMAs per product; opt-in fast mode)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the short comparison legs in the other compute modes")
@@ -297,7 +300,11 @@ def main():
         step()
     fence()
     st0 = arena.stats()
-    ctx.prof_enable(True)
+    # inside the timed region only the dominant kernel class and the move-boundary class record HIP events (two event records
+    # per launch; timing all nine classes cost ~1.3 ms of a 24 ms step in round 2's first run); the full breakdown is taken
+    # on extra steps after the timed region
+    dom = capi.PROF_WINO_GEMM if args.compute in ("wino", "wino_h2") else capi.PROF_CONV
+    ctx.prof_enable(True, classes=[dom, capi.PROF_MOVE])
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -306,6 +313,13 @@ def main():
     dt = time.perf_counter() - t0
     ctx.prof_enable(False)
     st1 = arena.stats()
+    dom_n, dom_ms = ctx.prof_read(dom)
+    move_n, _ = ctx.prof_read(capi.PROF_MOVE)
+    ctx.prof_enable(True)
+    for _ in range(6):
+        step()
+    fence()
+    ctx.prof_enable(False)
 
     sims = st1["sims_nonnull"] - st0["sims_nonnull"]
     sims_all = st1["sims_total"] - st0["sims_total"]
@@ -324,11 +338,14 @@ def main():
                     ("wino_in", capi.PROF_WINO_IN), ("wino_gemm", capi.PROF_WINO_GEMM), ("wino_out", capi.PROF_WINO_OUT)):
         n, ms = ctx.prof_read(k)
         prof[name] = {"launches": n, "avg_ms": (ms / n) if n else None, "total_ms": ms}
+    dom_name = "wino_gemm" if args.compute in ("wino", "wino_h2") else "conv_dual"
+    prof[dom_name + "_timed_region"] = {"launches": dom_n, "avg_ms": (dom_ms / dom_n) if dom_n else None, "total_ms": dom_ms}
+    prof["breakdown_note"] = "all classes: six extra steps after the timed region; *_timed_region: HIP events inside the timed region"
 
     # short comparison legs in the other compute modes (same arena, the games simply continue)
     legs = {}
     if world == 1 and not args.no_f32_leg:
-        for mode in ("f32", "bf16x3", "fp16x2", "wino"):
+        for mode in ("f32", "bf16x3", "fp16x2", "wino", "wino_h2"):
             if mode == args.compute:
                 continue
             for n_ in nets:
@@ -375,18 +392,23 @@ def main():
         conv_flops_launch = 2.0 * (G * hw) * (2 * K) * (9 * K)  # algorithmic FLOPs of one dual-block launch
         conv_ms = prof["conv_dual"]["avg_ms"]
         achieved = conv_flops_launch / (conv_ms * 1e-3) / 1e12 if conv_ms else None
-        peaks = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16X3_PEAK_TFLOPS, "fp16x2": FP16X2_PEAK_TFLOPS, "wino": BF16X3_PEAK_TFLOPS}
+        peaks = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16X3_PEAK_TFLOPS, "fp16x2": FP16X2_PEAK_TFLOPS, "wino": BF16X3_PEAK_TFLOPS,
+                 "wino_h2": FP16X2_PEAK_TFLOPS}
         peak = peaks[args.compute]
         wino_detail = None
         flops_launch, launch_ms, n_launch = conv_flops_launch, conv_ms, prof["conv_dual"]["launches"]
-        if args.compute == "wino" and prof["wino_gemm"]["avg_ms"]:
+        if dom_name == "conv_dual" and prof["conv_dual_timed_region"]["avg_ms"]:   # direct modes: the block kernel itself, timed in the region
+            launch_ms, n_launch = prof["conv_dual_timed_region"]["avg_ms"], prof["conv_dual_timed_region"]["launches"]
+            achieved = flops_launch / (launch_ms * 1e-3) / 1e12
+        if args.compute in ("wino", "wino_h2") and prof["wino_gemm"]["avg_ms"]:
             # dominant kernel of this mode: the 36 transform-domain GEMMs of one block (its own FLOPs, not the direct conv's)
             tiles = G * ((S + 3) // 4) ** 2
             flops_launch = 2.0 * 36 * tiles * K * (2 * K)
-            launch_ms, n_launch = prof["wino_gemm"]["avg_ms"], prof["wino_gemm"]["launches"]
+            launch_ms, n_launch = prof["wino_gemm_timed_region"]["avg_ms"], prof["wino_gemm_timed_region"]["launches"]
             achieved = flops_launch / (launch_ms * 1e-3) / 1e12
             in_bytes = 4.0 * (G * hw * K + 36 * tiles * K)            # x read once + V written
-            gemm_bytes = 4.0 * (36 * tiles * K + 36 * tiles * 2 * K)  # V read once + M written (weights stay in L2)
+            w_bytes = 36.0 * K * (2 * K) * (4 if args.compute == "wino_h2" else 6)   # the block's Winograd-domain weight image, read once
+            gemm_bytes = 4.0 * (36 * tiles * K + 36 * tiles * 2 * K) + w_bytes  # V read once + M written once + weights
             out_bytes = 4.0 * (36 * tiles * 2 * K + G * hw * K)       # M read + y written
             def gbs(b, ms):
                 return (b / (ms * 1e-3) / 1e9) if ms else None
@@ -396,13 +418,16 @@ def main():
                               "FLOPs a direct 3x3 convolution would need for the same result (3.61x the GEMM FLOPs on 19x19)",
                 "wino_in": {"avg_ms": prof["wino_in"]["avg_ms"], "bound": "hbm", "algorithmic_bytes": in_bytes,
                             "achieved_GBs": gbs(in_bytes, prof["wino_in"]["avg_ms"]), "peak_GBs": HBM_PEAK_GBS},
-                "wino_gemm": {"avg_ms": launch_ms, "bound": "mfma", "flops": flops_launch, "algorithmic_bytes": gemm_bytes,
-                              "achieved_GBs": gbs(gemm_bytes, launch_ms)},
+                "wino_gemm": {"avg_ms": launch_ms, "bound": "hbm" if args.compute == "wino_h2" else "mfma", "flops": flops_launch,
+                              "algorithmic_bytes": gemm_bytes, "achieved_GBs": gbs(gemm_bytes, launch_ms), "peak_GBs": HBM_PEAK_GBS,
+                              "tflops": achieved, "mfma_frac": achieved / peak, "mfma_peak_tflops": peak},
+                "block_algorithmic_bytes": in_bytes + gemm_bytes + out_bytes,
+                "block_achieved_GBs": gbs(in_bytes + gemm_bytes + out_bytes, conv_ms),
                 "wino_out": {"avg_ms": prof["wino_out"]["avg_ms"], "bound": "hbm", "algorithmic_bytes": out_bytes,
                              "achieved_GBs": gbs(out_bytes, prof["wino_out"]["avg_ms"]), "peak_GBs": HBM_PEAK_GBS}}
         traffic = None
         pmc_name = {"f32": "pmc_conv_dual.json", "bf16x3": "pmc_conv_x3.json", "fp16x2": "pmc_conv_h2.json",
-                    "wino": "pmc_wino_gemm.json"}[args.compute]
+                    "wino": "pmc_wino_gemm.json", "wino_h2": "pmc_wino_h2_gemm.json"}[args.compute]
         pmc_path = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc_path) and (S, K, L, G) == (19, 256, 20, 512):  # the PMC pass was taken on this exact shape
             try:
@@ -412,7 +437,7 @@ def main():
         for mode, leg in legs.items():
             if leg.get("conv_dual_avg_ms"):
                 leg["conv_dual_tflops"] = conv_flops_launch / (leg["conv_dual_avg_ms"] * 1e-3) / 1e12
-                if mode == "wino":
+                if mode in ("wino", "wino_h2"):
                     leg["note"] = "direct-equivalent FLOPs per block time (the mode executes 3.61x fewer)"
                 else:
                     leg["frac_of_its_roofline"] = leg["conv_dual_tflops"] / peaks[mode]
@@ -420,11 +445,13 @@ def main():
         dtypes = {"f32": "f32",
                   "bf16x3": "f32 (bf16x3 split: each fp32 operand = 3 exact bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate)",
                   "fp16x2": "f32 (fp16x2 split: power-of-two range scaling, 2 fp16 pieces = 23 significand bits, 3 fp16 MFMAs per product, fp32 accumulate)",
-                  "wino": "f32 (Winograd F(4x4,3x3): fp32 transforms; transform-domain products as bf16x3 = 3 exact bf16 pieces per fp32 operand, 6 bf16 MFMAs per product, fp32 accumulate)"}
+                  "wino": "f32 (Winograd F(4x4,3x3): fp32 transforms; transform-domain products as bf16x3 = 3 exact bf16 pieces per fp32 operand, 6 bf16 MFMAs per product, fp32 accumulate)",
+                  "wino_h2": "f32 (Winograd F(4x4,3x3): fp32 transforms; transform-domain products as fp16x2 = each fp32 operand scaled by a power of two and split into 2 fp16 pieces (22-23 significand bits, absolute error <= 2^-38 of the tensor range), 3 fp16 MFMAs per product, fp32 accumulate)"}
         kernels = {"f32": "conv3x3_mfma_kernel<2,2,2,DUAL> (fused dual-branch block)",
                    "bf16x3": "conv3x3_x3_kernel<DUAL> (fused dual-branch block, bf16x3)",
                    "fp16x2": "conv3x3_h2w_kernel (fused dual-branch block, fp16x2, 128x256 tile)",
-                   "wino": "wino_gemm_kernel (36 transform-domain GEMMs of one dual block, bf16x3 products; 0.70 of the block's 1.09 ms)"}
+                   "wino": "wino_gemm_kernel (36 transform-domain GEMMs of one dual block, bf16x3 products; 0.70 of the block's 1.09 ms)",
+                   "wino_h2": "wino_gemm_h2d_kernel<8,2,2> (36 transform-domain GEMMs of one dual block, fp16x2 products, 128x256 tile, A operand fetched two steps ahead; the largest of the block's three kernels)"}
         notes = {"f32": "dense fp32 MFMA peak",
                  "bf16x3": ("algorithmic fp32-grade FLOPs against the dense bf16 MFMA peak / 6 (six bf16 MFMAs per product); the same "
                             "FLOPs are %.2fx the fp32-MFMA peak of 157.3; measured bare-MFMA ceiling under the power cap on random "
@@ -433,7 +460,11 @@ def main():
                             "fp32-MFMA peak (DESIGN.md 4c)" % ((achieved or 0) / FP32_MFMA_PEAK_TFLOPS)),
                  "wino": ("FLOPs of the transform-domain GEMMs (what this formulation executes) against the dense bf16 MFMA peak / 6; "
                           "the block as a whole delivers the direct convolution's result at extra.wino.block_direct_equivalent_tflops "
-                          "(DESIGN.md 4d); the two transform kernels are HBM-bound, see extra.wino")}
+                          "(DESIGN.md 4d); the two transform kernels are HBM-bound, see extra.wino"),
+                 "wino_h2": ("with 3 fp16 MFMAs per product the GEMMs' arithmetic intensity (3 x 120.8 GFLOP of MFMA work over 1.44 GB = 252 FLOP/B) "
+                             "sits BELOW the ridge (2516.6 TFLOP/s / 8 TB/s = 315 FLOP/B): the kernel's roofline is the HBM roof. achieved = "
+                             "algorithmic bytes (V read once + M written once + the block's weights) / launch time; the MFMA-side fraction "
+                             "(transform-domain FLOPs against bf16 peak / 3) is extra.wino.wino_gemm.mfma_frac (DESIGN.md 4e)")}
         out = {
             "metric": "mcts_sims_per_sec", "value": sims_sum / t_max, "unit": "sims/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
@@ -446,14 +477,18 @@ def main():
                        "board": S, "K": K, "blocks": L, "games_per_gpu": G, "sims_per_move": args.budget,
                        "weights": "random-init seed 1337 (GlorotU conv, GlorotN FC; BN gamma=1 beta=0, identity stats)",
                        "parallelism": "games sharded %d/GPU, no data-path collective" % G},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": (achieved / peak) if achieved else None, "traffic": traffic,
+            "roofline": ({"bound": "hbm", "achieved": wino_detail["wino_gemm"]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": wino_detail["wino_gemm"]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                          "algorithmic_bytes_per_launch": wino_detail["wino_gemm"]["algorithmic_bytes"]}
+                         if (args.compute == "wino_h2" and wino_detail) else
+                         {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": (achieved / peak) if achieved else None, "traffic": traffic}) | {
                          "kernel": kernels[args.compute], "peak_note": notes[args.compute],
                          "flops_per_launch": flops_launch, "avg_launch_ms": launch_ms,
                          "launches": n_launch},
             "extra": {"nn_evals_per_s": evals_sum / t_max, "iterations_per_s": iters_sum / t_max,
                       "timed_region": {"moves_finished": st1["moves_played"] - st0["moves_played"],
-                                       "move_boundaries": prof["move"]["launches"] // 2,
+                                       "move_boundaries": move_n // 2,
                                        "mean_path_nodes": (st1["path_nodes"] - st0["path_nodes"]) / max(1, sims_all),
                                        "mean_children_per_select": (st1["children_read"] - st0["children_read"]) / max(1, (st1["path_nodes"] - st0["path_nodes"]) - sims_all),
                                        "opening_moves_mean": float(n_open.mean()), "opening_moves_max": int(n_open.max()),

@@ -24,6 +24,7 @@ extern "C" {
 #define AGZ_PROF_WINO_GEMM 7 /* the 36 transform-domain GEMMs (the dominant kernel of that mode) */
 #define AGZ_PROF_WINO_OUT 8  /* output transform + block epilogue */
 #define AGZ_PROF_NCLASS 9
+/* enable: 0 stop, 1 all classes, otherwise a mask with bit (k + 1) selecting class k (fewer event records per step) */
 int agz_ctx_prof_enable(agz_ctx* ctx, int enable);
 int agz_ctx_prof_read(agz_ctx* ctx, int klass, int64_t* launches, double* total_ms);
 

@@ -177,7 +177,88 @@ def test_config3_go9_k128_l10_400sims(ctx):
     _drive_with_gpu_net(ctx, capi.GAME_WQ, (9, 9), 7.5, capi.ENC_WQ, 18, 128, 10, 400, 3, (1, 0))
 
 
-@pytest.mark.parametrize("mode", [capi.COMPUTE_BF16X3, capi.COMPUTE_FP16X2])
+def _drive_full_concurrency(ctx, kind, okind, S, komi, enc, F, K, L, G, budget, plies, mode, k=0, watch=(0, 1, 2)):
+    """BASELINE configs[1]/[2] at their stated concurrency: G concurrent games (each on its own 0-6 move random opening so the
+    batch is not G copies of one game), `plies` searched plies; the watched games' trees against oracle arenas whose inferencer
+    is the same GPU network evaluated as a G-row batch of the one board (same kernels as the arena's batch)."""
+    net = make_net(ctx, K, L, S, F)
+    net.set_compute_mode(mode)
+    Aspace = net.conf.ActionSpace
+    arena = A.Arena(ctx, kind, S[0], S[1], k, komi, encoder=enc, n_games=G, Budget=budget)
+    arena.set_inferencer(0, capi.INF_NET, net)
+    arena.set_inferencer(1, capi.INF_NET, net)
+    ab = np.array([(g % 2) == 0 for g in range(G)], dtype=np.uint8)
+    arena.reset(ab)
+    n_open = (np.arange(G) % 7).astype(np.int32)
+    arena.random_moves(n_open, 4242)
+    # batch independence of this arithmetic at this batch size (what lets the oracle's one-board callback stand for a batch row)
+    rng = np.random.default_rng(3)
+    x = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), size=(G, F, S[0], S[1])).astype(np.float32)
+    p_all, _ = net.infer(x)
+    p_rep, _ = net.infer(np.repeat(x[5:6], G, axis=0))
+    np.testing.assert_array_equal(p_rep[G - 1], p_all[5])
+
+    def cb(planes):
+        p, v = net.infer(np.repeat(planes.reshape(1, F, S[0], S[1]), G, axis=0))
+        return p[0], float(v[0])
+
+    orcs = {}
+    for g in watch:
+        o = O.Arena(okind, S[0], S[1], k, komi, enc=enc, Budget=budget)
+        o.set_callback(0, cb, Aspace)
+        o.set_callback(1, cb, Aspace)
+        o.begin(int(ab[g]))
+        for _ in range(int(n_open[g])):
+            o.random_move(4242, g)
+        np.testing.assert_array_equal(arena.history(g), o.history())
+        orcs[g] = o
+    for ply in range(plies):
+        arena.begin_move()
+        arena.simulate(budget)
+        arena.end_move(True)
+        for g, o in orcs.items():
+            _, st0 = o.state()
+            if st0["ended"]:
+                continue
+            mover = O.BLACK if len(o.history()) % 2 == 0 else O.WHITE
+            agent = 0 if ((mover == O.BLACK) == bool(ab[g])) else 1
+            o.step(True)
+            omv, ovis, obs, _ = o.root_children(agent)
+            dmv, dvis, dbs, _ = arena.root_children(g, agent)
+            np.testing.assert_array_equal(dmv, omv, err_msg="game %d ply %d" % (g, ply))
+            np.testing.assert_array_equal(dvis, ovis, err_msg="game %d ply %d" % (g, ply))
+            np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+            assert arena.history(g)[-1] == o.history()[-1]
+    st = arena.stats()
+    assert st["tree_full"] == 0 and st["examples_dropped"] == 0
+    assert st["moves_played"] >= G * plies * 0.9
+    # examples of the watched games (planes, one-hot policies) bit for bit
+    dp, dq, dv, dg = arena.examples()
+    for g, o in orcs.items():
+        op, oq, ov = o.examples()
+        rows = np.where(dg == g)[0]
+        assert len(rows) == len(ov)
+        for r, i in zip(rows, range(len(ov))):
+            np.testing.assert_array_equal(dp[r].view(np.uint32), op[i].view(np.uint32))
+            np.testing.assert_array_equal(dq[r], oq[i])
+    arena.close()
+    net.close()
+
+
+def test_config2_connect4_256_concurrent_games_10_plies(ctx):
+    """BASELINE config #2 at its stated concurrency: Connect-4, K=64, 6 blocks, 256 concurrent games, 400 sims/move."""
+    _drive_full_concurrency(ctx, capi.GAME_C4, O.C4, (6, 7), 0.0, capi.ENC_TWOPLANE, 2, 64, 6, 256, 400, 10, capi.COMPUTE_F32_MFMA, k=4,
+                            watch=(0, 1, 130))
+
+
+def test_config3_go9_512_concurrent_games_10_plies(ctx):
+    """BASELINE config #3 at its stated concurrency: 9x9 Go, K=128, 10 blocks, 512 concurrent games, 400 sims/move, in the
+    arithmetic bench.py's 9x9 leg uses (bf16x3)."""
+    _drive_full_concurrency(ctx, capi.GAME_WQ, O.WQ, (9, 9), 7.5, capi.ENC_WQ, 18, 128, 10, 512, 400, 10, capi.COMPUTE_BF16X3,
+                            watch=(0, 3, 509))
+
+
+@pytest.mark.parametrize("mode", [capi.COMPUTE_BF16X3, capi.COMPUTE_FP16X2, capi.COMPUTE_WINO, capi.COMPUTE_WINO_H2])
 def test_engine_with_split_mode_network_bit_exact_vs_oracle(ctx, mode):
     """AGZ_COMPUTE_BF16X3 / AGZ_COMPUTE_FP16X2 under the engine: 32 concurrent 9x9 games (2592 GEMM rows: the throughput regime, bf16x3 dual
     blocks), device trees vs oracle trees.  The oracle's inferencer evaluates each leaf as a 32-row batch of the same
