@@ -396,6 +396,254 @@ __global__ __launch_bounds__(64) void k_select(Dev d, GameCfg c, MctsCfg mc, flo
   }
 }
 
+// ---- lane rounds (V > 1): the same round as k_select / k_expand with the lane-INDEPENDENT work moved out of the sequential
+// lane loop.  What must run lane after lane is only what reads or writes shared tree state: the PUCT descent (it sees the
+// virtual-loss marks of the earlier lanes), and — after the network — child-block allocation, backup and undoVirtualLoss.
+// The descent needs no board: the mover alternates with the path (c4: never), Passes() follows from the moves on the path,
+// the depth from its length.  Replaying the path on the board, the leaf's legal set, its input planes, and the expansion
+// list (renormalise + stable sort) depend on that lane's path / network row alone: one workgroup per (game, lane).
+// Results are bit-identical to the fused kernels (tests/test_parallel_lanes_gpu.py runs both against the oracle).
+__global__ __launch_bounds__(64) void k_select_paths(Dev d, GameCfg c, MctsCfg mc, int prep, int nl) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const size_t q0 = (size_t)g * d.V;
+  if (d.ended[g]) { if (lane < nl) d.leaf_kind[q0 + lane] = LEAF_NONE; return; }
+  const int agent = agent_of(d, g);
+  const int t = agent * d.G + g;
+  if (d.stalled[t]) { if (lane < nl) { d.leaf_kind[q0 + lane] = LEAF_NULL; d.path_len[q0 + lane] = 0; } return; }
+  const size_t base = pool_base(d, t, d.cur_pool[t]);
+  const int to_move0 = d.to_move[g], ply0 = d.ply[g], passes0 = d.passes[g];
+  for (int l = 0; l < nl; l++) {
+    const size_t q = q0 + l;
+    if (l > 0) { __threadfence(); __syncthreads(); }   // the previous lane's vl marks
+    int32_t* path = d.path + q * MAXPATH;
+    int node = 0, depth = 1, plen = 1, kind = LEAF_NONE, kids_seen = 0;
+    int to_move = to_move0, ply = ply0, passes = passes0;
+    if (lane == 0) path[0] = 0;
+    while (true) {
+      if (depth > mc.maxDepth) { kind = LEAF_NULL; plen--; break; }
+      if (lane == 0) d.vl[base + node] = 1;
+      const int off = d.kids_off[base + node];
+      if (off < 0) { kind = (c.has_passes && passes >= 2) ? LEAF_TERMINAL : LEAF_EXPAND; break; }
+      if (prep) { kind = LEAF_NONE; break; }
+      const int n = d.kids_n[base + node];
+      kids_seen += n;
+      const int ci = select_child(d, base, off, n, to_move, mc.PUCT, lane, true);
+      if (ci < 0) { kind = LEAF_NULL; break; }
+      const int child = off + ci;
+      const int mv = d.nmove[base + child];
+      // what Apply does to the scalars the descent reads (apply_move): mover, Passes(), move count
+      if (c.go_like) { if (mv != AGZ_PASS) passes = 0; else passes++; }
+      if (c.flip_in_tree) to_move = opp(to_move);
+      ply++;
+      if (lane == 0) path[plen] = child;
+      plen++;
+      node = child;
+      depth++;
+    }
+    if (lane == 0) {
+      d.leaf_kind[q] = kind;
+      d.leaf_player[q] = to_move;
+      d.leaf_ply[q] = move_number(c, ply);
+      d.leaf_result[q] = 0.f;
+      d.path_len[q] = plen;
+      if (!prep) {
+        atomicAdd(&d.counters[CNT_PATH], (unsigned long long)plen);
+        atomicAdd(&d.counters[CNT_KIDS], (unsigned long long)kids_seen);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// one workgroup per (game, lane): replay the lane's path on the board, then the leaf work of k_select
+__global__ __launch_bounds__(64) void k_leaf(Dev d, GameCfg c, MctsCfg mc, float* act_in0, float* act_in1, int prep, int nl) {
+  __shared__ Sh s;
+  const int g = blockIdx.x / nl, l = blockIdx.x - g * nl, lane = threadIdx.x;
+  const size_t q = (size_t)g * d.V + l;
+  const int kind = d.leaf_kind[q];
+  if (kind != LEAF_EXPAND && kind != LEAF_TERMINAL) return;
+  if (kind == LEAF_TERMINAL && prep) return;                 // root.Update(0): no board needed
+  const int agent = agent_of(d, g);
+  const int t = agent * d.G + g;
+  const bool use_ring = c.encoder == AGZ_ENC_WQ;
+  const size_t base = pool_base(d, t, d.cur_pool[t]);
+  St st;
+  load_state(c, d, g, s, st, use_ring, lane);
+  const int32_t* path = d.path + q * MAXPATH;
+  const int plen = d.path_len[q];
+  for (int j = 1; j < plen; j++) apply_move(c, d, s, st, d.nmove[base + path[j]], use_ring, lane);
+  if (kind == LEAF_TERMINAL) {   // combinedScore, utils.go:62-67
+    analyse(c, s, nullptr, lane);
+    float b, w;
+    area_scores(c, s, lane, &b, &w);
+    if (lane == 0) d.leaf_result[q] = __fsub_rn(__fsub_rn(b, w), c.komi);
+    return;
+  }
+  if (c.go_like) analyse(c, s, nullptr, lane);
+  legal_mask(c, s, st.to_move, d.leaf_legal + q * CELLS_PAD, lane);
+  for (int i = lane; i < c.cells; i += WAVE) d.leaf_board[q * CELLS_PAD + i] = s.board[i];
+  float* act = agent == 0 ? act_in0 : act_in1;
+  if (act) encode_nhwc(c, s, st, act + ((size_t)l * d.G + d.slot_of_game[g]) * (c.m + 2) * (c.n + 2) * 32, lane);
+}
+
+// one workgroup per (game, lane): the evaluation and the renormalised, sorted expansion list of an expandable leaf
+__global__ __launch_bounds__(64) void k_expand_prep(Dev d, GameCfg c, MctsCfg mc, InfDesc inf, int nl) {
+  __shared__ Sh s;
+  const int g = blockIdx.x / nl, l = blockIdx.x - g * nl, lane = threadIdx.x;
+  const size_t q = (size_t)g * d.V + l;
+  if (d.ended[g] || d.leaf_kind[q] != LEAF_EXPAND) return;
+  const int agent = agent_of(d, g);
+  const int player = d.leaf_player[q];
+  const uint8_t* legal = d.leaf_legal + q * CELLS_PAD;
+  const int ik = inf.kind[agent];
+  const int plen_pol = inf.policy_len[agent];
+  const float* pol = nullptr;
+  float value = 0.f;
+  uint32_t ph = 0;
+  if (ik == AGZ_INF_NET) {
+    const int slot = l * d.G + d.slot_of_game[g];
+    pol = inf.policy[agent] + (size_t)slot * plen_pol;
+    value = inf.value[agent][slot];
+  } else if (ik == AGZ_INF_DUMMY) {
+    const int dp = inf.dummy_player[agent];
+    value = dp == 1 ? 1.f : (dp == 2 ? -1.f : 0.f);
+  } else if (ik == AGZ_INF_SCRIPT) {
+    const int mn = d.leaf_ply[q];
+    value = (mn == 0 || mn == 1 || mn == 5) ? 0.5f : 0.f;
+  } else if (ik == AGZ_INF_HASH) {
+    uint32_t hsh = 0;
+    for (int i = lane; i < c.cells; i += WAVE) hsh += mix32((uint32_t)i * 4u + (uint32_t)d.leaf_board[q * CELLS_PAD + i] + 1u);
+    for (int o = 32; o > 0; o >>= 1) hsh += __shfl_xor(hsh, o, 64);
+    hsh += mix32(0xABCD0000u + (uint32_t)player);
+    ph = hsh;
+    value = (float)(mix32(hsh ^ 0xDEADBEEFu) >> 8) * (1.0f / 16777216.0f);
+  } else {
+    value = 1 / 25.0f;
+  }
+  auto policy_at = [&](int i) -> float {
+    switch (ik) {
+      case AGZ_INF_NET: return pol[i];
+      case AGZ_INF_DUMMY: return __fdiv_rn(1.f, (float)plen_pol);
+      case AGZ_INF_SCRIPT: {
+        const int mn = d.leaf_ply[q];
+        const int8_t cell[9] = {4, 0, 2, 6, 3, 5, 1, 7, 8};
+        if (mn >= 0 && mn < 9 && i == cell[mn]) return (mn & 1) ? 0.1f : 0.9f;
+        return 0.f;
+      }
+      case AGZ_INF_HASH: return (float)((mix32(ph + (uint32_t)i * 0x9E3779B9u) >> 8) + 1u) * (1.0f / 16777216.0f);
+      default: return 1 / 25.0f;
+    }
+  };
+  if (player == AGZ_WHITE) value = __fsub_rn(1.f, value);
+  int n = 0;
+  for (int b0 = 0; b0 < c.A; b0 += WAVE) {
+    const int i = b0 + lane;
+    const bool ok = i < c.A && legal[i];
+    const unsigned long long m = __ballot(ok);
+    if (ok) {
+      const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+      s.fscore[pos] = policy_at(i);
+      s.fmove[pos] = i;
+    }
+    n += __popcll(m);
+  }
+  if (legal[c.A]) {
+    if (lane == 0) { s.fscore[n] = policy_at(plen_pol - 1); s.fmove[n] = AGZ_PASS; }
+    n++;
+  }
+  __syncthreads();
+  float legalSum = 0.f;
+  if (lane == 0) { for (int i = 0; i < n; i++) legalSum = __fadd_rn(legalSum, s.fscore[i]); }
+  legalSum = __shfl(legalSum, 0, 64);
+  if (legalSum > 1.401298464e-45f) {
+    for (int i = lane; i < n; i += WAVE) s.fscore[i] = __fdiv_rn(s.fscore[i], legalSum);
+  } else {
+    const float prob = __fdiv_rn(1.f, (float)n);
+    for (int i = lane; i < n; i += WAVE) s.fscore[i] = prob;
+  }
+  __syncthreads();
+  for (int i = lane; i < n; i += WAVE) {   // stable descending rank sort (as k_expand)
+    const float si = s.fscore[i];
+    int rank = 0;
+    for (int j = 0; j < n; j++) { const float sj = s.fscore[j]; rank += (sj > si) || (sj == si && j < i); }
+    d.exp_score[q * CELLS_PAD + rank] = si;
+    d.exp_move[q * CELLS_PAD + rank] = (int16_t)s.fmove[i];
+  }
+  if (lane == 0) { d.exp_n[q] = n; d.exp_value[q] = value; }
+}
+
+// lanes in order: child blocks, Update along the path, undoVirtualLoss (the sequential half of k_expand)
+__global__ __launch_bounds__(64) void k_expand_commit(Dev d, GameCfg c, MctsCfg mc, int prep, int nl) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  if (d.ended[g]) return;
+  const int agent = agent_of(d, g);
+  const int t = agent * d.G + g;
+  const size_t q0 = (size_t)g * d.V;
+  const size_t base = pool_base(d, t, d.cur_pool[t]);
+  int n_null = 0, n_lanes = 0;
+  unsigned have_mask = 0;
+  for (int l = 0; l < nl; l++) {
+    const size_t q = q0 + l;
+    if (l > 0) { __threadfence(); __syncthreads(); }
+    const int kind = d.leaf_kind[q];
+    if (kind == LEAF_NONE) continue;
+    n_lanes++;
+    if (!prep && lane == 0) atomicAdd(&d.counters[CNT_SIMS], 1ull);
+    const int32_t* path = d.path + q * MAXPATH;
+    const int plen = d.path_len[q];
+    if (kind == LEAF_NULL) {
+      n_null++;
+      for (int j = lane; j < plen; j += WAVE) d.vl[base + path[j]] = 0;
+      continue;
+    }
+    const int node = path[plen - 1];
+    float result = d.leaf_result[q];
+    bool have = true, follower = false;
+    if (kind == LEAF_EXPAND && l > 0) {
+      for (int l2 = 0; l2 < l && !follower; l2++) {
+        const size_t q2 = q0 + l2;
+        if (d.leaf_kind[q2] == LEAF_EXPAND && d.path_len[q2] == plen && d.path[q2 * MAXPATH + plen - 1] == node) {
+          follower = true;
+          result = d.leaf_result[q2];
+          have = (have_mask >> l2) & 1u;
+        }
+      }
+    }
+    if (kind == LEAF_EXPAND && !follower) {
+      const int n = d.exp_n[q];
+      result = d.exp_value[q];
+      if (n > 0) {
+        const int off = d.n_nodes[t];
+        if (off + n > d.cap) {
+          if (lane == 0) { if (!d.overflow[t]) atomicAdd(&d.counters[CNT_FULL], 1ull); d.overflow[t] = 1; d.stalled[t] = 1; }
+          have = false;
+        } else {
+          for (int i = lane; i < n; i += WAVE) {
+            const size_t o = base + off + i;
+            d.prior[o] = d.exp_score[q * CELLS_PAD + i]; d.visits[o] = 1; d.bsum[o] = 0.f; d.kids_off[o] = -1; d.kids_n[o] = 0;
+            d.nmove[o] = d.exp_move[q * CELLS_PAD + i];
+          }
+          if (lane == 0) { d.kids_off[base + node] = off; d.kids_n[base + node] = (int16_t)n; d.n_nodes[t] = off + n; }
+        }
+      }
+      if (lane == 0) atomicAdd(&d.counters[CNT_EVALS], 1ull);
+    }
+    __syncthreads();
+    if (lane == 0) d.leaf_result[q] = result;
+    if (have) have_mask |= 1u << l;
+    if (have) {
+      for (int j = lane; j < plen; j += WAVE) {
+        const size_t o = base + path[j];
+        d.visits[o] = d.visits[o] + 1;
+        d.bsum[o] = __fadd_rn(d.bsum[o], result);
+      }
+      if (!prep && lane == 0) atomicAdd(&d.counters[CNT_NONNULL], 1ull);
+    }
+    for (int j = lane; j < plen; j += WAVE) d.vl[base + path[j]] = 0;
+  }
+  if (n_lanes > 0 && n_null == n_lanes && lane == 0) d.stalled[t] = 1;
+}
+
 // expandAndSimulate (mcts/search.go:259-339) after the network call + the BACKPROPAGATE half of pipeline().
 __global__ __launch_bounds__(64) void k_expand(Dev d, GameCfg c, MctsCfg mc, InfDesc inf, int prep, int nl) {
   __shared__ Sh s;
@@ -964,9 +1212,16 @@ int agz_arena::nn_step(int prep, int nl) {
   if (inf_kind[0] == AGZ_INF_NET) act0 = net[0]->d_act_in;
   if (inf_kind[1] == AGZ_INF_NET) act1 = split_nets() ? net[1]->d_act_in : (net[1]->d_act_in);
   if (split_nets()) { /* both nets see global slot indices; net B's sub-batch starts at slot nA */ }
+  static const int fused_env = [] { const char* e = getenv("AGZ_LANES_FUSED"); return e ? atoi(e) : 0; }();   // tests: the one-kernel lane loop
+  const bool split_lanes = d.V > 1 && !fused_env;
   {
     ProfScope ps(ctx, AGZ_PROF_SELECT);
-    hipLaunchKernelGGL(k_select, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, act0, act1, prep, nl);
+    if (split_lanes) {
+      hipLaunchKernelGGL(k_select_paths, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, prep, nl);
+      hipLaunchKernelGGL(k_leaf, dim3(G * nl), dim3(64), 0, ctx->stream, d, gc, mc, act0, act1, prep, nl);
+    } else {
+      hipLaunchKernelGGL(k_select, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, act0, act1, prep, nl);
+    }
   }
   InfDesc inf{};
   for (int a = 0; a < 2; a++) {
@@ -1003,7 +1258,12 @@ int agz_arena::nn_step(int prep, int nl) {
   }
   {
     ProfScope ps(ctx, AGZ_PROF_EXPAND);
-    hipLaunchKernelGGL(k_expand, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, inf, prep, nl);
+    if (split_lanes) {
+      hipLaunchKernelGGL(k_expand_prep, dim3(G * nl), dim3(64), 0, ctx->stream, d, gc, mc, inf, nl);
+      hipLaunchKernelGGL(k_expand_commit, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, prep, nl);
+    } else {
+      hipLaunchKernelGGL(k_expand, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, inf, prep, nl);
+    }
   }
   AGZ_HIP_TRY(hipGetLastError());
   return AGZ_OK;
@@ -1144,6 +1404,7 @@ int agz_arena_set_parallel(agz_arena* a, int lanes) {
 #define RL(p, cnt) if ((r = a->alloc(&d.p, (size_t)(cnt))) != AGZ_OK) return r;
   RL(leaf_kind, n) RL(leaf_player, n) RL(leaf_ply, n) RL(leaf_result, n) RL(leaf_board, n * CELLS_PAD) RL(leaf_legal, n * CELLS_PAD)
   RL(path, n * MAXPATH) RL(path_len, n)
+  RL(exp_score, n * CELLS_PAD) RL(exp_move, n * CELLS_PAD) RL(exp_n, n) RL(exp_value, n)
 #undef RL
   d.V = lanes;
   AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));

@@ -104,6 +104,11 @@ struct Dev {
   uint8_t* leaf_legal;    // [G*V][CELLS_PAD]  (index A = pass)
   int32_t* path;          // [G*V][MAXPATH]
   int32_t* path_len;      // [G*V]
+  // lane rounds (V > 1): the expansion list of every lane, prepared in parallel (k_expand_prep) and committed in lane order
+  float* exp_score;       // [G*V][CELLS_PAD] renormalised priors in child order (sorted)
+  int16_t* exp_move;      // [G*V][CELLS_PAD]
+  int32_t* exp_n;         // [G*V]
+  float* exp_value;       // [G*V] the evaluation (Black's view) the expansion backs up
   // ---- counters [8]: sims_total, sims_nonnull, nn_evals, moves_played, games_finished, examples, tree_full
   unsigned long long* counters;
   // ---- examples

@@ -756,8 +756,18 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   // ... or, for wide towers (K >= 256: 72 K-iterations per tile), would not even give every CU one tile: a round of 8-16
   // lanes of a single tree (agz_arena_set_parallel) — measured 1.135 -> 1.05 s per move at 8 lanes.  Narrow towers must
   // not take this branch (Connect-4, K=64, 168 tiles: 183 -> 139 games/s).
-  const bool latency = latency_mode && Kp >= 64 &&
-                       (tiles_dual * 4 <= ctx->num_cus || (Kp >= 256 && tiles_dual <= ctx->num_cus));  // 32-wide towers are launch-bound
+  const bool small = latency_mode && Kp >= 64 &&
+                     (tiles_dual * 4 <= ctx->num_cus || (Kp >= 256 && tiles_dual <= ctx->num_cus));  // 32-wide towers are launch-bound
+  // A split mode with AGZ_COMPUTE_FORCE keeps ITS tower at every batch size (so a lane round of 16 boards and the batch-1
+  // prepareRoot of the same search run the same arithmetic, bit for bit per board): measured on G19T (40 blocks), per block:
+  // 16 boards 0.086 ms Winograd fp16x2 vs 0.150 ms split-K fp32; 8 boards 0.068 vs 0.086; 1 board 0.053 vs 0.023 — the
+  // batch-1 evaluation happens once per move, the rounds 100 times (profiles/r02/latency_modes.log).  The heads keep the
+  // spread small-batch form either way.
+  const bool forced_split = compute_force && cfg == 0 && conf.SharedLayers > 0 &&
+                            (this->compute_mode == AGZ_COMPUTE_WINO_H2 || this->compute_mode == AGZ_COMPUTE_WINO ||
+                             this->compute_mode == AGZ_COMPUTE_BF16X3 || this->compute_mode == AGZ_COMPUTE_FP16X2);
+  const bool latency = small && !forced_split;          // split-K convolutions
+  const bool heads_spread = small || (latency_mode && B <= 64);
   float** wsp = latency ? &d_ws : nullptr;
   // the split kernels only pay once the 128-row tiles fill the chip (Connect-4, K=64, 256 games: 84 tiles -> the fp32
   // half-tile kernel is faster: 187 vs 162 / 158 games/s measured)
@@ -947,7 +957,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   size_t smem = (size_t)(3 * HW + 8 + conf.FC) * sizeof(float);
   {
     ProfScope ps(ctx, AGZ_PROF_HEADS);
-    if (latency) {
+    if (heads_spread) {
       // few boards: one workgroup per board would leave the 1.8 MB of FC weights to a single CU (0.26 ms at 19x19);
       // spread the 1x1 convs over pixels and the two FC layers over output columns instead
       size_t need = (size_t)B * (3 * HW + conf.ActionSpace + conf.FC);

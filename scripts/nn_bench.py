@@ -21,6 +21,8 @@ ap.add_argument("--x3", action="store_true")
 ap.add_argument("--h2", action="store_true", help="AGZ_COMPUTE_FP16X2")
 ap.add_argument("--wino", action="store_true", help="AGZ_COMPUTE_WINO (AGZ_WINO_CHUNK=n in the environment: boards per chunk)")
 ap.add_argument("--wino-h2", action="store_true", help="AGZ_COMPUTE_WINO_H2 (AGZ_WINO_H2_WIDE=1: 128x256 GEMM tile)")
+ap.add_argument("--force", action="store_true", help="AGZ_COMPUTE_FORCE: take the split kernels below the chip-filling threshold")
+ap.add_argument("--no-latency", action="store_true", help="agz_net_set_latency_mode(0)")
 ap.add_argument("--zero", action="store_true", help="all-zero weights (DVFS probe: same instruction stream, low toggle power)")
 args = ap.parse_args()
 ctx = A.Ctx(0)
@@ -36,7 +38,9 @@ if args.h2:
 if args.wino:
     net.set_compute_mode(A.capi.COMPUTE_WINO)
 if args.wino_h2:
-    net.set_compute_mode(A.capi.COMPUTE_WINO_H2)
+    net.set_compute_mode(A.capi.COMPUTE_WINO_H2 | (A.capi.COMPUTE_FORCE if args.force else 0))
+if args.no_latency:
+    net.set_latency_mode(False)
 x = torch.randint(-1, 2, (args.B, 18, S, S), device="cuda").float()
 pol = torch.empty((args.B, S * S + 1), device="cuda")
 val = torch.empty((args.B,), device="cuda")
