@@ -167,8 +167,9 @@ def go9_leg(ctx, compute="bf16x3"):
 
 def latency_leg(ctx, lanes_list=(1, 16), moves=3, sims=1600):
     """BASELINE config #5 (tournament Agent.Search): 19x19, K=256, 40 blocks, 1600 sims/move, ONE tree through the single-tree
-    boundary's engine; p50 wall time of a move (begin_move + simulate(Budget) + end_move + sync) on a short sample, sequential
-    search (lanes 1, the declared semantics) and in lane rounds."""
+    boundary's engine; p50 wall time of a move (begin_move + simulate(Budget) + end_move + sync) on a short sample: the
+    sequential search (lanes 1, the declared semantics; fp32 split-K tower) and lane rounds of 16 (deterministic, bit-exact vs
+    the oracle's parallelRound) with the Winograd fp16x2 tower kept at every batch size (AGZ_COMPUTE_FORCE)."""
     S, K, L = 19, 256, 40
     net = A.Net(ctx, K, L, 2 * K, S, S, 18, S * S + 1, BatchSize=1, bn_mode=capi.BN_IDENTITY)
     net.init_random(1337)
@@ -176,6 +177,7 @@ def latency_leg(ctx, lanes_list=(1, 16), moves=3, sims=1600):
     net.commit()
     out = {"workload": "config #5: 19x19 wq Agent.Search, K=256, 40 blocks, %d sims/move, one tree" % sims, "moves_timed": moves}
     for lanes in lanes_list:
+        net.set_compute_mode((capi.COMPUTE_WINO_H2 | capi.COMPUTE_FORCE) if lanes > 1 else capi.COMPUTE_F32_MFMA)
         arena = A.Arena(ctx, capi.GAME_WQ, S, S, komi=7.5, encoder=capi.ENC_WQ, n_games=1, seed=7, Budget=sims)
         arena.set_inferencer(0, capi.INF_NET, net)
         arena.set_inferencer(1, capi.INF_NET, net)
@@ -192,7 +194,8 @@ def latency_leg(ctx, lanes_list=(1, 16), moves=3, sims=1600):
             if mv >= 1:
                 lat.append(time.perf_counter() - t0)
         out["lanes_%d" % lanes] = {"p50_move_s": float(np.percentile(lat, 50)), "max_move_s": float(np.max(lat)),
-                                   "ms_per_sim": float(np.median(lat)) / sims * 1e3}
+                                   "ms_per_sim": float(np.median(lat)) / sims * 1e3,
+                                   "tower": "winograd fp16x2 (forced at every batch size)" if lanes > 1 else "fp32 MFMA split-K (latency regime)"}
         arena.close()
     net.close()
     return out

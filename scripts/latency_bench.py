@@ -25,7 +25,10 @@ ap.add_argument("--sims", type=int, default=1600)
 ap.add_argument("--moves", type=int, default=12)
 ap.add_argument("--games", type=int, default=1)
 ap.add_argument("--lanes", type=int, default=1, help="agz_arena_set_parallel: simulations per tree and round")
-ap.add_argument("--compute", choices=["f32", "wino"], default="f32", help="wino: AGZ_COMPUTE_WINO (with AGZ_WINO_LATENCY_TILES=<n> in the environment it also serves small lane rounds)")
+ap.add_argument("--compute", choices=["f32", "wino", "wino_h2"], default="f32",
+                help="wino_h2: AGZ_COMPUTE_WINO_H2 | AGZ_COMPUTE_FORCE (the Winograd fp16x2 tower at every batch size: lane rounds); "
+                     "wino: AGZ_COMPUTE_WINO (with AGZ_WINO_LATENCY_TILES=<n> in the environment it also serves small lane rounds)")
+ap.add_argument("--open", type=int, default=0, help="random opening moves before the timed moves (mid-game trees)")
 args = ap.parse_args()
 
 ctx = A.Ctx(0)
@@ -35,12 +38,16 @@ net.init_random(1337)
 net.commit()
 if args.compute == "wino":
     net.set_compute_mode(capi.COMPUTE_WINO)
+if args.compute == "wino_h2":
+    net.set_compute_mode(capi.COMPUTE_WINO_H2 | capi.COMPUTE_FORCE)
 arena = A.Arena(ctx, capi.GAME_WQ, S, S, komi=7.5, encoder=capi.ENC_WQ, n_games=args.games, seed=7, Budget=args.sims,
                 max_moves=S * S * 2)
 arena.set_inferencer(0, capi.INF_NET, net)
 arena.set_inferencer(1, capi.INF_NET, net)
 arena.set_parallel(args.lanes)
 arena.reset()
+if args.open:
+    arena.random_moves(np.full(args.games, args.open, np.int32), 1337)
 lat = []
 for mv in range(args.moves + 3):
     t0 = time.perf_counter()
@@ -61,7 +68,7 @@ n_exp, ms_exp = ctx.prof_read(capi.PROF_EXPAND)
 lat = np.array(lat)
 print(json.dumps({
     "workload": f"{S}x{S} wq Agent.Search, K={args.K}, L={args.L}, {args.sims} sims/move, {args.games} tree(s)",
-    "lanes": args.lanes, "moves_timed": len(lat), "p50_move_s": float(np.percentile(lat, 50)), "p90_move_s": float(np.percentile(lat, 90)),
+    "lanes": args.lanes, "compute": args.compute, "opening_moves": args.open, "moves_timed": len(lat), "p50_move_s": float(np.percentile(lat, 50)), "p90_move_s": float(np.percentile(lat, 90)),
     "ms_per_sim": float(np.median(lat)) / args.sims * 1e3,
     "dual_conv_ms": ms_conv / max(n_conv, 1), "init_conv_ms": ms_init / max(n_init, 1),
     "heads_ms": ms_head / max(n_head, 1), "select_ms": ms_sel / max(n_sel, 1), "expand_ms": ms_exp / max(n_exp, 1),

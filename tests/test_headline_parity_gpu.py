@@ -205,14 +205,23 @@ def test_config4_l40_network_batch1_and_lane_batches_vs_oracle(ctx):
     net.close()
 
 
-@pytest.mark.parametrize("lanes,latency", [(1, True), (8, True), (16, False)])
-def test_config4_one_tree_search_bit_exact_vs_oracle(ctx, lanes, latency):
+@pytest.mark.parametrize("lanes,latency,forced", [(1, True, None), (8, True, None), (16, False, None), (16, True, "wino_h2"), (8, True, "wino_h2")])
+def test_config4_one_tree_search_bit_exact_vs_oracle(ctx, lanes, latency, forced):
     """(iii-b) one tree, 40 blocks, sequential and lane rounds of 8 / 16, from a mid-game position through the single-tree
     boundary (agz_mcts_*): device tree == oracle tree given the same network outputs.  Batches 1 and 8 both take the latency
-    regime (bit-identical per board); a 16-lane round leaves it, so that case pins one regime for every batch size."""
+    regime (bit-identical per board); a 16-lane round leaves it, so that case pins one regime for every batch size.  forced:
+    the tournament setting bench.py's latency leg measures — AGZ_COMPUTE_WINO_H2 | AGZ_COMPUTE_FORCE keeps the Winograd fp16x2
+    tower at every batch size (lane rounds of 16 boards and the batch-1 prepareRoot run the same arithmetic per board)."""
     L, budget = 40, 48
     net = std_net(ctx, L)
     net.set_latency_mode(latency)
+    if forced:
+        net.set_compute_mode(MODES[forced] | capi.COMPUTE_FORCE)
+        x, _ = cached_midgame(512)
+        p1, v1 = net.infer(x[3:4])
+        p16, v16 = net.infer(x[:16])
+        np.testing.assert_array_equal(p16[3], p1[0])        # one arithmetic whatever the batch size
+        np.testing.assert_array_equal(v16[3], v1[0])
     g = O.Game(O.WQ, S, S, 0, 7.5)
     rng = np.random.default_rng(11)
     player, moves, boards = O.BLACK, [], []
