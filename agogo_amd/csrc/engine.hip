@@ -86,7 +86,7 @@ __device__ int apply_move(const GameCfg& c, const Dev& d, Sh& s, St& st, int mv,
     }
   } else {  // komi/game.go:104-130,277-313 ; wq/game.go:81-92 (+pass completion)
     if (mv != AGZ_PASS) {
-      analyse(c, s, d.ztable, lane);
+      analyse(c, s, d.ztable, lane, false);
       taken = go_apply(c, s, d.ztable, mv, player, &st.hash, lane);
       st.passes = 0;
     } else {
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64) void k_begin_move(Dev d, GameCfg c, MctsCfg mc)
     // fresh root: Pass if legal, else the first legal move (search.go:476-487); pool restarts empty
     int rootmv = AGZ_PASS;
     if (!c.pass_legal) {
-      if (c.go_like) analyse(c, s, nullptr, lane);
+      if (c.go_like) analyse(c, s, nullptr, lane, false);
       int first = 0x7fffffff;
       for (int i = lane; i < c.A; i += WAVE) {
         bool legal = c.go_like ? go_legal(c, s, i, player) : (s.board[i] == AGZ_NONE);
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64) void k_select(Dev d, GameCfg c, MctsCfg mc, flo
       depth++;
     }
     if (kind == LEAF_EXPAND) {
-      if (c.go_like) analyse(c, s, nullptr, lane);
+      if (c.go_like) analyse(c, s, nullptr, lane, false);
       legal_mask(c, s, st.to_move, d.leaf_legal + q * CELLS_PAD, lane);
       for (int i = lane; i < c.cells; i += WAVE) d.leaf_board[q * CELLS_PAD + i] = s.board[i];
       float* act = agent == 0 ? act_in0 : act_in1;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(64) void k_leaf(Dev d, GameCfg c, MctsCfg mc, float
     if (lane == 0) d.leaf_result[q] = __fsub_rn(__fsub_rn(b, w), c.komi);
     return;
   }
-  if (c.go_like) analyse(c, s, nullptr, lane);
+  if (c.go_like) analyse(c, s, nullptr, lane, false);
   legal_mask(c, s, st.to_move, d.leaf_legal + q * CELLS_PAD, lane);
   for (int i = lane; i < c.cells; i += WAVE) d.leaf_board[q * CELLS_PAD + i] = s.board[i];
   float* act = agent == 0 ? act_in0 : act_in1;
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
     if (best == AGZ_RESIGN) legal = true;
     else if (best == AGZ_PASS) legal = c.pass_legal;
     else if (best < 0 || best >= c.A) legal = false;
-    else if (c.go_like) { analyse(c, s, nullptr, lane); legal = go_legal(c, s, best, player); }
+    else if (c.go_like) { analyse(c, s, nullptr, lane, false); legal = go_legal(c, s, best, player); }
     else legal = s.board[best] == AGZ_NONE;
     if (!legal) {
       if (lane == 0) atomicAdd(&d.counters[CNT_ILLEGAL], 1ull);
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
     if (capw >= kf) { ended = 1; winner = AGZ_WHITE; }
     else if (capb >= kf) { ended = 1; winner = AGZ_BLACK; }
     else {
-      analyse(c, s, nullptr, lane);
+      analyse(c, s, nullptr, lane, false);
       int cur = 0, op = 0;
       for (int i = lane; i < c.cells; i += WAVE) { cur |= go_legal(c, s, i, next_colour); op |= go_legal(c, s, i, opp(next_colour)); }
       cur = __syncthreads_or(cur); op = __syncthreads_or(op);
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(64) void k_random_pick(Dev d, GameCfg c, int32_t* r
   St st;
   load_state(c, d, g, s, st, false, lane);
   const int player = st.to_move;
-  if (c.go_like) analyse(c, s, nullptr, lane);
+  if (c.go_like) analyse(c, s, nullptr, lane, false);
   int total = 0;
   for (int b0 = 0; b0 < c.A; b0 += WAVE) {
     const int i = b0 + lane;

@@ -174,7 +174,10 @@ __device__ __forceinline__ int nbr(const GameCfg& c, int i, int d) {
 // groups, sizes, group zobrist xor, and which colours each empty region touches.
 // Replaces the per-move flood fills of wq.go:237-290 / komi/game.go:348-402 (nolib) with one wave-parallel
 // min-label propagation; results (capture sets, legal sets) are identical — see tests.
-__device__ void analyse(const GameCfg& c, Sh& s, const int32_t* ztable, int lane) {
+// empties = false: only STONE groups are labelled (empty cells keep their own index).  Captures and legality need nothing else
+// (liberties are counted from the empty cells themselves), and label propagation then takes as many rounds as the widest stone
+// group is across instead of the widest empty region (tens of rounds on an open 19x19 board); area scoring needs empties = true.
+__device__ void analyse(const GameCfg& c, Sh& s, const int32_t* ztable, int lane, bool empties = true) {
   __syncthreads();
   for (int i = lane; i < c.cells; i += WAVE) {
     s.label[i] = i; s.libs[i] = 0; s.gsize[i] = 0; s.ghash[i] = 0; s.touch[i] = 0;
@@ -184,6 +187,7 @@ __device__ void analyse(const GameCfg& c, Sh& s, const int32_t* ztable, int lane
     int changed = 0;
     for (int i = lane; i < c.cells; i += WAVE) {
       int v = s.board[i];
+      if (v == AGZ_NONE && !empties) continue;
       int l0 = s.label[i];
       int l = l0;
 #pragma unroll
