@@ -18,7 +18,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # both device types: host-side bookkeeping tensors (digests, win counts) go over gloo, device buffers over RCCL
+            # (an nccl-only group raises "No backend type associated with device type cpu" on a CPU tensor: ADVICE r1)
+            backend = "cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo"
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
@@ -88,6 +90,17 @@ def gather_into_examples(arena, examples, local_device, group=None):
     return len(examples)
 
 
+def make_comm(ctx, group=None):
+    """An agz_comm (RCCL inside libagz, include/agz.h) for this rank's ctx: rank 0 draws the RCCL unique id, the process
+    group ships its 128 bytes (host side, any backend), every rank joins with agz_comm_init_rank.  The exchange itself then
+    runs entirely inside libagz: Comm.allgather_examples / Comm.allreduce_trainer — what a Go host calls through cgo."""
+    from . import capi
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [capi.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return capi.Comm.init_rank(ctx, world, rank, box[0])
+
+
 def shard_games(total_games, rank, world):
     """games [lo, hi) owned by `rank` (config #4: 4096 games sharded 512/GPU)"""
     per = total_games // world
@@ -108,7 +121,7 @@ def allreduce_gradients(trainer, local_device, group=None):
     ptr, n = trainer.grads_dev()
     trainer.ctx.sync()   # the gradients were produced on the ctx stream; the collective runs on torch's
     g = device_tensor(ptr, (n,), torch.device("cuda", local_device))
-    if dist.get_backend(group) == "gloo":
+    if str(dist.get_backend(group)) == "gloo":
         h = g.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
         g.copy_(h)

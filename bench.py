@@ -371,23 +371,32 @@ def main():
         for n_ in nets:
             n_.set_compute_mode(MODES[args.compute])
 
-    # optional: the one exchange step of the path — gather recorded examples across ranks (untimed leg)
-    gather_ms = None
+    # the one exchange step of the path, untimed for `value`: the examples recorded so far gathered over all ranks —
+    # inside libagz (agz_comm_* / agz_examples_allgather: RCCL grouped broadcasts over xGMI), the way the Go host would do it
+    gather = None
     if world > 1:
-        import ctypes as C
-        pp, po, pv, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int32(0)
-        capi._check(capi.lib().agz_arena_examples_dev(arena.h, C.byref(pp), C.byref(po), C.byref(pv), C.byref(n)), "examples_dev")
-        k = max(n.value, 1)
-        dev = torch.device("cuda", local)
-        tp = adist.device_tensor(pp.value, (k, 18 * S * S), dev)[: n.value]
-        tpo = adist.device_tensor(po.value, (k, Aspace), dev)[: n.value]
-        tv = adist.device_tensor(pv.value, (k,), dev)[: n.value]
-        fence()
-        g0 = time.perf_counter()
-        gp, _, _ = adist.all_gather_examples(tp, tpo, tv)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        n_gathered = int(gp.shape[0])
+        try:
+            ex = A.Examples(ctx, 18, S, S, Aspace)
+            comm = adist.make_comm(ctx)
+            # (agz_examples_append_arena takes finished games only; the bench's games are mid-way, so the arena rows go in raw)
+            import ctypes as C
+            pp, po, pv, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int32(0)
+            capi._check(capi.lib().agz_arena_examples_dev(arena.h, C.byref(pp), C.byref(po), C.byref(pv), C.byref(n)), "examples_dev")
+            if n.value:
+                ex.append_dev(pp.value, po.value, pv.value, n.value)
+            fence()
+            g0 = time.perf_counter()
+            comm.allgather_examples(ex)
+            ctx.sync()
+            g_ms = (time.perf_counter() - g0) * 1e3
+            gather = {"path": "libagz: agz_comm_init_rank + agz_examples_allgather (RCCL, one grouped set of broadcasts)",
+                      "ms": g_ms, "rows_this_rank": n.value, "rows_gathered": len(ex),
+                      "GB_per_s": len(ex) * (18 * S * S + Aspace + 1) * 4 / (g_ms * 1e-3) / 1e9}
+            comm.close()
+            ex.close()
+        except Exception as e:   # never lose the bench line to the untimed leg
+            gather = {"error": repr(e)}
+    gather_ms = gather
 
     if rank == 0:
         flops_eval = nets[0].flops_per_eval()
@@ -505,7 +514,7 @@ def main():
                                                      "this bench (one game of 722 moves x 800 sims takes ~3.5 h)"} if full_move else None),
                       "end_to_end_tflops": evals_sum * flops_eval / t_max / 1e12,
                       "end_to_end_frac_of_fp32_peak": evals_sum * flops_eval / t_max / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
-                      "kernel_classes": prof, "examples_allgather_ms": gather_ms, "compute": args.compute,
+                      "kernel_classes": prof, "examples_allgather": gather_ms, "compute": args.compute,
                       "other_compute_modes": legs, "wino": wino_detail,
                       "tree_full": st1["tree_full"]},
         }
