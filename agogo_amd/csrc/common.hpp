@@ -44,6 +44,8 @@ struct ProfClass {
 struct agz_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;          // second queue: the other half of a batch (agz_net two-stream tower), created on first use
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool prof_on = false;
   unsigned prof_mask = ~0u;   // classes that record events while prof_on (agz_ctx_prof_enable)
   agz::ProfClass prof[AGZ_PROF_NCLASS];

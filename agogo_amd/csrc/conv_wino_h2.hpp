@@ -505,6 +505,10 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2d_kernel(WinoH2Args h) {
   }
 }
 
+// (Measured and dropped, profiles/r02/gemm_double_buffer_ab.log: a double-buffered LDS stage with ONE barrier per K step and the next
+// step's stores issued between the two MFMA groups — 64 KB per workgroup, two workgroups per CU — 0.445 ms against 0.409 for the
+// single-stage 128x128 form at four workgroups per CU and 0.389 for the 128x256 form: occupancy beats barrier count here.)
+
 // wino_out_kernel + exact un-scaling + the per-board maximum of the block output (the next block's range).
 __global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
   const WinoArgs& a = h.w;
@@ -618,14 +622,15 @@ static float wino_build_u2(std::vector<_Float16>& u2, int Ntot, int C, Get get) 
 }
 
 // launches the stages of one block for a chunk of boards (h.w.V / Mb sized by the caller)
-static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0) {
+static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, hipStream_t st = nullptr) {
+  if (!st) st = ctx->stream;
   WinoArgs& a = h.w;
   a.nty = ceil_div(a.H, 4); a.ntx = ceil_div(a.W, 4); a.TPB = a.nty * a.ntx; a.T = a.B * a.TPB;
   a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
   {
     ProfScope ps(ctx, AGZ_PROF_WINO_IN);
     const size_t n_in = (size_t)a.T * (a.C / 2);
-    hipLaunchKernelGGL(wino_in_h2_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, ctx->stream, h);
+    hipLaunchKernelGGL(wino_in_h2_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, h);
   }
   {
     ProfScope ps(ctx, AGZ_PROF_WINO_GEMM);
@@ -633,7 +638,7 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0) 
     // the unrolled deep-prefetch form is instantiated per K extent (32-channel steps); K = 256 with every prefetch depth (tuning)
     const int nk = a.C >> 5;
     bool done = true;
-#define AGZ_H2D(NK_, PF_, NT_, G_) hipLaunchKernelGGL((wino_gemm_h2d_kernel<NK_, PF_, NT_>), G_, dim3(256), 0, ctx->stream, h)
+#define AGZ_H2D(NK_, PF_, NT_, G_) hipLaunchKernelGGL((wino_gemm_h2d_kernel<NK_, PF_, NT_>), G_, dim3(256), 0, st, h)
 #define AGZ_H2D_NK(NK_) { if (wide) AGZ_H2D(NK_, 2, 2, gw); else AGZ_H2D(NK_, 2, 1, gn); }
     if (pfa < 1 || (a.C & 31)) done = false;
     else if (nk == 8) {
@@ -649,12 +654,12 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0) 
 #undef AGZ_H2D_NK
 #undef AGZ_H2D
     if (done) {}
-    else if (wide) hipLaunchKernelGGL(wino_gemm_h2w_kernel, gw, dim3(256), 0, ctx->stream, h);
-    else hipLaunchKernelGGL(wino_gemm_h2_kernel, gn, dim3(256), 0, ctx->stream, h);
+    else if (wide) hipLaunchKernelGGL(wino_gemm_h2w_kernel, gw, dim3(256), 0, st, h);
+    else hipLaunchKernelGGL(wino_gemm_h2_kernel, gn, dim3(256), 0, st, h);
   }
   {
     ProfScope ps(ctx, AGZ_PROF_WINO_OUT);
     const size_t n_out = (size_t)a.T * a.Cout_p;
-    hipLaunchKernelGGL(wino_out_h2_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx->stream, h);
+    hipLaunchKernelGGL(wino_out_h2_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, h);
   }
 }

@@ -77,6 +77,9 @@ void agz_ctx_destroy(agz_ctx* c) {
   hipStreamSynchronize(c->stream);
   for (auto& p : c->prof)
     for (auto& pr : p.pairs) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  if (c->stream2) hipStreamDestroy(c->stream2);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
   hipStreamDestroy(c->stream);
   delete c;
 }

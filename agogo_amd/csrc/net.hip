@@ -571,6 +571,7 @@ using namespace agz;
 void agz_net::free_device() {
   auto f = [](float*& p) { if (p) { hipFree(p); p = nullptr; } };
   f(d_w_init); f(d_ep_init);
+  if (d_w3_init) { hipFree(d_w3_init); d_w3_init = nullptr; }
   for (auto& p : d_w_dual) f(p);
   for (auto& p : d_ep_dual) f(p);
   for (auto& p : d_w3_dual) if (p) { hipFree(p); p = nullptr; }
@@ -767,7 +768,9 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
                             (this->compute_mode == AGZ_COMPUTE_WINO_H2 || this->compute_mode == AGZ_COMPUTE_WINO ||
                              this->compute_mode == AGZ_COMPUTE_BF16X3 || this->compute_mode == AGZ_COMPUTE_FP16X2);
   const bool latency = small && !forced_split;          // split-K convolutions
-  const bool heads_spread = small || (latency_mode && B <= 64);
+  static const int spread_max = [] { const char* e = getenv("AGZ_HEADS_SPREAD_MAX"); return e ? atoi(e) : 64; }();   // tuning knob
+  // (wide towers: the spread form also wins at 512 boards — 0.17 vs 0.35 ms at 19x19 / K=256, profiles/r02/init_heads_ab.log)
+  const bool heads_spread = small || (latency_mode && (B <= spread_max || Kp >= 256));
   float** wsp = latency ? &d_ws : nullptr;
   // the split kernels only pay once the 128-row tiles fill the chip (Connect-4, K=64, 256 games: 84 tiles -> the fp32
   // half-tile kernel is faster: 187 vs 162 / 158 games/s measured)
@@ -799,7 +802,17 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     amax_cap = (size_t)B;
   }
   int rc;
-  if (cfg != 0) rc = launch_conv<4, 1, 1, false>(ctx, a, wsp, &ws_cap);
+  static const int init_x3_env = [] { const char* e = getenv("AGZ_INIT_X3"); return e ? atoi(e) : 1; }();   // tuning knob
+  if (split_ok && compute_mode != AGZ_COMPUTE_F32_MFMA && d_w3_init && Kp % 128 == 0 && init_x3_env &&
+      (size_t)B * Hp * Wp * Fp * sizeof(float) < ((size_t)1 << 32)) {
+    // the split modes: input convolution with bf16x3 products too (same fp32-grade arithmetic as AGZ_COMPUTE_BF16X3)
+    a.n_ntiles = ceil_div(a.Ntot, 128); a.n_mtiles = ceil_div(a.M, 128);
+    a.splits = 1; a.per = 0; a.ws = nullptr; a.raw = 0;
+    ProfScope ps(ctx, AGZ_PROF_CONV_INIT);
+    hipLaunchKernelGGL((conv3x3_x3_kernel<false>), dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, a, d_w3_init);
+    rc = AGZ_OK;
+  }
+  else if (cfg != 0) rc = launch_conv<4, 1, 1, false>(ctx, a, wsp, &ws_cap);
   else if (half_init) rc = launch_conv<2, 2, 1, false>(ctx, a, wsp, &ws_cap);
   else rc = launch_conv<2, 2, 2, false>(ctx, a, wsp, &ws_cap);
   if (rc != AGZ_OK) return rc;
@@ -873,21 +886,45 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     }
     AGZ_HIP_TRY(hipMemsetAsync(d_amax, 0, need_amax * sizeof(unsigned), ctx->stream));
     hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, ctx->stream, cur, d_amax, HW, W, Wp, Hp * Wp, Kp);
+    // Two-queue tower (AGZ_WINO_H2_STREAMS=2, tuning knob): the two halves of the batch run their block chains on two HIP
+    // streams, so one half's HBM-bound transform kernels overlap the other half's GEMM (chains of different boards are
+    // independent: per-board ranges, disjoint scratch halves)
+    static const int streams_env = [] { const char* e = getenv("AGZ_WINO_H2_STREAMS"); return e ? atoi(e) : 1; }();
+    const bool two = streams_env == 2 && B >= 64 && chunk >= B;
+    if (two && !ctx->stream2) {
+      AGZ_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      AGZ_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      AGZ_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    const int half0 = two ? B / 2 : B;
+    if (two) {
+      AGZ_HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+      AGZ_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    }
     for (int l = 0; l < conf.SharedLayers; l++) {
       ProfScope ps(ctx, AGZ_PROF_CONV);
-      for (int b0 = 0; b0 < B; b0 += chunk) {
+      for (int part = 0; part < (two ? 2 : 1); part++)
+      for (int b0 = two ? (part ? half0 : 0) : 0; b0 < (two ? (part ? B : half0) : B); b0 += chunk) {
         WinoH2Args hh{};
         WinoArgs& wa = hh.w;
         wa.x = cur + (size_t)b0 * Hp * Wp * Kp; wa.y = nxt + (size_t)b0 * Hp * Wp * Kp;
-        wa.V = d_wV; wa.Mb = d_wM; wa.ep = d_ep_dual[l];
-        wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
+        wa.V = d_wV + (two && part ? (size_t)36 * half0 * tpb * Kp : 0);
+        wa.Mb = d_wM + (two && part ? (size_t)36 * half0 * tpb * 2 * Kp : 0);
+        wa.ep = d_ep_dual[l];
+        wa.B = two ? (part ? B - half0 : half0) : std::min(chunk, B - b0);
+        wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
         hh.U2 = d_u2_dual[l]; hh.w_unscale = u_unscale[l];
         static const int dbg_env = [] { const char* e = getenv("AGZ_WINO_H2_DBG"); return e ? atoi(e) : 0; }();   // measurement knob
         hh.dbg = dbg_env;
         hh.amax_in = d_amax + (size_t)l * B + b0; hh.amax_out = d_amax + (size_t)(l + 1) * B + b0;
-        wino_h2_launch(ctx, hh, wide, pfa);
+        wino_h2_launch(ctx, hh, wide, pfa, (two && part) ? ctx->stream2 : ctx->stream);
+        if (two) break;
       }
       std::swap(cur, nxt);
+    }
+    if (two) {
+      AGZ_HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
+      AGZ_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     tower_done = true;
   }
@@ -1147,6 +1184,29 @@ int agz_net_commit(agz_net* n) {
     int r;
     if ((r = upload(&n->d_w_init, wt, s)) != AGZ_OK) return r;
     if ((r = upload(&n->d_ep_init, ep, s)) != AGZ_OK) return r;
+    if (n->cfg == 0) {
+      // bf16x3 image of the input filter for conv3x3_x3_kernel<false>: w3[cc16][tap][piece][n][16] (exact truncation split);
+      // in the split modes the F -> K input convolution runs on the bf16 pipe too (0.33 -> 0.1x ms at B=512: it pads F=18 to 32
+      // channels on the slow fp32 MFMA otherwise)
+      const int NC16 = Fp / 16;
+      std::vector<unsigned short> w3((size_t)9 * NC16 * 3 * Kp * 16, 0);
+      for (int t = 0; t < 9; t++) for (int nn = 0; nn < Kp; nn++) for (int ci = 0; ci < Fp; ci++) {
+        float v = wt[((size_t)t * Kp + nn) * Fp + ci];
+        uint32_t u, hu, mu, lu; memcpy(&u, &v, 4);
+        hu = u & 0xffff0000u; float hf; memcpy(&hf, &hu, 4);
+        float r1 = v - hf; uint32_t ru; memcpy(&ru, &r1, 4);
+        mu = ru & 0xffff0000u; float mf; memcpy(&mf, &mu, 4);
+        float r2 = r1 - mf; memcpy(&lu, &r2, 4);
+        size_t base = (((size_t)((ci / 16) * 9 + t) * 3) * Kp + nn) * 16 + (ci % 16);
+        w3[base] = (unsigned short)(hu >> 16);
+        w3[base + (size_t)Kp * 16] = (unsigned short)(mu >> 16);
+        w3[base + (size_t)2 * Kp * 16] = (unsigned short)(lu >> 16);
+      }
+      if (n->d_w3_init) { hipFree(n->d_w3_init); n->d_w3_init = nullptr; }
+      AGZ_HIP_TRY(hipMalloc(&n->d_w3_init, w3.size() * 2));
+      AGZ_HIP_TRY(hipMemcpyAsync(n->d_w3_init, w3.data(), w3.size() * 2, hipMemcpyHostToDevice, s));
+      AGZ_HIP_TRY(hipStreamSynchronize(s));
+    }
     pi += 3; bi++;
   }
   // --- dual blocks: n ordered per block tile [a-channels | b-channels]

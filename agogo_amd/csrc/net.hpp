@@ -37,6 +37,7 @@ struct agz_net {
   // device parameters (repacked)
   float* d_w_init = nullptr;    // [9][Ntot_init][Fp]
   float* d_ep_init = nullptr;   // float2 {scale,shift} [HW][Kp]
+  unsigned short* d_w3_init = nullptr;   // bf16x3 image of the input filter [Fp/16][9][3][Kp][16] (cfg 0), conv_x3.hpp
   std::vector<float*> d_w_dual;   // per layer [9][2*Kp][Kp] in block-tile order
   std::vector<float*> d_ep_dual;  // per layer float4 {sa,ta,sb,tb} [HW][Kp]
   std::vector<unsigned short*> d_w3_dual;  // per layer bf16x3 image [Kp/16][9][3][2*Kp][16] (cfg 0 only), conv_x3.hpp

@@ -57,6 +57,7 @@ t1 = time.perf_counter()
 ctx.prof_enable(False)
 n_conv, ms_conv = ctx.prof_read(A.capi.PROF_CONV)
 n_head, ms_head = ctx.prof_read(A.capi.PROF_HEADS)
+n_init, ms_init = ctx.prof_read(A.capi.PROF_CONV_INIT)
 wino = {}
 if args.wino or args.wino_h2:
     for nm, k in (("in", A.capi.PROF_WINO_IN), ("gemm", A.capi.PROF_WINO_GEMM), ("out", A.capi.PROF_WINO_OUT)):
@@ -67,5 +68,5 @@ flops = net.flops_per_eval() * args.B
 dt = (t1 - t0) / args.iters
 print(json.dumps({"B": args.B, "K": args.K, "L": args.L, "ms_per_pass": dt * 1e3, "evals_per_s": args.B / dt,
                   "tflops": flops / dt / 1e12, "frac_fp32_peak": flops / dt / 157.3e12,
-                  "conv_launches": n_conv, "conv_ms_avg": ms_conv / max(n_conv, 1), "heads_ms_avg": ms_head / max(n_head, 1),
+                  "conv_launches": n_conv, "conv_ms_avg": ms_conv / max(n_conv, 1), "heads_ms_avg": ms_head / max(n_head, 1), "init_ms_avg": ms_init / max(n_init, 1),
                   "wino": wino, "policy_sum": float(pol.sum().item()), "value_mean": float(val.mean().item())}))
