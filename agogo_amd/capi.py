@@ -181,6 +181,7 @@ def lib():
     sig("agz_mcts_policies", i32, vp, pf, i32)
     sig("agz_mcts_root_children", i32, vp, pi, pu, pf, pf, i32, pi)
     sig("agz_mcts_nodes", i32, vp, pi)
+    sig("agz_mcts_children", i32, vp, i32, pi, pi, pu, pf, pf, i32, pi)
     sig("agz_mcts_get_stats", i32, vp, C.POINTER(ArenaStats))
     sig("agz_mcts_reset", i32, vp)
     sig("agz_comm_init_all", i32, pvp, i32, pvp)
@@ -667,6 +668,34 @@ class Mcts:
         n = C.c_int32(0)
         _check(lib().agz_mcts_nodes(self.h, C.byref(n)), "agz_mcts_nodes")
         return n.value
+
+    def children(self, node=0):
+        """(*MCTS).Children(of): ids, moves, visits, blackScores, priors of the children of any node (0 = root)"""
+        cap = self.m * self.n + 2
+        ids = np.zeros(cap, dtype=np.int32)
+        mv = np.zeros(cap, dtype=np.int32)
+        vis = np.zeros(cap, dtype=np.uint32)
+        bs = np.zeros(cap, dtype=np.float32)
+        pr = np.zeros(cap, dtype=np.float32)
+        n = C.c_int32(0)
+        _check(lib().agz_mcts_children(self.h, int(node), _pi(ids), _pi(mv), vis.ctypes.data_as(C.POINTER(C.c_uint32)), _pf(bs),
+                                       _pf(pr), cap, C.byref(n)), "agz_mcts_children")
+        k = n.value
+        return ids[:k].copy(), mv[:k].copy(), vis[:k].copy(), bs[:k].copy(), pr[:k].copy()
+
+    def to_dot(self, max_nodes=200):
+        """(*MCTS).ToDot (mcts/graph.go:34) on the host: a Graphviz digraph of the most visited part of the tree"""
+        lines, todo, seen = ["digraph mcts {"], [0], 0
+        while todo and seen < max_nodes:
+            node = todo.pop(0)
+            ids, mv, vis, bs, pr = self.children(node)
+            for i, m_, v, b, p in zip(ids, mv, vis, bs, pr):
+                if v > 1:
+                    lines.append('  n%d -> n%d [label="%d"]; n%d [label="v=%d q=%.3f p=%.3f"];' % (node, i, m_, i, v, b / max(v, 1), p))
+                    todo.append(int(i))
+                    seen += 1
+        lines.append("}")
+        return "\n".join(lines)
 
     def stats(self):
         s = ArenaStats()

@@ -67,6 +67,15 @@ struct ProfScope {
   ~ProfScope() { if (on) c->prof_end(k); }
 };
 
+// a scope that only records when the launch really goes to the ctx stream (the timers' events are recorded there)
+struct ProfScopeOn {
+  agz_ctx* c;
+  int k;
+  bool on;
+  ProfScopeOn(agz_ctx* c_, int k_, bool enable) : c(c_), k(k_), on(enable && c_->prof_on && ((c_->prof_mask >> k_) & 1u)) { if (on) c->prof_begin(k); }
+  ~ProfScopeOn() { if (on) c->prof_end(k); }
+};
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

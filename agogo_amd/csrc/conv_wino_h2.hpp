@@ -26,7 +26,8 @@ struct WinoH2Args {
   WinoArgs w;                // geometry, x, V (reinterpreted as the fp16 piece image), Mb, ep, y
   const _Float16* U2;        // [36][C/32][2][Ntot][32]
   const unsigned* amax_in;   // [B] max |x| of every board of this block's input (float bits)
-  unsigned* amax_out;        // [B] max of this block's output, accumulated by wino_out_h2_kernel (zeroed by the caller)
+  unsigned* amax_out;        // [B] max of this block's output (wino_board_max_kernel over wave_max)
+  float* wave_max;           // [T][Cout_p/64] maximum of the 64 channels x 16 pixels one wave of wino_out_h2_kernel produced
   float w_unscale;           // 1 / su
   int dbg;                   // AGZ_WINO_H2_DBG (measurement only): 1 = no M stores, 2 = A fetched once per tile, 4 = B fetched once
 };
@@ -574,12 +575,23 @@ __global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
       }
     }
   }
-  // one atomic per wave: the 64 lanes of a wave are 64 channels of ONE tile (Cout_p is a multiple of 64), i.e. one board
-  if (h.amax_out) {
+  // the 64 lanes of a wave are 64 channels of ONE tile (Cout_p is a multiple of 64): one plain store per wave, reduced per board by
+  // wino_board_max_kernel (an atomicMax per wave into the board's word cost 0.03 of the kernel's 0.25 ms: scripts/probes/stream_probe P7)
+  if (h.wave_max) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(h.amax_out + b, __float_as_uint(mx));
+    if ((threadIdx.x & 63) == 0 && live) h.wave_max[(size_t)t * (a.Cout_p >> 6) + (c >> 6)] = mx;
   }
+}
+
+// amax_out[b] = max over the board's tiles and channel groups of wave_max (one wave per board)
+__global__ __launch_bounds__(64) void wino_board_max_kernel(const float* __restrict__ wave_max, unsigned* __restrict__ amax_out, int per_board) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float mx = 0.f;
+  for (int i = lane; i < per_board; i += 64) mx = fmaxf(mx, wave_max[(size_t)b * per_board + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) amax_out[b] = __float_as_uint(mx);
 }
 
 // Host: the Winograd-domain filter (as wino_build_u3) scaled by a power of two and split into two fp16 pieces:
@@ -628,12 +640,12 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
   a.nty = ceil_div(a.H, 4); a.ntx = ceil_div(a.W, 4); a.TPB = a.nty * a.ntx; a.T = a.B * a.TPB;
   a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
   {
-    ProfScope ps(ctx, AGZ_PROF_WINO_IN);
+    ProfScopeOn ps(ctx, AGZ_PROF_WINO_IN, st == ctx->stream);
     const size_t n_in = (size_t)a.T * (a.C / 2);
     hipLaunchKernelGGL(wino_in_h2_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, h);
   }
   {
-    ProfScope ps(ctx, AGZ_PROF_WINO_GEMM);
+    ProfScopeOn ps(ctx, AGZ_PROF_WINO_GEMM, st == ctx->stream);
     const dim3 gw(36 * a.n_mtiles * ceil_div(a.Ntot, 256)), gn(36 * a.n_mtiles * a.n_ntiles);
     // the unrolled deep-prefetch form is instantiated per K extent (32-channel steps); K = 256 with every prefetch depth (tuning)
     const int nk = a.C >> 5;
@@ -658,8 +670,10 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
     else hipLaunchKernelGGL(wino_gemm_h2_kernel, gn, dim3(256), 0, st, h);
   }
   {
-    ProfScope ps(ctx, AGZ_PROF_WINO_OUT);
+    ProfScopeOn ps(ctx, AGZ_PROF_WINO_OUT, st == ctx->stream);
     const size_t n_out = (size_t)a.T * a.Cout_p;
     hipLaunchKernelGGL(wino_out_h2_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, h);
+    if (h.wave_max && h.amax_out)
+      hipLaunchKernelGGL(wino_board_max_kernel, dim3(a.B), dim3(64), 0, st, h.wave_max, h.amax_out, a.TPB * (a.Cout_p >> 6));
   }
 }

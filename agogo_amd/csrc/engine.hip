@@ -1883,6 +1883,41 @@ int agz_mcts_root_children(agz_mcts* m, int32_t* moves, uint32_t* visits, float*
   return agz_arena_root_children(m->arena, 0, 0, moves, visits, black_scores, priors, cap, n);
 }
 
+// (*MCTS).Children(of) + the Node fields Log / ToDot print (mcts/unsafe_safe.go:15, graph.go:34, node.go:56-68): the children of
+// any node of the live tree — node 0 is the root, child_ids index further calls — so the host can walk or draw the tree.
+int agz_mcts_children(agz_mcts* m, int node, int32_t* child_ids, int32_t* moves, uint32_t* visits, float* black_scores, float* priors,
+                      int cap, int* n) {
+  AGZ_REQUIRE(m && n, AGZ_E_INVALID, "agz_mcts_children: NULL argument");
+  agz_arena* a = m->arena;
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  int32_t pool = 0, n_nodes = 0, hr = 0, off = -1;
+  int16_t kn = 0;
+  *n = 0;
+  AGZ_HIP_TRY(hipMemcpy(&hr, a->d.has_root, 4, hipMemcpyDeviceToHost));
+  if (!hr) return AGZ_OK;
+  AGZ_HIP_TRY(hipMemcpy(&pool, a->d.cur_pool, 4, hipMemcpyDeviceToHost));
+  AGZ_HIP_TRY(hipMemcpy(&n_nodes, a->d.n_nodes, 4, hipMemcpyDeviceToHost));
+  AGZ_REQUIRE(node >= 0 && node < n_nodes, AGZ_E_INVALID, "agz_mcts_children: node %d outside the tree (%d nodes)", node, n_nodes);
+  const size_t base = (size_t)pool * a->d.cap;
+  AGZ_HIP_TRY(hipMemcpy(&off, a->d.kids_off + base + node, 4, hipMemcpyDeviceToHost));
+  AGZ_HIP_TRY(hipMemcpy(&kn, a->d.kids_n + base + node, 2, hipMemcpyDeviceToHost));
+  if (off < 0) return AGZ_OK;
+  *n = kn;
+  const int k = std::min<int>(kn, cap);
+  if (k <= 0) return AGZ_OK;
+  if (child_ids) for (int i = 0; i < k; i++) child_ids[i] = off + i;
+  if (moves) {
+    std::vector<int16_t> mv(k);
+    AGZ_HIP_TRY(hipMemcpy(mv.data(), a->d.nmove + base + off, k * sizeof(int16_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < k; i++) moves[i] = mv[i];
+  }
+  if (visits) AGZ_HIP_TRY(hipMemcpy(visits, a->d.visits + base + off, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (black_scores) AGZ_HIP_TRY(hipMemcpy(black_scores, a->d.bsum + base + off, k * sizeof(float), hipMemcpyDeviceToHost));
+  if (priors) AGZ_HIP_TRY(hipMemcpy(priors, a->d.prior + base + off, k * sizeof(float), hipMemcpyDeviceToHost));
+  return AGZ_OK;
+}
+
 int agz_mcts_nodes(agz_mcts* m, int* n_nodes) {
   AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
   return agz_arena_tree_nodes(m->arena, 0, 0, n_nodes);

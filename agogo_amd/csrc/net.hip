@@ -866,63 +866,69 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     const bool wide = wide_env >= 0 ? wide_env != 0 : (2 * Kp) % 256 == 0;
     const int pfa = pfa_env >= 0 ? pfa_env : 2;
     const int tpb = ceil_div(H, 4) * ceil_div(W, 4);
-    const int chunk = (int)std::min<size_t>((size_t)B, (((size_t)1 << 32) - 1) / ((size_t)36 * tpb * Kp * 4));
-    if (chunk > wino_chunk_cap) {
+    // Board chunks and queues (tuning knobs AGZ_WINO_H2_CHUNK = boards per chunk, AGZ_WINO_H2_STREAMS = 1 | 2): chunk i runs its
+    // block chain on queue i % streams with that queue's scratch — chains of different boards are independent (per-board ranges),
+    // so one chunk's HBM-bound transform kernels can overlap another chunk's GEMM, and a chunk whose V + M fit the 256 MB Infinity
+    // Cache re-reads them from there.  Default: one chunk (bounded by the 32-bit V offsets), one queue.
+    static const int chunk_env = [] { const char* e = getenv("AGZ_WINO_H2_CHUNK"); return e ? atoi(e) : 0; }();
+    static const int streams_env = [] { const char* e = getenv("AGZ_WINO_H2_STREAMS"); return e ? atoi(e) : 1; }();
+    const int chunk_max = (int)std::min<size_t>((size_t)B, (((size_t)1 << 32) - 1) / ((size_t)36 * tpb * Kp * 4));
+    int chunk = chunk_env >= 1 ? std::min(chunk_env, chunk_max) : chunk_max;
+    const int ns = (streams_env == 2 && B >= 64) ? 2 : 1;
+    if (ns == 2 && chunk >= B) chunk = (B + 1) / 2;
+    const size_t v_elems = (size_t)36 * chunk * tpb * Kp, m_elems = (size_t)36 * chunk * tpb * 2 * Kp;
+    if (chunk * ns > wino_chunk_cap) {
       AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (ctx->stream2) AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream2));
       if (d_wV) hipFree(d_wV);
       if (d_wM) hipFree(d_wM);
       d_wV = d_wM = nullptr; wino_chunk_cap = 0;
-      AGZ_HIP_TRY(hipMalloc(&d_wV, (size_t)36 * chunk * tpb * Kp * sizeof(float)));
-      AGZ_HIP_TRY(hipMalloc(&d_wM, (size_t)36 * chunk * tpb * 2 * Kp * sizeof(float)));
-      wino_chunk_cap = chunk;
+      AGZ_HIP_TRY(hipMalloc(&d_wV, v_elems * ns * sizeof(float)));
+      AGZ_HIP_TRY(hipMalloc(&d_wM, m_elems * ns * sizeof(float)));
+      wino_chunk_cap = chunk * ns;
     }
-    const size_t need_amax = (size_t)(conf.SharedLayers + 1) * B;
+    // per-board ranges [blocks+1][B], then the per-wave maxima of the output kernel [queues][chunk tiles][Kp/64] (as floats)
+    const size_t wm_elems = (size_t)chunk * tpb * (Kp >> 6);
+    const size_t need_amax = (size_t)(conf.SharedLayers + 1) * B + wm_elems * ns;
     if (need_amax > amax_cap) {
       AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (ctx->stream2) AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream2));
       if (d_amax) hipFree(d_amax);
       d_amax = nullptr; amax_cap = 0;
       AGZ_HIP_TRY(hipMalloc(&d_amax, need_amax * sizeof(unsigned)));
       amax_cap = need_amax;
     }
-    AGZ_HIP_TRY(hipMemsetAsync(d_amax, 0, need_amax * sizeof(unsigned), ctx->stream));
+    float* d_wave_max = reinterpret_cast<float*>(d_amax + (size_t)(conf.SharedLayers + 1) * B);
     hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, ctx->stream, cur, d_amax, HW, W, Wp, Hp * Wp, Kp);
-    // Two-queue tower (AGZ_WINO_H2_STREAMS=2, tuning knob): the two halves of the batch run their block chains on two HIP
-    // streams, so one half's HBM-bound transform kernels overlap the other half's GEMM (chains of different boards are
-    // independent: per-board ranges, disjoint scratch halves)
-    static const int streams_env = [] { const char* e = getenv("AGZ_WINO_H2_STREAMS"); return e ? atoi(e) : 1; }();
-    const bool two = streams_env == 2 && B >= 64 && chunk >= B;
-    if (two && !ctx->stream2) {
-      AGZ_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-      AGZ_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-      AGZ_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
-    const int half0 = two ? B / 2 : B;
-    if (two) {
+    if (ns == 2) {
+      if (!ctx->stream2) {
+        AGZ_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        AGZ_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        AGZ_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+      }
       AGZ_HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
       AGZ_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     }
+    static const int dbg_env = [] { const char* e = getenv("AGZ_WINO_H2_DBG"); return e ? atoi(e) : 0; }();   // measurement knob
     for (int l = 0; l < conf.SharedLayers; l++) {
       ProfScope ps(ctx, AGZ_PROF_CONV);
-      for (int part = 0; part < (two ? 2 : 1); part++)
-      for (int b0 = two ? (part ? half0 : 0) : 0; b0 < (two ? (part ? B : half0) : B); b0 += chunk) {
+      int ci = 0;
+      for (int b0 = 0; b0 < B; b0 += chunk, ci++) {
+        const int q = ci % ns;
         WinoH2Args hh{};
         WinoArgs& wa = hh.w;
         wa.x = cur + (size_t)b0 * Hp * Wp * Kp; wa.y = nxt + (size_t)b0 * Hp * Wp * Kp;
-        wa.V = d_wV + (two && part ? (size_t)36 * half0 * tpb * Kp : 0);
-        wa.Mb = d_wM + (two && part ? (size_t)36 * half0 * tpb * 2 * Kp : 0);
-        wa.ep = d_ep_dual[l];
-        wa.B = two ? (part ? B - half0 : half0) : std::min(chunk, B - b0);
-        wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
+        wa.V = d_wV + (size_t)q * v_elems; wa.Mb = d_wM + (size_t)q * m_elems; wa.ep = d_ep_dual[l];
+        wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
         hh.U2 = d_u2_dual[l]; hh.w_unscale = u_unscale[l];
-        static const int dbg_env = [] { const char* e = getenv("AGZ_WINO_H2_DBG"); return e ? atoi(e) : 0; }();   // measurement knob
         hh.dbg = dbg_env;
         hh.amax_in = d_amax + (size_t)l * B + b0; hh.amax_out = d_amax + (size_t)(l + 1) * B + b0;
-        wino_h2_launch(ctx, hh, wide, pfa, (two && part) ? ctx->stream2 : ctx->stream);
-        if (two) break;
+        hh.wave_max = d_wave_max + (size_t)q * wm_elems;
+        wino_h2_launch(ctx, hh, wide, pfa, q ? ctx->stream2 : ctx->stream);
       }
       std::swap(cur, nxt);
     }
-    if (two) {
+    if (ns == 2) {
       AGZ_HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
       AGZ_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }

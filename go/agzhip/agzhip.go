@@ -439,6 +439,34 @@ func (t *MCTS) Nodes() int {
 	return int(n)
 }
 
+// Child is one entry of Children: what (*MCTS).Log / ToDot print per node (node.go:56-68).
+type Child struct {
+	ID          int // feeds further Children calls
+	Move        game.Single
+	Visits      uint32
+	BlackScores float32
+	Prior       float32
+}
+
+// Children (mcts/unsafe_safe.go:15): the children of any node of the live tree (0 = the root).
+func (t *MCTS) Children(of int) []Child {
+	defer t.ctx.enter()()
+	cap := t.cells + 2
+	ids, moves := make([]int32, cap), make([]int32, cap)
+	visits := make([]uint32, cap)
+	bs, pr := make([]float32, cap), make([]float32, cap)
+	var n C.int
+	if err := lastErr(C.agz_mcts_children(t.h, C.int(of), (*C.int32_t)(unsafe.Pointer(&ids[0])), (*C.int32_t)(unsafe.Pointer(&moves[0])),
+		(*C.uint32_t)(unsafe.Pointer(&visits[0])), (*C.float)(unsafe.Pointer(&bs[0])), (*C.float)(unsafe.Pointer(&pr[0])), C.int(cap), &n)); err != nil {
+		panic(err)
+	}
+	out := make([]Child, int(n))
+	for i := range out {
+		out[i] = Child{ID: int(ids[i]), Move: game.Single(moves[i]), Visits: visits[i], BlackScores: bs[i], Prior: pr[i]}
+	}
+	return out
+}
+
 // Reset (tree.go:249-276), completed to "a fresh tree" (what Arena.Play does next, arena.go:140-141,175-176).
 func (t *MCTS) Reset() { defer t.ctx.enter()(); C.agz_mcts_reset(t.h) }
 

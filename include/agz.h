@@ -362,6 +362,10 @@ int agz_mcts_search(agz_mcts* mcts, int player, int32_t* best);
 int agz_mcts_policies(agz_mcts* mcts, float* policy, int cap);
 /* root children after a search in bestMove's order (the debugging surface of (*MCTS).Children, unsafe_safe.go:15) */
 int agz_mcts_root_children(agz_mcts* mcts, int32_t* moves, uint32_t* visits, float* black_scores, float* priors, int cap, int* n);
+/* (*MCTS).Children(of) with the Node fields (*MCTS).Log / ToDot print (mcts/unsafe_safe.go:15, graph.go:34): the children of ANY
+ * node of the live tree — node 0 is the root, child_ids feed further calls; *n = number of children (0: not expanded) */
+int agz_mcts_children(agz_mcts* mcts, int node, int32_t* child_ids, int32_t* moves, uint32_t* visits, float* black_scores,
+                      float* priors, int cap, int* n);
 /* (*MCTS).Nodes() (tree.go:126): nodes of the live tree (the reference counts its arena slots, freed ones included) */
 int agz_mcts_nodes(agz_mcts* mcts, int* n_nodes);
 int agz_mcts_get_stats(agz_mcts* mcts, agz_arena_stats* out);

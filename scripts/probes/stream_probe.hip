@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 constexpr int T = 12800, N = 512, C = 256;
 
@@ -70,9 +71,73 @@ __global__ __launch_bounds__(256) void p4(const float* __restrict__ m, float* __
     for (int k = 0; k < 16; k++) y[((size_t)(t0 + u) * 16 + k) * C + c] = s[k];
   }
 }
+// P5-P7: the output-transform kernel rebuilt piece by piece on P1's loads: + the 16 parameter vectors (L2-resident table),
+// + the real At M A arithmetic and epilogue, + the per-board maximum (wave reduce + atomicMax)
+__device__ __forceinline__ void at4(const float m[6], float o[4]) {
+  o[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+  o[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
+  o[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
+  o[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+}
+template <int LEVEL>
+__global__ __launch_bounds__(256) void p5(const float* __restrict__ m, const float4* __restrict__ ep, float* __restrict__ y, unsigned* __restrict__ amax) {
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)(g % C), t = (int)(g / C);
+  const int b = t / 25, tt = t - b * 25, ty = tt / 5, tx = tt - ty * 5;
+  float v[2][36];
+#pragma unroll
+  for (int br = 0; br < 2; br++)
+#pragma unroll
+    for (int p = 0; p < 36; p++) v[br][p] = m[((size_t)p * T + t) * N + br * C + c];
+  float4 E[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    int hh = 4 * ty + (k >> 2), ww = 4 * tx + (k & 3);
+    hh = hh < 19 ? hh : 18; ww = ww < 19 ? ww : 18;
+    E[k] = ep[(size_t)(hh * 19 + ww) * C + c];
+  }
+  float Y[2][16];
+  if (LEVEL >= 6) {
+#pragma unroll
+    for (int br = 0; br < 2; br++) {
+      float tm[4][6];
+#pragma unroll
+      for (int nu = 0; nu < 6; nu++) {
+        float mm[6], o[4];
+#pragma unroll
+        for (int xi = 0; xi < 6; xi++) mm[xi] = v[br][xi * 6 + nu];
+        at4(mm, o);
+#pragma unroll
+        for (int k = 0; k < 4; k++) tm[k][nu] = o[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) at4(tm[k], &Y[br][4 * k]);
+    }
+  } else {
+#pragma unroll
+    for (int br = 0; br < 2; br++)
+#pragma unroll
+      for (int k = 0; k < 16; k++) Y[br][k] = v[br][k] + v[br][k + 16] + v[br][(k + 32) % 36];
+  }
+  float mx = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    float va = Y[0][k] * E[k].x + E[k].y, vb = Y[1][k] * E[k].z + E[k].w;
+    va = va > 0.f ? va : 0.f; vb = vb > 0.f ? vb : 0.f;
+    float s = va + vb;
+    s = s > 0.f ? s : 0.f;
+    const int hh = 4 * ty + (k >> 2), ww = 4 * tx + (k & 3);
+    if (hh < 19 && ww < 19) { y[((size_t)b * 441 + (hh + 1) * 21 + (ww + 1)) * C + c] = s; mx = fmaxf(mx, s); }
+  }
+  if (LEVEL >= 7) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax + b, __float_as_uint(mx));
+  }
+}
 int main() {
   float *m, *y;
-  const size_t nm = (size_t)36 * T * N, ny = (size_t)T * 16 * C;
+  const size_t nm = (size_t)36 * T * N, ny = (size_t)512 * 441 * C;   // y: padded NHWC of 512 boards (>= T*16*C)
   CK(hipMalloc(&m, nm * 4)); CK(hipMalloc(&y, ny * 4));
   CK(hipMemset(m, 0x3c, nm * 4)); CK(hipMemset(y, 0, ny * 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -90,6 +155,13 @@ int main() {
   run("P1 out-kernel map", [&] { hipLaunchKernelGGL((p1<false>), dim3(T * C / 256), dim3(256), 0, 0, m, y); }, rd + wr);
   run("P2 [T][36][N] layout", [&] { hipLaunchKernelGGL((p1<true>), dim3(T * C / 256), dim3(256), 0, 0, m, y); }, rd + wr);
   run("P3 dwordx2, channel pairs", [&] { hipLaunchKernelGGL(p3, dim3(T * C / 2 / 256), dim3(256), 0, 0, m, y); }, rd + wr);
+  float4* ep; unsigned* amax;
+  CK(hipMalloc(&ep, (size_t)361 * C * 16)); CK(hipMemset(ep, 0x3c, (size_t)361 * C * 16));
+  CK(hipMalloc(&amax, 512 * 4)); CK(hipMemset(amax, 0, 512 * 4));
+  const double wr2 = 512.0 * 361 * C * 4;
+  run("P5 + 16 parameter vectors", [&] { hipLaunchKernelGGL((p5<5>), dim3(T * C / 256), dim3(256), 0, 0, m, ep, y, amax); }, rd + wr2);
+  run("P6 + At M A and epilogue", [&] { hipLaunchKernelGGL((p5<6>), dim3(T * C / 256), dim3(256), 0, 0, m, ep, y, amax); }, rd + wr2);
+  run("P7 + per-board max", [&] { hipLaunchKernelGGL((p5<7>), dim3(T * C / 256), dim3(256), 0, 0, m, ep, y, amax); }, rd + wr2);
   run("P4 two tiles per thread", [&] { hipLaunchKernelGGL(p4, dim3(T / 2 * C / 256), dim3(256), 0, 0, m, y); }, rd + wr);
   return 0;
 }

@@ -57,11 +57,13 @@ def test_g19_network_full_size_spot_check_and_batch_independence(ctx):
         p1, v1 = net.infer(x[b:b + 1])
         np.testing.assert_allclose(p1[0], pol[b], atol=2e-5, rtol=2e-4)
         np.testing.assert_allclose(v1[0], val[b], atol=2e-4)
-    net.set_latency_mode(False)  # regime off: bit for bit
+    net.set_latency_mode(False)  # regime off: one arithmetic at every batch size, bit for bit
+    pol_off, val_off = net.infer(x)
+    np.testing.assert_allclose(pol_off, pol, atol=2e-5, rtol=2e-4)   # (on: wide towers take the spread heads at every batch size)
     for b in (0, 511, 257):
         p1, v1 = net.infer(x[b:b + 1])
-        np.testing.assert_array_equal(p1[0], pol[b])
-        np.testing.assert_array_equal(v1[0], val[b])
+        np.testing.assert_array_equal(p1[0], pol_off[b])
+        np.testing.assert_array_equal(v1[0], val_off[b])
     net.set_latency_mode(True)
     onet = oracle_twin(net, K, L, S, F, 362)
     po, vo = onet.infer(x[[0, 511]])

@@ -162,6 +162,34 @@ def test_reset_is_a_fresh_tree_and_argument_checks(ctx):
         dev.set_game(**bad)
 
 
+def test_children_walk_the_whole_tree(ctx):
+    """(*MCTS).Children / ToDot surface: walking the device tree from the root reaches every node exactly once, the visits obey
+    the backup law (a node's visits = 1 + the visits its children gained), and the root level equals agz_mcts_root_children."""
+    host = Host(O.MNK, 5, 5, 4, 0.0)
+    dev = A.Mcts(ctx, capi.GAME_MNK, 5, 5, 4, Budget=150)
+    dev.set_inferencer(capi.INF_HASH)
+    dev.set_game(**host.state_kw())
+    dev.search(O.BLACK)
+    ids0, mv0, vis0, bs0, pr0 = dev.children(0)
+    rmv, rvis, rbs, rpr = dev.root_children()
+    np.testing.assert_array_equal(mv0, rmv)
+    np.testing.assert_array_equal(vis0, rvis)
+    np.testing.assert_array_equal(bs0, rbs)
+    count, todo = 1, [(0, None)]
+    while todo:
+        node, own_visits = todo.pop()
+        ids, mv, vis, bs, pr = dev.children(node)
+        count += len(ids)
+        if own_visits is not None and len(ids):
+            assert own_visits == 1 + int((vis.astype(np.int64) - 1).sum()) + 1   # created with 1, +1 for the expansion's own backup
+        for i, v in zip(ids, vis):
+            todo.append((int(i), int(v)))
+    assert count == dev.nodes()
+    assert dev.to_dot().startswith("digraph mcts {")
+    with pytest.raises(A.AgzError, match="outside the tree"):
+        dev.children(10 ** 6)
+
+
 def test_single_tree_search_with_the_hip_network(ctx):
     """Agent.Search as the tournament uses it: one tree, the dual net as inferencer, a mid-game 9x9 position."""
     S, K, L, F = 9, 64, 2, 18
