@@ -387,6 +387,7 @@ __global__ __launch_bounds__(64) void k_select(Dev d, GameCfg c, MctsCfg mc, flo
       d.leaf_ply[q] = move_number(c, st.ply);
       d.leaf_result[q] = result;
       d.path_len[q] = plen;
+      if (prep && kind == LEAF_EXPAND) atomicAdd(&d.counters[CNT_PREP_EXPAND], 1ull);   // roots prepareRoot has to evaluate
       if (!prep) {   // measurement only: nodes on the path and children read by Select, summed over simulations
         atomicAdd(&d.counters[CNT_PATH], (unsigned long long)plen);
         atomicAdd(&d.counters[CNT_KIDS], (unsigned long long)kids_seen);
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(64) void k_select_paths(Dev d, GameCfg c, MctsCfg m
       d.leaf_ply[q] = move_number(c, ply);
       d.leaf_result[q] = 0.f;
       d.path_len[q] = plen;
+      if (prep && kind == LEAF_EXPAND) atomicAdd(&d.counters[CNT_PREP_EXPAND], 1ull);
       if (!prep) {
         atomicAdd(&d.counters[CNT_PATH], (unsigned long long)plen);
         atomicAdd(&d.counters[CNT_KIDS], (unsigned long long)kids_seen);
@@ -1161,6 +1163,7 @@ struct agz_arena {
   int32_t* d_forced = nullptr;   // agz_arena_apply_moves staging
   std::vector<int32_t> slot_host;
   int32_t* d_remaining = nullptr;   // agz_arena_random_moves staging
+  unsigned long long prep_expand_seen = 0;   // CNT_PREP_EXPAND at the last prepareRoot step
   int nA_slots = 0, nB_slots = 0;
   bool in_move = false;
   bool restart = false;  // continuous self-play: finished games restart immediately
@@ -1223,6 +1226,16 @@ int agz_arena::nn_step(int prep, int nl) {
       hipLaunchKernelGGL(k_select, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, act0, act1, prep, nl);
     }
   }
+  // prepareRoot evaluates the network only for a root without children (search.go:392-408).  With tree reuse that is the rare
+  // case: if NO game of this arena needs it, the batched forward is skipped (one 8-byte read-back per move)
+  bool need_forward = true;
+  if (prep) {
+    unsigned long long cnt = 0;
+    AGZ_HIP_TRY(hipMemcpyAsync(&cnt, d.counters + CNT_PREP_EXPAND, 8, hipMemcpyDeviceToHost, ctx->stream));
+    AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    need_forward = cnt != prep_expand_seen;
+    prep_expand_seen = cnt;
+  }
   InfDesc inf{};
   for (int a = 0; a < 2; a++) {
     inf.kind[a] = inf_kind[a];
@@ -1236,7 +1249,9 @@ int agz_arena::nn_step(int prep, int nl) {
       default: inf.policy_len[a] = 25; break;
     }
   }
-  if (!split_nets()) {
+  if (!need_forward) {
+    if (inf_kind[0] == AGZ_INF_NET && inf_kind[1] == AGZ_INF_NET && !split_nets()) { inf.policy[1] = d_policy[0]; inf.value[1] = d_value[0]; }
+  } else if (!split_nets()) {
     agz_net* n = inf_kind[0] == AGZ_INF_NET ? net[0] : (inf_kind[1] == AGZ_INF_NET ? net[1] : nullptr);
     if (n) {
       int a = inf_kind[0] == AGZ_INF_NET ? 0 : 1;
@@ -1430,7 +1445,7 @@ int agz_arena_reset(agz_arena* a, const uint8_t* a_is_black) {
   AGZ_HIP_TRY(hipStreamSynchronize(s));
   if (dab) hipFree(dab);
   for (int g = 0; g < a->G; g++) a->a_is_black[g] = (uint8_t)ab[g];
-  a->in_move = false; a->moves_done = 0;
+  a->in_move = false; a->moves_done = 0; a->prep_expand_seen = 0;
   a->seed += 0x9E3779B97F4A7C15ull;  // next reset draws new colours
   return a->update_slots();
 }
@@ -1942,6 +1957,7 @@ int agz_mcts_reset(agz_mcts* m) {
   }
   AGZ_HIP_TRY(hipMemsetAsync(a->d.counters, 0, CNT_N * sizeof(unsigned long long), s));
   AGZ_HIP_TRY(hipStreamSynchronize(s));
+  a->prep_expand_seen = 0;
   return AGZ_OK;
 }
 

@@ -909,7 +909,6 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       AGZ_HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
       AGZ_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     }
-    static const int dbg_env = [] { const char* e = getenv("AGZ_WINO_H2_DBG"); return e ? atoi(e) : 0; }();   // measurement knob
     for (int l = 0; l < conf.SharedLayers; l++) {
       ProfScope ps(ctx, AGZ_PROF_CONV);
       int ci = 0;
@@ -921,7 +920,6 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         wa.V = d_wV + (size_t)q * v_elems; wa.Mb = d_wM + (size_t)q * m_elems; wa.ep = d_ep_dual[l];
         wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
         hh.U2 = d_u2_dual[l]; hh.w_unscale = u_unscale[l];
-        hh.dbg = dbg_env;
         hh.amax_in = d_amax + (size_t)l * B + b0; hh.amax_out = d_amax + (size_t)(l + 1) * B + b0;
         hh.wave_max = d_wave_max + (size_t)q * wm_elems;
         wino_h2_launch(ctx, hh, wide, pfa, q ? ctx->stream2 : ctx->stream);
