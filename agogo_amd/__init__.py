@@ -5,4 +5,4 @@ package only binds it (ctypes) for tests and bench.py; there is no CPU fallback:
 library and a GPU every compute entry point raises.
 """
 from .capi import (AgzError, Arena, Comm, Ctx, Examples, GameConf, Mcts, MctsConf, Net, NetConf, State, Trainer, lib, lib_path,  # noqa: F401
-                   rotate_boards, wino_stages)
+                   rotate_boards, wino_h2_tile, wino_stages)

@@ -169,6 +169,7 @@ def lib():
     sig("agz_examples_raw_dev", i32, vp, pvp, pvp, pvp)
     sig("agz_rotate_boards", i32, vp, pf, i32, i32, i32, pf)
     sig("agz_wino_stages", i32, vp, pf, pf, i32, i32, i32, i32, i32, pf, pf)
+    sig("agz_wino_h2_tile", i32, i32, i32)
     sig("agz_arena_random_moves", i32, vp, pi, u64)
     sig("agz_arena_set_state", i32, vp, i32, C.POINTER(State))
     sig("agz_arena_examples_labelled_dev", i32, vp, pvp)
@@ -839,6 +840,11 @@ class Examples:
         v = np.zeros(rows, np.float32)
         _check(lib().agz_examples_get_tensors(self.h, _pf(x), _pf(p), _pf(v)), "agz_examples_get_tensors")
         return x, p, v
+
+
+def wino_h2_tile(H, W):
+    """measurement: Winograd tile size (4 or 5) COMPUTE_WINO_H2 uses on an H x W board (agz_debug.h)"""
+    return int(lib().agz_wino_h2_tile(H, W))
 
 
 def wino_stages(ctx, x, w):

@@ -22,22 +22,81 @@
 #pragma once
 // (included by net.hip INSIDE namespace agz, after conv_wino.hpp and conv_h2.hpp)
 
+// Transform matrices (Cook-Toom; the last interpolation point is infinity):
+//   TM = 4: F(4x4,3x3), points 0, +-1, +-2      (Lavin & Gray 2016; conv_wino.hpp)        6x6 = 36 positions per 16 outputs
+//   TM = 5: F(5x5,3x3), points 0, +-1, +-1/2, 2                                          7x7 = 49 positions per 25 outputs
+// A 19x19 board is 5x5 tiles of 4 (900 GEMM rows) or 4x4 tiles of 5 (784 rows: V, M and the GEMMs shrink by 13 %); a 9x9 board
+// 3x3 tiles of 4 (324 rows, 78 % overhang) or 2x2 tiles of 5 (196 rows).  One layer's rounding error on post-ReLU data (fp32
+// transforms, C = 256): 1.4e-6 of the output rms for TM 4, 2.3e-6 for TM 5 (direct fp32 accumulation: 2.1e-7) — both two orders
+// inside the network tolerance.  |Bt| row sums: 10 (TM 4), 7.5 (TM 5) -> |V| <= 100 / 56.25 max|d|: the range bound below.
+template <int TM> struct WinoT;
+template <> struct WinoT<4> {
+  static constexpr int AL = 6, VSHIFT = 7;    // |V| <= 2^VSHIFT * max|d|
+  static constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+  static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+  static constexpr double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+};
+template <> struct WinoT<5> {
+  static constexpr int AL = 7, VSHIFT = 6;
+  static constexpr float BT[7][7] = {{-0.5f, 0.25f, 2.5f, -1.25f, -2, 1, 0}, {0, 0.5f, 0.25f, -2.25f, -1, 1, 0}, {0, -0.5f, 0.75f, 1.75f, -3, 1, 0},
+                                     {0, 1, 1.5f, -2, -1.5f, 1, 0},          {0, -1, 2.5f, 0, -2.5f, 1, 0},       {0, 0.25f, 0, -1.25f, 0, 1, 0},
+                                     {0, -0.5f, 0.25f, 2.5f, -1.25f, -2, 1}};
+  static constexpr float AT[5][7] = {{1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 0.5f, -0.5f, 2, 0}, {0, 1, 1, 0.25f, 0.25f, 4, 0}, {0, 1, -1, 0.125f, -0.125f, 8, 0},
+                                     {0, 1, 1, 0.0625f, 0.0625f, 16, 1}};
+  static constexpr double G[7][3] = {{-2, 0, 0}, {-2.0 / 3, -2.0 / 3, -2.0 / 3}, {-2.0 / 9, 2.0 / 9, -2.0 / 9}, {16.0 / 9, 8.0 / 9, 4.0 / 9}, {16.0 / 15, -8.0 / 15, 4.0 / 15},
+                                     {2.0 / 45, 4.0 / 45, 8.0 / 45}, {0, 0, 1}};
+};
+// the 1-D transforms written out (shared sub-sums; a generic matrix-vector loop over the constexpr tables above compiled to 35 %
+// slower transform kernels: measured 0.19 vs 0.14 ms for the TM = 4 input transform)
+template <int TM> __device__ __forceinline__ void wino_btv(const float* d, float* o);
+template <int TM> __device__ __forceinline__ void wino_atv(const float* m, float* o);
+template <> __device__ __forceinline__ void wino_btv<4>(const float* d, float* o) { wino_bt6(d, o); }
+template <> __device__ __forceinline__ void wino_atv<4>(const float* m, float* o) { wino_at4(m, o); }
+template <> __device__ __forceinline__ void wino_btv<5>(const float* d, float* o) {
+  o[0] = -0.5f * d[0] + 0.25f * d[1] + 2.5f * d[2] - 1.25f * d[3] - 2.f * d[4] + d[5];
+  o[1] = 0.5f * d[1] + 0.25f * d[2] - 2.25f * d[3] - d[4] + d[5];
+  o[2] = -0.5f * d[1] + 0.75f * d[2] + 1.75f * d[3] - 3.f * d[4] + d[5];
+  o[3] = d[1] + 1.5f * d[2] - 2.f * d[3] - 1.5f * d[4] + d[5];
+  o[4] = -d[1] + 2.5f * (d[2] - d[4]) + d[5];
+  o[5] = 0.25f * d[1] - 1.25f * d[3] + d[5];
+  o[6] = -0.5f * d[1] + 0.25f * d[2] + 2.5f * d[3] - 1.25f * d[4] - 2.f * d[5] + d[6];
+}
+template <> __device__ __forceinline__ void wino_atv<5>(const float* m, float* o) {
+  const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = m[0] + s12 + s34 + m[5];
+  o[1] = d12 + 0.5f * d34 + 2.f * m[5];
+  o[2] = s12 + 0.25f * s34 + 4.f * m[5];
+  o[3] = d12 + 0.125f * d34 + 8.f * m[5];
+  o[4] = s12 + 0.0625f * s34 + 16.f * m[5] + m[6];
+}
+
+struct WinoH2Args;
+__device__ __forceinline__ size_t h2_row(const WinoH2Args& h, int pos, int t);
 struct WinoH2Args {
-  WinoArgs w;                // geometry, x, V (reinterpreted as the fp16 piece image), Mb, ep, y
+  WinoArgs w;                // geometry (nty/ntx/TPB/T in tiles of tm), x, V (reinterpreted as the fp16 piece image), Mb, ep, y
+  int tm, npos;              // tile size 4 or 5; (tm + 2)^2 positions
+  // Row of (position, tile t) in V and M = (t >> rsh) * rA + pos * rB + (t & rmask), set by wino_h2_launch.  Blocked layout
+  // (default): [T/128][npos][128 rows] — the 128-row tile a GEMM block produces is contiguous and a tile's positions lie
+  // within npos * 128 rows, so the transform kernels' (tm+2)^2 streams stay inside a few pages.  Plain layout: [npos][T + pad].
+  int rsh, rmask;
+  unsigned rA, rB;
   const _Float16* U2;        // [36][C/32][2][Ntot][32]
   const unsigned* amax_in;   // [B] max |x| of every board of this block's input (float bits)
   unsigned* amax_out;        // [B] max of this block's output (wino_board_max_kernel over wave_max)
   float* wave_max;           // [T][Cout_p/64] maximum of the 64 channels x 16 pixels one wave of wino_out_h2_kernel produced
   float w_unscale;           // 1 / su
 };
+__device__ __forceinline__ size_t h2_row(const WinoH2Args& h, int pos, int t) {
+  return (size_t)(t >> h.rsh) * h.rA + (size_t)pos * h.rB + (size_t)(t & h.rmask);
+}
 
-// s = 2^(134 - E): |V| <= 128 * amax < 2^(E - 119)  =>  |V * s| < 2^15.   inv = 1 / s.
-__device__ __forceinline__ void wino_h2_scales(unsigned amax_bits, float* s, float* inv) {
+// s = 2^(141 - shift - E): |V| <= 2^shift * amax < 2^(E - 126 + shift)  =>  |V * s| < 2^15.   inv = 1 / s.   (shift 7: 134 - E)
+__device__ __forceinline__ void wino_h2_scales(unsigned amax_bits, int shift, float* s, float* inv) {
   int e = (int)((amax_bits >> 23) & 0xffu);
   if (amax_bits == 0u) { *s = 1.f; *inv = 1.f; return; }
   e = e < 30 ? 30 : (e > 230 ? 230 : e);
-  *s = __uint_as_float((unsigned)(261 - e) << 23);
-  *inv = __uint_as_float((unsigned)(e - 7) << 23);
+  *s = __uint_as_float((unsigned)(268 - shift - e) << 23);
+  *inv = __uint_as_float((unsigned)(e - 14 + shift) << 23);
 }
 
 __device__ __forceinline__ unsigned wino_h2_pack(float a, float b, unsigned* lo) {
@@ -49,7 +108,10 @@ __device__ __forceinline__ unsigned wino_h2_pack(float a, float b, unsigned* lo)
 
 // One thread per (tile, channel pair) like wino_in_kernel; the result is scaled by the board's power of two, split, and
 // stored as one 4-byte hi word and one 4-byte lo word (16 lanes fill the 64-byte hi / lo halves of a 32-channel chunk).
+template <int TM>
 __global__ __launch_bounds__(256) void wino_in_h2_kernel(WinoH2Args h) {
+  using WT = WinoT<TM>;
+  constexpr int AL = WT::AL;
   const WinoArgs& a = h.w;
   const int C2 = a.C >> 1;
   const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -59,48 +121,48 @@ __global__ __launch_bounds__(256) void wino_in_h2_kernel(WinoH2Args h) {
   const int b = t / a.TPB, tt = t - b * a.TPB;
   const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
   float sb, inv_;
-  wino_h2_scales(h.amax_in[b], &sb, &inv_);
+  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &sb, &inv_);
   const float* xb = a.x + (size_t)b * a.Hp * a.Wp * a.C + 2 * c2;
-  // all 36 loads are issued unconditionally (clamped address, zeroed afterwards): a branch per load keeps only one column of
-  // six in flight (measured 4.2 TB/s of algorithmic bytes with the branches)
-  float2 d[6][6];
+  // all loads are issued unconditionally (clamped address, zeroed afterwards): a branch per load keeps only one column in
+  // flight (measured 4.2 TB/s of algorithmic bytes with the branches)
+  float2 d[AL][AL];
 #pragma unroll
-  for (int j = 0; j < 6; j++) {
-    const int px = 4 * tx + j, pxc = px < a.Wp ? px : a.Wp - 1;
+  for (int j = 0; j < AL; j++) {
+    const int px = TM * tx + j, pxc = px < a.Wp ? px : a.Wp - 1;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const int py = 4 * ty + i, pyc = py < a.Hp ? py : a.Hp - 1;
+    for (int i = 0; i < AL; i++) {
+      const int py = TM * ty + i, pyc = py < a.Hp ? py : a.Hp - 1;
       d[i][j] = *reinterpret_cast<const float2*>(xb + ((size_t)pyc * a.Wp + pxc) * a.C);
     }
   }
-  float tmx[6][6], tmy[6][6];
+  float tmx[AL][AL], tmy[AL][AL];
 #pragma unroll
-  for (int j = 0; j < 6; j++) {
-    const bool okx = 4 * tx + j < a.Wp;
-    float dx[6], dy[6], ox[6], oy[6];
+  for (int j = 0; j < AL; j++) {
+    const bool okx = TM * tx + j < a.Wp;
+    float dx[AL], dy[AL], ox[AL], oy[AL];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const bool ok = okx && 4 * ty + i < a.Hp;
+    for (int i = 0; i < AL; i++) {
+      const bool ok = okx && TM * ty + i < a.Hp;
       dx[i] = ok ? d[i][j].x : 0.f; dy[i] = ok ? d[i][j].y : 0.f;
     }
-    wino_bt6(dx, ox);
-    wino_bt6(dy, oy);
+    wino_btv<TM>(dx, ox);
+    wino_btv<TM>(dy, oy);
 #pragma unroll
-    for (int i = 0; i < 6; i++) { tmx[i][j] = ox[i]; tmy[i][j] = oy[i]; }
+    for (int i = 0; i < AL; i++) { tmx[i][j] = ox[i]; tmy[i][j] = oy[i]; }
   }
   unsigned* V2 = reinterpret_cast<unsigned*>(a.V);          // 4-byte words: [pos][T][C/32][2][16]
   const int c = 2 * c2;
   const size_t word_in_row = (size_t)(c >> 5) * 32 + ((c & 31) >> 1);   // hi word; the lo word sits 16 words further
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    float ox[6], oy[6];
-    wino_bt6(tmx[i], ox);
-    wino_bt6(tmy[i], oy);
+  for (int i = 0; i < AL; i++) {
+    float ox[AL], oy[AL];
+    wino_btv<TM>(tmx[i], ox);
+    wino_btv<TM>(tmy[i], oy);
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
+    for (int j = 0; j < AL; j++) {
       unsigned lo;
       const unsigned hi = wino_h2_pack(ox[j] * sb, oy[j] * sb, &lo);
-      unsigned* row = V2 + ((size_t)(i * 6 + j) * a.T + t) * a.C + word_in_row;
+      unsigned* row = V2 + h2_row(h, i * AL + j, t) * a.C + word_in_row;
       row[0] = hi;
       row[16] = lo;
     }
@@ -116,7 +178,7 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_h2_kernel(WinoH2Args h) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE];
 
   const int per_pos = a.n_mtiles * a.n_ntiles;
-  const int nblk = 36 * per_pos;
+  const int nblk = h.npos * per_pos;
   const int id = blockIdx.x;
   int q = nblk >> 3, rr = nblk & 7, xcd = id & 7, slot = id >> 3;
   int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
@@ -134,7 +196,7 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_h2_kernel(WinoH2Args h) {
   if (nrow >= a.Ntot) nrow = a.Ntot - 1;
   const int NK = a.C >> 5;
   const unsigned piece_bytes = (unsigned)a.Ntot * 64u;
-  unsigned xo_ = (unsigned)((((size_t)pos * a.T + mrow) * a.C) * 4) + (unsigned)shalf * 32u;
+  unsigned xo_ = (unsigned)((h2_row(h, pos, mrow) * a.C) * 4) + (unsigned)shalf * 32u;
   unsigned wo_ = (unsigned)pos * (unsigned)NK * 2u * piece_bytes + (unsigned)nrow * 64u + (unsigned)shalf * 32u;
   const unsigned s_off0 = h2_lds_off(srow, 2 * shalf), s_off1 = h2_lds_off(srow, 2 * shalf + 1);
 
@@ -211,7 +273,7 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_h2_kernel(WinoH2Args h) {
       const int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       const int m = m0 + row;
       if (m < a.T) {
-        float* dst = a.Mb + ((size_t)pos * a.T + m) * a.Ntot;
+        float* dst = a.Mb + h2_row(h, pos, m) * a.Ntot;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           const int c = n0 + (wn * 2 + j) * 32 + (lane & 31);
@@ -231,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2w_kernel(WinoH2Args h) {
 
   const int n_nt = (a.Ntot + 255) / 256;
   const int per_pos = a.n_mtiles * n_nt;
-  const int nblk = 36 * per_pos;
+  const int nblk = h.npos * per_pos;
   const int id = blockIdx.x;
   int q = nblk >> 3, rr = nblk & 7, xcd = id & 7, slot = id >> 3;
   int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
@@ -250,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2w_kernel(WinoH2Args h) {
   if (nr1 >= a.Ntot) nr1 = a.Ntot - 1;
   const int NK = a.C >> 5;
   const unsigned piece_bytes = (unsigned)a.Ntot * 64u;
-  unsigned xo_ = (unsigned)((((size_t)pos * a.T + mrow) * a.C) * 4) + (unsigned)shalf * 32u;
+  unsigned xo_ = (unsigned)((h2_row(h, pos, mrow) * a.C) * 4) + (unsigned)shalf * 32u;
   unsigned wo_ = (unsigned)pos * (unsigned)NK * 2u * piece_bytes;
   const unsigned b_g0 = (unsigned)nr0 * 64u + (unsigned)shalf * 32u, b_g1 = (unsigned)nr1 * 64u + (unsigned)shalf * 32u;
   const unsigned sa0 = h2_lds_off(srow, 2 * shalf), sa1 = h2_lds_off(srow, 2 * shalf + 1);
@@ -340,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2w_kernel(WinoH2Args h) {
       const int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       const int m = m0 + row;
       if (m < a.T) {
-        float* dst = a.Mb + ((size_t)pos * a.T + m) * a.Ntot;
+        float* dst = a.Mb + h2_row(h, pos, m) * a.Ntot;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const int c = n0 + wn * 128 + j * 32 + (lane & 31);
@@ -372,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2d_kernel(WinoH2Args h) {
 
   const int n_nt = (a.Ntot + BN - 1) / BN;
   const int per_pos = a.n_mtiles * n_nt;
-  const int nblk = 36 * per_pos;
+  const int nblk = h.npos * per_pos;
   const int id = blockIdx.x;
   int q = nblk >> 3, rr = nblk & 7, xcd = id & 7, slot = id >> 3;
   int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
@@ -390,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2d_kernel(WinoH2Args h) {
   for (int k = 0; k < 2; k++) {
     int m = m0 + sr + 64 * k;
     if (m >= a.T) m = a.T - 1;
-    xo[k] = (unsigned)((((size_t)pos * a.T + m) * a.C) * 4) + (unsigned)sc * 16u;
+    xo[k] = (unsigned)((h2_row(h, pos, m) * a.C) * 4) + (unsigned)sc * 16u;
     so_a[k] = h2_lds_off(sr + 64 * k, sc);
   }
 #pragma unroll
@@ -478,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2d_kernel(WinoH2Args h) {
   }
 
   const bool full = m0 + 128 <= a.T && n0 + BN <= a.Ntot;   // uniform
-  float* dst0 = a.Mb + ((size_t)pos * a.T + m0 + wm * 64 + 4 * (lane >> 5)) * a.Ntot + n0 + wn * (64 * NT) + (lane & 31);
+  float* dst0 = a.Mb + h2_row(h, pos, m0 + wm * 64 + 4 * (lane >> 5)) * a.Ntot + n0 + wn * (64 * NT) + (lane & 31);
   if (full) {
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -495,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2d_kernel(WinoH2Args h) {
       for (int r = 0; r < 16; r++) {
         const int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < a.T) {
-          float* d = a.Mb + ((size_t)pos * a.T + m) * a.Ntot;
+          float* d = a.Mb + h2_row(h, pos, m) * a.Ntot;
 #pragma unroll
           for (int j = 0; j < NJ; j++) {
             const int c = n0 + wn * (64 * NT) + j * 32 + (lane & 31);
@@ -511,7 +573,10 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2d_kernel(WinoH2Args h) {
 // single-stage 128x128 form at four workgroups per CU and 0.389 for the 128x256 form: occupancy beats barrier count here.)
 
 // wino_out_kernel + exact un-scaling + the per-board maximum of the block output (the next block's range).
+template <int TM>
 __global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
+  using WT = WinoT<TM>;
+  constexpr int AL = WT::AL;
   const WinoArgs& a = h.w;
   const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = g < (size_t)a.T * a.Cout_p;
@@ -521,47 +586,48 @@ __global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
   const int b = t / a.TPB, tt = t - b * a.TPB;
   const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
   float s_, unscale;
-  wino_h2_scales(h.amax_in[b], &s_, &unscale);
+  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &unscale);
   unscale *= h.w_unscale;
-  // the 16 epilogue parameter vectors of this (tile, channel): fetched up front with the M loads (clamped address) — loaded
-  // inside the per-pixel branch each one is a dependent L2 round trip (sixteen of them back to back per thread)
-  float4 E[4][4];
+  // All loads are issued before any arithmetic: the 2 x AL^2 values of M and the TM^2 epilogue parameter vectors (clamped
+  // address) — loaded inside the per-pixel branch each of those is a dependent L2 round trip per thread.  (Fetching branch by
+  // branch to lower the register count was measured: the compiler hoists the loads anyway and spills — 0.51 vs 0.24 ms.)
+  float4 E[TM][TM];
   {
     const float4* ep = reinterpret_cast<const float4*>(a.ep);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int hh = 4 * ty + k, hc = hh < a.H ? hh : a.H - 1;
+    for (int k = 0; k < TM; k++) {
+      const int hh = TM * ty + k, hc = hh < a.H ? hh : a.H - 1;
 #pragma unroll
-      for (int l = 0; l < 4; l++) {
-        const int ww = 4 * tx + l, wc = ww < a.W ? ww : a.W - 1;
+      for (int l = 0; l < TM; l++) {
+        const int ww = TM * tx + l, wc = ww < a.W ? ww : a.W - 1;
         E[k][l] = ep[(size_t)(hc * a.W + wc) * a.Cout_p + c];
       }
     }
   }
-  float Y[2][4][4];
+  float Y[2][TM][TM];
 #pragma unroll
   for (int br = 0; br < 2; br++) {
-    float tm[4][6];
+    float tm_[TM][AL];
 #pragma unroll
-    for (int nu = 0; nu < 6; nu++) {
-      float m[6], o[4];
+    for (int nu = 0; nu < AL; nu++) {
+      float m[AL], o[TM];
 #pragma unroll
-      for (int xi = 0; xi < 6; xi++) m[xi] = a.Mb[((size_t)(xi * 6 + nu) * a.T + t) * a.Ntot + br * a.Cout_p + c];
-      wino_at4(m, o);
+      for (int xi = 0; xi < AL; xi++) m[xi] = a.Mb[h2_row(h, xi * AL + nu, t) * a.Ntot + br * a.Cout_p + c];
+      wino_atv<TM>(m, o);
 #pragma unroll
-      for (int k = 0; k < 4; k++) tm[k][nu] = o[k];
+      for (int k = 0; k < TM; k++) tm_[k][nu] = o[k];
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) wino_at4(tm[k], Y[br][k]);
+    for (int k = 0; k < TM; k++) wino_atv<TM>(tm_[k], Y[br][k]);
   }
   float* yb = a.y + (size_t)b * a.Hp * a.Wp * a.Cout_p + c;
   float mx = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int hh = 4 * ty + k;
+  for (int k = 0; k < TM; k++) {
+    const int hh = TM * ty + k;
 #pragma unroll
-    for (int l = 0; l < 4; l++) {
-      const int ww = 4 * tx + l;
+    for (int l = 0; l < TM; l++) {
+      const int ww = TM * tx + l;
       const float4 e = E[k][l];
       float va = (Y[0][k][l] * unscale) * e.x + e.y;
       float vb = (Y[1][k][l] * unscale) * e.z + e.w;
@@ -584,6 +650,77 @@ __global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
   }
 }
 
+// The same output transform with one thread per (tile, channel, BRANCH): neighbouring lanes hold branch a and branch b of one
+// channel, each transforms its own AL^2 values of M and applies its own {scale, shift} half, the two exchange the finished values
+// with one lane swap per pixel and share the stores.  Half the live values per thread (TM 5: 49 + 50 instead of 98 + 100), twice
+// the threads.  A wave covers 32 channels of one tile: wave_max is indexed [T][Cout_p/32].
+template <int TM>
+__global__ __launch_bounds__(256) void wino_out_pair_h2_kernel(WinoH2Args h) {
+  using WT = WinoT<TM>;
+  constexpr int AL = WT::AL;
+  const WinoArgs& a = h.w;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)a.T * a.Cout_p * 2;
+  const bool live = g < total;
+  const size_t gg = live ? g : total - 1;
+  const int br = (int)(gg & 1);
+  const int c = (int)((gg >> 1) % a.Cout_p);
+  const int t = (int)((gg >> 1) / a.Cout_p);
+  const int b = t / a.TPB, tt = t - b * a.TPB;
+  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
+  float s_, unscale;
+  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &unscale);
+  unscale *= h.w_unscale;
+  const float2* ep2 = reinterpret_cast<const float2*>(a.ep);
+  float2 E[TM][TM];
+#pragma unroll
+  for (int k = 0; k < TM; k++) {
+    const int hh = TM * ty + k, hc = hh < a.H ? hh : a.H - 1;
+#pragma unroll
+    for (int l = 0; l < TM; l++) {
+      const int ww = TM * tx + l, wc = ww < a.W ? ww : a.W - 1;
+      E[k][l] = ep2[((size_t)(hc * a.W + wc) * a.Cout_p + c) * 2 + br];
+    }
+  }
+  float tm_[TM][AL];
+#pragma unroll
+  for (int nu = 0; nu < AL; nu++) {
+    float m[AL], o[TM];
+#pragma unroll
+    for (int xi = 0; xi < AL; xi++) m[xi] = a.Mb[h2_row(h, xi * AL + nu, t) * a.Ntot + br * a.Cout_p + c];
+    wino_atv<TM>(m, o);
+#pragma unroll
+    for (int k = 0; k < TM; k++) tm_[k][nu] = o[k];
+  }
+  float* yb = a.y + (size_t)b * a.Hp * a.Wp * a.Cout_p + c;
+  float mx = 0.f;
+#pragma unroll
+  for (int k = 0; k < TM; k++) {
+    float Yk[TM];
+    wino_atv<TM>(tm_[k], Yk);
+    const int hh = TM * ty + k;
+#pragma unroll
+    for (int l = 0; l < TM; l++) {
+      float v = (Yk[l] * unscale) * E[k][l].x + E[k][l].y;
+      v = v > 0.f ? v : 0.f;
+      const float other = __shfl_xor(v, 1, 64);
+      // relu(relu(a) + relu(b)): the operands are non-negative, so the sum is order-independent bit for bit and already >= 0
+      float sum = v + other;
+      sum = sum > 0.f ? sum : 0.f;
+      const int ww = TM * tx + l;
+      if (((k * TM + l) & 1) == br && live && hh < a.H && ww < a.W) {   // the two lanes of a pair share the pixels
+        yb[((size_t)(hh + 1) * a.Wp + (ww + 1)) * a.Cout_p] = sum;
+        mx = fmaxf(mx, sum);
+      }
+    }
+  }
+  if (h.wave_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && live) h.wave_max[(size_t)t * (a.Cout_p >> 5) + (c >> 5)] = mx;
+  }
+}
+
 // amax_out[b] = max over the board's tiles and channel groups of wave_max (one wave per board)
 __global__ __launch_bounds__(64) void wino_board_max_kernel(const float* __restrict__ wave_max, unsigned* __restrict__ amax_out, int per_board) {
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -594,33 +731,33 @@ __global__ __launch_bounds__(64) void wino_board_max_kernel(const float* __restr
   if (lane == 0) amax_out[b] = __float_as_uint(mx);
 }
 
-// Host: the Winograd-domain filter (as wino_build_u3) scaled by a power of two and split into two fp16 pieces:
+// Host: the Winograd-domain filter G g Gt (double, rounded once to fp32) scaled by a power of two and split into two fp16 pieces:
 // u2[pos][ci/32][piece][n][ci%32]; returns 1/su.
-template <typename Get>
+template <int TM, typename Get>
 static float wino_build_u2(std::vector<_Float16>& u2, int Ntot, int C, Get get) {
-  static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+  using WT = WinoT<TM>;
+  constexpr int AL = WT::AL, NP = AL * AL;
   const int NC = C / 32;
-  std::vector<float> U((size_t)36 * Ntot * C, 0.f);
+  std::vector<float> U((size_t)NP * Ntot * C, 0.f);
   float umax = 0.f;
   for (int n = 0; n < Ntot; n++)
     for (int ci = 0; ci < C; ci++) {
-      double g[3][3], tg[6][3];
+      double g[3][3], tg[AL][3];
       bool any = false;
       for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { g[i][j] = get(n, ci, i * 3 + j); any = any || g[i][j] != 0.0; }
       if (!any) continue;
-      for (int xi = 0; xi < 6; xi++) for (int j = 0; j < 3; j++) tg[xi][j] = G[xi][0] * g[0][j] + G[xi][1] * g[1][j] + G[xi][2] * g[2][j];
-      for (int xi = 0; xi < 6; xi++) for (int nu = 0; nu < 6; nu++) {
-        const float v = (float)(tg[xi][0] * G[nu][0] + tg[xi][1] * G[nu][1] + tg[xi][2] * G[nu][2]);   // rounded once to fp32, like u3
-        U[((size_t)(xi * 6 + nu) * Ntot + n) * C + ci] = v;
+      for (int xi = 0; xi < AL; xi++) for (int j = 0; j < 3; j++) tg[xi][j] = WT::G[xi][0] * g[0][j] + WT::G[xi][1] * g[1][j] + WT::G[xi][2] * g[2][j];
+      for (int xi = 0; xi < AL; xi++) for (int nu = 0; nu < AL; nu++) {
+        const float v = (float)(tg[xi][0] * WT::G[nu][0] + tg[xi][1] * WT::G[nu][1] + tg[xi][2] * WT::G[nu][2]);
+        U[((size_t)(xi * AL + nu) * Ntot + n) * C + ci] = v;
         umax = std::max(umax, std::fabs(v));
       }
     }
   int ex = 0;
   if (umax > 0.f) std::frexp(umax, &ex);
   const float su = umax > 0.f ? std::ldexp(1.0f, 14 - ex) : 1.0f;
-  u2.assign((size_t)36 * NC * 2 * Ntot * 32, (_Float16)0.f);
-  for (int pos = 0; pos < 36; pos++)
+  u2.assign((size_t)NP * NC * 2 * Ntot * 32, (_Float16)0.f);
+  for (int pos = 0; pos < NP; pos++)
     for (int n = 0; n < Ntot; n++)
       for (int ci = 0; ci < C; ci++) {
         const float xs = U[((size_t)pos * Ntot + n) * C + ci] * su;
@@ -633,20 +770,46 @@ static float wino_build_u2(std::vector<_Float16>& u2, int Ntot, int C, Get get) 
   return 1.0f / su;
 }
 
-// launches the stages of one block for a chunk of boards (h.w.V / Mb sized by the caller)
+// tile size with the fewest transform-domain rows for an H x W board
+static inline int wino_h2_pick_tm(int H, int W) {
+  static const int force = [] { const char* e = getenv("AGZ_WINO_H2_TM"); return e ? atoi(e) : 0; }();   // tuning knob
+  if (force == 4 || force == 5) return force;
+  const int r4 = 36 * ceil_div(H, 4) * ceil_div(W, 4), r5 = 49 * ceil_div(H, 5) * ceil_div(W, 5);
+  return r5 < r4 ? 5 : 4;
+}
+
+// Layout of V and M (tuning knob AGZ_WINO_H2_LAYOUT = blocked (default) | plain, AGZ_WINO_H2_PAD = rows of padding between the
+// positions of the plain layout; measured: no effect, the HBM address hash already spreads the power-of-two stride).
+static inline bool wino_h2_blocked() {
+  static const bool v = [] { const char* e = getenv("AGZ_WINO_H2_LAYOUT"); return !(e && !strcmp(e, "plain")); }();
+  return v;
+}
+static inline int wino_h2_pos_pad() {
+  static const int v = [] { const char* e = getenv("AGZ_WINO_H2_PAD"); return e ? atoi(e) : 0; }();
+  return v < 0 ? 0 : v;
+}
+// rows of V (and of M) the launch below addresses for `tiles` tiles: what the caller sizes the buffers by
+static inline size_t wino_h2_rows(int npos, size_t tiles) { return (size_t)npos * (((tiles + 127) / 128) * 128 + wino_h2_pos_pad()); }
+
+// launches the stages of one block for a chunk of boards (h.w.V / Mb sized by the caller: wino_h2_rows())
 static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, hipStream_t st = nullptr) {
   if (!st) st = ctx->stream;
   WinoArgs& a = h.w;
-  a.nty = ceil_div(a.H, 4); a.ntx = ceil_div(a.W, 4); a.TPB = a.nty * a.ntx; a.T = a.B * a.TPB;
+  const int tm = h.tm == 5 ? 5 : 4;
+  h.tm = tm; h.npos = (tm + 2) * (tm + 2);
+  a.nty = ceil_div(a.H, tm); a.ntx = ceil_div(a.W, tm); a.TPB = a.nty * a.ntx; a.T = a.B * a.TPB;
+  if (wino_h2_blocked()) { h.rsh = 7; h.rmask = 127; h.rA = (unsigned)h.npos * 128u; h.rB = 128u; }
+  else { h.rsh = 31; h.rmask = 0x7fffffff; h.rA = 0; h.rB = (unsigned)(a.T + wino_h2_pos_pad()); }
   a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
   {
     ProfScopeOn ps(ctx, AGZ_PROF_WINO_IN, st == ctx->stream);
     const size_t n_in = (size_t)a.T * (a.C / 2);
-    hipLaunchKernelGGL(wino_in_h2_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, h);
+    if (tm == 5) hipLaunchKernelGGL(wino_in_h2_kernel<5>, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, h);
+    else hipLaunchKernelGGL(wino_in_h2_kernel<4>, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, h);
   }
   {
     ProfScopeOn ps(ctx, AGZ_PROF_WINO_GEMM, st == ctx->stream);
-    const dim3 gw(36 * a.n_mtiles * ceil_div(a.Ntot, 256)), gn(36 * a.n_mtiles * a.n_ntiles);
+    const dim3 gw(h.npos * a.n_mtiles * ceil_div(a.Ntot, 256)), gn(h.npos * a.n_mtiles * a.n_ntiles);
     // the unrolled deep-prefetch form is instantiated per K extent (32-channel steps); K = 256 with every prefetch depth (tuning)
     const int nk = a.C >> 5;
     bool done = true;
@@ -672,8 +835,17 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
   {
     ProfScopeOn ps(ctx, AGZ_PROF_WINO_OUT, st == ctx->stream);
     const size_t n_out = (size_t)a.T * a.Cout_p;
-    hipLaunchKernelGGL(wino_out_h2_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, h);
+    static const int pair_env = [] { const char* e = getenv("AGZ_WINO_H2_OUT_PAIR"); return e ? atoi(e) : -1; }();   // tuning knob
+    const bool pair = pair_env >= 0 ? pair_env != 0 : tm == 5;
+    if (pair) {
+      const unsigned gp = (unsigned)((2 * n_out + 255) / 256);
+      if (tm == 5) hipLaunchKernelGGL(wino_out_pair_h2_kernel<5>, dim3(gp), dim3(256), 0, st, h);
+      else hipLaunchKernelGGL(wino_out_pair_h2_kernel<4>, dim3(gp), dim3(256), 0, st, h);
+    } else {
+      if (tm == 5) hipLaunchKernelGGL(wino_out_h2_kernel<5>, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, h);
+      else hipLaunchKernelGGL(wino_out_h2_kernel<4>, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, h);
+    }
     if (h.wave_max && h.amax_out)
-      hipLaunchKernelGGL(wino_board_max_kernel, dim3(a.B), dim3(64), 0, st, h.wave_max, h.amax_out, a.TPB * (a.Cout_p >> 6));
+      hipLaunchKernelGGL(wino_board_max_kernel, dim3(a.B), dim3(64), 0, st, h.wave_max, h.amax_out, a.TPB * (a.Cout_p >> (pair ? 5 : 6)));
   }
 }

@@ -582,7 +582,7 @@ void agz_net::free_device() {
   for (auto& p : d_u2_dual) if (p) { hipFree(p); p = nullptr; }
   d_u2_dual.clear();
   f(d_wV); f(d_wM);
-  wino_chunk_cap = 0;
+  wino_chunk_cap = 0; wino_v_cap = 0;
   d_w_dual.clear(); d_ep_dual.clear(); d_w3_dual.clear(); d_w2_dual.clear(); d_u3_dual.clear();
   f(d_head_conv); f(d_head_bn); f(d_Wp); f(d_bp); f(d_W1); f(d_b1); f(d_W2); f(d_b2);
   f(d_act_in); f(d_actA); f(d_actB); f(d_planes); f(d_policy); f(d_value); f(d_ws); f(d_hs);
@@ -714,7 +714,8 @@ int agz_net::build_wino_weights() {
 // the same Winograd-domain weights as two fp16 pieces (conv_wino_h2.hpp)
 int agz_net::build_wino_h2_weights() {
   AGZ_REQUIRE(cfg == 0, AGZ_E_UNSUPPORTED, "agz_net: the Winograd path needs K a multiple of 64");
-  AGZ_REQUIRE((size_t)36 * (Kp / 32) * 2 * (2 * Kp) * 64 < ((size_t)1 << 32), AGZ_E_UNSUPPORTED, "agz_net: K %d too wide for the Winograd weight image", conf.K);
+  wino_tm = agz::wino_h2_pick_tm(H, W);
+  AGZ_REQUIRE((size_t)(wino_tm + 2) * (wino_tm + 2) * (Kp / 32) * 2 * (2 * Kp) * 64 < ((size_t)1 << 32), AGZ_E_UNSUPPORTED, "agz_net: K %d too wide for the Winograd weight image", conf.K);
   AGZ_HIP_TRY(hipSetDevice(ctx->device));
   for (auto& p : d_u2_dual) if (p) hipFree(p);
   d_u2_dual.assign(conf.SharedLayers, nullptr);
@@ -726,11 +727,12 @@ int agz_net::build_wino_h2_weights() {
     const std::vector<float>& wa = params[pi].v;
     const std::vector<float>& wb = params[pi + 3].v;
     const int Kp_ = Kp;
-    u_unscale[l] = agz::wino_build_u2(u2, 2 * Kp, Kp, [&](int n, int ci, int tap) -> double {
+    auto getw = [&](int n, int ci, int tap) -> double {
       const int o = n < Kp_ ? n : n - Kp_;
       if (o >= K || ci >= K) return 0.0;
       return (double)(n < Kp_ ? wa : wb)[((size_t)o * K + ci) * 9 + tap];
-    });
+    };
+    u_unscale[l] = wino_tm == 5 ? agz::wino_build_u2<5>(u2, 2 * Kp, Kp, getw) : agz::wino_build_u2<4>(u2, 2 * Kp, Kp, getw);
     AGZ_HIP_TRY(hipMalloc(&d_u2_dual[l], u2.size() * 2));
     AGZ_HIP_TRY(hipMemcpyAsync(d_u2_dual[l], u2.data(), u2.size() * 2, hipMemcpyHostToDevice, ctx->stream));
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -836,7 +838,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         d_wV = d_wM = nullptr; wino_chunk_cap = 0;
         AGZ_HIP_TRY(hipMalloc(&d_wV, (size_t)36 * B * tpb * Kp * sizeof(float)));
         AGZ_HIP_TRY(hipMalloc(&d_wM, (size_t)36 * B * tpb * 2 * Kp * sizeof(float)));
-        wino_chunk_cap = B;
+        wino_chunk_cap = B; wino_v_cap = 0;
       }
       WinoArgs wa{};
       wa.V = d_wV; wa.Mb = d_wM;
@@ -865,19 +867,21 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     static const int pfa_env = [] { const char* e = getenv("AGZ_WINO_H2_PFA"); return e ? atoi(e) : -1; }();
     const bool wide = wide_env >= 0 ? wide_env != 0 : (2 * Kp) % 256 == 0;
     const int pfa = pfa_env >= 0 ? pfa_env : 2;
-    const int tpb = ceil_div(H, 4) * ceil_div(W, 4);
+    const int npos = (wino_tm + 2) * (wino_tm + 2);
+    const int tpb = ceil_div(H, wino_tm) * ceil_div(W, wino_tm);
     // Board chunks and queues (tuning knobs AGZ_WINO_H2_CHUNK = boards per chunk, AGZ_WINO_H2_STREAMS = 1 | 2): chunk i runs its
     // block chain on queue i % streams with that queue's scratch — chains of different boards are independent (per-board ranges),
     // so one chunk's HBM-bound transform kernels can overlap another chunk's GEMM, and a chunk whose V + M fit the 256 MB Infinity
     // Cache re-reads them from there.  Default: one chunk (bounded by the 32-bit V offsets), one queue.
     static const int chunk_env = [] { const char* e = getenv("AGZ_WINO_H2_CHUNK"); return e ? atoi(e) : 0; }();
     static const int streams_env = [] { const char* e = getenv("AGZ_WINO_H2_STREAMS"); return e ? atoi(e) : 1; }();
-    const int chunk_max = (int)std::min<size_t>((size_t)B, (((size_t)1 << 32) - 1) / ((size_t)36 * tpb * Kp * 4));
+    // 32-bit byte offsets into V: npos * (tiles rounded up to 128 + pad) * Kp * 4 < 2^32
+    const int chunk_max = (int)std::min<size_t>((size_t)B, ((((size_t)1 << 32) - 1) / ((size_t)npos * Kp * 4) - 127 - wino_h2_pos_pad()) / tpb);
     int chunk = chunk_env >= 1 ? std::min(chunk_env, chunk_max) : chunk_max;
     const int ns = (streams_env == 2 && B >= 64) ? 2 : 1;
     if (ns == 2 && chunk >= B) chunk = (B + 1) / 2;
-    const size_t v_elems = (size_t)36 * chunk * tpb * Kp, m_elems = (size_t)36 * chunk * tpb * 2 * Kp;
-    if (chunk * ns > wino_chunk_cap) {
+    const size_t v_elems = wino_h2_rows(npos, (size_t)chunk * tpb) * Kp, m_elems = 2 * v_elems;
+    if (v_elems * ns > wino_v_cap) {
       AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
       if (ctx->stream2) AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream2));
       if (d_wV) hipFree(d_wV);
@@ -885,10 +889,10 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       d_wV = d_wM = nullptr; wino_chunk_cap = 0;
       AGZ_HIP_TRY(hipMalloc(&d_wV, v_elems * ns * sizeof(float)));
       AGZ_HIP_TRY(hipMalloc(&d_wM, m_elems * ns * sizeof(float)));
-      wino_chunk_cap = chunk * ns;
+      wino_v_cap = v_elems * ns; wino_chunk_cap = 0;   // (the fp32-V Winograd path sizes by boards: force its re-allocation)
     }
     // per-board ranges [blocks+1][B], then the per-wave maxima of the output kernel [queues][chunk tiles][Kp/64] (as floats)
-    const size_t wm_elems = (size_t)chunk * tpb * (Kp >> 6);
+    const size_t wm_elems = (size_t)chunk * tpb * (Kp >> 5);   // (sized for the pair form of the output kernel: one word per 32 channels)
     const size_t need_amax = (size_t)(conf.SharedLayers + 1) * B + wm_elems * ns;
     if (need_amax > amax_cap) {
       AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -919,7 +923,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         wa.x = cur + (size_t)b0 * Hp * Wp * Kp; wa.y = nxt + (size_t)b0 * Hp * Wp * Kp;
         wa.V = d_wV + (size_t)q * v_elems; wa.Mb = d_wM + (size_t)q * m_elems; wa.ep = d_ep_dual[l];
         wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
-        hh.U2 = d_u2_dual[l]; hh.w_unscale = u_unscale[l];
+        hh.U2 = d_u2_dual[l]; hh.w_unscale = u_unscale[l]; hh.tm = wino_tm;
         hh.amax_in = d_amax + (size_t)l * B + b0; hh.amax_out = d_amax + (size_t)(l + 1) * B + b0;
         hh.wave_max = d_wave_max + (size_t)q * wm_elems;
         wino_h2_launch(ctx, hh, wide, pfa, q ? ctx->stream2 : ctx->stream);
@@ -965,7 +969,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         d_wV = d_wM = nullptr; wino_chunk_cap = 0;
         AGZ_HIP_TRY(hipMalloc(&d_wV, (size_t)36 * chunk * tpb * Kp * sizeof(float)));
         AGZ_HIP_TRY(hipMalloc(&d_wM, (size_t)36 * chunk * tpb * 2 * Kp * sizeof(float)));
-        wino_chunk_cap = chunk;
+        wino_chunk_cap = chunk; wino_v_cap = 0;
       }
       ProfScope ps(ctx, AGZ_PROF_CONV);
       for (int b0 = 0; b0 < B; b0 += chunk) {
@@ -1329,6 +1333,8 @@ int agz_net_commit(agz_net* n) {
   if (n->compute_mode == AGZ_COMPUTE_WINO_H2 && n->cfg == 0) return n->build_wino_h2_weights();
   return AGZ_OK;
 }
+
+int agz_wino_h2_tile(int H, int W) { return agz::wino_h2_pick_tm(H, W); }
 
 int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, int W, int C, int N, float* V, float* M) {
   AGZ_REQUIRE(ctx && x && w && V && M, AGZ_E_INVALID, "agz_wino_stages: NULL argument");

@@ -135,9 +135,9 @@ def games_leg(ctx, compute="bf16x3"):
     return out
 
 
-def go9_leg(ctx, compute="bf16x3"):
+def go9_leg(ctx, compute="wino_h2"):
     """Measured games/s on BASELINE config #3: 9x9 Go (wq), K=128, 10 blocks, 512 concurrent games, 400 sims/move,
-    continuous self-play until 512 complete games have finished (bf16x3: the measured-fastest arithmetic on this shape)."""
+    continuous self-play until 512 complete games have finished (wino_h2 with F(5x5,3x3): 4 tiles x 49 positions per board, measured 15 % less time per 512-board pass than bf16x3 on this shape)."""
     K, L, G, sims = 128, 10, 512, 400
     net = A.Net(ctx, K, L, 2 * K, 9, 9, 18, 82, bn_mode=capi.BN_IDENTITY)
     net.init_random(1337)
@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--no-games-leg", action="store_true", help="skip the measured games/s leg (config #2)")
     ap.add_argument("--two-nets", action="store_true", help="agents A and B hold different networks")
     ap.add_argument("--compute", choices=["wino_h2", "wino", "bf16x3", "f32", "fp16x2"], default="wino_h2",
-                    help="dual-block conv arithmetic: wino_h2 = Winograd F(4x4,3x3), fp32 transforms, the transform-domain operand "
+                    help="dual-block conv arithmetic: wino_h2 = Winograd F(5x5,3x3) (F(4x4,3x3) where that needs fewer rows), fp32 transforms, the transform-domain operand "
                          "written pre-split into two fp16 pieces (per-board power-of-two range from a proven bound), 3 fp16 MFMAs per "
                          "product; wino = the same with bf16x3 products (6 MFMAs per product); bf16x3 = direct conv, exact "
                          "3-way bf16 split on the bf16 matrix pipe (fp32-grade), f32 = v_mfma_f32_32x32x2_f32, fp16x2 = "
@@ -414,26 +414,31 @@ def main():
                  "wino_h2": FP16X2_PEAK_TFLOPS}
         peak = peaks[args.compute]
         wino_detail = None
+        wtm = capi.wino_h2_tile(S, S) if args.compute == "wino_h2" else 4   # Winograd tile size of the mode (F(m x m, 3x3))
+        npos = (wtm + 2) ** 2
         flops_launch, launch_ms, n_launch = conv_flops_launch, conv_ms, prof["conv_dual"]["launches"]
         if dom_name == "conv_dual" and prof["conv_dual_timed_region"]["avg_ms"]:   # direct modes: the block kernel itself, timed in the region
             launch_ms, n_launch = prof["conv_dual_timed_region"]["avg_ms"], prof["conv_dual_timed_region"]["launches"]
             achieved = flops_launch / (launch_ms * 1e-3) / 1e12
         if args.compute in ("wino", "wino_h2") and prof["wino_gemm"]["avg_ms"]:
-            # dominant kernel of this mode: the 36 transform-domain GEMMs of one block (its own FLOPs, not the direct conv's)
-            tiles = G * ((S + 3) // 4) ** 2
-            flops_launch = 2.0 * 36 * tiles * K * (2 * K)
+            # dominant kernel of this mode: the transform-domain GEMMs of one block (its own FLOPs, not the direct conv's).
+            # F(m x m, 3x3): npos = (m + 2)^2 positions, ceil(S/m)^2 tiles per board; wino = m 4, wino_h2 = agz_wino_h2_tile (5 on 19x19)
+            tiles = G * ((S + wtm - 1) // wtm) ** 2
+            flops_launch = 2.0 * npos * tiles * K * (2 * K)
             launch_ms, n_launch = prof["wino_gemm_timed_region"]["avg_ms"], prof["wino_gemm_timed_region"]["launches"]
             achieved = flops_launch / (launch_ms * 1e-3) / 1e12
-            in_bytes = 4.0 * (G * hw * K + 36 * tiles * K)            # x read once + V written
-            w_bytes = 36.0 * K * (2 * K) * (4 if args.compute == "wino_h2" else 6)   # the block's Winograd-domain weight image, read once
-            gemm_bytes = 4.0 * (36 * tiles * K + 36 * tiles * 2 * K) + w_bytes  # V read once + M written once + weights
-            out_bytes = 4.0 * (36 * tiles * 2 * K + G * hw * K)       # M read + y written
+            in_bytes = 4.0 * (G * hw * K + npos * tiles * K)            # x read once + V written
+            w_bytes = float(npos) * K * (2 * K) * (4 if args.compute == "wino_h2" else 6)   # the block's Winograd-domain weight image, read once
+            gemm_bytes = 4.0 * (npos * tiles * K + npos * tiles * 2 * K) + w_bytes  # V read once + M written once + weights
+            out_bytes = 4.0 * (npos * tiles * 2 * K + G * hw * K)       # M read + y written
             def gbs(b, ms):
                 return (b / (ms * 1e-3) / 1e9) if ms else None
             wino_detail = {
                 "block_avg_ms": conv_ms, "block_direct_equivalent_tflops": conv_flops_launch / (conv_ms * 1e-3) / 1e12 if conv_ms else None,
-                "block_note": "one dual block = input transform + 36 GEMMs + output transform/epilogue; direct-equivalent = the "
-                              "FLOPs a direct 3x3 convolution would need for the same result (3.61x the GEMM FLOPs on 19x19)",
+                "tile": wtm, "positions": npos, "tiles_per_launch": tiles,
+                "block_note": "one dual block = input transform + %d GEMMs + output transform/epilogue; direct-equivalent = the "
+                              "FLOPs a direct 3x3 convolution would need for the same result (%.2fx the GEMM FLOPs here)"
+                              % (npos, conv_flops_launch / flops_launch),
                 "wino_in": {"avg_ms": prof["wino_in"]["avg_ms"], "bound": "hbm", "algorithmic_bytes": in_bytes,
                             "achieved_GBs": gbs(in_bytes, prof["wino_in"]["avg_ms"]), "peak_GBs": HBM_PEAK_GBS},
                 "wino_gemm": {"avg_ms": launch_ms, "bound": "hbm" if args.compute == "wino_h2" else "mfma", "flops": flops_launch,
@@ -456,7 +461,7 @@ def main():
             if leg.get("conv_dual_avg_ms"):
                 leg["conv_dual_tflops"] = conv_flops_launch / (leg["conv_dual_avg_ms"] * 1e-3) / 1e12
                 if mode in ("wino", "wino_h2"):
-                    leg["note"] = "direct-equivalent FLOPs per block time (the mode executes 3.61x fewer)"
+                    leg["note"] = "direct-equivalent FLOPs per block time (the Winograd modes execute 3.6-4.1x fewer)"
                 else:
                     leg["frac_of_its_roofline"] = leg["conv_dual_tflops"] / peaks[mode]
                     leg["roofline_peak_tflops"] = peaks[mode]
@@ -464,12 +469,12 @@ def main():
                   "bf16x3": "f32 (bf16x3 split: each fp32 operand = 3 exact bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate)",
                   "fp16x2": "f32 (fp16x2 split: power-of-two range scaling, 2 fp16 pieces = 23 significand bits, 3 fp16 MFMAs per product, fp32 accumulate)",
                   "wino": "f32 (Winograd F(4x4,3x3): fp32 transforms; transform-domain products as bf16x3 = 3 exact bf16 pieces per fp32 operand, 6 bf16 MFMAs per product, fp32 accumulate)",
-                  "wino_h2": "f32 (Winograd F(4x4,3x3): fp32 transforms; transform-domain products as fp16x2 = each fp32 operand scaled by a power of two and split into 2 fp16 pieces (22-23 significand bits, absolute error <= 2^-38 of the tensor range), 3 fp16 MFMAs per product, fp32 accumulate)"}
+                  "wino_h2": "f32 (Winograd F(%dx%d,3x3): fp32 transforms; transform-domain products as fp16x2 = each fp32 operand scaled by a power of two and split into 2 fp16 pieces (22-23 significand bits, absolute error <= 2^-38 of the tensor range), 3 fp16 MFMAs per product, fp32 accumulate)" % (wtm, wtm)}
         kernels = {"f32": "conv3x3_mfma_kernel<2,2,2,DUAL> (fused dual-branch block)",
                    "bf16x3": "conv3x3_x3_kernel<DUAL> (fused dual-branch block, bf16x3)",
                    "fp16x2": "conv3x3_h2w_kernel (fused dual-branch block, fp16x2, 128x256 tile)",
                    "wino": "wino_gemm_kernel (36 transform-domain GEMMs of one dual block, bf16x3 products; 0.70 of the block's 1.09 ms)",
-                   "wino_h2": "wino_gemm_h2d_kernel<8,2,2> (36 transform-domain GEMMs of one dual block, fp16x2 products, 128x256 tile, A operand fetched two steps ahead; the largest of the block's three kernels)"}
+                   "wino_h2": "wino_gemm_h2d_kernel<8,2,2> (the %d transform-domain GEMMs of one dual block, F(%dx%d,3x3), fp16x2 products, 128x256 tile, A operand fetched two steps ahead; the largest of the block's three kernels)" % (npos, wtm, wtm)}
         notes = {"f32": "dense fp32 MFMA peak",
                  "bf16x3": ("algorithmic fp32-grade FLOPs against the dense bf16 MFMA peak / 6 (six bf16 MFMAs per product); the same "
                             "FLOPs are %.2fx the fp32-MFMA peak of 157.3; measured bare-MFMA ceiling under the power cap on random "
@@ -479,10 +484,12 @@ def main():
                  "wino": ("FLOPs of the transform-domain GEMMs (what this formulation executes) against the dense bf16 MFMA peak / 6; "
                           "the block as a whole delivers the direct convolution's result at extra.wino.block_direct_equivalent_tflops "
                           "(DESIGN.md 4d); the two transform kernels are HBM-bound, see extra.wino"),
-                 "wino_h2": ("with 3 fp16 MFMAs per product the GEMMs' arithmetic intensity (3 x 120.8 GFLOP of MFMA work over 1.44 GB = 252 FLOP/B) "
+                 "wino_h2": ("with 3 fp16 MFMAs per product the GEMMs' arithmetic intensity (3 x %.1f GFLOP of MFMA work over %.2f GB = %.0f FLOP/B) "
                              "sits BELOW the ridge (2516.6 TFLOP/s / 8 TB/s = 315 FLOP/B): the kernel's roofline is the HBM roof. achieved = "
                              "algorithmic bytes (V read once + M written once + the block's weights) / launch time; the MFMA-side fraction "
-                             "(transform-domain FLOPs against bf16 peak / 3) is extra.wino.wino_gemm.mfma_frac (DESIGN.md 4e)")}
+                             "(transform-domain FLOPs against bf16 peak / 3) is extra.wino.wino_gemm.mfma_frac (DESIGN.md 4e)"
+                             % ((flops_launch / 1e9, wino_detail["wino_gemm"]["algorithmic_bytes"] / 1e9,
+                                 3 * flops_launch / wino_detail["wino_gemm"]["algorithmic_bytes"]) if wino_detail else (0, 0, 0)))}
         out = {
             "metric": "mcts_sims_per_sec", "value": sims_sum / t_max, "unit": "sims/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,

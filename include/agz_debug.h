@@ -33,6 +33,10 @@ int agz_ctx_prof_read(agz_ctx* ctx, int klass, int64_t* launches, double* total_
  * T = B * ceil(H/4) * ceil(W/4) tiles in (board, tile row, tile column) order, pos = 6 * xi + nu. */
 int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, int W, int C, int N, float* V, float* M);
 
+/* Measurement: the Winograd tile size m (F(m x m, 3x3), m = 4 or 5) AGZ_COMPUTE_WINO_H2 uses on an H x W board — the one with
+ * the fewest transform-domain rows, (m + 2)^2 * ceil(H/m) * ceil(W/m); bench.py prices the kernels' algorithmic bytes with it. */
+int agz_wino_h2_tile(int H, int W);
+
 #ifdef __cplusplus
 }
 #endif

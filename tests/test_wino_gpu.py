@@ -166,3 +166,58 @@ np.save(sys.argv[1], np.concatenate([pol.ravel(), val.ravel()]))
         subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env=env, timeout=120)
         outs.append(np.load(path))
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+H2_KNOBS = [
+    {"AGZ_WINO_H2_TM": "4"},                                       # F(4x4,3x3) on boards where F(5x5,3x3) is the default
+    {"AGZ_WINO_H2_TM": "5", "AGZ_WINO_H2_OUT_PAIR": "0"},          # F(5x5,3x3) with the one-thread-per-channel output transform
+    {"AGZ_WINO_H2_TM": "4", "AGZ_WINO_H2_OUT_PAIR": "1"},          # F(4x4,3x3) with the lane-pair output transform
+    {"AGZ_WINO_H2_LAYOUT": "plain", "AGZ_WINO_H2_PAD": "9"},       # [position][tile] layout of V and M, padded
+    {"AGZ_WINO_H2_CHUNK": "16"},                                   # board chunks
+    {"AGZ_WINO_H2_CHUNK": "16", "AGZ_WINO_H2_STREAMS": "2"},       # board chunks on two queues
+    {"AGZ_WINO_H2_WIDE": "0", "AGZ_WINO_H2_PFA": "0"},             # 128x128 GEMM tile, no operand prefetch
+]
+
+
+@pytest.mark.parametrize("knobs", H2_KNOBS, ids=lambda k: ",".join("%s=%s" % (a[12:], b) for a, b in k.items()))
+def test_wino_h2_tuning_knobs_in_a_subprocess(knobs):
+    """The AGZ_WINO_H2_* tuning knobs (read once per process) select other tile sizes, layouts and schedules of the same
+    arithmetic: every one of them stays inside the network tolerance against the fp32-MFMA path, and the ones that only move
+    data (layout, chunks, queues, GEMM tile) reproduce the default bit for bit."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, os, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import agogo_amd as A
+from test_net_gpu import make_pair, rand_planes
+ctx = A.Ctx(0)
+out = []
+for (K, L, S, B) in ((256, 2, 19, 70), (64, 2, 9, 37)):
+    onet, gnet = make_pair(ctx, K, L, 32, S, S, 18, S * S + 1, 2)
+    x = rand_planes(B, 18, S, S, seed=11)
+    pf, vf = gnet.infer(x)
+    gnet.set_compute_mode(A.capi.COMPUTE_WINO_H2 | A.capi.COMPUTE_FORCE)
+    pol, val = gnet.infer(x)
+    out += [pf.ravel(), vf.ravel(), pol.ravel(), val.ravel()]
+np.save(sys.argv[1], np.concatenate(out))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    base = {k: v for k, v in os.environ.items() if not k.startswith("AGZ_WINO_H2_")}
+    for tag, env in (("default", base), ("knob", dict(base, **knobs))):
+        path = os.path.join(root, "gpurun_out", "wino_h2_%s.npy" % tag)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env=env, timeout=180)
+        outs.append(np.load(path))
+    n = 0
+    for (S, B) in ((19, 70), (9, 37)):
+        A_ = S * S + 1
+        pf = outs[1][n:n + B * A_]; vf = outs[1][n + B * A_:n + B * A_ + B]
+        pg = outs[1][n + B * A_ + B:n + 2 * B * A_ + B]; vg = outs[1][n + 2 * B * A_ + B:n + 2 * B * A_ + 2 * B]
+        np.testing.assert_allclose(pg, pf, atol=POL_ATOL, rtol=POL_RTOL)
+        np.testing.assert_allclose(vg, vf, atol=VAL_ATOL)
+        n += 2 * B * A_ + 2 * B
+    if "AGZ_WINO_H2_TM" not in knobs:      # same arithmetic in the same order: only the data movement differs
+        np.testing.assert_array_equal(outs[0], outs[1])
