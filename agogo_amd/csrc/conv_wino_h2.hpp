@@ -70,6 +70,7 @@ template <> __device__ __forceinline__ void wino_atv<5>(const float* m, float* o
   o[4] = s12 + 0.0625f * s34 + 16.f * m[5] + m[6];
 }
 
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 struct WinoH2Args;
 __device__ __forceinline__ size_t h2_row(const WinoH2Args& h, int pos, int t);
 struct WinoH2Args {
@@ -80,6 +81,7 @@ struct WinoH2Args {
   // within npos * 128 rows, so the transform kernels' (tm+2)^2 streams stay inside a few pages.  Plain layout: [npos][T + pad].
   int rsh, rmask;
   unsigned rA, rB;
+  int swap_st;               // GEMM stores through v_permlane32_swap (256-byte runs); tuning knob AGZ_WINO_H2_SWAPST, default off (measured: no effect)
   const _Float16* U2;        // [36][C/32][2][Ntot][32]
   const unsigned* amax_in;   // [B] max |x| of every board of this block's input (float bits)
   unsigned* amax_out;        // [B] max of this block's output (wino_board_max_kernel over wave_max)
@@ -541,7 +543,26 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2d_kernel(WinoH2Args h) {
 
   const bool full = m0 + 128 <= a.T && n0 + BN <= a.Ntot;   // uniform
   float* dst0 = a.Mb + h2_row(h, pos, m0 + wm * 64 + 4 * (lane >> 5)) * a.Ntot + n0 + wn * (64 * NT) + (lane & 31);
-  if (full) {
+  if (full && h.swap_st) {
+    // The 32x32 accumulator layout puts rows m and m + 4 in the two halves of a wave, so a plain store moves two 128-byte runs.
+    // v_permlane32_swap of the accumulators of two neighbouring 32-column groups gives each of the two registers ONE row over
+    // 64 columns: every store is one 256-byte run.
+    float* dsts = a.Mb + h2_row(h, pos, m0 + wm * 64) * a.Ntot + n0 + wn * (64 * NT) + lane;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float* dA = dsts + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.Ntot;
+        float* dB = dA + (size_t)4 * a.Ntot;
+#pragma unroll
+        for (int j = 0; j + 1 < NJ; j += 2) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][r]), __float_as_uint(acc[i][j + 1][r]), false, false);
+          const unsigned s0 = sw[0], s1 = sw[1];   // (elements copied to scalars: see the note at h2_ldf2)
+          dA[j * 32] = __uint_as_float(s0);
+          dB[j * 32] = __uint_as_float(s1);
+        }
+      }
+  } else if (full) {
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -721,6 +742,253 @@ __global__ __launch_bounds__(256) void wino_out_pair_h2_kernel(WinoH2Args h) {
   }
 }
 
+// The output transform, block-per-tile form.  Measured on the kernels above (ISA count + timing with the arithmetic or the
+// parameter loads removed): they are bound by VALU ISSUE, not by HBM — ~1100 vector instructions per thread of which ~600 are
+// 64-bit address arithmetic (quarter-rate v_mul_lo_u32 / v_mad_u64_u32 for every one of the 74 loads), against ~300 of transform
+// arithmetic.  Here one 128-thread block owns ONE tile (64 channels x 2 branches, lanes (2i, 2i+1) = branches a, b of channel i):
+// tile, board, pixel and position are block-uniform, so every address is a scalar base (SALU) plus one per-lane 32-bit offset,
+// and the 1-D transforms run two columns / two rows at a time on the packed-fp32 pipe (v_pk_fma_f32).  Grid: x = tile, y = 64-channel group.
+typedef float f2v __attribute__((ext_vector_type(2)));
+// Buffer addressing for the block-per-tile transform kernels: a scalar descriptor over a block-uniform base, one per-lane 32-bit
+// byte offset and a scalar byte offset per access (position / pixel) — no vector address arithmetic at all.  (Plain pointer
+// arithmetic does not get there: the compiler re-associates base + lane offset first and then adds every position's offset
+// with a 64-bit v_mad_u64_u32 per load.)  Raw buffer, range check on the lane offset only.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t h2_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float h2_ldf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+// 8-byte load.  NOTE: `__builtin_bit_cast(T, vec[i])` applied directly to a vector ELEMENT expression reads element 0 with
+// this compiler (seen in the ISA: a b64 load narrowed to one dword, both halves of a permlane swap storing the same register);
+// elements are copied to scalars first.
+__device__ __forceinline__ float2 h2_ldf2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  const unsigned x = v[0], y = v[1];
+  return make_float2(__uint_as_float(x), __uint_as_float(y));
+}
+template <typename T> __device__ __forceinline__ T h2_ldg(const void* sbase, unsigned voff_bytes) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(sbase) + voff_bytes);
+}
+__device__ __forceinline__ void h2_stf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+template <int TM, typename V> __device__ __forceinline__ void wino_atv_t(const V* m, V* o);
+template <> __device__ __forceinline__ void wino_atv_t<4, float>(const float* m, float* o) { wino_at4(m, o); }
+template <> __device__ __forceinline__ void wino_atv_t<5, float>(const float* m, float* o) { wino_atv<5>(m, o); }
+template <> __device__ __forceinline__ void wino_atv_t<4, f2v>(const f2v* m, f2v* o) {
+  const f2v s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = m[0] + s12 + s34;
+  o[1] = d12 + 2.f * d34;
+  o[2] = s12 + 4.f * s34;
+  o[3] = d12 + 8.f * d34 + m[5];
+}
+template <> __device__ __forceinline__ void wino_atv_t<5, f2v>(const f2v* m, f2v* o) {
+  const f2v s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = m[0] + s12 + s34 + m[5];
+  o[1] = d12 + 0.5f * d34 + 2.f * m[5];
+  o[2] = s12 + 0.25f * s34 + 4.f * m[5];
+  o[3] = d12 + 0.125f * d34 + 8.f * m[5];
+  o[4] = s12 + 0.0625f * s34 + 16.f * m[5] + m[6];
+}
+
+template <int TM>
+__global__ __launch_bounds__(128) void wino_out_tile_h2_kernel(WinoH2Args h) {
+  using WT = WinoT<TM>;
+  constexpr int AL = WT::AL;
+  const WinoArgs& a = h.w;
+  const int t = blockIdx.x, cg = blockIdx.y;                       // uniform
+  const int tid = threadIdx.x, br = tid & 1, cl = tid >> 1;
+  const int b = t / a.TPB, tt = t - b * a.TPB;
+  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
+  float s_, unscale;
+  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &unscale);
+  unscale *= h.w_unscale;
+  // {scale, shift} of this lane's branch: float2 index (pixel * Cout_p + c) * 2 + br = pixel * 2 Cout_p + cg * 128 + tid
+  const float2* ep2 = reinterpret_cast<const float2*>(a.ep) + (size_t)cg * 128;
+  const unsigned e_lane = (unsigned)tid * 8u;
+  float2 E[TM][TM];
+#pragma unroll
+  for (int k = 0; k < TM; k++) {
+    const int hh = TM * ty + k, hc = hh < a.H ? hh : a.H - 1;
+#pragma unroll
+    for (int l = 0; l < TM; l++) {
+      const int ww = TM * tx + l, wc = ww < a.W ? ww : a.W - 1;
+      E[k][l] = h2_ldg<float2>(ep2 + (size_t)(hc * a.W + wc) * (2 * a.Cout_p), e_lane);
+    }
+  }
+  // M: base = this tile's row at position 0 (+ the channel group); position p adds p * rB rows (the launch checks 32 bits suffice)
+  const __amdgpu_buffer_rsrc_t mr = h2_rsrc(a.Mb + ((size_t)(t >> h.rsh) * h.rA + (size_t)(t & h.rmask)) * a.Ntot + cg * 64);
+  const unsigned pos_stride = h.rB * (unsigned)a.Ntot * 4u;        // bytes, uniform
+  const unsigned lane_off = (unsigned)(br * a.Cout_p + cl) * 4u;   // bytes
+  float tm_[TM][AL];
+#pragma unroll
+  for (int nu = 0; nu + 1 < AL; nu += 2) {       // two columns at a time
+    f2v m[AL], o[TM];
+#pragma unroll
+    for (int xi = 0; xi < AL; xi++) {
+      m[xi].x = h2_ldf(mr, lane_off, (unsigned)(xi * AL + nu) * pos_stride);
+      m[xi].y = h2_ldf(mr, lane_off, (unsigned)(xi * AL + nu + 1) * pos_stride);
+    }
+    wino_atv_t<TM, f2v>(m, o);
+#pragma unroll
+    for (int k = 0; k < TM; k++) { tm_[k][nu] = o[k].x; tm_[k][nu + 1] = o[k].y; }
+  }
+  if (AL & 1) {
+    constexpr int nu = AL - 1;
+    float m[AL], o[TM];
+#pragma unroll
+    for (int xi = 0; xi < AL; xi++) m[xi] = h2_ldf(mr, lane_off, (unsigned)(xi * AL + nu) * pos_stride);
+    wino_atv_t<TM, float>(m, o);
+#pragma unroll
+    for (int k = 0; k < TM; k++) tm_[k][nu] = o[k];
+  }
+  float Y[TM][TM];
+#pragma unroll
+  for (int k = 0; k + 1 < TM; k += 2) {          // two rows at a time
+    f2v r[AL], o[TM];
+#pragma unroll
+    for (int nu = 0; nu < AL; nu++) { r[nu].x = tm_[k][nu]; r[nu].y = tm_[k + 1][nu]; }
+    wino_atv_t<TM, f2v>(r, o);
+#pragma unroll
+    for (int l = 0; l < TM; l++) { Y[k][l] = o[l].x; Y[k + 1][l] = o[l].y; }
+  }
+  if (TM & 1) wino_atv_t<TM, float>(tm_[TM - 1], Y[TM - 1]);
+  const __amdgpu_buffer_rsrc_t yr = h2_rsrc(a.y + (size_t)b * a.Hp * a.Wp * a.Cout_p + cg * 64);   // this board, this channel group
+  const unsigned y_lane = (unsigned)cl * 4u, y_pix = (unsigned)a.Cout_p * 4u;
+  float mx = 0.f;
+#pragma unroll
+  for (int k = 0; k < TM; k++) {
+    const int hh = TM * ty + k;
+#pragma unroll
+    for (int l = 0; l < TM; l++) {
+      float v = (Y[k][l] * unscale) * E[k][l].x + E[k][l].y;
+      v = v > 0.f ? v : 0.f;
+      // relu(relu(a) + relu(b)): both operands are finite-or-inf and non-negative, so the sum is already >= 0
+      // the partner lane's value: quad_perm [1,0,3,2] on the DPP path (no LDS crossbar)
+      const float sum = v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+      const int ww = TM * tx + l;
+      if (hh < a.H && ww < a.W) {                                   // uniform
+        if (((k * TM + l) & 1) == br) {                             // the two lanes of a pair share the pixels
+          h2_stf(yr, y_lane, (unsigned)((hh + 1) * a.Wp + (ww + 1)) * y_pix, sum);
+          mx = fmaxf(mx, sum);
+        }
+      }
+    }
+  }
+  if (h.wave_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) h.wave_max[(size_t)t * (a.Cout_p >> 5) + cg * 2 + (tid >> 6)] = mx;
+  }
+}
+
+// Block-per-tile form with one thread per channel and the two branches one after the other: a wave's 64 lanes are 64 consecutive
+// channels, so every M load and every y store of a wave is one 256-byte run (the lane-pair forms above move two 128-byte runs per
+// instruction and measured slower per byte: the memory pipeline tracks requests per instruction), and finishing branch a before
+// branch b's loads are issued keeps the live set at ~49 + 50 + 25 values.  The asm barrier keeps the compiler from hoisting
+// branch b's loads to the top (which is what made the thread-per-channel kernel above need 256 registers).
+template <int TM>
+__global__ __launch_bounds__(256) void wino_out_seq_h2_kernel(WinoH2Args h) {
+  using WT = WinoT<TM>;
+  constexpr int AL = WT::AL;
+  const WinoArgs& a = h.w;
+  const int t = blockIdx.x;                                        // uniform: one tile per block
+  const int tid = threadIdx.x, c = blockIdx.y * blockDim.x + tid;  // this lane's channel
+  const int b = t / a.TPB, tt = t - b * a.TPB;
+  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
+  float s_, unscale;
+  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &unscale);
+  unscale *= h.w_unscale;
+  const __amdgpu_buffer_rsrc_t mr = h2_rsrc(a.Mb + ((size_t)(t >> h.rsh) * h.rA + (size_t)(t & h.rmask)) * a.Ntot);
+  const unsigned pos_stride = h.rB * (unsigned)a.Ntot * 4u;        // bytes, uniform
+  const __amdgpu_buffer_rsrc_t er = h2_rsrc(a.ep);                 // float2 index (pixel * Cout_p + c) * 2 + branch
+  const unsigned e_pix = (unsigned)a.Cout_p * 16u;                 // bytes per pixel
+  float va[TM][TM];
+#pragma unroll
+  for (int br = 0; br < 2; br++) {
+    const unsigned lane_off = (unsigned)(br * a.Cout_p + c) * 4u;
+    const unsigned e_lane = (unsigned)(c * 2 + br) * 8u;
+    float tm_[TM][AL];
+#pragma unroll
+    for (int nu = 0; nu + 1 < AL; nu += 2) {       // two columns at a time on the packed-fp32 pipe
+      f2v m[AL], o[TM];
+#pragma unroll
+      for (int xi = 0; xi < AL; xi++) {
+        m[xi].x = h2_ldf(mr, lane_off, (unsigned)(xi * AL + nu) * pos_stride);
+        m[xi].y = h2_ldf(mr, lane_off, (unsigned)(xi * AL + nu + 1) * pos_stride);
+      }
+      wino_atv_t<TM, f2v>(m, o);
+#pragma unroll
+      for (int k = 0; k < TM; k++) { tm_[k][nu] = o[k].x; tm_[k][nu + 1] = o[k].y; }
+    }
+    if (AL & 1) {
+      constexpr int nu = AL - 1;
+      float m[AL], o[TM];
+#pragma unroll
+      for (int xi = 0; xi < AL; xi++) m[xi] = h2_ldf(mr, lane_off, (unsigned)(xi * AL + nu) * pos_stride);
+      wino_atv_t<TM, float>(m, o);
+#pragma unroll
+      for (int k = 0; k < TM; k++) tm_[k][nu] = o[k];
+    }
+    float2 E[TM][TM];
+#pragma unroll
+    for (int k = 0; k < TM; k++) {
+      const int hh = TM * ty + k, hc = hh < a.H ? hh : a.H - 1;
+#pragma unroll
+      for (int l = 0; l < TM; l++) {
+        const int ww = TM * tx + l, wc = ww < a.W ? ww : a.W - 1;
+        E[k][l] = h2_ldf2(er, e_lane, (unsigned)(hc * a.W + wc) * e_pix);
+      }
+    }
+    float Y[TM][TM];
+#pragma unroll
+    for (int k = 0; k + 1 < TM; k += 2) {          // two rows at a time
+      f2v r[AL], o[TM];
+#pragma unroll
+      for (int nu = 0; nu < AL; nu++) { r[nu].x = tm_[k][nu]; r[nu].y = tm_[k + 1][nu]; }
+      wino_atv_t<TM, f2v>(r, o);
+#pragma unroll
+      for (int l = 0; l < TM; l++) { Y[k][l] = o[l].x; Y[k + 1][l] = o[l].y; }
+    }
+    if (TM & 1) wino_atv_t<TM, float>(tm_[TM - 1], Y[TM - 1]);
+#pragma unroll
+    for (int k = 0; k < TM; k++)
+#pragma unroll
+      for (int l = 0; l < TM; l++) {
+        float v = (Y[k][l] * unscale) * E[k][l].x + E[k][l].y;
+        v = v > 0.f ? v : 0.f;
+        va[k][l] = br == 0 ? v : va[k][l] + v;      // relu(a) + relu(b) >= 0 already
+      }
+    if (br == 0) {   // branch a's results exist before any of branch b's loads is issued (values through an ordered empty asm)
+#pragma unroll
+      for (int k = 0; k < TM; k++)
+#pragma unroll
+        for (int l = 0; l < TM; l++) asm volatile("" : "+v"(va[k][l]) : : "memory");
+    }
+  }
+  const __amdgpu_buffer_rsrc_t yr = h2_rsrc(a.y + (size_t)b * a.Hp * a.Wp * a.Cout_p);
+  const unsigned y_lane = (unsigned)c * 4u, y_pix = (unsigned)a.Cout_p * 4u;
+  float mx = 0.f;
+#pragma unroll
+  for (int k = 0; k < TM; k++) {
+    const int hh = TM * ty + k;
+#pragma unroll
+    for (int l = 0; l < TM; l++) {
+      const int ww = TM * tx + l;
+      if (hh < a.H && ww < a.W) {                   // uniform
+        h2_stf(yr, y_lane, (unsigned)((hh + 1) * a.Wp + (ww + 1)) * y_pix, va[k][l]);
+        mx = fmaxf(mx, va[k][l]);
+      }
+    }
+  }
+  if (h.wave_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) h.wave_max[(size_t)t * (a.Cout_p >> 6) + (c >> 6)] = mx;
+  }
+}
+
 // amax_out[b] = max over the board's tiles and channel groups of wave_max (one wave per board)
 __global__ __launch_bounds__(64) void wino_board_max_kernel(const float* __restrict__ wave_max, unsigned* __restrict__ amax_out, int per_board) {
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -801,6 +1069,8 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
   if (wino_h2_blocked()) { h.rsh = 7; h.rmask = 127; h.rA = (unsigned)h.npos * 128u; h.rB = 128u; }
   else { h.rsh = 31; h.rmask = 0x7fffffff; h.rA = 0; h.rB = (unsigned)(a.T + wino_h2_pos_pad()); }
   a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
+  static const int swap_env = [] { const char* e = getenv("AGZ_WINO_H2_SWAPST"); return e ? atoi(e) : 0; }();
+  h.swap_st = swap_env;
   {
     ProfScopeOn ps(ctx, AGZ_PROF_WINO_IN, st == ctx->stream);
     const size_t n_in = (size_t)a.T * (a.C / 2);
@@ -835,9 +1105,25 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
   {
     ProfScopeOn ps(ctx, AGZ_PROF_WINO_OUT, st == ctx->stream);
     const size_t n_out = (size_t)a.T * a.Cout_p;
-    static const int pair_env = [] { const char* e = getenv("AGZ_WINO_H2_OUT_PAIR"); return e ? atoi(e) : -1; }();   // tuning knob
-    const bool pair = pair_env >= 0 ? pair_env != 0 : tm == 5;
-    if (pair) {
+    // Forms of the output transform (tuning knob AGZ_WINO_H2_OUT_PAIR): 0 = thread per channel, both branches at once;
+    // 1 = lane pair per channel; 2 = block per tile, lane pair; 3 = block per tile, thread per channel, branch after branch.
+    // Default: 3 for F(5x5,3x3) (0.237 ms against 0.30 / 0.28 / 0.27 for forms 0 / 1 / 2 on the headline block),
+    // 0 for F(4x4,3x3) (0.231 against 0.255 for form 3).
+    static const int form_env = [] { const char* e = getenv("AGZ_WINO_H2_OUT_PAIR"); return e ? atoi(e) : -1; }();
+    const bool fits32 = (size_t)h.npos * h.rB * a.Ntot * 4 < ((size_t)1 << 32);   // scalar position offsets of the tile forms
+    int form = form_env >= 0 && form_env <= 3 ? form_env : (tm == 5 ? 3 : 0);
+    if (form >= 2 && !fits32) form = form == 3 ? 0 : 1;
+    const bool pair = form == 1 || form == 2;            // wave_max holds one word per 32 channels (else per 64)
+    if (form == 3) {
+      const unsigned bd = a.Cout_p % 256 == 0 ? 256u : (a.Cout_p % 128 == 0 ? 128u : 64u);
+      const dim3 gs((unsigned)a.T, (unsigned)a.Cout_p / bd);
+      if (tm == 5) hipLaunchKernelGGL(wino_out_seq_h2_kernel<5>, gs, dim3(bd), 0, st, h);
+      else hipLaunchKernelGGL(wino_out_seq_h2_kernel<4>, gs, dim3(bd), 0, st, h);
+    } else if (form == 2) {
+      const dim3 gt((unsigned)a.T, (unsigned)(a.Cout_p / 64));
+      if (tm == 5) hipLaunchKernelGGL(wino_out_tile_h2_kernel<5>, gt, dim3(128), 0, st, h);
+      else hipLaunchKernelGGL(wino_out_tile_h2_kernel<4>, gt, dim3(128), 0, st, h);
+    } else if (form == 1) {
       const unsigned gp = (unsigned)((2 * n_out + 255) / 256);
       if (tm == 5) hipLaunchKernelGGL(wino_out_pair_h2_kernel<5>, dim3(gp), dim3(256), 0, st, h);
       else hipLaunchKernelGGL(wino_out_pair_h2_kernel<4>, dim3(gp), dim3(256), 0, st, h);
