@@ -887,7 +887,8 @@ __global__ __launch_bounds__(128) void wino_out_tile_h2_kernel(WinoH2Args h) {
 // channels, so every M load and every y store of a wave is one 256-byte run (the lane-pair forms above move two 128-byte runs per
 // instruction and measured slower per byte: the memory pipeline tracks requests per instruction), and finishing branch a before
 // branch b's loads are issued keeps the live set at ~49 + 50 + 25 values.  The asm barrier keeps the compiler from hoisting
-// branch b's loads to the top (which is what made the thread-per-channel kernel above need 256 registers).
+// branch b's loads to the top (which is what made the thread-per-channel kernel above need 256 registers).  (Also tried: the
+// parameter loads issued only after the first transform pass, 127 registers / 4 waves per SIMD: 0.249 against 0.238 ms.)
 template <int TM>
 __global__ __launch_bounds__(256) void wino_out_seq_h2_kernel(WinoH2Args h) {
   using WT = WinoT<TM>;
