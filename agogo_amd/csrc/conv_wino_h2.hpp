@@ -81,6 +81,7 @@ struct WinoH2Args {
   // within npos * 128 rows, so the transform kernels' (tm+2)^2 streams stay inside a few pages.  Plain layout: [npos][T + pad].
   int rsh, rmask;
   unsigned rA, rB;
+  int in_swap;               // input transform stores 256-byte runs through lane swaps (C % 128 == 0; tuning knob AGZ_WINO_H2_IN_SWAP)
   int swap_st;               // GEMM stores through v_permlane32_swap (256-byte runs); tuning knob AGZ_WINO_H2_SWAPST, default off (measured: no effect)
   const _Float16* U2;        // [36][C/32][2][Ntot][32]
   const unsigned* amax_in;   // [B] max |x| of every board of this block's input (float bits)
@@ -155,6 +156,12 @@ __global__ __launch_bounds__(256) void wino_in_h2_kernel(WinoH2Args h) {
   unsigned* V2 = reinterpret_cast<unsigned*>(a.V);          // 4-byte words: [pos][T][C/32][2][16]
   const int c = 2 * c2;
   const size_t word_in_row = (size_t)(c >> 5) * 32 + ((c & 31) >> 1);   // hi word; the lo word sits 16 words further
+  // Store forms (h.in_swap, uniform).  0: every lane stores its own hi and lo word — per instruction four 64-byte runs (16 lanes
+  // fill the hi half of a 32-channel chunk).  1 (C % 128 == 0, the block size keeps a wave inside one tile): v_permlane16_swap
+  // gathers a chunk's hi and lo halves into 32 neighbouring lanes and v_permlane32_swap puts two neighbouring chunks into one
+  // register: per instruction ONE 256-byte run (lanes 0..63 = 64 consecutive words of the row).
+  const int lane = threadIdx.x & 63;
+  const size_t swap_word = (size_t)((c2 >> 6) * 4) * 32 + lane;           // chunks 4q, 4q+1 of the wave's 4 chunks; the others 64 words on
 #pragma unroll
   for (int i = 0; i < AL; i++) {
     float ox[AL], oy[AL];
@@ -164,9 +171,18 @@ __global__ __launch_bounds__(256) void wino_in_h2_kernel(WinoH2Args h) {
     for (int j = 0; j < AL; j++) {
       unsigned lo;
       const unsigned hi = wino_h2_pack(ox[j] * sb, oy[j] * sb, &lo);
-      unsigned* row = V2 + h2_row(h, i * AL + j, t) * a.C + word_in_row;
-      row[0] = hi;
-      row[16] = lo;
+      unsigned* rowp = V2 + h2_row(h, i * AL + j, t) * a.C;
+      if (h.in_swap) {
+        const auto s16 = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);   // [hi r0, lo r0, hi r2, lo r2], [hi r1, lo r1, hi r3, lo r3]
+        const unsigned e0 = s16[0], e1 = s16[1];
+        const auto s32 = __builtin_amdgcn_permlane32_swap(e0, e1, false, false);   // [chunk 0, chunk 1], [chunk 2, chunk 3]
+        const unsigned w0 = s32[0], w1 = s32[1];
+        rowp[swap_word] = w0;
+        rowp[swap_word + 64] = w1;
+      } else {
+        rowp[word_in_row] = hi;
+        rowp[word_in_row + 16] = lo;
+      }
     }
   }
 }
@@ -1072,6 +1088,8 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
   a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
   static const int swap_env = [] { const char* e = getenv("AGZ_WINO_H2_SWAPST"); return e ? atoi(e) : 0; }();
   h.swap_st = swap_env;
+  static const int in_swap_env = [] { const char* e = getenv("AGZ_WINO_H2_IN_SWAP"); return e ? atoi(e) : 1; }();
+  h.in_swap = (in_swap_env && a.C % 128 == 0) ? 1 : 0;   // a wave = 64 channel pairs of ONE tile
   {
     ProfScopeOn ps(ctx, AGZ_PROF_WINO_IN, st == ctx->stream);
     const size_t n_in = (size_t)a.T * (a.C / 2);
