@@ -81,6 +81,10 @@ struct WinoH2Args {
   // within npos * 128 rows, so the transform kernels' (tm+2)^2 streams stay inside a few pages.  Plain layout: [npos][T + pad].
   int rsh, rmask;
   unsigned rA, rB;
+  int fuse_prev;             // 1: this block's input range is reduced by the input transform itself from wave_max (what the
+                             // previous block's output transform left there) and written to amax_self; 0: amax_in is ready
+  int wm_per_board;          // words of wave_max per board (set by wino_h2_launch)
+  unsigned* amax_self;       // = amax_in, writable
   int in_swap;               // input transform stores 256-byte runs through lane swaps (C % 128 == 0; tuning knob AGZ_WINO_H2_IN_SWAP)
   int swap_st;               // GEMM stores through v_permlane32_swap (256-byte runs); tuning knob AGZ_WINO_H2_SWAPST, default off (measured: no effect)
   const _Float16* U2;        // [36][C/32][2][Ntot][32]
@@ -123,8 +127,22 @@ __global__ __launch_bounds__(256) void wino_in_h2_kernel(WinoH2Args h) {
   const int t = (int)(g / C2);
   const int b = t / a.TPB, tt = t - b * a.TPB;
   const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
+  unsigned amax_bits;
+  if (h.fuse_prev) {   // (uniform; C % 128 == 0: the wave's 64 lanes are one tile of one board)
+    // the board's range = max over the per-wave maxima the previous block's output transform stored: 64..128 words, L2-resident;
+    // every wave reduces them itself (this replaces a one-wave-per-board kernel between every two blocks)
+    const float* wp = h.wave_max + (size_t)b * h.wm_per_board;
+    float mx = 0.f;
+    for (int i = threadIdx.x & 63; i < h.wm_per_board; i += 64) mx = fmaxf(mx, wp[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    amax_bits = __float_as_uint(mx);
+    if (tt == 0 && c2 == 0) h.amax_self[b] = amax_bits;   // for this block's output transform
+  } else {
+    amax_bits = h.amax_in[b];
+  }
   float sb, inv_;
-  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &sb, &inv_);
+  wino_h2_scales(amax_bits, WT::VSHIFT, &sb, &inv_);
   const float* xb = a.x + (size_t)b * a.Hp * a.Wp * a.C + 2 * c2;
   // all loads are issued unconditionally (clamped address, zeroed afterwards): a branch per load keeps only one column in
   // flight (measured 4.2 TB/s of algorithmic bytes with the branches)
@@ -1090,6 +1108,21 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
   h.swap_st = swap_env;
   static const int in_swap_env = [] { const char* e = getenv("AGZ_WINO_H2_IN_SWAP"); return e ? atoi(e) : 1; }();
   h.in_swap = (in_swap_env && a.C % 128 == 0) ? 1 : 0;   // a wave = 64 channel pairs of ONE tile
+  // Forms of the output transform (tuning knob AGZ_WINO_H2_OUT_PAIR): 0 = thread per channel, both branches at once;
+  // 1 = lane pair per channel; 2 = block per tile, lane pair; 3 = block per tile, thread per channel, branch after branch.
+  // Default: 3 for F(5x5,3x3) (0.237 ms against 0.30 / 0.28 / 0.27 for forms 0 / 1 / 2 on the headline block),
+  // 0 for F(4x4,3x3) (0.231 against 0.255 for form 3).
+  static const int form_env = [] { const char* e = getenv("AGZ_WINO_H2_OUT_PAIR"); return e ? atoi(e) : -1; }();
+  const bool fits32 = (size_t)h.npos * h.rB * a.Ntot * 4 < ((size_t)1 << 32);   // scalar position offsets of the tile forms
+  int form = form_env >= 0 && form_env <= 3 ? form_env : (tm == 5 ? 3 : 0);
+  if (form >= 2 && !fits32) form = form == 3 ? 0 : 1;
+  const bool pair = form == 1 || form == 2;            // wave_max holds one word per 32 channels (else per 64)
+  // the board-range reduction between two blocks rides in the next block's input transform (tuning knob AGZ_WINO_H2_FUSE_MAX)
+  static const int fuse_env = [] { const char* e = getenv("AGZ_WINO_H2_FUSE_MAX"); return e ? atoi(e) : 1; }();
+  const bool fuse = fuse_env && a.C % 128 == 0 && h.wave_max != nullptr;
+  h.wm_per_board = a.TPB * (a.Cout_p >> (pair ? 5 : 6));
+  h.fuse_prev = (h.fuse_prev && fuse) ? 1 : 0;
+  h.amax_self = const_cast<unsigned*>(h.amax_in);
   {
     ProfScopeOn ps(ctx, AGZ_PROF_WINO_IN, st == ctx->stream);
     const size_t n_in = (size_t)a.T * (a.C / 2);
@@ -1124,15 +1157,6 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
   {
     ProfScopeOn ps(ctx, AGZ_PROF_WINO_OUT, st == ctx->stream);
     const size_t n_out = (size_t)a.T * a.Cout_p;
-    // Forms of the output transform (tuning knob AGZ_WINO_H2_OUT_PAIR): 0 = thread per channel, both branches at once;
-    // 1 = lane pair per channel; 2 = block per tile, lane pair; 3 = block per tile, thread per channel, branch after branch.
-    // Default: 3 for F(5x5,3x3) (0.237 ms against 0.30 / 0.28 / 0.27 for forms 0 / 1 / 2 on the headline block),
-    // 0 for F(4x4,3x3) (0.231 against 0.255 for form 3).
-    static const int form_env = [] { const char* e = getenv("AGZ_WINO_H2_OUT_PAIR"); return e ? atoi(e) : -1; }();
-    const bool fits32 = (size_t)h.npos * h.rB * a.Ntot * 4 < ((size_t)1 << 32);   // scalar position offsets of the tile forms
-    int form = form_env >= 0 && form_env <= 3 ? form_env : (tm == 5 ? 3 : 0);
-    if (form >= 2 && !fits32) form = form == 3 ? 0 : 1;
-    const bool pair = form == 1 || form == 2;            // wave_max holds one word per 32 channels (else per 64)
     if (form == 3) {
       const unsigned bd = a.Cout_p % 256 == 0 ? 256u : (a.Cout_p % 128 == 0 ? 128u : 64u);
       const dim3 gs((unsigned)a.T, (unsigned)a.Cout_p / bd);
@@ -1150,7 +1174,7 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
       if (tm == 5) hipLaunchKernelGGL(wino_out_h2_kernel<5>, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, h);
       else hipLaunchKernelGGL(wino_out_h2_kernel<4>, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, h);
     }
-    if (h.wave_max && h.amax_out)
+    if (h.wave_max && h.amax_out && !fuse)   // (fused: the next block's input transform reduces wave_max itself)
       hipLaunchKernelGGL(wino_board_max_kernel, dim3(a.B), dim3(64), 0, st, h.wave_max, h.amax_out, a.TPB * (a.Cout_p >> (pair ? 5 : 6)));
   }
 }

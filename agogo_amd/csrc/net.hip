@@ -892,8 +892,10 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       wino_v_cap = v_elems * ns; wino_chunk_cap = 0;   // (the fp32-V Winograd path sizes by boards: force its re-allocation)
     }
     // per-board ranges [blocks+1][B], then the per-wave maxima of the output kernel [queues][chunk tiles][Kp/64] (as floats)
-    const size_t wm_elems = (size_t)chunk * tpb * (Kp >> 5);   // (sized for the pair form of the output kernel: one word per 32 channels)
-    const size_t need_amax = (size_t)(conf.SharedLayers + 1) * B + wm_elems * ns;
+    // per-wave maxima of the output kernel: every chunk of boards keeps its own region from one block to the next (the next
+    // block's input transform reduces them), board stride <= tpb * Kp/32 words (the pair forms: one word per 32 channels)
+    const size_t wm_board = (size_t)tpb * (Kp >> 5);
+    const size_t need_amax = (size_t)(conf.SharedLayers + 1) * B + wm_board * B;
     if (need_amax > amax_cap) {
       AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
       if (ctx->stream2) AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream2));
@@ -925,7 +927,8 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
         hh.U2 = d_u2_dual[l]; hh.w_unscale = u_unscale[l]; hh.tm = wino_tm;
         hh.amax_in = d_amax + (size_t)l * B + b0; hh.amax_out = d_amax + (size_t)(l + 1) * B + b0;
-        hh.wave_max = d_wave_max + (size_t)q * wm_elems;
+        hh.wave_max = d_wave_max + (size_t)b0 * wm_board;
+        hh.fuse_prev = l > 0;   // block 0's input range comes from board_amax_kernel above
         wino_h2_launch(ctx, hh, wide, pfa, q ? ctx->stream2 : ctx->stream);
       }
       std::swap(cur, nxt);

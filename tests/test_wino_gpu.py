@@ -176,6 +176,8 @@ H2_KNOBS = [
     {"AGZ_WINO_H2_TM": "4", "AGZ_WINO_H2_OUT_PAIR": "3"},          # block-per-tile branch-after-branch form on F(4x4,3x3)
     {"AGZ_WINO_H2_SWAPST": "1"},                                   # GEMM stores through v_permlane32_swap
     {"AGZ_WINO_H2_IN_SWAP": "0"},                                  # input transform stores without the lane swaps
+    {"AGZ_WINO_H2_FUSE_MAX": "0"},                                 # board ranges by the separate one-wave-per-board kernel
+    {"AGZ_WINO_H2_FUSE_MAX": "0", "AGZ_WINO_H2_CHUNK": "16"},
     {"AGZ_WINO_H2_LAYOUT": "plain", "AGZ_WINO_H2_PAD": "9"},       # [position][tile] layout of V and M, padded
     {"AGZ_WINO_H2_CHUNK": "16"},                                   # board chunks
     {"AGZ_WINO_H2_CHUNK": "16", "AGZ_WINO_H2_STREAMS": "2"},       # board chunks on two queues
