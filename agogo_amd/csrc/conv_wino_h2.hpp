@@ -81,6 +81,9 @@ struct WinoH2Args {
   // within npos * 128 rows, so the transform kernels' (tm+2)^2 streams stay inside a few pages.  Plain layout: [npos][T + pad].
   int rsh, rmask;
   unsigned rA, rB;
+  int raw;                   // 1 (training convolutions): the output stage is wino_out_raw_h2_kernel — At M A un-scaled, no epilogue,
+                             // all Ntot columns as they are, y [B][Hp][Wp][Ntot] — and w_unscale is read from w_unscale_dev
+  const float* w_unscale_dev;
   int fuse_prev;             // 1: this block's input range is reduced by the input transform itself from wave_max (what the
                              // previous block's output transform left there) and written to amax_self; 0: amax_in is ready
   int wm_per_board;          // words of wave_max per board (set by wino_h2_launch)
@@ -1024,6 +1027,119 @@ __global__ __launch_bounds__(256) void wino_out_seq_h2_kernel(WinoH2Args h) {
   }
 }
 
+// Output transform without an epilogue (dual.Train's forward and data-gradient convolutions, train.hip): y = At M A * (1 / (s_b su)),
+// every one of the Ntot GEMM columns its own output channel.  One workgroup per tile, one thread per column, buffer addressing as above.
+template <int TM>
+__global__ __launch_bounds__(256) void wino_out_raw_h2_kernel(WinoH2Args h) {
+  using WT = WinoT<TM>;
+  constexpr int AL = WT::AL;
+  const WinoArgs& a = h.w;
+  const int t = blockIdx.x;                                        // uniform: one tile per block
+  const int tid = threadIdx.x, c = blockIdx.y * blockDim.x + tid;  // this lane's column
+  const int b = t / a.TPB, tt = t - b * a.TPB;
+  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
+  float s_, unscale;
+  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &unscale);
+  unscale *= h.w_unscale_dev[0];
+  const __amdgpu_buffer_rsrc_t mr = h2_rsrc(a.Mb + ((size_t)(t >> h.rsh) * h.rA + (size_t)(t & h.rmask)) * a.Ntot);
+  const unsigned pos_stride = h.rB * (unsigned)a.Ntot * 4u;
+  const unsigned lane_off = (unsigned)c * 4u;
+  float tm_[TM][AL];
+#pragma unroll
+  for (int nu = 0; nu + 1 < AL; nu += 2) {
+    f2v m[AL], o[TM];
+#pragma unroll
+    for (int xi = 0; xi < AL; xi++) {
+      m[xi].x = h2_ldf(mr, lane_off, (unsigned)(xi * AL + nu) * pos_stride);
+      m[xi].y = h2_ldf(mr, lane_off, (unsigned)(xi * AL + nu + 1) * pos_stride);
+    }
+    wino_atv_t<TM, f2v>(m, o);
+#pragma unroll
+    for (int k = 0; k < TM; k++) { tm_[k][nu] = o[k].x; tm_[k][nu + 1] = o[k].y; }
+  }
+  if (AL & 1) {
+    constexpr int nu = AL - 1;
+    float m[AL], o[TM];
+#pragma unroll
+    for (int xi = 0; xi < AL; xi++) m[xi] = h2_ldf(mr, lane_off, (unsigned)(xi * AL + nu) * pos_stride);
+    wino_atv_t<TM, float>(m, o);
+#pragma unroll
+    for (int k = 0; k < TM; k++) tm_[k][nu] = o[k];
+  }
+  const __amdgpu_buffer_rsrc_t yr = h2_rsrc(a.y + (size_t)b * a.Hp * a.Wp * a.Ntot);
+  const unsigned y_pix = (unsigned)a.Ntot * 4u;
+#pragma unroll
+  for (int k = 0; k < TM; k++) {
+    float Yk[TM];
+    wino_atv_t<TM, float>(tm_[k], Yk);
+    const int hh = TM * ty + k;
+#pragma unroll
+    for (int l = 0; l < TM; l++) {
+      const int ww = TM * tx + l;
+      if (hh < a.H && ww < a.W) h2_stf(yr, lane_off, (unsigned)((hh + 1) * a.Wp + (ww + 1)) * y_pix, Yk[l] * unscale);   // uniform condition
+    }
+  }
+}
+
+// Winograd-domain weights built ON THE DEVICE (training: the filters change every step).  w [tap 9][N][C] fp32 ->
+// u2[pos][C/32][piece 2][N][32] fp16 with the layer's power-of-two scale (max|U| su in [2^13, 2^14), like wino_build_u2 on the
+// host); pass 1 reduces max|U| into umax_bits, pass 2 scales, splits and stores and writes 1 / su.  One thread per (n, ci).
+template <int TM>
+__device__ __forceinline__ void wino_u_of(const float* __restrict__ w, int N, int C, int n, int ci, float* U) {
+  using WT = WinoT<TM>;
+  constexpr int AL = WT::AL;
+  double g[3][3], tg[AL][3];
+#pragma unroll
+  for (int tap = 0; tap < 9; tap++) g[tap / 3][tap % 3] = (double)w[((size_t)tap * N + n) * C + ci];
+#pragma unroll
+  for (int xi = 0; xi < AL; xi++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) tg[xi][j] = WT::G[xi][0] * g[0][j] + WT::G[xi][1] * g[1][j] + WT::G[xi][2] * g[2][j];
+#pragma unroll
+  for (int xi = 0; xi < AL; xi++)
+#pragma unroll
+    for (int nu = 0; nu < AL; nu++)
+      U[xi * AL + nu] = (float)(tg[xi][0] * WT::G[nu][0] + tg[xi][1] * WT::G[nu][1] + tg[xi][2] * WT::G[nu][2]);
+}
+template <int TM>
+__global__ __launch_bounds__(256) void wino_u_absmax_kernel(const float* __restrict__ w, int N, int C, unsigned* __restrict__ umax_bits) {
+  constexpr int NP = WinoT<TM>::AL * WinoT<TM>::AL;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  float mx = 0.f;
+  if (g < (size_t)N * C) {
+    float U[NP];
+    wino_u_of<TM>(w, N, C, (int)(g / C), (int)(g % C), U);
+#pragma unroll
+    for (int i = 0; i < NP; i++) mx = fmaxf(mx, fabsf(U[i]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(umax_bits, __float_as_uint(mx));
+}
+template <int TM>
+__global__ __launch_bounds__(256) void wino_u_build_kernel(const float* __restrict__ w, int N, int C, const unsigned* __restrict__ umax_bits,
+                                                           _Float16* __restrict__ u2, float* __restrict__ unscale_out) {
+  constexpr int NP = WinoT<TM>::AL * WinoT<TM>::AL;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  float su, inv;
+  h2_scales(umax_bits[0], &su, &inv);      // 2^(13 - floor(log2 max|U|)) and its inverse
+  if (g == 0) unscale_out[0] = inv;
+  if (g >= (size_t)N * C) return;
+  const int n = (int)(g / C), ci = (int)(g % C);
+  float U[NP];
+  wino_u_of<TM>(w, N, C, n, ci, U);
+  const int NC = C / 32;
+#pragma unroll
+  for (int pos = 0; pos < NP; pos++) {
+    const float xs = U[pos] * su;
+    const _Float16 hi = (_Float16)xs;
+    const _Float16 lo = (_Float16)(xs - (float)hi);
+    const size_t base = ((((size_t)pos * NC + ci / 32) * 2) * N + n) * 32 + (ci % 32);
+    u2[base] = hi;
+    u2[base + (size_t)N * 32] = lo;
+  }
+}
+
 // amax_out[b] = max over the board's tiles and channel groups of wave_max (one wave per board)
 __global__ __launch_bounds__(64) void wino_board_max_kernel(const float* __restrict__ wave_max, unsigned* __restrict__ amax_out, int per_board) {
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -1157,7 +1273,12 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
   {
     ProfScopeOn ps(ctx, AGZ_PROF_WINO_OUT, st == ctx->stream);
     const size_t n_out = (size_t)a.T * a.Cout_p;
-    if (form == 3) {
+    if (h.raw) {
+      const unsigned bd = a.Ntot % 256 == 0 ? 256u : (a.Ntot % 128 == 0 ? 128u : (a.Ntot % 64 == 0 ? 64u : 32u));
+      const dim3 gr((unsigned)a.T, (unsigned)a.Ntot / bd);
+      if (tm == 5) hipLaunchKernelGGL(wino_out_raw_h2_kernel<5>, gr, dim3(bd), 0, st, h);
+      else hipLaunchKernelGGL(wino_out_raw_h2_kernel<4>, gr, dim3(bd), 0, st, h);
+    } else if (form == 3) {
       const unsigned bd = a.Cout_p % 256 == 0 ? 256u : (a.Cout_p % 128 == 0 ? 128u : 64u);
       const dim3 gs((unsigned)a.T, (unsigned)a.Cout_p / bd);
       if (tm == 5) hipLaunchKernelGGL(wino_out_seq_h2_kernel<5>, gs, dim3(bd), 0, st, h);

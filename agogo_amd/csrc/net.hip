@@ -684,6 +684,63 @@ int agz::conv3x3_raw_x3(agz_ctx* ctx, const float* x, const unsigned short* w3, 
   return AGZ_OK;
 }
 
+bool agz::conv3x3_raw_wino_h2_fits(int B, int H, int W, int Cin_p, int Cout_p) {
+  const int tm = wino_h2_pick_tm(H, W), npos = (tm + 2) * (tm + 2);
+  const size_t tiles = (size_t)B * ceil_div(H, tm) * ceil_div(W, tm);
+  return Cin_p % 32 == 0 && Cin_p >= 32 && Cout_p % 32 == 0 &&
+         wino_h2_rows(npos, tiles) * Cin_p * 4 < ((size_t)1 << 32) &&                 // 32-bit byte offsets into V
+         (size_t)npos * (Cin_p / 32) * 2 * Cout_p * 64 < ((size_t)1 << 32) &&         // ... and into the weight image
+         wino_h2_rows(npos, tiles) * Cout_p * 4 < ((size_t)1 << 32);                  // scalar position offsets of the output stage
+}
+
+void agz::wino_raw_scratch_free(WinoRawScratch* sc) {
+  if (sc->V) hipFree(sc->V);
+  if (sc->M) hipFree(sc->M);
+  if (sc->U2) hipFree(sc->U2);
+  if (sc->words) hipFree(sc->words);
+  *sc = WinoRawScratch{};
+}
+
+int agz::conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc) {
+  AGZ_REQUIRE(conv3x3_raw_wino_h2_fits(B, H, W, Cin_p, Cout_p), AGZ_E_UNSUPPORTED, "conv3x3_raw_wino_h2: shape %d x %dx%d, %d -> %d not supported", B, H, W, Cin_p, Cout_p);
+  hipStream_t s = ctx->stream;
+  const int tm = wino_h2_pick_tm(H, W), npos = (tm + 2) * (tm + 2);
+  const size_t tiles = (size_t)B * ceil_div(H, tm) * ceil_div(W, tm);
+  const size_t v_need = wino_h2_rows(npos, tiles) * Cin_p, m_need = wino_h2_rows(npos, tiles) * Cout_p;
+  const size_t u_need = (size_t)npos * (Cin_p / 32) * 2 * Cout_p * 32;   // fp16 elements
+  if (v_need > sc->v_cap || m_need > sc->m_cap || u_need > sc->u_cap || B > sc->b_cap) {
+    AGZ_HIP_TRY(hipStreamSynchronize(s));
+    if (v_need > sc->v_cap) { if (sc->V) hipFree(sc->V); sc->V = nullptr; sc->v_cap = 0; AGZ_HIP_TRY(hipMalloc(&sc->V, v_need * 4)); sc->v_cap = v_need; }
+    if (m_need > sc->m_cap) { if (sc->M) hipFree(sc->M); sc->M = nullptr; sc->m_cap = 0; AGZ_HIP_TRY(hipMalloc(&sc->M, m_need * 4)); sc->m_cap = m_need; }
+    if (u_need > sc->u_cap) { if (sc->U2) hipFree(sc->U2); sc->U2 = nullptr; sc->u_cap = 0; AGZ_HIP_TRY(hipMalloc(&sc->U2, u_need * 2)); sc->u_cap = u_need; }
+    if (B > sc->b_cap) { if (sc->words) hipFree(sc->words); sc->words = nullptr; sc->b_cap = 0; AGZ_HIP_TRY(hipMalloc(&sc->words, ((size_t)B + 2) * 4)); sc->b_cap = B; }
+  }
+  unsigned* umax = sc->words + sc->b_cap;
+  float* unscale = reinterpret_cast<float*>(sc->words + sc->b_cap + 1);
+  const int Hp = H + 2, Wp = W + 2;
+  // the layer's Winograd-domain weights and their scale
+  AGZ_HIP_TRY(hipMemsetAsync(umax, 0, 4, s));
+  const unsigned gw = (unsigned)(((size_t)Cout_p * Cin_p + 255) / 256);
+  if (tm == 5) {
+    hipLaunchKernelGGL(wino_u_absmax_kernel<5>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax);
+    hipLaunchKernelGGL(wino_u_build_kernel<5>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax, (_Float16*)sc->U2, unscale);
+  } else {
+    hipLaunchKernelGGL(wino_u_absmax_kernel<4>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax);
+    hipLaunchKernelGGL(wino_u_build_kernel<4>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax, (_Float16*)sc->U2, unscale);
+  }
+  // per-board range of the input (training activations are signed: the kernel takes |x|)
+  hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, s, x, sc->words, H * W, W, Wp, Hp * Wp, Cin_p);
+  WinoH2Args hh{};
+  WinoArgs& wa = hh.w;
+  wa.x = x; wa.y = y; wa.V = sc->V; wa.Mb = sc->M; wa.ep = nullptr;
+  wa.B = B; wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Cin_p; wa.Cout_p = Cout_p; wa.Ntot = Cout_p;
+  hh.U2 = (const _Float16*)sc->U2; hh.w_unscale = 1.f; hh.w_unscale_dev = unscale; hh.raw = 1; hh.tm = tm;
+  hh.amax_in = sc->words; hh.amax_out = nullptr; hh.wave_max = nullptr; hh.fuse_prev = 0;
+  wino_h2_launch(ctx, hh, Cout_p % 256 == 0, 2, s);
+  AGZ_HIP_TRY(hipGetLastError());
+  return AGZ_OK;
+}
+
 // Winograd-domain weights of every dual block (conv_wino.hpp): columns [0,Kp) branch a, [Kp,2Kp) branch b, natural order
 int agz_net::build_wino_weights() {
   AGZ_REQUIRE(cfg == 0, AGZ_E_UNSUPPORTED, "agz_net: the Winograd path needs K a multiple of 64");

@@ -19,6 +19,16 @@ int conv3x3_raw_x3(agz_ctx* ctx, const float* x, const unsigned short* w3, float
 // w [9][N][Cin_p] fp32 (device) -> w3 [Cin_p/16][9][3][N][16] bf16 pieces (device); exact truncation split
 int split_w3(agz_ctx* ctx, const float* w, unsigned short* w3, int N, int Cin_p);
 inline size_t w3_elems(int N, int Cin_p) { return (size_t)9 * 3 * N * Cin_p; }
+// the same convolution through the Winograd fp16x2 path (conv_wino_h2.hpp) with its weights transformed on the device from
+// w [9][Cout_p][Cin_p] fp32: input range per board, U2 build (two small kernels), input transform, GEMMs, raw output transform.
+// Cin_p % 32 == 0.  The scratch grows on demand and is owned by the caller (dual.Train: one per trainer).
+struct WinoRawScratch {
+  float* V = nullptr; float* M = nullptr; void* U2 = nullptr; unsigned* words = nullptr;   // words: [B] board ranges, max|U| bits, 1/su
+  size_t v_cap = 0, m_cap = 0, u_cap = 0; int b_cap = 0;
+};
+int conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc);
+bool conv3x3_raw_wino_h2_fits(int B, int H, int W, int Cin_p, int Cout_p);
+void wino_raw_scratch_free(WinoRawScratch* sc);
 }  // namespace agz
 
 struct agz_net {

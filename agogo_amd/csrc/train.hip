@@ -178,6 +178,125 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
       }
 }
 
+// ---- the same weight gradient on the bf16 matrix pipe (AGZ_COMPUTE_BF16X3) ------------------------------------------------
+// Both GEMM operands are activations here (dz and x), so both are split on the way into LDS: every fp32 value = three bf16
+// pieces by exact truncation (conv_x3.hpp), six v_mfma_f32_32x32x16_bf16 per product instead of sixteen fp32-MFMA passes.  The
+// reduction dimension is the pixel row r, and the MFMA wants eight consecutive k per lane: a thread fetches the SAME column of
+// eight consecutive rows (a wave = 64 consecutive columns of one row per load: 256-byte runs), splits, and writes the eight
+// bf16 of one piece as one 16-byte LDS word.  LDS image per operand and piece: [128 columns][32 k] bf16, the 16-byte slot of
+// (column, k group) XOR-ed with bits 2..3 of the column: ds_write_b128 (16 lanes = 16 columns, one k group) and the fragment
+// ds_read_b128 (16 lanes = 16 columns) both touch 16 different slots of the 256-byte bank window.
+// Tile 128 (n) x 128 (c), 4 waves of 64 x 64, K step 32 rows; next step's 32 values per thread are fetched under the MFMAs.
+typedef short wg_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned wg_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wg_split(float v, unsigned& h, unsigned& m, unsigned& l) {
+  unsigned hu = __float_as_uint(v) & 0xffff0000u;
+  float r = v - __uint_as_float(hu);
+  unsigned mu = __float_as_uint(r) & 0xffff0000u;
+  float r2 = r - __uint_as_float(mu);
+  h = hu; m = mu; l = __float_as_uint(r2);
+}
+__device__ __forceinline__ unsigned wg_pack(unsigned e0, unsigned e1) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
+__device__ __forceinline__ unsigned wg_lds_off(int col, int kg) { return (unsigned)(col * 64 + ((kg ^ ((col >> 2) & 3)) << 4)); }
+
+__global__ __launch_bounds__(256, 2) void k_wgrad_x3(WgArgs a) {
+  constexpr int PIECE = 128 * 64;                 // one piece image of one operand: 128 columns x 32 k x 2 B
+  __shared__ __attribute__((aligned(16))) unsigned char lds[6 * PIECE];   // A (dz) pieces 0..2, B (x) pieces 3..5
+  int bid = blockIdx.x;
+  const int ct = bid % a.c_tiles; bid /= a.c_tiles;
+  const int nt = bid % a.n_tiles; bid /= a.n_tiles;
+  const int tap = bid % 9, chunk = bid / 9;
+  const int n0 = nt * 128, c0 = ct * 128;
+  const int ky = tap / 3, kx = tap - ky * 3;
+  const long tapoff = (long)(ky - 1) * a.g.Wp + (kx - 1);
+  const int r_begin = chunk * a.rows_per_block, r_end = min(r_begin + a.rows_per_block, a.g.M);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
+  const int kg = wid;                             // staging: this wave's k group = rows rb + 8 kg .. + 7
+  const bool na0 = n0 + lane < a.N, na1 = n0 + 64 + lane < a.N;
+  const bool cb0 = c0 + lane < a.Cin, cb1 = c0 + 64 + lane < a.Cin;
+  const float* dzp = a.dz + n0 + lane;
+  const float* xp = a.x + c0 + lane;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  float va0[8], va1[8], vb0[8], vb1[8];
+  auto fetch = [&](int rb) {
+    const int r0 = rb + kg * 8;                   // wave-uniform
+    int b = r0 / a.g.HW, p = r0 - b * a.g.HW;
+    int h = p / a.g.W, w = p - h * a.g.W;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const bool ok = r0 + q < r_end;             // uniform
+      const size_t po = ((size_t)b * a.g.Hp + h + 1) * a.g.Wp + w + 1;
+      const float* dr = dzp + po * a.N;
+      const float* xr = xp + (size_t)((long)po + tapoff) * a.Cin;
+      va0[q] = ok && na0 ? dr[0] : 0.f;
+      va1[q] = ok && na1 ? dr[64] : 0.f;
+      vb0[q] = ok && cb0 ? xr[0] : 0.f;
+      vb1[q] = ok && cb1 ? xr[64] : 0.f;
+      if (++w == a.g.W) { w = 0; if (++h == a.g.H) { h = 0; ++b; } }
+    }
+  };
+  auto stage = [&](const float* v, int piece0, int col) {   // split eight k of one column, one 16-byte word per piece
+    unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) wg_split(v[q], hh[q], mm[q], ll[q]);
+    wg_u32x4_t ph, pm, pl;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      ph[q] = wg_pack(hh[2 * q], hh[2 * q + 1]);
+      pm[q] = wg_pack(mm[2 * q], mm[2 * q + 1]);
+      pl[q] = wg_pack(ll[2 * q], ll[2 * q + 1]);
+    }
+    const unsigned off = wg_lds_off(col, kg);
+    *reinterpret_cast<wg_u32x4_t*>(lds + (piece0 + 0) * PIECE + off) = ph;
+    *reinterpret_cast<wg_u32x4_t*>(lds + (piece0 + 1) * PIECE + off) = pm;
+    *reinterpret_cast<wg_u32x4_t*>(lds + (piece0 + 2) * PIECE + off) = pl;
+  };
+  fetch(r_begin);
+  for (int rb = r_begin; rb < r_end; rb += 32) {
+    stage(va0, 0, lane); stage(va1, 0, 64 + lane);
+    stage(vb0, 3, lane); stage(vb1, 3, 64 + lane);
+    __syncthreads();
+    if (rb + 32 < r_end) fetch(rb + 32);          // in flight under the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const int kgr = ks * 2 + (lane >> 5);
+      wg_bf16x8_t A_[2][3], B_[2][3];
+#pragma unroll
+      for (int pz = 0; pz < 3; pz++) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+          A_[i][pz] = *reinterpret_cast<const wg_bf16x8_t*>(lds + pz * PIECE + wg_lds_off(wm * 64 + i * 32 + (lane & 31), kgr));
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          B_[j][pz] = *reinterpret_cast<const wg_bf16x8_t*>(lds + (3 + pz) * PIECE + wg_lds_off(wn * 64 + j * 32 + (lane & 31), kgr));
+      }
+#define WG_MF(I, J, PA, PB) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[I][PA], B_[J][PB], acc[I][J], 0, 0, 0);
+#define WG_QUAD(PA, PB) WG_MF(0, 0, PA, PB) WG_MF(0, 1, PA, PB) WG_MF(1, 0, PA, PB) WG_MF(1, 1, PA, PB)
+      WG_QUAD(2, 0) WG_QUAD(0, 2) WG_QUAD(1, 1) WG_QUAD(1, 0) WG_QUAD(0, 1) WG_QUAD(0, 0)   // smallest terms first
+#undef WG_QUAD
+#undef WG_MF
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int c = c0 + wn * 64 + j * 32 + (lane & 31);
+        if (n < a.N && c < a.Cin) atomicAdd(&a.dw[((size_t)tap * a.N + n) * a.Cin + c], acc[i][j][r]);
+      }
+}
+
 // wt[8-tap][c][n] = wf[tap][n][c]   (data-gradient weights: flipped taps, transposed)
 __global__ void k_make_wt(const float* __restrict__ wf, float* __restrict__ wt, int N, int Cin) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -429,6 +548,12 @@ struct agz_trainer {
   float *logits = nullptr, *hpre = nullptr, *o = nullptr, *cost = nullptr;
   float *d_planes = nullptr, *d_pi = nullptr, *d_v = nullptr;
   bool x3 = false, x3_force = false;   // agz_trainer_set_compute_mode (FORCE: also below the chip-filling threshold, tests)
+  bool wino = false;                   // AGZ_COMPUTE_WINO_H2: forward / data-gradient convolutions through conv_wino_h2.hpp (x3 stays on for the rest)
+  WinoRawScratch wsc;
+  bool use_wino(int cin, int cout) const {
+    return wino && cin % 32 == 0 && cin >= 64 && conv3x3_raw_wino_h2_fits(B, g.H, g.W, cin, cout) &&
+           (x3_force || (size_t)((g.M + 127) / 128) * ((cout + 127) / 128) >= (size_t)ctx->num_cus);
+  }
   // bf16x3 only where the 128-row tiles fill the chip (same rule as inference) and the filter has whole 16-channel chunks
   bool use_x3(const TLayer& ly, int cin, int cout) const {
     return x3 && ly.w3f && cin % 16 == 0 && cin >= 64 &&
@@ -456,7 +581,9 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   for (int l = 0; l <= L; l++) {
     TLayer& ly = layers[l];
     int r;
-    if (use_x3(ly, ly.Cin_p, ly.Cout_p)) {
+    if (use_wino(ly.Cin_p, ly.Cout_p)) {
+      r = conv3x3_raw_wino_h2(ctx, cur, P + ly.o_wf, ly.z, B, g.H, g.W, ly.Cin_p, ly.Cout_p, &wsc);
+    } else if (use_x3(ly, ly.Cin_p, ly.Cout_p)) {
       if ((r = split_w3(ctx, P + ly.o_wf, ly.w3f, ly.Cout_p, ly.Cin_p)) != AGZ_OK) return r;
       r = conv3x3_raw_x3(ctx, cur, ly.w3f, ly.z, B, g.H, g.W, ly.Cin_p, ly.Cout_p);
     } else {
@@ -507,11 +634,18 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     wa.dz = dz; wa.x = xin; wa.dw = G + ly.o_wf; wa.g = g; wa.N = C; wa.Cin = ly.Cin_p; wa.rows_per_block = 2048;
     wa.n_tiles = ceil_div(C, 128); wa.c_tiles = ceil_div(ly.Cin_p, 128);
     int chunks = ceil_div(g.M, wa.rows_per_block);
-    hipLaunchKernelGGL(k_wgrad, dim3(wa.n_tiles * wa.c_tiles * 9 * chunks), dim3(256), 0, s, wa);
+    // bf16x3 mode: the weight gradient runs on the bf16 pipe as well (tuning knob AGZ_WGRAD_X3=0 keeps the fp32-MFMA kernel)
+    static const int wg_x3_env = [] { const char* e = getenv("AGZ_WGRAD_X3"); return e ? atoi(e) : 1; }();
+    if (x3 && wg_x3_env && (x3_force || (size_t)wa.n_tiles * wa.c_tiles * 9 * chunks >= (size_t)ctx->num_cus))
+      hipLaunchKernelGGL(k_wgrad_x3, dim3(wa.n_tiles * wa.c_tiles * 9 * chunks), dim3(256), 0, s, wa);
+    else
+      hipLaunchKernelGGL(k_wgrad, dim3(wa.n_tiles * wa.c_tiles * 9 * chunks), dim3(256), 0, s, wa);
     if (l > 0) {  // data gradient: the forward GEMM with flipped/transposed weights over the [a|b] channels of dz
       hipLaunchKernelGGL(k_make_wt, dim3(nblk((size_t)9 * C * ly.Cin_p)), dim3(256), 0, s, P + ly.o_wf, ly.wt, C, ly.Cin_p);
       int r;
-      if (use_x3(ly, C, ly.Cin_p)) {
+      if (use_wino(C, ly.Cin_p)) {
+        r = conv3x3_raw_wino_h2(ctx, dz, ly.wt, dnext, B, g.H, g.W, C, ly.Cin_p, &wsc);
+      } else if (use_x3(ly, C, ly.Cin_p)) {
         if ((r = split_w3(ctx, ly.wt, ly.w3t, ly.Cin_p, C)) != AGZ_OK) return r;
         r = conv3x3_raw_x3(ctx, dz, ly.w3t, dnext, B, g.H, g.W, C, ly.Cin_p);
       } else {
@@ -592,6 +726,7 @@ void agz_trainer_destroy(agz_trainer* t) {
   hipSetDevice(t->ctx->device);
   hipStreamSynchronize(t->ctx->stream);
   for (void* p : t->allocs) hipFree(p);
+  wino_raw_scratch_free(&t->wsc);
   delete t;
 }
 
@@ -823,23 +958,25 @@ int agz_trainer_batch(agz_trainer* t, const float* planes, const float* pi, cons
   return AGZ_OK;
 }
 
-// AGZ_COMPUTE_F32_MFMA (default) or AGZ_COMPUTE_BF16X3 for the forward and data-gradient convolutions (the weight
-// gradient keeps its fp32-MFMA kernel).  Same gradient tolerance against the oracle in both modes.
+// AGZ_COMPUTE_F32_MFMA (default); AGZ_COMPUTE_BF16X3: forward, data-gradient and weight-gradient GEMMs on the bf16 pipe;
+// AGZ_COMPUTE_WINO_H2: the forward and data-gradient convolutions of the dual blocks through the Winograd fp16x2 path (weights
+// transformed on the device every step), everything else as in BF16X3.  Same gradient tolerance against the oracle in all modes.
 int agz_trainer_set_compute_mode(agz_trainer* t, int mode) {
   AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
   const bool force = (mode & AGZ_COMPUTE_FORCE) != 0;
   mode &= ~AGZ_COMPUTE_FORCE;
-  AGZ_REQUIRE(mode == AGZ_COMPUTE_F32_MFMA || mode == AGZ_COMPUTE_BF16X3, AGZ_E_INVALID, "agz_trainer_set_compute_mode: mode %d not available for training", mode);
+  AGZ_REQUIRE(mode == AGZ_COMPUTE_F32_MFMA || mode == AGZ_COMPUTE_BF16X3 || mode == AGZ_COMPUTE_WINO_H2, AGZ_E_INVALID, "agz_trainer_set_compute_mode: mode %d not available for training", mode);
   AGZ_HIP_TRY(hipSetDevice(t->ctx->device));
   t->x3_force = force;
-  if (mode == AGZ_COMPUTE_BF16X3)
+  if (mode == AGZ_COMPUTE_BF16X3 || mode == AGZ_COMPUTE_WINO_H2)
     for (auto& ly : t->layers)
       if (!ly.w3f) {
         int r = t->alloc(&ly.w3f, w3_elems(ly.Cout_p, ly.Cin_p));
         if (r == AGZ_OK) r = t->alloc(&ly.w3t, w3_elems(ly.Cin_p, ly.Cout_p));
         if (r != AGZ_OK) return r;
       }
-  t->x3 = mode == AGZ_COMPUTE_BF16X3;
+  t->x3 = mode == AGZ_COMPUTE_BF16X3 || mode == AGZ_COMPUTE_WINO_H2;
+  t->wino = mode == AGZ_COMPUTE_WINO_H2;
   return AGZ_OK;
 }
 

@@ -168,8 +168,10 @@ int agz_trainer_forward_backward(agz_trainer* t, const float* planes, const floa
 int agz_trainer_forward_backward_dev(agz_trainer* t, const float* planes_dev, const float* pi_dev, const float* v_dev, float* cost);
 int agz_trainer_apply(agz_trainer* t, float lr, float grad_scale);
 int agz_trainer_grads_dev(agz_trainer* t, float** dev_ptr, size_t* n_floats);
-/* AGZ_COMPUTE_F32_MFMA (default) or AGZ_COMPUTE_BF16X3 for the forward and data-gradient convolutions of training
- * (weights are re-split on the device every step; the weight gradient keeps its fp32-MFMA kernel). */
+/* Arithmetic of training's three GEMMs (forward convolution, data gradient, weight gradient): AGZ_COMPUTE_F32_MFMA (default),
+ * AGZ_COMPUTE_BF16X3 (all three on the bf16 pipe; weights re-split on the device every step) or AGZ_COMPUTE_WINO_H2 (forward and
+ * data-gradient convolutions of the dual blocks through the Winograd fp16x2 path, weights transformed on the device every step;
+ * the weight gradient as in BF16X3).  Same gradient tolerance against the reference arithmetic in every mode. */
 int agz_trainer_set_compute_mode(agz_trainer* t, int mode);
 /* dual.Train(d, Xs, policies, values, batches, iterations) (dualnet/meta.go:16-54): lr 0.1 vanilla SGD, shuffleBatch
  * after every iteration (build RNG; Xs/policies/values are shuffled in place like the reference). */

@@ -8,13 +8,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--K", type=int, default=256); ap.add_argument("--L", type=int, default=20)
 ap.add_argument("--B", type=int, default=256); ap.add_argument("--size", type=int, default=19)
 ap.add_argument("--steps", type=int, default=3)
-ap.add_argument("--x3", action="store_true", help="AGZ_COMPUTE_BF16X3 forward / data-gradient convolutions")
+ap.add_argument("--x3", action="store_true", help="AGZ_COMPUTE_BF16X3 forward / data-gradient / weight-gradient GEMMs")
+ap.add_argument("--wino-h2", action="store_true", help="AGZ_COMPUTE_WINO_H2 forward / data-gradient convolutions (bf16x3 weight gradient)")
 args = ap.parse_args()
 S = args.size
 ctx = A.Ctx(0)
 t = A.Trainer(ctx, args.K, args.L, 2 * args.K, S, S, 18, S * S + 1, args.B)
 t0 = time.perf_counter(); t.init_random(1337); t_init = time.perf_counter() - t0
-if args.x3:
+if args.wino_h2:
+    t.set_compute_mode(A.capi.COMPUTE_WINO_H2)
+elif args.x3:
     t.set_compute_mode(A.capi.COMPUTE_BF16X3)
 rng = np.random.default_rng(0)
 x = rng.choice(np.array([-1, 0, 1], np.float32), size=(args.B, 18, S, S)).astype(np.float32)

@@ -58,12 +58,14 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("x3", [False, True])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "wino_h2"])
 @pytest.mark.parametrize("K,L,FC,W,H,F,Aspace,B", CASES)
-def test_forward_backward_matches_oracle(ctx, K, L, FC, W, H, F, Aspace, B, x3):
+def test_forward_backward_matches_oracle(ctx, K, L, FC, W, H, F, Aspace, B, mode):
     ot, dt = make_pair(ctx, K, L, FC, W, H, F, Aspace, B)
-    if x3:   # bf16x3 forward / data-gradient convolutions (taken for Cin >= 64; forced below the chip-filling threshold)
+    if mode == "bf16x3":   # bf16x3 forward / data-gradient convolutions (Cin >= 64) and weight gradient; forced below the chip-filling threshold
         dt.set_compute_mode(capi.COMPUTE_BF16X3 | capi.COMPUTE_FORCE)
+    elif mode == "wino_h2":   # Winograd fp16x2 forward / data-gradient convolutions (Cin >= 64, weights transformed on the device)
+        dt.set_compute_mode(capi.COMPUTE_WINO_H2 | capi.COMPUTE_FORCE)
     x, pi, v = batch_data(B, F, H, W, Aspace, seed=K + B)
     co = ot.batch(x, pi, v, lr=0.0)
     cd = dt.forward_backward(x, pi, v)
