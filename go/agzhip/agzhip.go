@@ -109,6 +109,8 @@ const (
 	ComputeBF16X3  = C.AGZ_COMPUTE_BF16X3
 	ComputeFP16X2  = C.AGZ_COMPUTE_FP16X2 // opt-in: range-managed 2-way fp16 split, 3 MFMAs per product
 	ComputeWino    = C.AGZ_COMPUTE_WINO   // opt-in: Winograd F(4x4,3x3) with bf16x3 products, ~1.9x BF16X3 at self-play batch sizes
+	ComputeWinoH2  = C.AGZ_COMPUTE_WINO_H2 // Winograd F(5x5,3x3) / F(4x4,3x3) with range-managed fp16x2 products: the fastest at self-play batch sizes
+	ComputeForce   = C.AGZ_COMPUTE_FORCE  // flag: keep the mode's tower at every batch size
 )
 
 func (n *Net) Close() error { defer n.ctx.enter()(); C.agz_net_destroy(n.h); n.h = nil; return nil }
@@ -534,6 +536,13 @@ func (t *Trainer) TrainDev(ex *Examples, iterations int, seed uint64) error {
 }
 
 // Export is dual.Infer's copy loop (meta.go:141-146): row 0 of every learnable into an inference Net.
+// SetComputeMode selects the arithmetic of training's GEMMs: ComputeF32MFMA (default), ComputeBF16X3 (forward, data- and
+// weight-gradient GEMMs on the bf16 pipe) or ComputeWinoH2 (Winograd forward / data-gradient convolutions; 1.9x the default's step rate).
+func (t *Trainer) SetComputeMode(mode int) error {
+	defer t.ctx.enter()()
+	return lastErr(C.agz_trainer_set_compute_mode(t.h, C.int(mode)))
+}
+
 func (t *Trainer) Export(n *Net) error { defer t.ctx.enter()(); return lastErr(C.agz_trainer_export(t.h, n.h)) }
 
 func (t *Trainer) Close() error { defer t.ctx.enter()(); C.agz_trainer_destroy(t.h); t.h = nil; return nil }
