@@ -550,7 +550,10 @@ struct agz_trainer {
   bool x3 = false, x3_force = false;   // agz_trainer_set_compute_mode (FORCE: also below the chip-filling threshold, tests)
   bool wino = false;                   // AGZ_COMPUTE_WINO_H2: forward / data-gradient convolutions through conv_wino_h2.hpp (x3 stays on for the rest)
   WinoRawScratch wsc;
-  bool use_wino(int cin, int cout) const {
+  bool use_wino(int cin, int cout, bool dgrad = false) const {
+    static const int fwd_env = [] { const char* e = getenv("AGZ_TRAIN_WINO_FWD"); return e ? atoi(e) : 1; }();      // tuning knobs
+    static const int dgrad_env = [] { const char* e = getenv("AGZ_TRAIN_WINO_DGRAD"); return e ? atoi(e) : 1; }();
+    if (dgrad ? !dgrad_env : !fwd_env) return false;
     return wino && cin % 32 == 0 && cin >= 64 && conv3x3_raw_wino_h2_fits(B, g.H, g.W, cin, cout) &&
            (x3_force || (size_t)((g.M + 127) / 128) * ((cout + 127) / 128) >= (size_t)ctx->num_cus);
   }
@@ -643,7 +646,7 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     if (l > 0) {  // data gradient: the forward GEMM with flipped/transposed weights over the [a|b] channels of dz
       hipLaunchKernelGGL(k_make_wt, dim3(nblk((size_t)9 * C * ly.Cin_p)), dim3(256), 0, s, P + ly.o_wf, ly.wt, C, ly.Cin_p);
       int r;
-      if (use_wino(C, ly.Cin_p)) {
+      if (use_wino(C, ly.Cin_p, true)) {
         r = conv3x3_raw_wino_h2(ctx, dz, ly.wt, dnext, B, g.H, g.W, C, ly.Cin_p, &wsc);
       } else if (use_x3(ly, C, ly.Cin_p)) {
         if ((r = split_w3(ctx, ly.wt, ly.w3t, ly.Cin_p, C)) != AGZ_OK) return r;
