@@ -380,28 +380,43 @@ def main():
     # the one exchange step of the path, untimed for `value`: the examples recorded so far gathered over all ranks —
     # inside libagz (agz_comm_* / agz_examples_allgather: RCCL grouped broadcasts over xGMI), the way the Go host would do it
     gather = None
+    gather_hung = False
     if world > 1:
-        try:
-            ex = A.Examples(ctx, 18, S, S, Aspace)
-            comm = adist.make_comm(ctx)
-            # (agz_examples_append_arena takes finished games only; the bench's games are mid-way, so the arena rows go in raw)
-            import ctypes as C
-            pp, po, pv, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int32(0)
-            capi._check(capi.lib().agz_arena_examples_dev(arena.h, C.byref(pp), C.byref(po), C.byref(pv), C.byref(n)), "examples_dev")
-            if n.value:
-                ex.append_dev(pp.value, po.value, pv.value, n.value)
-            fence()
-            g0 = time.perf_counter()
-            comm.allgather_examples(ex)
-            ctx.sync()
-            g_ms = (time.perf_counter() - g0) * 1e3
-            gather = {"path": "libagz: agz_comm_init_rank + agz_examples_allgather (RCCL, one grouped set of broadcasts)",
-                      "ms": g_ms, "rows_this_rank": n.value, "rows_gathered": len(ex),
-                      "GB_per_s": len(ex) * (18 * S * S + Aspace + 1) * 4 / (g_ms * 1e-3) / 1e9}
-            comm.close()
-            ex.close()
-        except Exception as e:   # never lose the bench line to the untimed leg
-            gather = {"error": repr(e)}
+        def gather_leg():
+            try:
+                ex = A.Examples(ctx, 18, S, S, Aspace)
+                comm = adist.make_comm(ctx)
+                # (agz_examples_append_arena takes finished games only; the bench's games are mid-way, so the arena rows go in raw)
+                import ctypes as C
+                pp, po, pv, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int32(0)
+                capi._check(capi.lib().agz_arena_examples_dev(arena.h, C.byref(pp), C.byref(po), C.byref(pv), C.byref(n)), "examples_dev")
+                if n.value:
+                    ex.append_dev(pp.value, po.value, pv.value, n.value)
+                fence()
+                g0 = time.perf_counter()
+                comm.allgather_examples(ex)
+                ctx.sync()
+                g_ms = (time.perf_counter() - g0) * 1e3
+                res = {"path": "libagz: agz_comm_init_rank + agz_examples_allgather (RCCL, one grouped set of broadcasts)",
+                       "ms": g_ms, "rows_this_rank": n.value, "rows_gathered": len(ex),
+                       "GB_per_s": len(ex) * (18 * S * S + Aspace + 1) * 4 / (g_ms * 1e-3) / 1e9}
+                comm.close()
+                ex.close()
+                return res
+            except Exception as e:   # never lose the bench line to the untimed leg
+                return {"error": repr(e)}
+        # ... nor to a collective that never returns (N > 1 over xGMI has not been run anywhere yet): the leg runs on its own thread
+        # (ctypes calls release the GIL) and is given two minutes; a hung leg is reported as such and the process then leaves
+        # through os._exit after the line is out
+        import threading
+        box = {}
+        th = threading.Thread(target=lambda: box.__setitem__("gather", gather_leg()), daemon=True)
+        th.start()
+        th.join(120.0)
+        if th.is_alive():
+            gather, gather_hung = {"error": "the example all-gather leg did not return within 120 s"}, True
+        else:
+            gather = box.get("gather")
     gather_ms = gather
 
     if rank == 0:
@@ -553,6 +568,8 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "sims/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if gather_hung:
+        os._exit(0)   # a thread is stuck inside a collective: no clean teardown possible (the line is out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
