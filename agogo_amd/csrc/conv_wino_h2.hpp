@@ -89,7 +89,6 @@ struct WinoH2Args {
   int wm_per_board;          // words of wave_max per board (set by wino_h2_launch)
   unsigned* amax_self;       // = amax_in, writable
   int in_swap;               // input transform stores 256-byte runs through lane swaps (C % 128 == 0; tuning knob AGZ_WINO_H2_IN_SWAP)
-  int swap_st;               // GEMM stores through v_permlane32_swap (256-byte runs); tuning knob AGZ_WINO_H2_SWAPST, default off (measured: no effect)
   const _Float16* U2;        // [36][C/32][2][Ntot][32]
   const unsigned* amax_in;   // [B] max |x| of every board of this block's input (float bits)
   unsigned* amax_out;        // [B] max of this block's output (wino_board_max_kernel over wave_max)
@@ -580,26 +579,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2d_kernel(WinoH2Args h) {
 
   const bool full = m0 + 128 <= a.T && n0 + BN <= a.Ntot;   // uniform
   float* dst0 = a.Mb + h2_row(h, pos, m0 + wm * 64 + 4 * (lane >> 5)) * a.Ntot + n0 + wn * (64 * NT) + (lane & 31);
-  if (full && h.swap_st) {
-    // The 32x32 accumulator layout puts rows m and m + 4 in the two halves of a wave, so a plain store moves two 128-byte runs.
-    // v_permlane32_swap of the accumulators of two neighbouring 32-column groups gives each of the two registers ONE row over
-    // 64 columns: every store is one 256-byte run.
-    float* dsts = a.Mb + h2_row(h, pos, m0 + wm * 64) * a.Ntot + n0 + wn * (64 * NT) + lane;
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float* dA = dsts + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.Ntot;
-        float* dB = dA + (size_t)4 * a.Ntot;
-#pragma unroll
-        for (int j = 0; j + 1 < NJ; j += 2) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][r]), __float_as_uint(acc[i][j + 1][r]), false, false);
-          const unsigned s0 = sw[0], s1 = sw[1];   // (elements copied to scalars: see the note at h2_ldf2)
-          dA[j * 32] = __uint_as_float(s0);
-          dB[j * 32] = __uint_as_float(s1);
-        }
-      }
-  } else if (full) {
+  if (full) {
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -708,83 +688,17 @@ __global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
   }
 }
 
-// The same output transform with one thread per (tile, channel, BRANCH): neighbouring lanes hold branch a and branch b of one
-// channel, each transforms its own AL^2 values of M and applies its own {scale, shift} half, the two exchange the finished values
-// with one lane swap per pixel and share the stores.  Half the live values per thread (TM 5: 49 + 50 instead of 98 + 100), twice
-// the threads.  A wave covers 32 channels of one tile: wave_max is indexed [T][Cout_p/32].
-template <int TM>
-__global__ __launch_bounds__(256) void wino_out_pair_h2_kernel(WinoH2Args h) {
-  using WT = WinoT<TM>;
-  constexpr int AL = WT::AL;
-  const WinoArgs& a = h.w;
-  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t total = (size_t)a.T * a.Cout_p * 2;
-  const bool live = g < total;
-  const size_t gg = live ? g : total - 1;
-  const int br = (int)(gg & 1);
-  const int c = (int)((gg >> 1) % a.Cout_p);
-  const int t = (int)((gg >> 1) / a.Cout_p);
-  const int b = t / a.TPB, tt = t - b * a.TPB;
-  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
-  float s_, unscale;
-  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &unscale);
-  unscale *= h.w_unscale;
-  const float2* ep2 = reinterpret_cast<const float2*>(a.ep);
-  float2 E[TM][TM];
-#pragma unroll
-  for (int k = 0; k < TM; k++) {
-    const int hh = TM * ty + k, hc = hh < a.H ? hh : a.H - 1;
-#pragma unroll
-    for (int l = 0; l < TM; l++) {
-      const int ww = TM * tx + l, wc = ww < a.W ? ww : a.W - 1;
-      E[k][l] = ep2[((size_t)(hc * a.W + wc) * a.Cout_p + c) * 2 + br];
-    }
-  }
-  float tm_[TM][AL];
-#pragma unroll
-  for (int nu = 0; nu < AL; nu++) {
-    float m[AL], o[TM];
-#pragma unroll
-    for (int xi = 0; xi < AL; xi++) m[xi] = a.Mb[h2_row(h, xi * AL + nu, t) * a.Ntot + br * a.Cout_p + c];
-    wino_atv<TM>(m, o);
-#pragma unroll
-    for (int k = 0; k < TM; k++) tm_[k][nu] = o[k];
-  }
-  float* yb = a.y + (size_t)b * a.Hp * a.Wp * a.Cout_p + c;
-  float mx = 0.f;
-#pragma unroll
-  for (int k = 0; k < TM; k++) {
-    float Yk[TM];
-    wino_atv<TM>(tm_[k], Yk);
-    const int hh = TM * ty + k;
-#pragma unroll
-    for (int l = 0; l < TM; l++) {
-      float v = (Yk[l] * unscale) * E[k][l].x + E[k][l].y;
-      v = v > 0.f ? v : 0.f;
-      const float other = __shfl_xor(v, 1, 64);
-      // relu(relu(a) + relu(b)): the operands are non-negative, so the sum is order-independent bit for bit and already >= 0
-      float sum = v + other;
-      sum = sum > 0.f ? sum : 0.f;
-      const int ww = TM * tx + l;
-      if (((k * TM + l) & 1) == br && live && hh < a.H && ww < a.W) {   // the two lanes of a pair share the pixels
-        yb[((size_t)(hh + 1) * a.Wp + (ww + 1)) * a.Cout_p] = sum;
-        mx = fmaxf(mx, sum);
-      }
-    }
-  }
-  if (h.wave_max) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0 && live) h.wave_max[(size_t)t * (a.Cout_p >> 5) + (c >> 5)] = mx;
-  }
-}
-
-// The output transform, block-per-tile form.  Measured on the kernels above (ISA count + timing with the arithmetic or the
-// parameter loads removed): they are bound by VALU ISSUE, not by HBM — ~1100 vector instructions per thread of which ~600 are
-// 64-bit address arithmetic (quarter-rate v_mul_lo_u32 / v_mad_u64_u32 for every one of the 74 loads), against ~300 of transform
-// arithmetic.  Here one 128-thread block owns ONE tile (64 channels x 2 branches, lanes (2i, 2i+1) = branches a, b of channel i):
-// tile, board, pixel and position are block-uniform, so every address is a scalar base (SALU) plus one per-lane 32-bit offset,
-// and the 1-D transforms run two columns / two rows at a time on the packed-fp32 pipe (v_pk_fma_f32).  Grid: x = tile, y = 64-channel group.
+// ---- block-per-tile transform kernels -----------------------------------------------------------------------------------
+// What the measurements of round 2 said about the thread-per-(tile, channel) kernel above on the F(5x5,3x3) shape
+// (profiles/r02/wino_h2_out_forms_ab.log, wino_out_decomposition.log, pmc_wino_out_tile_form.json):
+//  * ~1100 vector instructions per thread, ~600 of them 64-bit address arithmetic (quarter-rate v_mul_lo_u32 / v_mad_u64_u32 for
+//    every one of 74 loads).  With ONE tile per workgroup, tile / board / pixel / position are uniform and every address is a
+//    buffer descriptor over a scalar base + one per-lane 32-bit offset + a scalar offset: 350 vector instructions — and no time
+//    gained (0.282 -> 0.277 ms): instruction issue was not the limit.
+//  * A lane-pair mapping (lanes 2i, 2i+1 = branches a, b of one channel; two 128-byte runs per memory instruction) measured
+//    0.31 ms where one 256-byte run per instruction measured 0.24 ms for the same bytes (F(4x4) shape): the memory pipeline's
+//    throughput goes with the bytes one instruction moves in one run.  Both lane-pair kernels were removed after the A/B.
+// Kept: scalar buffer addressing, packed-fp32 1-D transforms two columns / rows at a time, and the kernel below.
 typedef float f2v __attribute__((ext_vector_type(2)));
 // Buffer addressing for the block-per-tile transform kernels: a scalar descriptor over a block-uniform base, one per-lane 32-bit
 // byte offset and a scalar byte offset per access (position / pixel) — no vector address arithmetic at all.  (Plain pointer
@@ -829,100 +743,8 @@ template <> __device__ __forceinline__ void wino_atv_t<5, f2v>(const f2v* m, f2v
   o[4] = s12 + 0.0625f * s34 + 16.f * m[5] + m[6];
 }
 
-template <int TM>
-__global__ __launch_bounds__(128) void wino_out_tile_h2_kernel(WinoH2Args h) {
-  using WT = WinoT<TM>;
-  constexpr int AL = WT::AL;
-  const WinoArgs& a = h.w;
-  const int t = blockIdx.x, cg = blockIdx.y;                       // uniform
-  const int tid = threadIdx.x, br = tid & 1, cl = tid >> 1;
-  const int b = t / a.TPB, tt = t - b * a.TPB;
-  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
-  float s_, unscale;
-  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &unscale);
-  unscale *= h.w_unscale;
-  // {scale, shift} of this lane's branch: float2 index (pixel * Cout_p + c) * 2 + br = pixel * 2 Cout_p + cg * 128 + tid
-  const float2* ep2 = reinterpret_cast<const float2*>(a.ep) + (size_t)cg * 128;
-  const unsigned e_lane = (unsigned)tid * 8u;
-  float2 E[TM][TM];
-#pragma unroll
-  for (int k = 0; k < TM; k++) {
-    const int hh = TM * ty + k, hc = hh < a.H ? hh : a.H - 1;
-#pragma unroll
-    for (int l = 0; l < TM; l++) {
-      const int ww = TM * tx + l, wc = ww < a.W ? ww : a.W - 1;
-      E[k][l] = h2_ldg<float2>(ep2 + (size_t)(hc * a.W + wc) * (2 * a.Cout_p), e_lane);
-    }
-  }
-  // M: base = this tile's row at position 0 (+ the channel group); position p adds p * rB rows (the launch checks 32 bits suffice)
-  const __amdgpu_buffer_rsrc_t mr = h2_rsrc(a.Mb + ((size_t)(t >> h.rsh) * h.rA + (size_t)(t & h.rmask)) * a.Ntot + cg * 64);
-  const unsigned pos_stride = h.rB * (unsigned)a.Ntot * 4u;        // bytes, uniform
-  const unsigned lane_off = (unsigned)(br * a.Cout_p + cl) * 4u;   // bytes
-  float tm_[TM][AL];
-#pragma unroll
-  for (int nu = 0; nu + 1 < AL; nu += 2) {       // two columns at a time
-    f2v m[AL], o[TM];
-#pragma unroll
-    for (int xi = 0; xi < AL; xi++) {
-      m[xi].x = h2_ldf(mr, lane_off, (unsigned)(xi * AL + nu) * pos_stride);
-      m[xi].y = h2_ldf(mr, lane_off, (unsigned)(xi * AL + nu + 1) * pos_stride);
-    }
-    wino_atv_t<TM, f2v>(m, o);
-#pragma unroll
-    for (int k = 0; k < TM; k++) { tm_[k][nu] = o[k].x; tm_[k][nu + 1] = o[k].y; }
-  }
-  if (AL & 1) {
-    constexpr int nu = AL - 1;
-    float m[AL], o[TM];
-#pragma unroll
-    for (int xi = 0; xi < AL; xi++) m[xi] = h2_ldf(mr, lane_off, (unsigned)(xi * AL + nu) * pos_stride);
-    wino_atv_t<TM, float>(m, o);
-#pragma unroll
-    for (int k = 0; k < TM; k++) tm_[k][nu] = o[k];
-  }
-  float Y[TM][TM];
-#pragma unroll
-  for (int k = 0; k + 1 < TM; k += 2) {          // two rows at a time
-    f2v r[AL], o[TM];
-#pragma unroll
-    for (int nu = 0; nu < AL; nu++) { r[nu].x = tm_[k][nu]; r[nu].y = tm_[k + 1][nu]; }
-    wino_atv_t<TM, f2v>(r, o);
-#pragma unroll
-    for (int l = 0; l < TM; l++) { Y[k][l] = o[l].x; Y[k + 1][l] = o[l].y; }
-  }
-  if (TM & 1) wino_atv_t<TM, float>(tm_[TM - 1], Y[TM - 1]);
-  const __amdgpu_buffer_rsrc_t yr = h2_rsrc(a.y + (size_t)b * a.Hp * a.Wp * a.Cout_p + cg * 64);   // this board, this channel group
-  const unsigned y_lane = (unsigned)cl * 4u, y_pix = (unsigned)a.Cout_p * 4u;
-  float mx = 0.f;
-#pragma unroll
-  for (int k = 0; k < TM; k++) {
-    const int hh = TM * ty + k;
-#pragma unroll
-    for (int l = 0; l < TM; l++) {
-      float v = (Y[k][l] * unscale) * E[k][l].x + E[k][l].y;
-      v = v > 0.f ? v : 0.f;
-      // relu(relu(a) + relu(b)): both operands are finite-or-inf and non-negative, so the sum is already >= 0
-      // the partner lane's value: quad_perm [1,0,3,2] on the DPP path (no LDS crossbar)
-      const float sum = v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-      const int ww = TM * tx + l;
-      if (hh < a.H && ww < a.W) {                                   // uniform
-        if (((k * TM + l) & 1) == br) {                             // the two lanes of a pair share the pixels
-          h2_stf(yr, y_lane, (unsigned)((hh + 1) * a.Wp + (ww + 1)) * y_pix, sum);
-          mx = fmaxf(mx, sum);
-        }
-      }
-    }
-  }
-  if (h.wave_max) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((tid & 63) == 0) h.wave_max[(size_t)t * (a.Cout_p >> 5) + cg * 2 + (tid >> 6)] = mx;
-  }
-}
-
 // Block-per-tile form with one thread per channel and the two branches one after the other: a wave's 64 lanes are 64 consecutive
-// channels, so every M load and every y store of a wave is one 256-byte run (the lane-pair forms above move two 128-byte runs per
-// instruction and measured slower per byte: the memory pipeline tracks requests per instruction), and finishing branch a before
+// channels, so every M load and every y store of a wave is one 256-byte run, and finishing branch a before
 // branch b's loads are issued keeps the live set at ~49 + 50 + 25 values.  The asm barrier keeps the compiler from hoisting
 // branch b's loads to the top (which is what made the thread-per-channel kernel above need 256 registers).  (Also tried: the
 // parameter loads issued only after the first transform pass, 127 registers / 4 waves per SIMD: 0.249 against 0.238 ms.)
@@ -1220,23 +1042,19 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
   if (wino_h2_blocked()) { h.rsh = 7; h.rmask = 127; h.rA = (unsigned)h.npos * 128u; h.rB = 128u; }
   else { h.rsh = 31; h.rmask = 0x7fffffff; h.rA = 0; h.rB = (unsigned)(a.T + wino_h2_pos_pad()); }
   a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
-  static const int swap_env = [] { const char* e = getenv("AGZ_WINO_H2_SWAPST"); return e ? atoi(e) : 0; }();
-  h.swap_st = swap_env;
   static const int in_swap_env = [] { const char* e = getenv("AGZ_WINO_H2_IN_SWAP"); return e ? atoi(e) : 1; }();
   h.in_swap = (in_swap_env && a.C % 128 == 0) ? 1 : 0;   // a wave = 64 channel pairs of ONE tile
-  // Forms of the output transform (tuning knob AGZ_WINO_H2_OUT_PAIR): 0 = thread per channel, both branches at once;
-  // 1 = lane pair per channel; 2 = block per tile, lane pair; 3 = block per tile, thread per channel, branch after branch.
-  // Default: 3 for F(5x5,3x3) (0.237 ms against 0.30 / 0.28 / 0.27 for forms 0 / 1 / 2 on the headline block),
-  // 0 for F(4x4,3x3) (0.231 against 0.255 for form 3).
+  // Forms of the output transform (tuning knob AGZ_WINO_H2_OUT_PAIR): 0 = thread per (tile, channel), both branches at once;
+  // 3 = block per tile, thread per channel, branch after branch.  Default: 3 for F(5x5,3x3) (0.237 ms against 0.30 for form 0 on
+  // the headline block), 0 for F(4x4,3x3) (0.231 against 0.255 for form 3).  (1 and 2 were the removed lane-pair forms.)
   static const int form_env = [] { const char* e = getenv("AGZ_WINO_H2_OUT_PAIR"); return e ? atoi(e) : -1; }();
-  const bool fits32 = (size_t)h.npos * h.rB * a.Ntot * 4 < ((size_t)1 << 32);   // scalar position offsets of the tile forms
-  int form = form_env >= 0 && form_env <= 3 ? form_env : (tm == 5 ? 3 : 0);
-  if (form >= 2 && !fits32) form = form == 3 ? 0 : 1;
-  const bool pair = form == 1 || form == 2;            // wave_max holds one word per 32 channels (else per 64)
+  const bool fits32 = (size_t)h.npos * h.rB * a.Ntot * 4 < ((size_t)1 << 32);   // scalar position offsets of the tile form
+  int form = (form_env == 0 || form_env == 3) ? form_env : (tm == 5 ? 3 : 0);
+  if (form == 3 && !fits32) form = 0;
   // the board-range reduction between two blocks rides in the next block's input transform (tuning knob AGZ_WINO_H2_FUSE_MAX)
   static const int fuse_env = [] { const char* e = getenv("AGZ_WINO_H2_FUSE_MAX"); return e ? atoi(e) : 1; }();
   const bool fuse = fuse_env && a.C % 128 == 0 && h.wave_max != nullptr;
-  h.wm_per_board = a.TPB * (a.Cout_p >> (pair ? 5 : 6));
+  h.wm_per_board = a.TPB * (a.Cout_p >> 6);             // wave_max: one word per tile and 64 channels
   h.fuse_prev = (h.fuse_prev && fuse) ? 1 : 0;
   h.amax_self = const_cast<unsigned*>(h.amax_in);
   {
@@ -1283,19 +1101,11 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
       const dim3 gs((unsigned)a.T, (unsigned)a.Cout_p / bd);
       if (tm == 5) hipLaunchKernelGGL(wino_out_seq_h2_kernel<5>, gs, dim3(bd), 0, st, h);
       else hipLaunchKernelGGL(wino_out_seq_h2_kernel<4>, gs, dim3(bd), 0, st, h);
-    } else if (form == 2) {
-      const dim3 gt((unsigned)a.T, (unsigned)(a.Cout_p / 64));
-      if (tm == 5) hipLaunchKernelGGL(wino_out_tile_h2_kernel<5>, gt, dim3(128), 0, st, h);
-      else hipLaunchKernelGGL(wino_out_tile_h2_kernel<4>, gt, dim3(128), 0, st, h);
-    } else if (form == 1) {
-      const unsigned gp = (unsigned)((2 * n_out + 255) / 256);
-      if (tm == 5) hipLaunchKernelGGL(wino_out_pair_h2_kernel<5>, dim3(gp), dim3(256), 0, st, h);
-      else hipLaunchKernelGGL(wino_out_pair_h2_kernel<4>, dim3(gp), dim3(256), 0, st, h);
     } else {
       if (tm == 5) hipLaunchKernelGGL(wino_out_h2_kernel<5>, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, h);
       else hipLaunchKernelGGL(wino_out_h2_kernel<4>, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, h);
     }
     if (h.wave_max && h.amax_out && !fuse)   // (fused: the next block's input transform reduces wave_max itself)
-      hipLaunchKernelGGL(wino_board_max_kernel, dim3(a.B), dim3(64), 0, st, h.wave_max, h.amax_out, a.TPB * (a.Cout_p >> (pair ? 5 : 6)));
+      hipLaunchKernelGGL(wino_board_max_kernel, dim3(a.B), dim3(64), 0, st, h.wave_max, h.amax_out, h.wm_per_board);
   }
 }

@@ -950,8 +950,8 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     }
     // per-board ranges [blocks+1][B], then the per-wave maxima of the output kernel [queues][chunk tiles][Kp/64] (as floats)
     // per-wave maxima of the output kernel: every chunk of boards keeps its own region from one block to the next (the next
-    // block's input transform reduces them), board stride <= tpb * Kp/32 words (the pair forms: one word per 32 channels)
-    const size_t wm_board = (size_t)tpb * (Kp >> 5);
+    // block's input transform reduces them), one word per tile and 64 channels
+    const size_t wm_board = (size_t)tpb * (Kp >> 6);
     const size_t need_amax = (size_t)(conf.SharedLayers + 1) * B + wm_board * B;
     if (need_amax > amax_cap) {
       AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));

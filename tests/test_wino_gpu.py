@@ -171,10 +171,7 @@ np.save(sys.argv[1], np.concatenate([pol.ravel(), val.ravel()]))
 H2_KNOBS = [
     {"AGZ_WINO_H2_TM": "4"},                                       # F(4x4,3x3) on boards where F(5x5,3x3) is the default
     {"AGZ_WINO_H2_TM": "5", "AGZ_WINO_H2_OUT_PAIR": "0"},          # F(5x5,3x3) with the one-thread-per-channel output transform
-    {"AGZ_WINO_H2_TM": "4", "AGZ_WINO_H2_OUT_PAIR": "1"},          # F(4x4,3x3) with the lane-pair output transform
-    {"AGZ_WINO_H2_TM": "5", "AGZ_WINO_H2_OUT_PAIR": "2"},          # block-per-tile lane-pair form (buffer addressing)
     {"AGZ_WINO_H2_TM": "4", "AGZ_WINO_H2_OUT_PAIR": "3"},          # block-per-tile branch-after-branch form on F(4x4,3x3)
-    {"AGZ_WINO_H2_SWAPST": "1"},                                   # GEMM stores through v_permlane32_swap
     {"AGZ_WINO_H2_IN_SWAP": "0"},                                  # input transform stores without the lane swaps
     {"AGZ_WINO_H2_FUSE_MAX": "0"},                                 # board ranges by the separate one-wave-per-board kernel
     {"AGZ_WINO_H2_FUSE_MAX": "0", "AGZ_WINO_H2_CHUNK": "16"},
