@@ -747,7 +747,10 @@ template <> __device__ __forceinline__ void wino_atv_t<5, f2v>(const f2v* m, f2v
 // channels, so every M load and every y store of a wave is one 256-byte run, and finishing branch a before
 // branch b's loads are issued keeps the live set at ~49 + 50 + 25 values.  The asm barrier keeps the compiler from hoisting
 // branch b's loads to the top (which is what made the thread-per-channel kernel above need 256 registers).  (Also tried: the
-// parameter loads issued only after the first transform pass, 127 registers / 4 waves per SIMD: 0.249 against 0.238 ms.)
+// parameter loads issued only after the first transform pass, 127 registers / 4 waves per SIMD: 0.249 against 0.238 ms; and,
+// because the epilogue parameters come from L2 once per workgroup — as many bytes as the workgroup's M — a (tile position,
+// channel group)-major workgroup order with 64 / 128 / 256 threads so that a CU's resident workgroups share their parameter
+// slice: 0.251 / 0.273 / 0.260 against 0.236 ms, profiles/r02/wino_out_workgroup_order_ab.log.)
 template <int TM>
 __global__ __launch_bounds__(256) void wino_out_seq_h2_kernel(WinoH2Args h) {
   using WT = WinoT<TM>;
