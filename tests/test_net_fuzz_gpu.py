@@ -40,12 +40,14 @@ def test_random_network_shape(ctx, seed):
     np.testing.assert_allclose(val_g, val_o, atol=VAL_ATOL)
 
 
+@pytest.mark.parametrize("wmode", [capi.COMPUTE_WINO, capi.COMPUTE_WINO_H2], ids=["wino", "wino_h2"])
 @pytest.mark.parametrize("seed", fuzz_seeds(16))
-def test_random_network_shape_winograd(ctx, seed):
-    """the same family in AGZ_COMPUTE_WINO (forced below the chip-filling threshold): K a multiple of 64, boards from 3x3 (one ragged
-    tile) to 13x13, batches on both sides of the latency regime (which keeps its own kernels unless AGZ_WINO_LATENCY_TILES is set)"""
+def test_random_network_shape_winograd(ctx, seed, wmode):
+    """the same family in the Winograd modes (forced below the chip-filling threshold): K a multiple of 64 (with and without the
+    C % 128 fast paths of WINO_H2: lane-swapped stores, the board range reduced by the next input transform), boards from 3x3 (one
+    ragged tile) to 13x13 — WINO_H2 picks F(5x5,3x3) or F(4x4,3x3) by row count —, batches on both sides of the latency regime"""
     rng = np.random.default_rng(2500 + seed)
-    K = int(rng.choice([64, 128, 192]))
+    K = int(rng.choice([64, 128, 192, 256]))
     L = int(rng.integers(1, 4))
     FC = int(rng.choice([2, 7, 16, 33, 64]))
     H, W = int(rng.integers(3, 14)), int(rng.integers(3, 14))
@@ -54,7 +56,7 @@ def test_random_network_shape_winograd(ctx, seed):
     bn_mode = int(rng.integers(0, 3))
     B = int(rng.choice([3, 9, 33, 70]))
     onet, gnet = make_pair(ctx, K, L, FC, W, H, F, Aspace, bn_mode, seed=seed + 11)
-    gnet.set_compute_mode(capi.COMPUTE_WINO | capi.COMPUTE_FORCE)
+    gnet.set_compute_mode(wmode | capi.COMPUTE_FORCE)
     if rng.integers(0, 2):
         gnet.set_latency_mode(False)
     x = rand_planes(B, F, H, W, seed=seed)
