@@ -922,10 +922,13 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     // steps ahead 0.385 ms, 128x128 0.40 ms, the plain single-prefetch kernels 0.47-0.50 ms.  Tuning knobs override.
     static const int wide_env = [] { const char* e = getenv("AGZ_WINO_H2_WIDE"); return e ? atoi(e) : -1; }();
     static const int pfa_env = [] { const char* e = getenv("AGZ_WINO_H2_PFA"); return e ? atoi(e) : -1; }();
-    const bool wide = wide_env >= 0 ? wide_env != 0 : (2 * Kp) % 256 == 0;
     const int pfa = pfa_env >= 0 ? pfa_env : 2;
     const int npos = (wino_tm + 2) * (wino_tm + 2);
     const int tpb = ceil_div(H, wino_tm) * ceil_div(W, wino_tm);
+    // ... and the 128-column tile when the 256-column grid would leave CUs without a workgroup (a lane round of 16 boards: 196
+    // against 392 workgroups, 0.0747 -> 0.0726 ms per block, p50 move 0.250 -> 0.241 s)
+    const bool wide = wide_env >= 0 ? wide_env != 0
+                                    : ((2 * Kp) % 256 == 0 && (size_t)npos * ceil_div(B * tpb, 128) * ((2 * Kp) / 256) >= (size_t)ctx->num_cus);
     // Board chunks and queues (tuning knobs AGZ_WINO_H2_CHUNK = boards per chunk, AGZ_WINO_H2_STREAMS = 1 | 2): chunk i runs its
     // block chain on queue i % streams with that queue's scratch — chains of different boards are independent (per-board ranges),
     // so one chunk's HBM-bound transform kernels can overlap another chunk's GEMM, and a chunk whose V + M fit the 256 MB Infinity
