@@ -168,6 +168,7 @@ def lib():
     sig("agz_examples_get_tensors", i32, vp, pf, pf, pf)
     sig("agz_examples_raw_dev", i32, vp, pvp, pvp, pvp)
     sig("agz_rotate_boards", i32, vp, pf, i32, i32, i32, pf)
+    sig("agz_ctx_prof_set_stride", i32, vp, i32, i32)
     sig("agz_wino_stages", i32, vp, pf, pf, i32, i32, i32, i32, i32, pf, pf)
     sig("agz_wino_h2_tile", i32, i32, i32)
     sig("agz_arena_random_moves", i32, vp, pi, u64)
@@ -251,6 +252,10 @@ class Ctx:
             _check(lib().agz_ctx_prof_enable(self.h, mask), "agz_ctx_prof_enable")
             return
         return self._prof_enable_all(on)
+
+    def prof_set_stride(self, klass, stride):
+        """bracket only every stride-th launch of class klass (agz_debug.h)"""
+        _check(lib().agz_ctx_prof_set_stride(self.h, int(klass), int(stride)), "agz_ctx_prof_set_stride")
 
     def _prof_enable_all(self, on=True):
         _check(lib().agz_ctx_prof_enable(self.h, int(on)), "agz_ctx_prof_enable")

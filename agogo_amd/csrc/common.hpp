@@ -48,6 +48,9 @@ struct agz_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool prof_on = false;
   unsigned prof_mask = ~0u;   // classes that record events while prof_on (agz_ctx_prof_enable)
+  int prof_stride[AGZ_PROF_NCLASS];   // every prof_stride[k]-th launch of class k is bracketed (agz_ctx_prof_set_stride; default 1)
+  int64_t prof_seen[AGZ_PROF_NCLASS] = {};
+  agz_ctx() { for (auto& v : prof_stride) v = 1; }
   agz::ProfClass prof[AGZ_PROF_NCLASS];
   int prof_open = 0;   // scopes begun and not yet ended (classes nest: a layer scope around its kernels' scopes)
   int num_cus = 256;
@@ -63,7 +66,7 @@ struct ProfScope {
   agz_ctx* c;
   int k;
   bool on;
-  ProfScope(agz_ctx* c_, int k_) : c(c_), k(k_), on(c_->prof_on && ((c_->prof_mask >> k_) & 1u)) { if (on) c->prof_begin(k); }
+  ProfScope(agz_ctx* c_, int k_) : c(c_), k(k_), on(c_->prof_on && ((c_->prof_mask >> k_) & 1u) && (c_->prof_seen[k_]++ % c_->prof_stride[k_]) == 0) { if (on) c->prof_begin(k); }
   ~ProfScope() { if (on) c->prof_end(k); }
 };
 
@@ -72,7 +75,8 @@ struct ProfScopeOn {
   agz_ctx* c;
   int k;
   bool on;
-  ProfScopeOn(agz_ctx* c_, int k_, bool enable) : c(c_), k(k_), on(enable && c_->prof_on && ((c_->prof_mask >> k_) & 1u)) { if (on) c->prof_begin(k); }
+  ProfScopeOn(agz_ctx* c_, int k_, bool enable)
+      : c(c_), k(k_), on(enable && c_->prof_on && ((c_->prof_mask >> k_) & 1u) && (c_->prof_seen[k_]++ % c_->prof_stride[k_]) == 0) { if (on) c->prof_begin(k); }
   ~ProfScopeOn() { if (on) c->prof_end(k); }
 };
 

@@ -104,6 +104,12 @@ int agz_ctx_prof_enable(agz_ctx* c, int enable) {
   }
   return AGZ_OK;
 }
+int agz_ctx_prof_set_stride(agz_ctx* c, int klass, int stride) {
+  AGZ_REQUIRE(c && klass >= 0 && klass < AGZ_PROF_NCLASS && stride >= 1, AGZ_E_INVALID, "agz_ctx_prof_set_stride: bad argument");
+  c->prof_stride[klass] = stride;
+  c->prof_seen[klass] = 0;
+  return AGZ_OK;
+}
 int agz_ctx_prof_read(agz_ctx* c, int klass, int64_t* launches, double* total_ms) {
   AGZ_REQUIRE(c && klass >= 0 && klass < AGZ_PROF_NCLASS, AGZ_E_INVALID, "bad prof class");
   int r = c->prof_collect();

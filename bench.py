@@ -226,6 +226,8 @@ def main():
                     help="skip the untimed whole move and the tree pre-growth (the timed steps then run on the first simulations of a move)")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the configs[4] single-tree move-latency sample")
     ap.add_argument("--no-go9-leg", action="store_true", help="skip the measured 9x9 games/s leg (configs[2])")
+    ap.add_argument("--prof-stride", type=int, default=4,
+                    help="inside the timed region every N-th launch of the dominant kernel is bracketed with HIP events (0: none)")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="debug: all ranks use GPU 0 and gloo collectives (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -313,7 +315,11 @@ def main():
     # per launch; timing all nine classes cost ~1.3 ms of a 24 ms step in round 2's first run); the full breakdown is taken
     # on extra steps after the timed region
     dom = capi.PROF_WINO_GEMM if args.compute in ("wino", "wino_h2") else capi.PROF_CONV
-    ctx.prof_enable(True, classes=[dom, capi.PROF_MOVE])
+    # ... and of the dominant kernel only every --prof-stride-th launch (default 4: 100+ of the timed region's 400+ launches):
+    # the roofline needs the kernel's AVERAGE duration over the region, and each bracketed launch costs two event records
+    if args.prof_stride > 0:
+        ctx.prof_set_stride(dom, args.prof_stride)
+        ctx.prof_enable(True, classes=[dom, capi.PROF_MOVE])
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -324,6 +330,7 @@ def main():
     st1 = arena.stats()
     dom_n, dom_ms = ctx.prof_read(dom)
     move_n, _ = ctx.prof_read(capi.PROF_MOVE)
+    ctx.prof_set_stride(dom, 1)
     ctx.prof_enable(True)
     for _ in range(6):
         step()
@@ -441,6 +448,8 @@ def main():
             tiles = G * ((S + wtm - 1) // wtm) ** 2
             flops_launch = 2.0 * npos * tiles * K * (2 * K)
             launch_ms, n_launch = prof["wino_gemm_timed_region"]["avg_ms"], prof["wino_gemm_timed_region"]["launches"]
+            if not launch_ms:   # --prof-stride 0: nothing bracketed inside the timed region -> the breakdown steps' average
+                launch_ms, n_launch = prof["wino_gemm"]["avg_ms"], prof["wino_gemm"]["launches"]
             achieved = flops_launch / (launch_ms * 1e-3) / 1e12
             in_bytes = 4.0 * (G * hw * K + npos * tiles * K)            # x read once + V written
             w_bytes = float(npos) * K * (2 * K) * (4 if args.compute == "wino_h2" else 6)   # the block's Winograd-domain weight image, read once
@@ -525,7 +534,10 @@ def main():
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic}) | {
                          "kernel": kernels[args.compute], "peak_note": notes[args.compute],
                          "flops_per_launch": flops_launch, "avg_launch_ms": launch_ms,
-                         "launches": n_launch},
+                         "launches": n_launch,
+                         "timing": ("HIP events on the launch stream around every %d-th launch of the kernel inside the timed region "
+                                    "(%d launches bracketed)" % (args.prof_stride, n_launch)) if args.prof_stride > 0 else
+                                   "HIP events on the launch stream, steps after the timed region (--prof-stride 0)"},
             "extra": {"nn_evals_per_s": evals_sum / t_max, "iterations_per_s": iters_sum / t_max,
                       "timed_region": {"moves_finished": st1["moves_played"] - st0["moves_played"],
                                        "move_boundaries": move_n // 2,

@@ -27,6 +27,9 @@ extern "C" {
 /* enable: 0 stop, 1 all classes, otherwise a mask with bit (k + 1) selecting class k (fewer event records per step) */
 int agz_ctx_prof_enable(agz_ctx* ctx, int enable);
 int agz_ctx_prof_read(agz_ctx* ctx, int klass, int64_t* launches, double* total_ms);
+/* bracket only every stride-th launch of class klass (default 1): two event records per bracketed launch cost GPU time, and a
+ * timed region that wants a kernel's average duration does not need every launch */
+int agz_ctx_prof_set_stride(agz_ctx* ctx, int klass, int stride);
 
 /* Diagnostics (tests): the first two stages of the Winograd path on host data.  x [B][H][W][C] (NHWC, C % 16 == 0),
  * w [N][C][3][3]  ->  V [36][T][C] = Bt d B of every 6x6 input tile, M [36][T][N] = V[pos] * (G g Gt)[pos],
