@@ -1,4 +1,4 @@
-// Winograd F(4x4,3x3) dual block with fp16x2 products in the transform domain — AGZ_COMPUTE_WINO_H2.
+// Winograd F(5x5,3x3) / F(4x4,3x3) dual block with fp16x2 products in the transform domain — AGZ_COMPUTE_WINO_H2.
 //
 // conv_wino.hpp's block spends 0.68 of its 1.07 ms in 36 GEMMs whose bf16x3 products cost six MFMAs each and whose staging
 // splits every fp32 activation into three pieces on the VALU.  Here the transform-domain operands are written ALREADY SPLIT:
@@ -8,17 +8,21 @@
 // matrix instructions of the bf16x3 form, none of its split arithmetic.
 //
 // Range management.  fp16 has 5 exponent bits, so each operand is scaled by a power of two (exact):
-//   weights  U = G g Gt: per layer, max|U| * su in [2^13, 2^14)  — fixed at commit;
-//   V = Bt d B of board b: |V| <= 100 * max|d| (the rows of Bt sum to at most 10 in magnitude), so with amax_b = max |x| over
-//   the board's layer input, s_b = 2^(134 - E(amax_b)) puts every |V*s_b| below 2^15 (fp16 max 65504): overflow is impossible,
-//   and an element hi+lo carries an ABSOLUTE error <= 2^-25 in scaled units, i.e. <= 2^-38 of the largest representable |V| —
-//   far below fp32's own 2^-24 relative rounding of the accumulated sums.  amax_b is a per-board word (one atomicMax per
-//   wave in the producing kernel), so a board's result does not depend on what else is in the batch, bit for bit.
+//   weights  U = G g Gt: per layer, max|U| * su in [2^13, 2^14)  — fixed at commit (inference) or computed on the device
+//   from the current filter (training, wino_u_*_kernel);
+//   V = Bt d B of board b: |V| <= (max row sum of |Bt|)^2 * max|d| <= 2^VSHIFT max|d| (100 for F(4x4), 56.25 for F(5x5)), so with
+//   amax_b = max |x| over the board's layer input, s_b = 2^(141 - VSHIFT - E(amax_b)) puts every |V*s_b| below 2^15 (fp16 max
+//   65504): overflow is impossible, and an element hi+lo carries an ABSOLUTE error <= 2^-25 in scaled units, i.e. <= 2^-38 of the
+//   largest representable |V| — far below fp32's own 2^-24 relative rounding of the accumulated sums.  amax_b is a per-board
+//   quantity — every wave of the producing output transform stores the maximum of what it wrote, the consuming input transform
+//   reduces its board's words — so a board's result does not depend on what else is in the batch, bit for bit.
 //   M = V U comes out scaled by s_b*su and is un-scaled (exactly) after the output transform.
 //
-// Kernels per block:   wino_in_h2_kernel (x -> V2, HBM-bound) ; wino_gemm_h2[w]_kernel (MFMA/HBM) ; wino_out_h2_kernel
-// (M -> y + amax of y for the next block, HBM-bound).  Layouts: V2[pos][T][C/32][piece 2][32] fp16 (a row's K range is
-// contiguous: 128 B per 32-channel chunk, hi then lo);  U2[pos][C/32][piece 2][Ntot][32] fp16;  M[pos][T][Ntot] fp32.
+// Kernels per block:   wino_in_h2_kernel (x -> V2, HBM-bound) ; wino_gemm_h2d_kernel (HBM/MFMA; plain fallbacks for other K
+// extents) ; wino_out_seq_h2_kernel / wino_out_h2_kernel (M -> y + per-wave maxima of y for the next block, HBM-bound) ;
+// training: wino_out_raw_h2_kernel.  Layouts (blocked, default): V2[T/128][pos][128 rows][C/32][piece 2][32] fp16 (a row's K
+// range is contiguous: 128 B per 32-channel chunk, hi then lo);  U2[pos][C/32][piece 2][Ntot][32] fp16;
+// M[T/128][pos][128 rows][Ntot] fp32.  Measurements and the history of each kernel: DESIGN.md section 4e.
 #pragma once
 // (included by net.hip INSIDE namespace agz, after conv_wino.hpp and conv_h2.hpp)
 
