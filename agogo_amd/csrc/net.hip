@@ -796,11 +796,14 @@ int agz_net::build_wino_h2_weights() {
     AGZ_HIP_TRY(hipMalloc(&d_u2_dual[l], u2.size() * 2));
     AGZ_HIP_TRY(hipMemcpyAsync(d_u2_dual[l], u2.data(), u2.size() * 2, hipMemcpyHostToDevice, ctx->stream));
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (want_f4 && wino_tm == 4) { d_u2_f4[l] = d_u2_dual[l]; u_unscale_f4[l] = u_unscale[l]; }
-    else if (want_f4) {
-      u_unscale_f4[l] = agz::wino_build_u2<4>(u2, 2 * Kp, Kp, getw);
-      AGZ_HIP_TRY(hipMalloc(&d_u2_f4[l], u2.size() * 2));
-      AGZ_HIP_TRY(hipMemcpyAsync(d_u2_f4[l], u2.data(), u2.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    if (want_f4) {
+      // the fused kernel's image: F(4x4,3x3) weights in MFMA operand order per (position, K step, column block)
+      if (wino_tm == 4) u_unscale_f4[l] = u_unscale[l];
+      else u_unscale_f4[l] = agz::wino_build_u2<4>(u2, 2 * Kp, Kp, getw);
+      std::vector<_Float16> uf;
+      agz::wino_fused_permute_u2(u2, Kp, Kp, uf);
+      AGZ_HIP_TRY(hipMalloc(&d_u2_f4[l], uf.size() * 2));
+      AGZ_HIP_TRY(hipMemcpyAsync(d_u2_f4[l], uf.data(), uf.size() * 2, hipMemcpyHostToDevice, ctx->stream));
       AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
   }
@@ -808,8 +811,7 @@ int agz_net::build_wino_h2_weights() {
 }
 
 void agz_net::free_wino_h2_weights() {
-  for (size_t l = 0; l < d_u2_f4.size(); l++)
-    if (d_u2_f4[l] && (l >= d_u2_dual.size() || d_u2_f4[l] != d_u2_dual[l])) hipFree(d_u2_f4[l]);
+  for (auto& p : d_u2_f4) if (p) hipFree(p);
   d_u2_f4.clear();
   for (auto& p : d_u2_dual) if (p) hipFree(p);
   d_u2_dual.clear();
