@@ -85,11 +85,6 @@ struct WinoH2Args {
   // within npos * 128 rows, so the transform kernels' (tm+2)^2 streams stay inside a few pages.  Plain layout: [npos][T + pad].
   int rsh, rmask;
   unsigned rA, rB;
-  // V word address of (row R, 32-channel chunk q, word w) = R * v_row_w + q * v_chunk_w + w.  Three-kernel block: v_row_w = C,
-  // v_chunk_w = 32 (a row's whole K range contiguous).  Fused kernel (conv_wino_fused.hpp): v_row_w = 32, v_chunk_w = 64 * 32 with
-  // R = (t / 64) * (npos * NK * 64) + pos * (NK * 64) + t % 64 — the 64 rows x 128 B of one (row block, position, K step) contiguous.
-  unsigned v_row_w, v_chunk_w;
-  int tile_major;            // 1 (fused kernel): V rows are ordered (tile position, board) — row = tt * B + b — instead of (board, tile position)
   int raw;                   // 1 (training convolutions): the output stage is wino_out_raw_h2_kernel — At M A un-scaled, no epilogue,
                              // all Ntot columns as they are, y [B][Hp][Wp][Ntot] — and w_unscale is read from w_unscale_dev
   const float* w_unscale_dev;
@@ -184,14 +179,13 @@ __global__ __launch_bounds__(256) void wino_in_h2_kernel(WinoH2Args h) {
   }
   unsigned* V2 = reinterpret_cast<unsigned*>(a.V);          // 4-byte words: [pos][T][C/32][2][16]
   const int c = 2 * c2;
-  const size_t word_in_row = (size_t)(c >> 5) * h.v_chunk_w + ((c & 31) >> 1);   // hi word; the lo word sits 16 words further
+  const size_t word_in_row = (size_t)(c >> 5) * 32 + ((c & 31) >> 1);   // hi word; the lo word sits 16 words further
   // Store forms (h.in_swap, uniform).  0: every lane stores its own hi and lo word — per instruction four 64-byte runs (16 lanes
   // fill the hi half of a 32-channel chunk).  1 (C % 128 == 0, the block size keeps a wave inside one tile): v_permlane16_swap
   // gathers a chunk's hi and lo halves into 32 neighbouring lanes and v_permlane32_swap puts two neighbouring chunks into one
   // register: per instruction ONE 256-byte run (lanes 0..63 = 64 consecutive words of the row).
   const int lane = threadIdx.x & 63;
-  const int trow = h.tile_major ? tt * a.B + b : t;
-  const size_t swap_word = (size_t)((c2 >> 6) * 4 + (lane >> 5)) * h.v_chunk_w + (lane & 31);   // chunks 4q, 4q+1 of the wave's 4 chunks; the others two chunks on
+  const size_t swap_word = (size_t)((c2 >> 6) * 4) * 32 + lane;           // chunks 4q, 4q+1 of the wave's 4 chunks; the others 64 words on
 #pragma unroll
   for (int i = 0; i < AL; i++) {
     float ox[AL], oy[AL];
@@ -201,14 +195,14 @@ __global__ __launch_bounds__(256) void wino_in_h2_kernel(WinoH2Args h) {
     for (int j = 0; j < AL; j++) {
       unsigned lo;
       const unsigned hi = wino_h2_pack(ox[j] * sb, oy[j] * sb, &lo);
-      unsigned* rowp = V2 + h2_row(h, i * AL + j, trow) * h.v_row_w;
+      unsigned* rowp = V2 + h2_row(h, i * AL + j, t) * a.C;
       if (h.in_swap) {
         const auto s16 = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);   // [hi r0, lo r0, hi r2, lo r2], [hi r1, lo r1, hi r3, lo r3]
         const unsigned e0 = s16[0], e1 = s16[1];
         const auto s32 = __builtin_amdgcn_permlane32_swap(e0, e1, false, false);   // [chunk 0, chunk 1], [chunk 2, chunk 3]
         const unsigned w0 = s32[0], w1 = s32[1];
         rowp[swap_word] = w0;
-        rowp[swap_word + 2 * (size_t)h.v_chunk_w] = w1;
+        rowp[swap_word + 64] = w1;
       } else {
         rowp[word_in_row] = hi;
         rowp[word_in_row + 16] = lo;
@@ -1054,7 +1048,6 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
   a.nty = ceil_div(a.H, tm); a.ntx = ceil_div(a.W, tm); a.TPB = a.nty * a.ntx; a.T = a.B * a.TPB;
   if (wino_h2_blocked()) { h.rsh = 7; h.rmask = 127; h.rA = (unsigned)h.npos * 128u; h.rB = 128u; }
   else { h.rsh = 31; h.rmask = 0x7fffffff; h.rA = 0; h.rB = (unsigned)(a.T + wino_h2_pos_pad()); }
-  h.v_row_w = (unsigned)a.C; h.v_chunk_w = 32u; h.tile_major = 0;
   a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
   static const int in_swap_env = [] { const char* e = getenv("AGZ_WINO_H2_IN_SWAP"); return e ? atoi(e) : 1; }();
   h.in_swap = (in_swap_env && a.C % 128 == 0) ? 1 : 0;   // a wave = 64 channel pairs of ONE tile

@@ -298,7 +298,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 #include "conv_wino.hpp"
 #include "conv_h2.hpp"
 #include "conv_wino_h2.hpp"
-#include "conv_wino_fused.hpp"
 
 
 // device-side weight split for the trainer (weights change every step): one thread per (tap, n, ci)
@@ -580,9 +579,10 @@ void agz_net::free_device() {
   if (d_amax) { hipFree(d_amax); d_amax = nullptr; }
   amax_cap = 0;
   for (auto& p : d_u3_dual) if (p) { hipFree(p); p = nullptr; }
-  free_wino_h2_weights();
+  for (auto& p : d_u2_dual) if (p) { hipFree(p); p = nullptr; }
+  d_u2_dual.clear();
   f(d_wV); f(d_wM);
-  wino_chunk_cap = 0; wino_v_cap = 0; wino_m_cap = 0;
+  wino_chunk_cap = 0; wino_v_cap = 0;
   d_w_dual.clear(); d_ep_dual.clear(); d_w3_dual.clear(); d_w2_dual.clear(); d_u3_dual.clear();
   f(d_head_conv); f(d_head_bn); f(d_Wp); f(d_bp); f(d_W1); f(d_b1); f(d_W2); f(d_b2);
   f(d_act_in); f(d_actA); f(d_actB); f(d_planes); f(d_policy); f(d_value); f(d_ws); f(d_hs);
@@ -774,12 +774,9 @@ int agz_net::build_wino_h2_weights() {
   wino_tm = agz::wino_h2_pick_tm(H, W);
   AGZ_REQUIRE((size_t)(wino_tm + 2) * (wino_tm + 2) * (Kp / 32) * 2 * (2 * Kp) * 64 < ((size_t)1 << 32), AGZ_E_UNSUPPORTED, "agz_net: K %d too wide for the Winograd weight image", conf.K);
   AGZ_HIP_TRY(hipSetDevice(ctx->device));
-  free_wino_h2_weights();
+  for (auto& p : d_u2_dual) if (p) hipFree(p);
   d_u2_dual.assign(conf.SharedLayers, nullptr);
   u_unscale.assign(conf.SharedLayers, 1.0f);
-  d_u2_f4.assign(conf.SharedLayers, nullptr);
-  u_unscale_f4.assign(conf.SharedLayers, 1.0f);
-  const bool want_f4 = agz::wino_fused_nk_ok(Kp);
   const int K = conf.K;
   size_t pi = 3;
   std::vector<_Float16> u2;
@@ -796,25 +793,8 @@ int agz_net::build_wino_h2_weights() {
     AGZ_HIP_TRY(hipMalloc(&d_u2_dual[l], u2.size() * 2));
     AGZ_HIP_TRY(hipMemcpyAsync(d_u2_dual[l], u2.data(), u2.size() * 2, hipMemcpyHostToDevice, ctx->stream));
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (want_f4) {
-      // the fused kernel's image: F(4x4,3x3) weights in MFMA operand order per (position, K step, column block)
-      if (wino_tm == 4) u_unscale_f4[l] = u_unscale[l];
-      else u_unscale_f4[l] = agz::wino_build_u2<4>(u2, 2 * Kp, Kp, getw);
-      std::vector<_Float16> uf;
-      agz::wino_fused_permute_u2(u2, Kp, Kp, uf);
-      AGZ_HIP_TRY(hipMalloc(&d_u2_f4[l], uf.size() * 2));
-      AGZ_HIP_TRY(hipMemcpyAsync(d_u2_f4[l], uf.data(), uf.size() * 2, hipMemcpyHostToDevice, ctx->stream));
-      AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
   }
   return AGZ_OK;
-}
-
-void agz_net::free_wino_h2_weights() {
-  for (auto& p : d_u2_f4) if (p) hipFree(p);
-  d_u2_f4.clear();
-  for (auto& p : d_u2_dual) if (p) hipFree(p);
-  d_u2_dual.clear();
 }
 
 int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
@@ -915,7 +895,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         d_wV = d_wM = nullptr; wino_chunk_cap = 0;
         AGZ_HIP_TRY(hipMalloc(&d_wV, (size_t)36 * B * tpb * Kp * sizeof(float)));
         AGZ_HIP_TRY(hipMalloc(&d_wM, (size_t)36 * B * tpb * 2 * Kp * sizeof(float)));
-        wino_chunk_cap = B; wino_v_cap = 0; wino_m_cap = 0;
+        wino_chunk_cap = B; wino_v_cap = 0;
       }
       WinoArgs wa{};
       wa.V = d_wV; wa.Mb = d_wM;
@@ -943,17 +923,8 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     static const int wide_env = [] { const char* e = getenv("AGZ_WINO_H2_WIDE"); return e ? atoi(e) : -1; }();
     static const int pfa_env = [] { const char* e = getenv("AGZ_WINO_H2_PFA"); return e ? atoi(e) : -1; }();
     const int pfa = pfa_env >= 0 ? pfa_env : 2;
-    // Fused form (conv_wino_fused.hpp, round 3): F(4x4,3x3) with the output transform and the epilogue inside the GEMM kernel — no
-    // M in memory.  Taken when its workgroups (64 tiles x 32 channels) fill the chip at least twice; AGZ_WINO_H2_FUSED=0 keeps
-    // the three-kernel block, =2 takes the fused form at every batch size (tuning / A-B / test knob).
-    static const int fused_env = [] { const char* e = getenv("AGZ_WINO_H2_FUSED"); return e ? atoi(e) : 1; }();
-    const int tpb4 = ceil_div(H, 4) * ceil_div(W, 4);
-    const bool fused = fused_env && agz::wino_fused_nk_ok(Kp) && (int)d_u2_f4.size() == conf.SharedLayers && d_u2_f4[0] &&
-                       (fused_env == 2 || (size_t)ceil_div(B * tpb4, 64) * (Kp / 32) >= (size_t)2 * ctx->num_cus) &&
-                       wino_h2_rows(36, (size_t)B * tpb4) * Kp * 4 < ((size_t)1 << 31);
-    const int tm_run = fused ? 4 : wino_tm;
-    const int npos = (tm_run + 2) * (tm_run + 2);
-    const int tpb = ceil_div(H, tm_run) * ceil_div(W, tm_run);
+    const int npos = (wino_tm + 2) * (wino_tm + 2);
+    const int tpb = ceil_div(H, wino_tm) * ceil_div(W, wino_tm);
     // ... and the 128-column tile when the 256-column grid would leave CUs without a workgroup (a lane round of 16 boards: 196
     // against 392 workgroups, 0.0747 -> 0.0726 ms per block, p50 move 0.250 -> 0.241 s)
     const bool wide = wide_env >= 0 ? wide_env != 0
@@ -961,36 +932,29 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     // Board chunks and queues (tuning knobs AGZ_WINO_H2_CHUNK = boards per chunk, AGZ_WINO_H2_STREAMS = 1 | 2): chunk i runs its
     // block chain on queue i % streams with that queue's scratch — chains of different boards are independent (per-board ranges),
     // so one chunk's HBM-bound transform kernels can overlap another chunk's GEMM, and a chunk whose V + M fit the 256 MB Infinity
-    // Cache re-reads them from there.  Default: one chunk (bounded by the 32-bit V offsets), one queue.  (The fused form: one chunk.)
+    // Cache re-reads them from there.  Default: one chunk (bounded by the 32-bit V offsets), one queue.
     static const int chunk_env = [] { const char* e = getenv("AGZ_WINO_H2_CHUNK"); return e ? atoi(e) : 0; }();
     static const int streams_env = [] { const char* e = getenv("AGZ_WINO_H2_STREAMS"); return e ? atoi(e) : 1; }();
     // 32-bit byte offsets into V: npos * (tiles rounded up to 128 + pad) * Kp * 4 < 2^32
     const int chunk_max = (int)std::min<size_t>((size_t)B, ((((size_t)1 << 32) - 1) / ((size_t)npos * Kp * 4) - 127 - wino_h2_pos_pad()) / tpb);
-    int chunk = fused ? B : (chunk_env >= 1 ? std::min(chunk_env, chunk_max) : chunk_max);
-    const int ns = (!fused && streams_env == 2 && B >= 64) ? 2 : 1;
+    int chunk = chunk_env >= 1 ? std::min(chunk_env, chunk_max) : chunk_max;
+    const int ns = (streams_env == 2 && B >= 64) ? 2 : 1;
     if (ns == 2 && chunk >= B) chunk = (B + 1) / 2;
-    const size_t v_elems = wino_h2_rows(npos, (size_t)chunk * tpb) * Kp, m_elems = fused ? 0 : 2 * v_elems;
-    if (v_elems * ns > wino_v_cap || m_elems * ns > wino_m_cap) {
+    const size_t v_elems = wino_h2_rows(npos, (size_t)chunk * tpb) * Kp, m_elems = 2 * v_elems;
+    if (v_elems * ns > wino_v_cap) {
       AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
       if (ctx->stream2) AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream2));
-      if (v_elems * ns > wino_v_cap) {
-        if (d_wV) hipFree(d_wV);
-        d_wV = nullptr; wino_v_cap = 0;
-        AGZ_HIP_TRY(hipMalloc(&d_wV, v_elems * ns * sizeof(float)));
-        wino_v_cap = v_elems * ns;
-      }
-      if (m_elems * ns > wino_m_cap) {
-        if (d_wM) hipFree(d_wM);
-        d_wM = nullptr; wino_m_cap = 0;
-        AGZ_HIP_TRY(hipMalloc(&d_wM, m_elems * ns * sizeof(float)));
-        wino_m_cap = m_elems * ns;
-      }
-      wino_chunk_cap = 0;   // (the fp32-V Winograd path sizes by boards: force its re-allocation)
+      if (d_wV) hipFree(d_wV);
+      if (d_wM) hipFree(d_wM);
+      d_wV = d_wM = nullptr; wino_chunk_cap = 0;
+      AGZ_HIP_TRY(hipMalloc(&d_wV, v_elems * ns * sizeof(float)));
+      AGZ_HIP_TRY(hipMalloc(&d_wM, m_elems * ns * sizeof(float)));
+      wino_v_cap = v_elems * ns; wino_chunk_cap = 0;   // (the fp32-V Winograd path sizes by boards: force its re-allocation)
     }
-    // per-board ranges [blocks+1][B], then the per-tile maxima of the output stage [chunk tiles][Kp/64] (three-kernel form) or
-    // [tiles][Kp/32] (fused form), as floats: every chunk of boards keeps its own region from one block to the next (the next
-    // block's input transform reduces them)
-    const size_t wm_board = (size_t)tpb * (fused ? (Kp >> 5) : (Kp >> 6));
+    // per-board ranges [blocks+1][B], then the per-wave maxima of the output kernel [queues][chunk tiles][Kp/64] (as floats)
+    // per-wave maxima of the output kernel: every chunk of boards keeps its own region from one block to the next (the next
+    // block's input transform reduces them), one word per tile and 64 channels
+    const size_t wm_board = (size_t)tpb * (Kp >> 6);
     const size_t need_amax = (size_t)(conf.SharedLayers + 1) * B + wm_board * B;
     if (need_amax > amax_cap) {
       AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1021,12 +985,11 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         wa.x = cur + (size_t)b0 * Hp * Wp * Kp; wa.y = nxt + (size_t)b0 * Hp * Wp * Kp;
         wa.V = d_wV + (size_t)q * v_elems; wa.Mb = d_wM + (size_t)q * m_elems; wa.ep = d_ep_dual[l];
         wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
-        hh.U2 = fused ? d_u2_f4[l] : d_u2_dual[l]; hh.w_unscale = fused ? u_unscale_f4[l] : u_unscale[l]; hh.tm = tm_run;
+        hh.U2 = d_u2_dual[l]; hh.w_unscale = u_unscale[l]; hh.tm = wino_tm;
         hh.amax_in = d_amax + (size_t)l * B + b0; hh.amax_out = d_amax + (size_t)(l + 1) * B + b0;
         hh.wave_max = d_wave_max + (size_t)b0 * wm_board;
         hh.fuse_prev = l > 0;   // block 0's input range comes from board_amax_kernel above
-        if (fused) wino_fused_launch(ctx, hh, ctx->stream);
-        else wino_h2_launch(ctx, hh, wide, pfa, q ? ctx->stream2 : ctx->stream);
+        wino_h2_launch(ctx, hh, wide, pfa, q ? ctx->stream2 : ctx->stream);
       }
       std::swap(cur, nxt);
     }
@@ -1069,7 +1032,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         d_wV = d_wM = nullptr; wino_chunk_cap = 0;
         AGZ_HIP_TRY(hipMalloc(&d_wV, (size_t)36 * chunk * tpb * Kp * sizeof(float)));
         AGZ_HIP_TRY(hipMalloc(&d_wM, (size_t)36 * chunk * tpb * 2 * Kp * sizeof(float)));
-        wino_chunk_cap = chunk; wino_v_cap = 0; wino_m_cap = 0;
+        wino_chunk_cap = chunk; wino_v_cap = 0;
       }
       ProfScope ps(ctx, AGZ_PROF_CONV);
       for (int b0 = 0; b0 < B; b0 += chunk) {
@@ -1427,7 +1390,8 @@ int agz_net_commit(agz_net* n) {
     (void)A; (void)FCn;
   }
   n->committed = true;
-  n->free_wino_h2_weights();
+  for (auto& p : n->d_u2_dual) if (p) hipFree(p);
+  n->d_u2_dual.clear();
   if ((n->compute_mode == AGZ_COMPUTE_WINO || n->compute_mode == AGZ_COMPUTE_AUTO) && n->cfg == 0) return n->build_wino_weights();
   if (n->compute_mode == AGZ_COMPUTE_WINO_H2 && n->cfg == 0) return n->build_wino_h2_weights();
   return AGZ_OK;

@@ -56,14 +56,9 @@ struct agz_net {
   std::vector<unsigned short*> d_u3_dual;  // per layer Winograd-domain bf16x3 image [36][Kp/16][3][2*Kp][16] (AGZ_COMPUTE_WINO), conv_wino.hpp
   std::vector<_Float16*> d_u2_dual;        // per layer Winograd-domain fp16x2 image [36][Kp/32][2][2*Kp][32] (AGZ_COMPUTE_WINO_H2), conv_wino_h2.hpp
   std::vector<float> u_unscale;            // per layer 1 / (power-of-two scale of that image)
-  // the F(4x4,3x3) image of the fused GEMM + output-transform kernel (conv_wino_fused.hpp): [36][Kp/32][Kp/32][8][64][8]
-  std::vector<_Float16*> d_u2_f4;
-  std::vector<float> u_unscale_f4;
-  void free_wino_h2_weights();
   int build_wino_h2_weights();
   int wino_tm = 4;                         // tile size of that path: 4 = F(4x4,3x3), 5 = F(5x5,3x3), chosen per board size
   size_t wino_v_cap = 0;                   // floats the V scratch holds (fp16x2 path)
-  size_t wino_m_cap = 0;                   // floats the M scratch holds (fp16x2 path; the fused form needs none)
   float* d_wV = nullptr;                   // Winograd scratch: transformed input [36][T][Kp] and GEMM output [36][T][2*Kp] of one chunk
   float* d_wM = nullptr;
   int wino_chunk_cap = 0;                  // boards the scratch is sized for
