@@ -110,6 +110,7 @@ def lib():
     sig("agz_net_infer", i32, vp, pf, i32, pf, pf)
     sig("agz_net_infer_dev", i32, vp, vp, i32, vp, vp)
     sig("agz_net_set_latency_mode", i32, vp, i32)
+    sig("agz_net_set_tower_queues", i32, vp, i32)
     sig("agz_net_set_compute_mode", i32, vp, i32)
     sig("agz_net_flops_per_eval", f64, vp)
     sig("agz_net_save", i32, vp, C.c_char_p)
@@ -332,6 +333,9 @@ class Net:
 
     def set_latency_mode(self, on=True):
         _check(lib().agz_net_set_latency_mode(self.h, int(on)), "agz_net_set_latency_mode")
+
+    def set_tower_queues(self, queues):
+        _check(lib().agz_net_set_tower_queues(self.h, int(queues)), "agz_net_set_tower_queues")
 
     def infer_dev(self, planes_ptr, B, policy_ptr, value_ptr):
         """device pointers (ints); asynchronous on the ctx stream"""

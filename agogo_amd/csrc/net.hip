@@ -929,16 +929,17 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     // against 392 workgroups, 0.0747 -> 0.0726 ms per block, p50 move 0.250 -> 0.241 s)
     const bool wide = wide_env >= 0 ? wide_env != 0
                                     : ((2 * Kp) % 256 == 0 && (size_t)npos * ceil_div(B * tpb, 128) * ((2 * Kp) / 256) >= (size_t)ctx->num_cus);
-    // Board chunks and queues (tuning knobs AGZ_WINO_H2_CHUNK = boards per chunk, AGZ_WINO_H2_STREAMS = 1 | 2): chunk i runs its
-    // block chain on queue i % streams with that queue's scratch — chains of different boards are independent (per-board ranges),
-    // so one chunk's HBM-bound transform kernels can overlap another chunk's GEMM, and a chunk whose V + M fit the 256 MB Infinity
-    // Cache re-reads them from there.  Default: one chunk (bounded by the 32-bit V offsets), one queue.
+    // Board chunks and queues (agz_net_set_tower_queues; AGZ_WINO_H2_CHUNK = boards per chunk, AGZ_WINO_H2_QUEUES = 1 | 2 override):
+    // chunk i runs its block chain on queue i % queues with that queue's scratch — chains of different boards are independent
+    // (per-board ranges, bit-identical results), so one half-batch's HBM-bound transform kernels run under the other's GEMM and
+    // fill the GEMM's last partial round of workgroups: 15.39 -> 14.51 ms per 512-board pass (round 2), the default from 256 boards.
     static const int chunk_env = [] { const char* e = getenv("AGZ_WINO_H2_CHUNK"); return e ? atoi(e) : 0; }();
-    static const int streams_env = [] { const char* e = getenv("AGZ_WINO_H2_STREAMS"); return e ? atoi(e) : 1; }();
+    static const int queues_env = [] { const char* e = getenv("AGZ_WINO_H2_QUEUES"); return e ? atoi(e) : 0; }();
+    const int queues_want = queues_env > 0 ? queues_env : (tower_queues > 0 ? tower_queues : (B >= 256 ? 2 : 1));
     // 32-bit byte offsets into V: npos * (tiles rounded up to 128 + pad) * Kp * 4 < 2^32
     const int chunk_max = (int)std::min<size_t>((size_t)B, ((((size_t)1 << 32) - 1) / ((size_t)npos * Kp * 4) - 127 - wino_h2_pos_pad()) / tpb);
     int chunk = chunk_env >= 1 ? std::min(chunk_env, chunk_max) : chunk_max;
-    const int ns = (streams_env == 2 && B >= 64) ? 2 : 1;
+    const int ns = (queues_want == 2 && B >= 64) ? 2 : 1;
     if (ns == 2 && chunk >= B) chunk = (B + 1) / 2;
     const size_t v_elems = wino_h2_rows(npos, (size_t)chunk * tpb) * Kp, m_elems = 2 * v_elems;
     if (v_elems * ns > wino_v_cap) {
@@ -1448,6 +1449,12 @@ int agz_net_set_compute_mode(agz_net* n, int mode) {
   n->compute_force = (mode & AGZ_COMPUTE_FORCE) != 0;
   if ((base == AGZ_COMPUTE_WINO || base == AGZ_COMPUTE_AUTO) && n->committed && n->cfg == 0 && n->d_u3_dual.empty()) return n->build_wino_weights();
   if (base == AGZ_COMPUTE_WINO_H2 && n->committed && n->cfg == 0 && n->d_u2_dual.empty()) return n->build_wino_h2_weights();
+  return AGZ_OK;
+}
+
+int agz_net_set_tower_queues(agz_net* n, int queues) {
+  AGZ_REQUIRE(n && queues >= 0 && queues <= 2, AGZ_E_INVALID, "agz_net_set_tower_queues: queues must be 0 (auto), 1 or 2");
+  n->tower_queues = queues;
   return AGZ_OK;
 }
 

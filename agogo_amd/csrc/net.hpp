@@ -89,6 +89,7 @@ struct agz_net {
   size_t ws_cap = 0;
   float* d_hs = nullptr;      // latency-regime head scratch: [B][3][HW] features + [B][A+FC] columns
   size_t hs_cap = 0;
+  int tower_queues = 0;       // agz_net_set_tower_queues: 0 = auto (two from 256 boards), 1, 2
   bool latency_mode = true;   // allow the small-batch regime (split-K tower + spread heads), agz_net_set_latency_mode
 
   int ensure_batch(int B);

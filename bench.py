@@ -228,6 +228,9 @@ def main():
     ap.add_argument("--no-go9-leg", action="store_true", help="skip the measured 9x9 games/s leg (configs[2])")
     ap.add_argument("--prof-stride", type=int, default=4,
                     help="inside the timed region every N-th launch of the dominant kernel is bracketed with HIP events (0: none)")
+    ap.add_argument("--tower-queues", type=int, default=0, choices=[0, 1, 2],
+                    help="agz_net_set_tower_queues: 0 = library default (two queues from 256 boards), 1, 2.  With two queues the per-kernel "
+                         "durations of the roofline are taken on isolated one-queue steps right after the timed region")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="debug: all ranks use GPU 0 and gloo collectives (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -256,6 +259,7 @@ def main():
         standard_bn_init(net)
         net.commit()
         net.set_compute_mode(MODES[args.compute])
+        net.set_tower_queues(args.tower_queues)
         nets.append(net)
     arena = A.Arena(ctx, capi.GAME_WQ, S, S, komi=7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337 + rank,
                     Budget=args.budget, PUCT=1.0, RandomCount=0, DumbPass=True,
@@ -317,9 +321,15 @@ def main():
     dom = capi.PROF_WINO_GEMM if args.compute in ("wino", "wino_h2") else capi.PROF_CONV
     # ... and of the dominant kernel only every --prof-stride-th launch (default 4: 100+ of the timed region's 400+ launches):
     # the roofline needs the kernel's AVERAGE duration over the region, and each bracketed launch costs two event records
-    if args.prof_stride > 0:
+    # Two queues (the library default from 256 boards for wino_h2): the half-batch chains overlap, every kernel's own duration
+    # inflates and only queue 0's launches could be bracketed — per-kernel time is then taken on the isolated one-queue steps below
+    two_queues = args.compute == "wino_h2" and G >= 256 and args.tower_queues != 1
+    in_region_prof = args.prof_stride > 0 and not two_queues
+    if in_region_prof:
         ctx.prof_set_stride(dom, args.prof_stride)
         ctx.prof_enable(True, classes=[dom, capi.PROF_MOVE])
+    elif two_queues:
+        ctx.prof_enable(True, classes=[capi.PROF_MOVE])
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -331,11 +341,17 @@ def main():
     dom_n, dom_ms = ctx.prof_read(dom)
     move_n, _ = ctx.prof_read(capi.PROF_MOVE)
     ctx.prof_set_stride(dom, 1)
+    if two_queues:
+        for n_ in nets:
+            n_.set_tower_queues(1)
     ctx.prof_enable(True)
     for _ in range(6):
         step()
     fence()
     ctx.prof_enable(False)
+    if two_queues:
+        for n_ in nets:
+            n_.set_tower_queues(args.tower_queues)
 
     sims = st1["sims_nonnull"] - st0["sims_nonnull"]
     sims_all = st1["sims_total"] - st0["sims_total"]
@@ -356,7 +372,10 @@ def main():
         prof[name] = {"launches": n, "avg_ms": (ms / n) if n else None, "total_ms": ms}
     dom_name = "wino_gemm" if args.compute in ("wino", "wino_h2") else "conv_dual"
     prof[dom_name + "_timed_region"] = {"launches": dom_n, "avg_ms": (dom_ms / dom_n) if dom_n else None, "total_ms": dom_ms}
-    prof["breakdown_note"] = "all classes: six extra steps after the timed region; *_timed_region: HIP events inside the timed region"
+    prof["breakdown_note"] = ("all classes: six extra steps after the timed region%s; *_timed_region: HIP events inside the timed region"
+                              % (" on ONE queue (the timed region runs the tower on two)" if two_queues else ""))
+    if not in_region_prof:
+        prof[dom_name + "_timed_region"] = {"launches": 0, "avg_ms": None, "total_ms": 0.0}
 
     # short comparison legs in the other compute modes (same arena, the games simply continue)
     legs = {}
@@ -525,7 +544,8 @@ def main():
                                    % (K, L, 2 * K, Aspace, G, args.budget, G, str(not args.two_nets)),
                        "board": S, "K": K, "blocks": L, "games_per_gpu": G, "sims_per_move": args.budget,
                        "weights": "random-init seed 1337 (GlorotU conv, GlorotN FC; BN gamma=1 beta=0, identity stats)",
-                       "parallelism": "games sharded %d/GPU, no data-path collective" % G},
+                       "parallelism": "games sharded %d/GPU, no data-path collective" % G,
+                       "tower_queues": 2 if two_queues else 1},
             "roofline": ({"bound": "hbm", "achieved": wino_detail["wino_gemm"]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": wino_detail["wino_gemm"]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                           "algorithmic_bytes_per_launch": wino_detail["wino_gemm"]["algorithmic_bytes"]}
@@ -536,7 +556,11 @@ def main():
                          "flops_per_launch": flops_launch, "avg_launch_ms": launch_ms,
                          "launches": n_launch,
                          "timing": ("HIP events on the launch stream around every %d-th launch of the kernel inside the timed region "
-                                    "(%d launches bracketed)" % (args.prof_stride, n_launch)) if args.prof_stride > 0 else
+                                    "(%d launches bracketed)" % (args.prof_stride, n_launch)) if in_region_prof else
+                                   ("HIP events on the launch stream around every launch of the kernel on six ONE-queue steps right after "
+                                    "the timed region (%d launches): the timed region runs the tower on two queues (agz_net_set_tower_queues), "
+                                    "where the half-batch chains overlap and a kernel's own duration is not defined; "
+                                    "`bench.py --tower-queues 1` measures the same kernel inside the timed region" % n_launch) if two_queues else
                                    "HIP events on the launch stream, steps after the timed region (--prof-stride 0)"},
             "extra": {"nn_evals_per_s": evals_sum / t_max, "iterations_per_s": iters_sum / t_max,
                       "timed_region": {"moves_finished": st1["moves_played"] - st0["moves_played"],

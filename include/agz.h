@@ -112,6 +112,11 @@ int agz_net_infer_dev(agz_net* net, const float* planes_dev, int B, float* polic
  * two regimes the fp32 summation order differs (same tolerance vs the reference).  Turn it off for strict bitwise
  * batch-size independence at every batch size. */
 int agz_net_set_latency_mode(agz_net* net, int on);
+/* Queues the Winograd fp16x2 tower (AGZ_COMPUTE_WINO_H2) runs on: 2 = the batch is split into two halves whose block chains
+ * run on two HIP streams, so one half's HBM-bound transform kernels run under the other half's GEMM (boards are independent:
+ * results are bit-identical to one queue); 1 = one launch chain over the whole batch; 0 = auto (two queues from 256 boards
+ * on, the default).  Per-kernel durations inflate under the overlap: measure kernels with 1. */
+int agz_net_set_tower_queues(agz_net* net, int queues);
 /* Arithmetic of the dual-block convolutions (both are fp32-grade and meet the same parity tolerance):
  *   AGZ_COMPUTE_F32_MFMA  v_mfma_f32_32x32x2_f32, exact fp32 products (default)
  *   AGZ_COMPUTE_BF16X3    every fp32 operand split exactly into three bf16 pieces, six bf16 MFMAs per product

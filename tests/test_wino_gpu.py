@@ -168,6 +168,28 @@ np.save(sys.argv[1], np.concatenate([pol.ravel(), val.ravel()]))
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+def test_wino_h2_two_queue_tower_is_bit_identical(ctx):
+    """agz_net_set_tower_queues: the batch split into two half chains on two HIP streams (the default from 256 boards on) gives the
+    same bits as one chain over the whole batch — boards are independent (per-board ranges) — at a batch the auto rule splits (256)
+    and at an odd one, forced."""
+    onet, gnet = make_pair(ctx, 64, 2, 32, 9, 9, 18, 82, 2)
+    gnet.set_compute_mode(A.capi.COMPUTE_WINO_H2 | A.capi.COMPUTE_FORCE)
+    for B in (256, 77):
+        x = rand_planes(B, 18, 9, 9, seed=B)
+        gnet.set_tower_queues(1)
+        p1, v1 = gnet.infer(x)
+        gnet.set_tower_queues(2)
+        p2, v2 = gnet.infer(x)
+        gnet.set_tower_queues(0)
+        p0, v0 = gnet.infer(x)
+        np.testing.assert_array_equal(p1, p2)
+        np.testing.assert_array_equal(v1, v2)
+        np.testing.assert_array_equal(p1, p0)
+        np.testing.assert_array_equal(v1, v0)
+    with pytest.raises(A.AgzError):
+        gnet.set_tower_queues(3)
+
+
 H2_KNOBS = [
     {"AGZ_WINO_H2_TM": "4"},                                       # F(4x4,3x3) on boards where F(5x5,3x3) is the default
     {"AGZ_WINO_H2_TM": "5", "AGZ_WINO_H2_OUT_PAIR": "0"},          # F(5x5,3x3) with the one-thread-per-channel output transform
@@ -177,7 +199,7 @@ H2_KNOBS = [
     {"AGZ_WINO_H2_FUSE_MAX": "0", "AGZ_WINO_H2_CHUNK": "16"},
     {"AGZ_WINO_H2_LAYOUT": "plain", "AGZ_WINO_H2_PAD": "9"},       # [position][tile] layout of V and M, padded
     {"AGZ_WINO_H2_CHUNK": "16"},                                   # board chunks
-    {"AGZ_WINO_H2_CHUNK": "16", "AGZ_WINO_H2_STREAMS": "2"},       # board chunks on two queues
+    {"AGZ_WINO_H2_CHUNK": "16", "AGZ_WINO_H2_QUEUES": "2"},        # board chunks on two queues
     {"AGZ_WINO_H2_WIDE": "0", "AGZ_WINO_H2_PFA": "0"},             # 128x128 GEMM tile, no operand prefetch
 ]
 
