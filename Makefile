@@ -11,7 +11,11 @@ SRCS := $(CS)/ctx.hip $(CS)/net.hip $(CS)/engine.hip $(CS)/train.hip $(CS)/examp
 OBJS := $(OUT)/ctx.o $(OUT)/net.o $(OUT)/engine.o $(OUT)/train.o $(OUT)/examples.o $(OUT)/comm.o
 HDRS := $(wildcard $(CS)/*.hpp) include/agz.h
 
-all: $(OUT)/libagz.so oracle tests/cpp/az_learn_ttt tests/cpp/gtp_main
+all: $(OUT)/libagz.so oracle tests/cpp/az_learn_ttt tests/cpp/gtp_main tests/fake_rccl/librccl_fake.so
+
+# TEST INFRASTRUCTURE: a process-per-rank stand-in for librccl (AGZ_RCCL_LIB) so the N > 1 exchange executes on a one-GPU box
+tests/fake_rccl/librccl_fake.so: tests/fake_rccl/fake_rccl.cpp
+	g++ -std=c++17 -O1 -shared -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include $< -o $@ -L/opt/rocm/lib -lamdhip64 -lrt -Wl,-rpath,/opt/rocm/lib
 
 # host-side C++ mirror of the reference API (agogo_amd/host/agogo.hpp) exercised over the C ABI
 tests/cpp/az_learn_ttt: tests/cpp/az_learn_ttt.cpp agogo_amd/host/agogo.hpp include/agz.h $(OUT)/libagz.so

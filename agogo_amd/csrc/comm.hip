@@ -8,6 +8,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include <mutex>
@@ -19,8 +20,15 @@ const Rccl* rccl() {
   static std::once_flag once;
   static std::string err;
   std::call_once(once, [] {
-    // a copy already mapped into the process (e.g. PyTorch's) is reused: two RCCL instances on one device fight over IPC handles
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    // AGZ_RCCL_LIB=<path>: the RCCL build to bind (a site-specific build; tests/fake_rccl's process-per-rank double on one-GPU
+    // boxes).  Otherwise a copy already mapped into the process (e.g. PyTorch's) is reused: two RCCL instances on one device
+    // fight over IPC handles.
+    void* h = nullptr;
+    if (const char* path = getenv("AGZ_RCCL_LIB")) {
+      h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+      if (!h) { err = std::string("AGZ_RCCL_LIB=") + path + ": " + (dlerror() ? dlerror() : "?"); return; }
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
@@ -108,6 +116,8 @@ int agz_comm_size(const agz_comm* c) { return c ? c->size : 0; }
 
 int agz_trainer_allreduce(agz_comm* c, agz_trainer* t) {
   AGZ_REQUIRE(c && t, AGZ_E_INVALID, "agz_trainer_allreduce: NULL argument");
+  // the gradients are produced on the trainer's ctx stream and reduced on the communicator's: they must be the same queue
+  AGZ_REQUIRE(agz_trainer_ctx(t) == c->ctx, AGZ_E_INVALID, "agz_trainer_allreduce: the communicator and the trainer belong to different contexts");
   const Rccl* R = rccl();
   if (!R) return AGZ_E_UNSUPPORTED;
   AGZ_HIP_TRY(hipSetDevice(c->ctx->device));

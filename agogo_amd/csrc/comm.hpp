@@ -26,6 +26,9 @@ struct Rccl {
 const Rccl* rccl();
 }  // namespace agz
 
+// (train.hip) the context a trainer was created on
+agz_ctx* agz_trainer_ctx(const agz_trainer* t);
+
 struct agz_comm {
   agz_ctx* ctx = nullptr;
   ncclComm_t comm = nullptr;

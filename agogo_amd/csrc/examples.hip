@@ -232,10 +232,24 @@ int agz_examples_allgather(agz_comm* c, agz_examples* e) {
   for (int r = 0; r < n; r++) total += (size_t)cnt[r];
   if (n == 1 || total == 0) return AGZ_OK;          // one rank: the store already is the union
   float *p = nullptr, *q = nullptr, *v = nullptr;
-  if (hipMalloc(&p, total * e->xs * 4) != hipSuccess || hipMalloc(&q, total * e->A1 * 4) != hipSuccess || hipMalloc(&v, total * 4) != hipSuccess) {
-    hipFree(p); hipFree(q); hipFree(v);
-    agz::set_error("agz_examples_allgather: out of device memory for %zu gathered examples", total);
-    return AGZ_E_NOMEM;
+  const bool got = hipMalloc(&p, total * e->xs * 4) == hipSuccess && hipMalloc(&q, total * e->A1 * 4) == hipSuccess && hipMalloc(&v, total * 4) == hipSuccess;
+  // every rank must enter the broadcast group or none: the ranks agree on "everybody has its receive store" with a one-word sum
+  {
+    unsigned long long* d_fail = nullptr;
+    unsigned long long fails = got ? 0 : 1, all_fails = 1;
+    he = hipMalloc(&d_fail, 16);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_fail, &fails, 8, hipMemcpyHostToDevice, s);
+    nr = he == hipSuccess ? R->AllReduce(d_fail, d_fail + 1, 1, ncclUint64, ncclSum, c->comm, s) : ncclSuccess;
+    if (he == hipSuccess && nr == ncclSuccess) he = hipMemcpyAsync(&all_fails, d_fail + 1, 8, hipMemcpyDeviceToHost, s);
+    if (he == hipSuccess && nr == ncclSuccess) he = hipStreamSynchronize(s);
+    if (d_fail) hipFree(d_fail);
+    if (nr != ncclSuccess || he != hipSuccess || all_fails != 0) {
+      hipFree(p); hipFree(q); hipFree(v);
+      AGZ_REQUIRE(nr == ncclSuccess, AGZ_E_HIP, "agz_examples_allgather: allocation agreement -> %s", R->GetErrorString(nr));
+      AGZ_HIP_TRY(he);
+      agz::set_error("agz_examples_allgather: out of device memory for %zu gathered examples on %llu rank(s); no rank gathered", total, all_fails);
+      return AGZ_E_NOMEM;
+    }
   }
   nr = R->GroupStart();
   size_t off = 0;

@@ -663,6 +663,9 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   return AGZ_OK;
 }
 
+// (comm.hip) the context a trainer was created on
+agz_ctx* agz_trainer_ctx(const agz_trainer* t) { return t ? t->ctx : nullptr; }
+
 extern "C" {
 
 int agz_trainer_create(agz_ctx* ctx, const agz_net_conf* c, agz_trainer** out) {

@@ -1,7 +1,9 @@
 """Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" on CPU).
 
-Self-play shards by independent games: zero data-path collectives.  The only exchange step is the
-gather of per-rank example buffers before dual.Train (agogo.go:118-133): variable-count all-gather below.
+Self-play shards by independent games: zero data-path collectives.  The only exchange steps are the gather of
+per-rank example buffers before dual.Train (agogo.go:118-133) and the gradient sum of the data-parallel step — both RCCL calls
+INSIDE libagz (agz_examples_allgather, agz_trainer_allreduce); this module only sets the process group up, ships the
+communicator id and aggregates the bench counters.
 """
 import os
 
@@ -25,80 +27,24 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
-class _DevArray:
-    """zero-copy view of a libagz device buffer for torch.as_tensor (CUDA array interface v2)"""
-
-    def __init__(self, ptr, shape, typestr="<f4"):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
-
-
-def device_tensor(ptr, shape, device):
-    return torch.as_tensor(_DevArray(ptr, shape), device=device)
-
-
-def all_gather_examples(planes, policy, value, group=None):
-    """Variable-count all-gather of example records {Board[F*HW], Policy[A+1], Value} (datatypes.go:41-46).
-
-    Inputs are this rank's [n_r, *] tensors (any device the backend supports).  Returns the concatenation
-    over ranks in rank order.  Direct all-gather of padded blocks: with RCCL every peer pair uses its own
-    xGMI link concurrently, so the exchange is bound by one link's bandwidth per peer, not by a ring.
-    """
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return planes, policy, value
-    world = dist.get_world_size(group)
-    n = torch.tensor([planes.shape[0]], dtype=torch.int64, device=planes.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    nmax = max(counts)
-    if nmax == 0:
-        return planes, policy, value
-    out = []
-    for t in (planes, policy, value.reshape(-1, 1)):
-        pad = torch.zeros((nmax, t.shape[1]), dtype=t.dtype, device=t.device)
-        pad[: t.shape[0]] = t
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad, group=group)
-        out.append(torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0))
-    return out[0], out[1], out[2].reshape(-1)
-
-
-def gather_into_examples(arena, examples, local_device, group=None):
-    """The per-epoch exchange of SURVEY 8(e) end to end on the device: this rank's recorded examples (arena buffers)
-    -> RCCL all-gather over xGMI -> appended to an `Examples` set (agz_examples_append_dev), ready for
-    Examples.prepare + Trainer.train_dev.  Single process: a device-to-device append.  Every rank ends up with the
-    same set in rank order (within a rank: the reference's episode order)."""
+def exchange_unique_id(group=None):
+    """rank 0 draws the RCCL unique id (agz_comm_unique_id), the process group ships its 128 bytes (host side, any backend)"""
     from . import capi
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        examples.append_arena(arena)
-        return len(examples)
-    local = capi.Examples(examples.ctx, examples.F, examples.H, examples.W, examples.A1)
-    local.append_arena(arena)           # canonical (episode) order first, then exchange
-    n = len(local)
-    dev = torch.device("cuda", local_device)
-    p, q, v = local.raw_dev()
-    planes = device_tensor(p, (n, examples.F * examples.H * examples.W), dev) if n else torch.zeros((0, examples.F * examples.H * examples.W), device=dev)
-    policy = device_tensor(q, (n, examples.A1), dev) if n else torch.zeros((0, examples.A1), device=dev)
-    value = device_tensor(v, (n,), dev) if n else torch.zeros((0,), device=dev)
-    P, Q, V = all_gather_examples(planes, policy, value, group=group)
-    P, Q, V = P.contiguous(), Q.contiguous(), V.contiguous()
-    torch.cuda.synchronize(dev)
-    examples.append_dev(P.data_ptr(), Q.data_ptr(), V.data_ptr(), int(V.shape[0]))
-    examples.ctx.sync()
-    local.close()
-    return len(examples)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [capi.Comm.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    return box[0]
 
 
 def make_comm(ctx, group=None):
     """An agz_comm (RCCL inside libagz, include/agz.h) for this rank's ctx: rank 0 draws the RCCL unique id, the process
-    group ships its 128 bytes (host side, any backend), every rank joins with agz_comm_init_rank.  The exchange itself then
-    runs entirely inside libagz: Comm.allgather_examples / Comm.allreduce_trainer — what a Go host calls through cgo."""
+    group ships it, every rank joins with agz_comm_init_rank.  The exchange itself then runs entirely inside libagz:
+    Comm.allgather_examples / Comm.allreduce_trainer — what a Go host calls through cgo.  (There is no torch-side copy of the
+    gather or of the gradient sum any more: one implementation, the one the boundary exports.)"""
     from . import capi
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    box = [capi.Comm.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0, group=group)
-    return capi.Comm.init_rank(ctx, world, rank, box[0])
+    return capi.Comm.init_rank(ctx, world, rank, exchange_unique_id(group))
 
 
 def shard_games(total_games, rank, world):
@@ -110,22 +56,13 @@ def shard_games(total_games, rank, world):
     return lo, hi
 
 
-def allreduce_gradients(trainer, local_device, group=None):
-    """Data-parallel dual.Train: ONE all-reduce over the trainer's flat gradient buffer (all learnables of
-    the network in one contiguous device buffer), in place.  With RCCL (backend nccl) the device buffer is reduced
-    directly over xGMI; with gloo (CPU test rigs) it is staged through host memory.  Returns the world size; follow with
-    trainer.apply(lr, grad_scale=1/world) for gradient averaging."""
+def reduce_step_timing(seconds, counts, group=None, device=None):
+    """bench.py's aggregation over ranks: MAX of the timed region's wall time, SUM of the per-rank counters (sims, evals, ...).
+    Returns (t_max, [sums...]).  One rank: the inputs."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return 1
-    world = dist.get_world_size(group)
-    ptr, n = trainer.grads_dev()
-    trainer.ctx.sync()   # the gradients were produced on the ctx stream; the collective runs on torch's
-    g = device_tensor(ptr, (n,), torch.device("cuda", local_device))
-    if str(dist.get_backend(group)) == "gloo":
-        h = g.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
-        g.copy_(h)
-    else:
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
-    torch.cuda.synchronize()
-    return world
+        return float(seconds), [float(c) for c in counts]
+    tt = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
+    cc = torch.tensor([float(c) for c in counts], dtype=torch.float64, device=device)
+    dist.all_reduce(cc, op=dist.ReduceOp.SUM, group=group)
+    return float(tt.item()), [float(x) for x in cc.tolist()]

@@ -356,14 +356,11 @@ def main():
     sims = st1["sims_nonnull"] - st0["sims_nonnull"]
     sims_all = st1["sims_total"] - st0["sims_total"]
     evals = st1["nn_evals"] - st0["nn_evals"]
-    t_max, sims_sum, evals_sum, iters_sum = dt, sims, evals, sims_all
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        cc = torch.tensor([sims, evals, sims_all], dtype=torch.float64, device="cuda")
-        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
-        t_max, sims_sum, evals_sum, iters_sum = float(tt.item()), float(cc[0].item()), float(cc[1].item()), float(cc[2].item())
-
+    # MAX of the wall time, SUM of the counters over ranks; the per-rank sims travel along so that the line is self-checking
+    per_rank = [0.0] * world
+    per_rank[rank] = float(sims)
+    t_max, sums = adist.reduce_step_timing(dt, [sims, evals, sims_all] + per_rank, device="cuda" if world > 1 else None)
+    sims_sum, evals_sum, iters_sum, per_rank_sims = sums[0], sums[1], sums[2], sums[3:]
     prof = {}
     for name, k in (("conv_dual", capi.PROF_CONV), ("conv_init", capi.PROF_CONV_INIT), ("heads", capi.PROF_HEADS),
                     ("select", capi.PROF_SELECT), ("expand", capi.PROF_EXPAND), ("move", capi.PROF_MOVE),
@@ -424,7 +421,8 @@ def main():
                 ctx.sync()
                 g_ms = (time.perf_counter() - g0) * 1e3
                 res = {"path": "libagz: agz_comm_init_rank + agz_examples_allgather (RCCL, one grouped set of broadcasts)",
-                       "ms": g_ms, "rows_this_rank": n.value, "rows_gathered": len(ex),
+                       "note": "self-check: rccl_ranks must equal n_gpus and rows_gathered the sum of every rank's rows_this_rank",
+                       "ms": g_ms, "rows_this_rank": n.value, "rows_gathered": len(ex), "rccl_ranks": comm.size(), "rccl_rank": comm.rank(),
                        "GB_per_s": len(ex) * (18 * S * S + Aspace + 1) * 4 / (g_ms * 1e-3) / 1e9}
                 comm.close()
                 ex.close()
@@ -563,6 +561,7 @@ def main():
                                     "`bench.py --tower-queues 1` measures the same kernel inside the timed region" % n_launch) if two_queues else
                                    "HIP events on the launch stream, steps after the timed region (--prof-stride 0)"},
             "extra": {"nn_evals_per_s": evals_sum / t_max, "iterations_per_s": iters_sum / t_max,
+                      "per_rank_sims": per_rank_sims, "world_size": world,
                       "timed_region": {"moves_finished": st1["moves_played"] - st0["moves_played"],
                                        "move_boundaries": move_n // 2,
                                        "mean_path_nodes": (st1["path_nodes"] - st0["path_nodes"]) / max(1, sims_all),

@@ -1,5 +1,5 @@
 """Data-parallel dual.Train check (run under torch.distributed.run with 2 ranks; --shared-gpu lets both ranks use
-GPU 0 with gloo on a 1-GPU box).  Each rank computes gradients on its own batch, ONE all-reduce over the flat
+GPU 0 on a 1-GPU box: gloo for the process group, AGZ_RCCL_LIB=tests/fake_rccl/librccl_fake.so for libagz's collectives).  Each rank computes gradients on its own batch, ONE all-reduce over the flat
 gradient buffer, averaged SGD step.  Rank 0 verifies against a single-process run over both batches."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,8 +31,10 @@ def data(seed):
 t = A.Trainer(ctx, K, L, FC, W, H, F, Asp, B)
 t.init_random(42)                      # identical replicas
 x, pi, v = data(1000 + rank)           # rank-specific batch
+comm = adist.make_comm(ctx) if world > 1 else A.Comm.init_all([ctx])[0]
 t.forward_backward(x, pi, v)
-w = adist.allreduce_gradients(t, local)
+comm.allreduce_trainer(t)          # ONE RCCL all-reduce inside libagz over the flat gradient buffer
+w = comm.size()
 t.apply(0.1, 1.0 / w)
 ctx.sync()
 ok = True
@@ -68,7 +70,9 @@ def play(seed):
 
 mine = play(500 + rank)
 ex = A.Examples(ctx, 2, 3, 3, 10)
-n_all = adist.gather_into_examples(mine, ex, local)
+ex.append_arena(mine)              # canonical (episode) order first, then the exchange inside libagz
+comm.allgather_examples(ex)
+n_all = len(ex)
 got = ex.get()
 batches = ex.prepare(8, 0, seed=31)       # same seed on every rank -> identical training tensors everywhere
 X, P, V = ex.tensors()
@@ -98,5 +102,5 @@ ok = ok and ok2
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()
-ex.close(); mine.close(); t.close(); ctx.close()
+comm.close(); ex.close(); mine.close(); t.close(); ctx.close()
 sys.exit(0 if ok else 1)

@@ -1,6 +1,6 @@
 """One AZ.Learn epoch (agogo.go:100-172) across N ranks, one GPU each — BASELINE configs[3]'s flow end to end:
   1. self-play: the games are sharded over the ranks (no data-path collective),
-  2. the recorded examples are all-gathered (RCCL over xGMI; gloo in the 1-GPU test rig) into a device Examples set,
+  2. the recorded examples are all-gathered (agz_examples_allgather: RCCL over xGMI; tests/fake_rccl on the 1-GPU test rig) into a device Examples set,
   3. prepareExamples with a shared seed (every rank holds the same tensors),
   4. dual.Train data-parallel: rank r takes batch (step*world + r), ONE all-reduce of the flat gradient buffer per step,
      averaged vanilla SGD (lr 0.1) — every rank ends with identical learnables,
@@ -63,7 +63,10 @@ t_play = time.perf_counter() - t0
 
 # 2. + 3. gather, prepare (same seed everywhere)
 ex = A.Examples(ctx, 2, S, S, Aspace)
-n_all = adist.gather_into_examples(sp, ex, local)
+comm = adist.make_comm(ctx) if world > 1 else A.Comm.init_all([ctx])[0]
+ex.append_arena(sp)
+comm.allgather_examples(ex)          # agz_examples_allgather: RCCL inside libagz
+n_all = len(ex)
 batches = ex.prepare(args.batch, 0, seed=77)
 xd, pd, vd, rows, _ = ex.tensors_dev()
 if batches < world:
@@ -82,8 +85,8 @@ for it in range(args.nniters):
         c = trainB.forward_backward_dev(xd + row0 * xs, pd + row0 * ps, vd + row0 * 4, want_cost=last)
         if last:
             cost = c
-        w = adist.allreduce_gradients(trainB, local)
-        trainB.apply(0.1, 1.0 / w)
+        comm.allreduce_trainer(trainB)   # agz_trainer_allreduce: one RCCL all-reduce per step
+        trainB.apply(0.1, 1.0 / comm.size())
         steps += 1
 ctx.sync()
 # every rank must hold the same learnables
@@ -115,7 +118,7 @@ if rank == 0:
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()
-for h in (ev, netB, ex, sp, trainB, netA):
+for h in (comm, ev, netB, ex, sp, trainB, netA):
     h.close()
 ctx.close()
 sys.exit(0 if same else 1)

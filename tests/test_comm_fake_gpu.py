@@ -1,0 +1,131 @@
+"""GPU: the N > 1 branches of libagz's exchange step (/root/reference agogo.go:110-133 runs dual.Train on the union of
+all episodes' examples) executed on a ONE-GPU box.  Ranks are processes sharing device 0; librccl is replaced by
+tests/fake_rccl/librccl_fake.so (AGZ_RCCL_LIB: the dlopen path libagz honours for any RCCL build), a shared-memory stand-in with
+NCCL's semantics for the ten entry points comm.hip binds.  What runs is the PRODUCT code: agz_comm_unique_id / agz_comm_init_rank,
+agz_examples_allgather (count exchange, allocation agreement, one grouped set of n broadcasts with rank r the root of its own rows,
+received in place, store swap) with uneven counts including a zero-count rank, and agz_trainer_allreduce + agz_trainer_apply(1/n).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_rccl", "librccl_fake.so")
+
+WORKER = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import agogo_amd as A
+rank, n, out, counts = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], [int(c) for c in sys.argv[4].split(",")]
+ctx = A.Ctx(0)
+idf = out + ".uid"
+if rank == 0:
+    uid = A.Comm.unique_id()
+    with open(idf + ".tmp", "wb") as f:
+        f.write(uid)
+    os.replace(idf + ".tmp", idf)
+else:
+    t0 = time.time()
+    while not os.path.exists(idf):
+        assert time.time() - t0 < 60, "rank 0 never published the unique id"
+        time.sleep(0.01)
+    uid = open(idf, "rb").read()
+comm = A.Comm.init_rank(ctx, n, rank, uid)
+assert comm.size() == n and comm.rank() == rank
+# --- examples: this rank's rows are recognisable: planes = 1000*rank + row + column/1000
+F, H, W, A1 = 2, 3, 3, 10
+k = counts[rank]
+ex = A.Examples(ctx, F, H, W, A1)
+rows = np.arange(k, dtype=np.float32)[:, None]
+p = (1000.0 * rank + rows + np.arange(F * H * W, dtype=np.float32)[None, :] / 1000.0).astype(np.float32)
+q = (0.5 * rank + rows / 100.0 + np.arange(A1, dtype=np.float32)[None, :]).astype(np.float32)
+v = (10.0 * rank + np.arange(k)).astype(np.float32)
+if k:
+    ex.append_host(p, q, v)
+comm.allgather_examples(ex)
+gp, gq, gv = ex.get()
+# a second gather on the gathered set: every rank now contributes the whole union (n * total rows, rank-major)
+comm.allgather_examples(ex)
+gp2, gq2, gv2 = ex.get()
+# --- data-parallel step: same initial learnables, rank-specific batch, ONE all-reduce over the flat gradient buffer
+tr = A.Trainer(ctx, 32, 1, 16, 3, 3, 2, 10, 4)
+tr.init_random(3)
+rng = np.random.default_rng(100 + rank)
+x = rng.choice(np.array([-1, 0.001, 1], np.float32), size=(4, 2, 3, 3)).astype(np.float32)
+pi = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 4)]
+val = rng.choice(np.array([-1, 0, 1], np.float32), size=4).astype(np.float32)
+tr.forward_backward(x, pi, val)
+local = [tr.get_grad(i).copy() for i in range(tr.num_params())]
+before = [tr.get_param(i).copy() for i in range(tr.num_params())]
+comm.allreduce_trainer(tr)
+ctx.sync()
+summed = [tr.get_grad(i).copy() for i in range(tr.num_params())]
+tr.apply(0.1, 1.0 / n)
+ctx.sync()
+after = [tr.get_param(i).copy() for i in range(tr.num_params())]
+np.savez(out + ".r%d.npz" % rank, gp=gp, gq=gq, gv=gv, gp2=gp2, gv2=gv2, own_p=p, own_q=q, own_v=v,
+         **{"local%d" % i: g for i, g in enumerate(local)}, **{"sum%d" % i: g for i, g in enumerate(summed)},
+         **{"before%d" % i: g for i, g in enumerate(before)}, **{"after%d" % i: g for i, g in enumerate(after)}, nparams=tr.num_params())
+comm.close()
+"""
+
+
+@pytest.mark.parametrize("counts", [(4, 7), (5, 0, 3), (0, 6), (2, 1, 0)])
+def test_allgather_and_allreduce_over_n_ranks_on_one_gpu(counts, tmp_path):
+    assert os.path.exists(FAKE), "tests/fake_rccl/librccl_fake.so is built by `make` (__graft_entry__.build)"
+    n = len(counts)
+    out = str(tmp_path / "x")
+    env = dict(os.environ, AGZ_RCCL_LIB=FAKE)
+    procs = [subprocess.Popen([sys.executable, "-c", WORKER, str(r), str(n), out, ",".join(map(str, counts))], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(n)]
+    logs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    for r, pr in enumerate(procs):
+        assert pr.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-3000:])
+    R = [np.load(out + ".r%d.npz" % r) for r in range(n)]
+    # the union, rank after rank, on every rank
+    exp_p = np.concatenate([R[r]["own_p"] for r in range(n)])
+    exp_q = np.concatenate([R[r]["own_q"] for r in range(n)])
+    exp_v = np.concatenate([R[r]["own_v"] for r in range(n)])
+    assert exp_v.size == sum(counts)
+    for r in range(n):
+        np.testing.assert_array_equal(R[r]["gp"], exp_p)
+        np.testing.assert_array_equal(R[r]["gq"], exp_q)
+        np.testing.assert_array_equal(R[r]["gv"], exp_v)
+        np.testing.assert_array_equal(R[r]["gp2"], np.concatenate([exp_p] * n))
+        np.testing.assert_array_equal(R[r]["gv2"], np.concatenate([exp_v] * n))
+    # gradients: the sum of what each rank computed alone (rank order, fp32), identical on every rank; averaged SGD step
+    npar = int(R[0]["nparams"])
+    for i in range(npar):
+        s = R[0]["local%d" % i].astype(np.float32).copy()
+        for r in range(1, n):
+            s = (s + R[r]["local%d" % i]).astype(np.float32)
+        assert any(np.abs(R[r]["local%d" % i]).max() > 0 for r in range(n)) or s.size == 0
+        for r in range(n):
+            np.testing.assert_array_equal(R[r]["sum%d" % i], s)
+            np.testing.assert_array_equal(R[r]["before%d" % i], R[0]["before%d" % i])
+            np.testing.assert_array_equal(R[r]["after%d" % i], R[0]["after%d" % i])
+        np.testing.assert_allclose(R[0]["after%d" % i], R[0]["before%d" % i] - np.float32(0.1 / n) * s, rtol=2e-6, atol=1e-7)
+    # rank-specific batches really differed
+    assert not np.array_equal(R[0]["local0"], R[1]["local0"])
+
+
+def test_fake_rccl_is_test_infrastructure_only():
+    """the product never names the double: it only honours AGZ_RCCL_LIB"""
+    for d, _, fs in os.walk(os.path.join(ROOT, "agogo_amd")):
+        for f in fs:
+            if f.endswith((".hip", ".hpp", ".py", ".h")):
+                assert "fake_rccl" not in open(os.path.join(d, f), errors="replace").read().replace("tests/fake_rccl's", ""), f

@@ -1,15 +1,19 @@
-"""CPU, world_size 2, gloo: the N>1 path of the hot path — game sharding (no data-path collective) and the
-one exchange step (variable-count all-gather of example records before dual.Train)."""
+"""CPU, world_size 2, gloo: the host side of the N > 1 path — game sharding (no data-path collective), the communicator-id
+exchange in front of agz_comm_init_rank, and bench.py's aggregation over ranks (MAX of the wall time, SUM of the counters).
+The exchange itself (agz_examples_allgather / agz_trainer_allreduce) is device code inside libagz: it runs in -m gpu
+(tests/test_comm_fake_gpu.py: n = 2 and 3 ranks on one GPU through tests/fake_rccl; tests/test_comm_gpu.py: real RCCL at n = 1)."""
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from agogo_amd import dist as adist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_rccl", "librccl_fake.so")
 
 
 def _free_port():
@@ -22,18 +26,15 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
+                      LOCAL_RANK=str(rank), AGZ_RCCL_LIB=FAKE)
     r, l, w = adist.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
-    # ranks own disjoint game ranges; examples differ in count per rank
     lo, hi = adist.shard_games(7, rank, world)
-    n = (hi - lo) * (rank + 2)
-    F, A = 18 * 9, 10
-    planes = torch.full((n, F), float(rank + 1))
-    policy = torch.full((n, A), 0.1 * (rank + 1))
-    value = torch.arange(n, dtype=torch.float32) + 100 * rank
-    gp, gpo, gv = adist.all_gather_examples(planes, policy, value)
-    q.put((rank, lo, hi, n, gp.shape[0], float(gp.sum()), float(gpo.sum()), gv.tolist()))
+    # the 128-byte communicator id: drawn on rank 0 inside libagz (agz_comm_unique_id), shipped over the process group
+    uid = adist.exchange_unique_id()
+    # bench.py's aggregation: rank r timed 1 + r seconds and counted (100 (r + 1), 7) units
+    t_max, sums = adist.reduce_step_timing(1.0 + rank, [100.0 * (rank + 1), 7.0])
+    q.put((rank, lo, hi, bytes(uid), t_max, sums))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,7 +51,8 @@ def test_shard_games_partition():
     assert adist.shard_games(4096, 3, 8) == (1536, 2048)  # config #4: 512 games per GPU
 
 
-def test_all_gather_examples_world2_gloo():
+def test_id_exchange_sharding_and_bench_aggregation_world2_gloo():
+    assert os.path.exists(FAKE), "tests/fake_rccl/librccl_fake.so is built by `make`"
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -62,16 +64,12 @@ def test_all_gather_examples_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, lo0, hi0, n0, tot0, s0, sp0, v0), (r1, lo1, hi1, n1, tot1, s1, sp1, v1) = res
+    (r0, lo0, hi0, id0, t0, s0), (r1, lo1, hi1, id1, t1, s1) = res
     assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 7)
-    assert n0 == 8 and n1 == 9
-    assert tot0 == tot1 == n0 + n1
-    F = 18 * 9
-    assert s0 == s1 == pytest.approx(n0 * F * 1.0 + n1 * F * 2.0)
-    assert v0 == v1 == [float(i) for i in range(n0)] + [100.0 + i for i in range(n1)]
+    assert len(id0) == 128 and id0 == id1 and any(id0)
+    assert t0 == t1 == 2.0                    # MAX over ranks
+    assert s0 == s1 == [300.0, 14.0]          # SUM over ranks
 
 
 def test_single_process_passthrough():
-    p, po, v = torch.zeros(3, 4), torch.zeros(3, 2), torch.zeros(3)
-    a, b, c = adist.all_gather_examples(p, po, v)
-    assert a is p and b is po and c is v
+    assert adist.reduce_step_timing(0.5, [3, 4]) == (0.5, [3.0, 4.0])

@@ -171,12 +171,13 @@ def test_agz_train_loop_runs_and_shuffles(ctx):
 
 def test_data_parallel_step_two_ranks(ctx):
     """C2: two ranks, rank-specific batches, ONE all-reduce over the flat gradient buffer, averaged SGD step
-    == single-process average.  Both ranks share GPU 0 here (gloo); on a multi-GPU node the same code runs over RCCL."""
+    == single-process average.  Both ranks share GPU 0 here (process group over gloo, libagz's collectives through
+    tests/fake_rccl); on a multi-GPU node the same code runs over RCCL."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", AGZ_RCCL_LIB=os.path.join(root, "tests", "fake_rccl", "librccl_fake.so"))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", "29577", os.path.join(root, "scripts", "dp_train_check.py"), "--shared-gpu"],
                          capture_output=True, text=True, timeout=300, env=env)
@@ -224,14 +225,14 @@ def test_trainer_init_random_is_the_oracles_sequential_stream(ctx):
 
 def test_learn_epoch_two_ranks_end_to_end(ctx):
     """scripts/learn_epoch_dist.py: sharded self-play -> example all-gather -> shared-seed prepareExamples -> data-parallel
-    dual.Train (one gradient all-reduce per step) -> SwitchToInference -> sharded arena games; two ranks on GPU 0 (gloo).
+    dual.Train (one gradient all-reduce per step) -> SwitchToInference -> sharded arena games; two ranks on GPU 0 (tests/fake_rccl).
     The replicas must end with identical learnables."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", AGZ_RCCL_LIB=os.path.join(root, "tests", "fake_rccl", "librccl_fake.so"))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", "29591", os.path.join(root, "scripts", "learn_epoch_dist.py"), "--shared-gpu"],
                          capture_output=True, text=True, timeout=300, env=env)
