@@ -37,8 +37,9 @@ __device__ __forceinline__ void h2_scales(unsigned amax_bits, float* s, float* i
 
 // max |x| over one board's interior pixels and channels -> amax[b] (float bits; activations are >= 0 but |.| keeps it
 // general).  One workgroup per board; the tensor was just written, so this mostly reads the Infinity Cache.
+// (t != nullptr: max |x * t[c]| — the Winograd fp16x2 path's equilibrated input range, conv_wino_h2.hpp)
 __global__ __launch_bounds__(256) void board_amax_kernel(const float* __restrict__ x, unsigned* __restrict__ amax, int HW, int W, int Wp,
-                                                         int HpWp, int C) {
+                                                         int HpWp, int C, const float* __restrict__ t = nullptr) {
   __shared__ float red[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int c4 = C >> 2;
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256) void board_amax_kernel(const float* __restrict
     int p = i / c4, c = (i - p * c4) << 2;
     int h = p / W, w = p - h * W;
     float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * HpWp + (h + 1) * Wp + (w + 1)) * C + c);
+    if (t) { const float4 tt = *reinterpret_cast<const float4*>(t + c); v.x *= tt.x; v.y *= tt.y; v.z *= tt.z; v.w *= tt.w; }
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
   }
 #pragma unroll

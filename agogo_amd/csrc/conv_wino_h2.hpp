@@ -97,7 +97,15 @@ struct WinoH2Args {
   const unsigned* amax_in;   // [B] max |x| of every board of this block's input (float bits)
   unsigned* amax_out;        // [B] max of this block's output (wino_board_max_kernel over wave_max)
   float* wave_max;           // [T][Cout_p/64] maximum of the 64 channels x 16 pixels one wave of wino_out_h2_kernel produced
-  float w_unscale;           // 1 / su
+  float w_unscale;           // 1 / su (one power of two for the whole layer: the device-built training image)
+  // Equilibrated inference image (wino_build_u2): input channel ci of U is divided by the power of two t_in[ci] and V's channel
+  // ci multiplied by it (exact, the products do not change); every GEMM column n has its own power-of-two scale, col_unscale[n]
+  // = 1 / su_n.  A layer whose channels / filters differ by many octaves then keeps fp32-grade pieces everywhere.
+  // nullptr: no channel scaling / the scalar w_unscale.  t_next = the NEXT block's t_in: the per-wave maxima this block's output
+  // transform records are maxima of y * t_next (what the next input transform's range bound needs).
+  const float* t_in;
+  const float* col_unscale;
+  const float* t_next;
 };
 __device__ __forceinline__ size_t h2_row(const WinoH2Args& h, int pos, int t) {
   return (size_t)(t >> h.rsh) * h.rA + (size_t)pos * h.rB + (size_t)(t & h.rmask);
@@ -149,6 +157,8 @@ __global__ __launch_bounds__(256) void wino_in_h2_kernel(WinoH2Args h) {
   }
   float sb, inv_;
   wino_h2_scales(amax_bits, WT::VSHIFT, &sb, &inv_);
+  // (amax_bits bounds |x * t_in| over the board, so |V * sb * t| < 2^15 for every channel)
+  const float sbx = h.t_in ? sb * h.t_in[2 * c2] : sb, sby = h.t_in ? sb * h.t_in[2 * c2 + 1] : sb;
   const float* xb = a.x + (size_t)b * a.Hp * a.Wp * a.C + 2 * c2;
   // all loads are issued unconditionally (clamped address, zeroed afterwards): a branch per load keeps only one column in
   // flight (measured 4.2 TB/s of algorithmic bytes with the branches)
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(256) void wino_in_h2_kernel(WinoH2Args h) {
 #pragma unroll
     for (int j = 0; j < AL; j++) {
       unsigned lo;
-      const unsigned hi = wino_h2_pack(ox[j] * sb, oy[j] * sb, &lo);
+      const unsigned hi = wino_h2_pack(ox[j] * sbx, oy[j] * sby, &lo);
       unsigned* rowp = V2 + h2_row(h, i * AL + j, t) * a.C;
       if (h.in_swap) {
         const auto s16 = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);   // [hi r0, lo r0, hi r2, lo r2], [hi r1, lo r1, hi r3, lo r3]
@@ -629,7 +639,9 @@ __global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
   const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
   float s_, unscale;
   wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &unscale);
-  unscale *= h.w_unscale;
+  const float un_a = unscale * (h.col_unscale ? h.col_unscale[c] : h.w_unscale);
+  const float un_b = unscale * (h.col_unscale ? h.col_unscale[a.Cout_p + c] : h.w_unscale);
+  const float tn = h.t_next ? h.t_next[c] : 1.f;
   // All loads are issued before any arithmetic: the 2 x AL^2 values of M and the TM^2 epilogue parameter vectors (clamped
   // address) — loaded inside the per-pixel branch each of those is a dependent L2 round trip per thread.  (Fetching branch by
   // branch to lower the register count was measured: the compiler hoists the loads anyway and spills — 0.51 vs 0.24 ms.)
@@ -671,15 +683,15 @@ __global__ __launch_bounds__(256) void wino_out_h2_kernel(WinoH2Args h) {
     for (int l = 0; l < TM; l++) {
       const int ww = TM * tx + l;
       const float4 e = E[k][l];
-      float va = (Y[0][k][l] * unscale) * e.x + e.y;
-      float vb = (Y[1][k][l] * unscale) * e.z + e.w;
+      float va = (Y[0][k][l] * un_a) * e.x + e.y;
+      float vb = (Y[1][k][l] * un_b) * e.z + e.w;
       va = va > 0.f ? va : 0.f;
       vb = vb > 0.f ? vb : 0.f;
       float s = va + vb;
       s = s > 0.f ? s : 0.f;
       if (live && hh < a.H && ww < a.W) {
         yb[((size_t)(hh + 1) * a.Wp + (ww + 1)) * a.Cout_p] = s;
-        mx = fmaxf(mx, s);
+        mx = fmaxf(mx, s * tn);
       }
     }
   }
@@ -764,9 +776,9 @@ __global__ __launch_bounds__(256) void wino_out_seq_h2_kernel(WinoH2Args h) {
   const int tid = threadIdx.x, c = blockIdx.y * blockDim.x + tid;  // this lane's channel
   const int b = t / a.TPB, tt = t - b * a.TPB;
   const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
-  float s_, unscale;
-  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &unscale);
-  unscale *= h.w_unscale;
+  float s_, unscale0;
+  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &unscale0);
+  const float tn = h.t_next ? h.t_next[c] : 1.f;
   const __amdgpu_buffer_rsrc_t mr = h2_rsrc(a.Mb + ((size_t)(t >> h.rsh) * h.rA + (size_t)(t & h.rmask)) * a.Ntot);
   const unsigned pos_stride = h.rB * (unsigned)a.Ntot * 4u;        // bytes, uniform
   const __amdgpu_buffer_rsrc_t er = h2_rsrc(a.ep);                 // float2 index (pixel * Cout_p + c) * 2 + branch
@@ -776,6 +788,7 @@ __global__ __launch_bounds__(256) void wino_out_seq_h2_kernel(WinoH2Args h) {
   for (int br = 0; br < 2; br++) {
     const unsigned lane_off = (unsigned)(br * a.Cout_p + c) * 4u;
     const unsigned e_lane = (unsigned)(c * 2 + br) * 8u;
+    const float unscale = unscale0 * (h.col_unscale ? h.col_unscale[br * a.Cout_p + c] : h.w_unscale);
     float tm_[TM][AL];
 #pragma unroll
     for (int nu = 0; nu + 1 < AL; nu += 2) {       // two columns at a time on the packed-fp32 pipe
@@ -845,7 +858,7 @@ __global__ __launch_bounds__(256) void wino_out_seq_h2_kernel(WinoH2Args h) {
       const int ww = TM * tx + l;
       if (hh < a.H && ww < a.W) {                   // uniform
         h2_stf(yr, y_lane, (unsigned)((hh + 1) * a.Wp + (ww + 1)) * y_pix, va[k][l]);
-        mx = fmaxf(mx, va[k][l]);
+        mx = fmaxf(mx, va[k][l] * tn);
       }
     }
   }
@@ -979,15 +992,18 @@ __global__ __launch_bounds__(64) void wino_board_max_kernel(const float* __restr
   if (lane == 0) amax_out[b] = __float_as_uint(mx);
 }
 
-// Host: the Winograd-domain filter G g Gt (double, rounded once to fp32) scaled by a power of two and split into two fp16 pieces:
-// u2[pos][ci/32][piece][n][ci%32]; returns 1/su.
+// Host: the Winograd-domain filter G g Gt (double, rounded once to fp32), EQUILIBRATED by powers of two — input channel ci divided by
+// t_in[ci] = 2^floor(log2 max_{pos,n} |U|) (the input transform multiplies V's channel ci by the same factor: exact, the products do
+// not change), then every column n scaled by its own su_n with max_{pos,ci} |U / t| * su_n in [2^13, 2^14) — and split into two fp16
+// pieces: u2[pos][ci/32][piece][n][ci%32].  col_unscale[n] = 1 / su_n.  A layer whose filters or input channels differ by many
+// octaves keeps 22-bit pieces in every row and column that matters (tests/test_wino_gpu.py, heterogeneous ranges).
 template <int TM, typename Get>
-static float wino_build_u2(std::vector<_Float16>& u2, int Ntot, int C, Get get) {
+static void wino_build_u2(std::vector<_Float16>& u2, int Ntot, int C, Get get, std::vector<float>& t_in, std::vector<float>& col_unscale) {
   using WT = WinoT<TM>;
   constexpr int AL = WT::AL, NP = AL * AL;
   const int NC = C / 32;
   std::vector<float> U((size_t)NP * Ntot * C, 0.f);
-  float umax = 0.f;
+  std::vector<float> rmax(C, 0.f);
   for (int n = 0; n < Ntot; n++)
     for (int ci = 0; ci < C; ci++) {
       double g[3][3], tg[AL][3];
@@ -998,24 +1014,45 @@ static float wino_build_u2(std::vector<_Float16>& u2, int Ntot, int C, Get get) 
       for (int xi = 0; xi < AL; xi++) for (int nu = 0; nu < AL; nu++) {
         const float v = (float)(tg[xi][0] * WT::G[nu][0] + tg[xi][1] * WT::G[nu][1] + tg[xi][2] * WT::G[nu][2]);
         U[((size_t)(xi * AL + nu) * Ntot + n) * C + ci] = v;
-        umax = std::max(umax, std::fabs(v));
+        rmax[ci] = std::max(rmax[ci], std::fabs(v));
       }
     }
-  int ex = 0;
-  if (umax > 0.f) std::frexp(umax, &ex);
-  const float su = umax > 0.f ? std::ldexp(1.0f, 14 - ex) : 1.0f;
+  t_in.assign(C, 1.0f);
+  for (int ci = 0; ci < C; ci++)
+    if (rmax[ci] > 0.f && std::isfinite(rmax[ci])) {
+      int ex = 0;
+      std::frexp(rmax[ci], &ex);                       // rmax = m * 2^ex, m in [0.5, 1)
+      ex = std::max(-100, std::min(100, ex - 1));      // (clamped: t and 1/t stay normal fp32 numbers with room for the activations)
+      t_in[ci] = std::ldexp(1.0f, ex);
+    }
+  std::vector<float> cmax(Ntot, 0.f);
+  for (int pos = 0; pos < NP; pos++)
+    for (int n = 0; n < Ntot; n++)
+      for (int ci = 0; ci < C; ci++) {
+        float& v = U[((size_t)pos * Ntot + n) * C + ci];
+        v /= t_in[ci];                                  // exact (power of two)
+        cmax[n] = std::max(cmax[n], std::fabs(v));
+      }
+  col_unscale.assign(Ntot, 1.0f);
+  std::vector<float> su(Ntot, 1.0f);
+  for (int n = 0; n < Ntot; n++)
+    if (cmax[n] > 0.f && std::isfinite(cmax[n])) {
+      int ex = 0;
+      std::frexp(cmax[n], &ex);
+      su[n] = std::ldexp(1.0f, 14 - ex);
+      col_unscale[n] = 1.0f / su[n];
+    }
   u2.assign((size_t)NP * NC * 2 * Ntot * 32, (_Float16)0.f);
   for (int pos = 0; pos < NP; pos++)
     for (int n = 0; n < Ntot; n++)
       for (int ci = 0; ci < C; ci++) {
-        const float xs = U[((size_t)pos * Ntot + n) * C + ci] * su;
+        const float xs = U[((size_t)pos * Ntot + n) * C + ci] * su[n];
         const _Float16 hi = (_Float16)xs;
         const _Float16 lo = (_Float16)(xs - (float)hi);
         const size_t base = ((((size_t)pos * NC + ci / 32) * 2) * Ntot + n) * 32 + (ci % 32);
         u2[base] = hi;
         u2[base + (size_t)Ntot * 32] = lo;
       }
-  return 1.0f / su;
 }
 
 // tile size with the fewest transform-domain rows for an H x W board

@@ -581,6 +581,10 @@ void agz_net::free_device() {
   for (auto& p : d_u3_dual) if (p) { hipFree(p); p = nullptr; }
   for (auto& p : d_u2_dual) if (p) { hipFree(p); p = nullptr; }
   d_u2_dual.clear();
+  for (auto& p : d_u2_tin) if (p) hipFree(p);
+  d_u2_tin.clear();
+  for (auto& p : d_u2_colun) if (p) hipFree(p);
+  d_u2_colun.clear();
   f(d_wV); f(d_wM);
   wino_chunk_cap = 0; wino_v_cap = 0;
   d_w_dual.clear(); d_ep_dual.clear(); d_w3_dual.clear(); d_w2_dual.clear(); d_u3_dual.clear();
@@ -775,8 +779,13 @@ int agz_net::build_wino_h2_weights() {
   AGZ_REQUIRE((size_t)(wino_tm + 2) * (wino_tm + 2) * (Kp / 32) * 2 * (2 * Kp) * 64 < ((size_t)1 << 32), AGZ_E_UNSUPPORTED, "agz_net: K %d too wide for the Winograd weight image", conf.K);
   AGZ_HIP_TRY(hipSetDevice(ctx->device));
   for (auto& p : d_u2_dual) if (p) hipFree(p);
+  for (auto& p : d_u2_tin) if (p) hipFree(p);
+  for (auto& p : d_u2_colun) if (p) hipFree(p);
   d_u2_dual.assign(conf.SharedLayers, nullptr);
+  d_u2_tin.assign(conf.SharedLayers, nullptr);
+  d_u2_colun.assign(conf.SharedLayers, nullptr);
   u_unscale.assign(conf.SharedLayers, 1.0f);
+  std::vector<float> tin, colun;
   const int K = conf.K;
   size_t pi = 3;
   std::vector<_Float16> u2;
@@ -789,8 +798,13 @@ int agz_net::build_wino_h2_weights() {
       if (o >= K || ci >= K) return 0.0;
       return (double)(n < Kp_ ? wa : wb)[((size_t)o * K + ci) * 9 + tap];
     };
-    u_unscale[l] = wino_tm == 5 ? agz::wino_build_u2<5>(u2, 2 * Kp, Kp, getw) : agz::wino_build_u2<4>(u2, 2 * Kp, Kp, getw);
+    if (wino_tm == 5) agz::wino_build_u2<5>(u2, 2 * Kp, Kp, getw, tin, colun);
+    else agz::wino_build_u2<4>(u2, 2 * Kp, Kp, getw, tin, colun);
     AGZ_HIP_TRY(hipMalloc(&d_u2_dual[l], u2.size() * 2));
+    AGZ_HIP_TRY(hipMalloc(&d_u2_tin[l], tin.size() * 4));
+    AGZ_HIP_TRY(hipMalloc(&d_u2_colun[l], colun.size() * 4));
+    AGZ_HIP_TRY(hipMemcpyAsync(d_u2_tin[l], tin.data(), tin.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    AGZ_HIP_TRY(hipMemcpyAsync(d_u2_colun[l], colun.data(), colun.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     AGZ_HIP_TRY(hipMemcpyAsync(d_u2_dual[l], u2.data(), u2.size() * 2, hipMemcpyHostToDevice, ctx->stream));
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
@@ -966,7 +980,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       amax_cap = need_amax;
     }
     float* d_wave_max = reinterpret_cast<float*>(d_amax + (size_t)(conf.SharedLayers + 1) * B);
-    hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, ctx->stream, cur, d_amax, HW, W, Wp, Hp * Wp, Kp);
+    hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, ctx->stream, cur, d_amax, HW, W, Wp, Hp * Wp, Kp, (const float*)d_u2_tin[0]);
     if (ns == 2) {
       if (!ctx->stream2) {
         AGZ_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -986,7 +1000,8 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         wa.x = cur + (size_t)b0 * Hp * Wp * Kp; wa.y = nxt + (size_t)b0 * Hp * Wp * Kp;
         wa.V = d_wV + (size_t)q * v_elems; wa.Mb = d_wM + (size_t)q * m_elems; wa.ep = d_ep_dual[l];
         wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
-        hh.U2 = d_u2_dual[l]; hh.w_unscale = u_unscale[l]; hh.tm = wino_tm;
+        hh.U2 = d_u2_dual[l]; hh.w_unscale = 1.f; hh.tm = wino_tm;
+        hh.t_in = d_u2_tin[l]; hh.col_unscale = d_u2_colun[l]; hh.t_next = l + 1 < conf.SharedLayers ? d_u2_tin[l + 1] : nullptr;
         hh.amax_in = d_amax + (size_t)l * B + b0; hh.amax_out = d_amax + (size_t)(l + 1) * B + b0;
         hh.wave_max = d_wave_max + (size_t)b0 * wm_board;
         hh.fuse_prev = l > 0;   // block 0's input range comes from board_amax_kernel above
@@ -1393,6 +1408,10 @@ int agz_net_commit(agz_net* n) {
   n->committed = true;
   for (auto& p : n->d_u2_dual) if (p) hipFree(p);
   n->d_u2_dual.clear();
+  for (auto& p : n->d_u2_tin) if (p) hipFree(p);
+  n->d_u2_tin.clear();
+  for (auto& p : n->d_u2_colun) if (p) hipFree(p);
+  n->d_u2_colun.clear();
   if ((n->compute_mode == AGZ_COMPUTE_WINO || n->compute_mode == AGZ_COMPUTE_AUTO) && n->cfg == 0) return n->build_wino_weights();
   if (n->compute_mode == AGZ_COMPUTE_WINO_H2 && n->cfg == 0) return n->build_wino_h2_weights();
   return AGZ_OK;

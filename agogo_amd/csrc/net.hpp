@@ -55,7 +55,9 @@ struct agz_net {
   std::vector<float> w_unscale;            // per layer 2^-eb of the fp16x2 weight scale
   std::vector<unsigned short*> d_u3_dual;  // per layer Winograd-domain bf16x3 image [36][Kp/16][3][2*Kp][16] (AGZ_COMPUTE_WINO), conv_wino.hpp
   std::vector<_Float16*> d_u2_dual;        // per layer Winograd-domain fp16x2 image [36][Kp/32][2][2*Kp][32] (AGZ_COMPUTE_WINO_H2), conv_wino_h2.hpp
-  std::vector<float> u_unscale;            // per layer 1 / (power-of-two scale of that image)
+  std::vector<float> u_unscale;            // (unused by the equilibrated image: kept 1)
+  std::vector<float*> d_u2_tin;            // per layer [Kp] power-of-two input-channel factors of that image (conv_wino_h2.hpp)
+  std::vector<float*> d_u2_colun;          // per layer [2*Kp] 1 / (power-of-two scale of GEMM column n)
   int build_wino_h2_weights();
   int wino_tm = 4;                         // tile size of that path: 4 = F(4x4,3x3), 5 = F(5x5,3x3), chosen per board size
   size_t wino_v_cap = 0;                   // floats the V scratch holds (fp16x2 path)

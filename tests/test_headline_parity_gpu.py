@@ -85,9 +85,9 @@ def cached_midgame(B):
 
 @pytest.mark.parametrize("mode", list(MODES))
 def test_headline_network_l20_b512_midgame_boards_vs_oracle(ctx, mode):
-    """(i) K=256, L=20, B=512, 19x19 in the measured arithmetic: four boards (an early, two middle, the deepest position)
-    against the oracle, every board of the batch finite and normalised, and the batch agrees with the default fp32-MFMA
-    arithmetic within the same tolerance."""
+    """(i) K=256, L=20, B=512, 19x19 in the measured arithmetic: 32 boards spread evenly over the opening depths (the earliest and
+    the deepest position included) against the oracle — one oracle thread per board, the oracle network is read-only — every
+    board of the batch finite and normalised, and the batch agrees with the default fp32-MFMA arithmetic within the same tolerance."""
     L, B = 20, 512
     net = std_net(ctx, L)
     x, depth = cached_midgame(B)
@@ -101,27 +101,32 @@ def test_headline_network_l20_b512_midgame_boards_vs_oracle(ctx, mode):
         assert not np.array_equal(pol, p32), "the mode under test did not change the arithmetic"
     np.testing.assert_allclose(pol, p32, atol=POL_ATOL, rtol=POL_RTOL)
     np.testing.assert_allclose(val, v32, atol=VAL_ATOL)
-    pick = [int(np.argmin(depth)), int(np.argsort(depth)[B // 3]), int(np.argsort(depth)[2 * B // 3]), int(np.argmax(depth))]
+    order = np.argsort(depth, kind="stable")
+    pick = [int(order[i]) for i in np.linspace(0, B - 1, 32).round().astype(int)]
     key = ("oracle", L, tuple(pick))
-    if key not in _CACHE:   # the same net (seed 1337) and boards in every mode: the oracle runs once
-        _CACHE[key] = oracle_twin(net, L).infer(x[pick])
+    if key not in _CACHE:   # the same net (seed 1337) and boards in every mode: the oracle runs once, one thread per board
+        from concurrent.futures import ThreadPoolExecutor
+        onet = oracle_twin(net, L)
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 4)) as ex:
+            res = list(ex.map(lambda b: onet.infer(x[b:b + 1]), pick))
+        _CACHE[key] = (np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res]))
     po, vo = _CACHE[key]
     dp, dv = np.abs(pol[pick] - po).max(), np.abs(val[pick] - vo).max()
-    print("\n[headline parity] mode=%s boards=%s (moves played %s): max|dpolicy|=%.3g max|dvalue|=%.3g (tolerance %g + %g*|p|, %g)"
-          % (mode, pick, depth[pick].tolist(), dp, dv, POL_ATOL, POL_RTOL, VAL_ATOL))
+    print("\n[headline parity] mode=%s %d boards vs the oracle (moves played %d..%d): max|dpolicy|=%.3g max|dvalue|=%.3g (tolerance %g + %g*|p|, %g)"
+          % (mode, len(pick), depth[pick].min(), depth[pick].max(), dp, dv, POL_ATOL, POL_RTOL, VAL_ATOL))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "headline_parity.txt"), "a") as f:
-            f.write("mode=%s boards=%s depth=%s max_dpolicy=%.4g max_dvalue=%.4g max_policy=%.4g\n"
-                    % (mode, pick, depth[pick].tolist(), dp, dv, float(po.max())))
+            f.write("mode=%s oracle_boards=%d depth=%d..%d max_dpolicy=%.4g max_dvalue=%.4g max_policy=%.4g\n"
+                    % (mode, len(pick), depth[pick].min(), depth[pick].max(), dp, dv, float(po.max())))
     np.testing.assert_allclose(pol[pick], po, atol=POL_ATOL, rtol=POL_RTOL)
     np.testing.assert_allclose(val[pick], vo, atol=VAL_ATOL)
-    assert np.abs(pol[pick[0]] - pol[pick[3]]).max() > 1e-6
+    assert np.abs(pol[pick[0]] - pol[pick[-1]]).max() > 1e-6
     # batch independence of the measured arithmetic: a board evaluated as 512 copies of itself gives the same bits
-    rep, vrep = net.infer(np.repeat(x[pick[2]:pick[2] + 1], B, axis=0))
-    np.testing.assert_array_equal(rep[0], pol[pick[2]])
-    np.testing.assert_array_equal(rep[B - 1], pol[pick[2]])
-    np.testing.assert_array_equal(vrep[7], val[pick[2]])
+    rep, vrep = net.infer(np.repeat(x[pick[20]:pick[20] + 1], B, axis=0))
+    np.testing.assert_array_equal(rep[0], pol[pick[20]])
+    np.testing.assert_array_equal(rep[B - 1], pol[pick[20]])
+    np.testing.assert_array_equal(vrep[7], val[pick[20]])
     net.close()
 
 

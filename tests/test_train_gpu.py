@@ -85,44 +85,29 @@ def test_forward_backward_headline_width_19x19(ctx, mode):
     two boards so the oracle finishes in seconds): the shapes the G19 step runs — 128-multiple tiles, F(5x5,3x3) with the ragged
     last tile row and column, 512-channel data gradient — against the oracle.
 
-    bf16x3: the strict per-tensor tolerance of the small shapes on the first data draw.  wino_h2: the Winograd forward
-    convolution's rounding error (~2e-6 of the output rms against ~2e-7 for direct accumulation) makes it likely that, among the
-    370 k pre-activations of this block, one within that distance of zero lands on the other side of the ReLU than in the oracle.
-    ReLU is not differentiable there: the flip moves that unit's own gamma/beta entry and its channel's filter by up to percent,
-    and — through the batch means of the BatchNorm backward — everything upstream by a few 1e-5 (seen on draw 77: one unit of
-    branch a, 'L1_0_beta' 1.8e-3, its filter 9e-4, 'FilterInit' 4.8e-5, everything of branch b and of the heads <= 7e-6; with
-    only the data gradient on the Winograd path every tensor is <= 1.2e-5).  So, like the fuzz test, this mode is judged over
-    several data draws: EVERY draw must have the cost inside 1e-4, every tensor's MEDIAN error inside the strict tolerance and no
-    element off by more than 5 % of its tensor's maximum (a wrong kernel is off everywhere), and AT LEAST ONE draw must be
-    inside the strict tolerance everywhere."""
+    Both modes: the strict per-tensor tolerance of the small shapes (every gradient tensor within 2e-5 of its maximum) on EVERY one
+    of several data draws.  (Round 2's Winograd FORWARD convolution did not meet this — a ReLU unit flipped against the oracle on
+    every other draw — and was removed from the trainer; AGZ_COMPUTE_WINO_H2 now puts only the data gradient on the Winograd path.)"""
     K, L, FC, W, H, F, Aspace, B = 256, 1, 32, 19, 19, 18, 362, 2
     ot, dt = make_pair(ctx, K, L, FC, W, H, F, Aspace, B)
     dt.set_compute_mode((capi.COMPUTE_BF16X3 if mode == "bf16x3" else capi.COMPUTE_WINO_H2) | capi.COMPUTE_FORCE)
-    clean, report = 0, []
-    draws = [77] if mode == "bf16x3" else [77, 78, 79, 80, 81, 82, 83, 84]
-    for seed in draws:
+    report = []
+    for seed in (77, 78, 79, 80):
         x, pi, v = batch_data(B, F, H, W, Aspace, seed=seed)
         co = ot.batch(x, pi, v, lr=0.0)
         cd = dt.forward_backward(x, pi, v)
         # (the cost is a mean of large cancelling logit terms — weights x3, 362 actions — so its error does not scale with |cost|:
         #  3e-4 absolute in every mode incl. fp32-MFMA on these draws; the small-shape tests hold it to 1e-5 relative)
         assert abs(cd - co) <= 1e-4 * max(1.0, abs(co)), (seed, cd, co)
-        worst, worst_out = 0.0, 0.0
+        worst = 0.0
         for i in range(ot.num_params()):
             go, gd = ot.get_grad(i), dt.get_grad(i)
             scale = float(np.abs(go).max())
-            d = np.abs(gd - go)
-            err = float(d.max())
-            outside = float(np.mean(d > 2e-5 * scale + 1e-7))
-            worst, worst_out = max(worst, err / (scale + 1e-30)), max(worst_out, outside)
-            assert float(np.median(d)) <= 2e-5 * scale + 1e-7 and err <= 5e-2 * scale, (seed, ot.param_name(i), outside, err, scale)
-        report.append("draw %d: worst %.1e, share outside %.1e" % (seed, worst, worst_out))
-        if worst_out == 0.0:
-            clean += 1
-            if mode == "wino_h2":
-                break
+            err = float(np.abs(gd - go).max())
+            worst = max(worst, err / (scale + 1e-30))
+            assert err <= 2e-5 * scale + 1e-7, (seed, ot.param_name(i), err, scale)
+        report.append("draw %d: worst %.1e" % (seed, worst))
     print("trainer %s at K=256 / 19x19 (strict tolerance 2e-5 of the tensor maximum): %s" % (mode, "; ".join(report)))
-    assert clean >= 1, report
 
 
 def test_sgd_steps_and_export(ctx):

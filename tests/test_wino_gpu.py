@@ -246,3 +246,79 @@ np.save(sys.argv[1], np.concatenate(out))
         n += 2 * B * A_ + 2 * B
     if "AGZ_WINO_H2_TM" not in knobs:      # same arithmetic in the same order: only the data movement differs
         np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def _heterogeneous_pair(ctx, K, L, W, H, F, Aspace, E, seed=5):
+    """A network whose function equals a tame random network's, written with wildly different magnitudes INSIDE every layer:
+    output channel c of every layer (both branches of a dual block) carries the scale s_c = 2^u, u ~ U[-E, E]; its filters have
+    norms a_c = 2^u' (independently log-uniform, per branch), gamma makes up the rest (s_c / a_c, exact powers of two), beta is scaled
+    by s_c, and whatever consumes channel c (the next block's filters, the head convolutions) is scaled by 1 / s_c.  ReLU commutes
+    with positive scales, so only the rounding differs from the tame network — activations and weights now span 2^(2E) within one
+    board / one layer, which is what the per-board / per-layer power-of-two ranges of the fp16x2 modes have to live with."""
+    onet, gnet = make_pair(ctx, K, L, 32, W, H, F, Aspace, 2, seed=seed)
+    rng = np.random.default_rng(seed + 77)
+    HW = W * H
+    names = [onet.param_name(i) for i in range(onet.num_params())]
+    P = {n: onet.get_param(i).astype(np.float64).copy() for i, n in enumerate(names)}
+
+    def pow2(n):
+        return np.exp2(rng.integers(-E, E + 1, size=n).astype(np.float64))
+
+    s_prev = None
+    layers = [("FilterInit", "Init_gamma", "Init_beta", None, None, None)]
+    for l in range(L):
+        layers.append(("FilterLayer1 of Shared Layer %d" % l, "L1_%d_gamma" % l, "L1_%d_beta" % l,
+                       "FilterLayer2 of Shared Layer %d" % l, "L2_%d_gamma" % l, "L2_%d_beta" % l))
+    for (fa, ga, ba, fb, gb, bb) in layers:
+        s = pow2(K)
+        for (f, g, b_) in ((fa, ga, ba), (fb, gb, bb)):
+            if f is None:
+                continue
+            cin = P[f].size // (K * 9)
+            w = P[f].reshape(K, cin, 9)
+            a = pow2(K)
+            w *= a[:, None, None]
+            if s_prev is not None:
+                w /= s_prev[None, :, None]
+            P[f] = w.reshape(-1)
+            P[g] = (P[g].reshape(K, HW) * (s / a)[:, None]).reshape(-1)
+            P[b_] = (P[b_].reshape(K, HW) * s[:, None]).reshape(-1)
+        s_prev = s
+    for f in ("FilterPolicyHead", "FilterValueHead"):
+        w = P[f].reshape(-1, K)
+        P[f] = (w / s_prev[None, :]).reshape(-1)
+    for i, n in enumerate(names):
+        v = P[n].astype(np.float32)
+        onet.set_param(i, v)
+        gnet.set_param(i, v)
+    gnet.commit()
+    return onet, gnet
+
+
+@pytest.mark.parametrize("E", [4, 8, 12])
+@pytest.mark.parametrize("wmode", [A.capi.COMPUTE_WINO_H2, A.capi.COMPUTE_FP16X2])
+def test_fp16x2_modes_with_heterogeneous_ranges_inside_a_layer_k256(ctx, wmode, E):
+    """channels (and filters) whose magnitudes differ by up to 2^(2E) inside one board / one layer, K = 256,
+    19x19, against the oracle with the tolerance of every other network test.  AGZ_COMPUTE_WINO_H2 equilibrates every layer by
+    exact powers of two (per input channel and per GEMM column, conv_wino_h2.hpp wino_build_u2) and has to hold it at every E;
+    AGZ_COMPUTE_FP16X2 (one range per board / per layer, documented as such) is held to it at E = 4."""
+    K, L, W, H, F, Aspace, B = 256, 2, 19, 19, 18, 362, 6
+    onet, gnet = _heterogeneous_pair(ctx, K, L, W, H, F, Aspace, E)
+    x = rand_planes(B, F, H, W, seed=E)
+    pol_f, val_f = gnet.infer(x)
+    gnet.set_compute_mode(wmode | A.capi.COMPUTE_FORCE)
+    pol_g, val_g = gnet.infer(x)
+    idx = [0, B - 1]
+    pol_o, val_o = onet.infer(x[idx])
+    print("\n[heterogeneous ranges] mode=%d E=%d: max|dpol| vs oracle %.3e (f32 path %.3e), vs f32 path %.3e; max|dval| %.3e; max p %.3e"
+          % (wmode, E, np.abs(pol_g[idx] - pol_o).max(), np.abs(pol_f[idx] - pol_o).max(), np.abs(pol_g - pol_f).max(),
+             np.abs(val_g[idx] - val_o).max(), pol_o.max()))
+    assert np.all(np.isfinite(pol_g)) and np.all(np.isfinite(val_g))
+    assert pol_o.max() < 0.9, "the test network saturated: parity on a one-hot policy would be vacuous"
+    np.testing.assert_allclose(pol_f[idx], pol_o, atol=POL_ATOL, rtol=POL_RTOL)       # the exact-product path, for reference
+    if wmode == A.capi.COMPUTE_FP16X2 and E > 4:
+        # the direct fp16x2 mode keeps one range per board and one per layer (include/agz.h: elements more than 2^17 below their
+        # board's / layer's maximum lose relative precision — opt-in mode): beyond E = 4 only finiteness is promised
+        return
+    np.testing.assert_allclose(pol_g[idx], pol_o, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(val_g[idx], val_o, atol=VAL_ATOL)
