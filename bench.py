@@ -59,16 +59,8 @@ def standard_bn_init(net):
             net.set_param(i, np.zeros(n, np.float32))
 
 
-def cpu_baseline(size, K, L, budget_s=20.0, max_threads=32):
-    """The oracle (CPU restatement of the reference algorithm: per-leaf inference, sequential pipeline) timed on the box's
-    host cores, on a bounded sample of the same workload: T threads (one independent 19x19 game each, the way the
-    reference would use its cores: SURVEY 8(d)), each from its own random mid-game opening (the same generator as the GPU
-    leg), one move of a few simulations per game.  The oracle calls run outside the GIL (ctypes), so the threads are real."""
-    import threading
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    A_ = size * size + 1
-    net = O.Net(K, L, 2 * K, size, size, 18, A_, bn_mode=2)
+def _oracle_net(O, K, L, FC, W, H, F, A_):
+    net = O.Net(K, L, FC, W, H, F, A_, bn_mode=2)
     net.init_random(1337)
     for i in range(net.num_params()):
         nm = net.param_name(i)
@@ -76,37 +68,119 @@ def cpu_baseline(size, K, L, budget_s=20.0, max_threads=32):
             net.set_param(i, np.ones_like(net.get_param(i)))
         elif nm.endswith("_beta"):
             net.set_param(i, np.zeros_like(net.get_param(i)))
-    x = np.zeros((1, 18, size, size), np.float32)
-    t0 = time.perf_counter()
-    net.infer(x)
-    t_eval = time.perf_counter() - t0
-    T = max(1, min(max_threads, (os.cpu_count() or 2) // 2))
-    # under T concurrent evaluations one evaluation takes ~2.2x its solo time on this class of host (memory bandwidth)
-    sims = int(max(2, min(64, budget_s / max(2.2 * t_eval, 1e-3) - 1)))
+    return net
+
+
+def _oracle_selfplay_leg(O, T, kind, m, n, k, komi, enc, net, budget, moves_per_thread, opening=None, complete=False, max_moves=0):
+    """T oracle arenas, one thread each (the oracle calls run outside the GIL): every thread plays `moves_per_thread` searched moves
+    (complete=True: whole games until Ended) of its own game.  Returns measured sims/s, evals/s, moves/s, games finished."""
+    import threading
     arenas = []
     rng = np.random.default_rng(1337)
     for g in range(T):
-        ar = O.Arena(O.WQ, size, size, komi=7.5, enc=O.ENC_WQ, Budget=sims, seed=1337 + g)
+        ar = O.Arena(kind, m, n, k, komi=komi, enc=enc, Budget=budget, seed=1337 + g, max_moves=max_moves)
         ar.set_inferencer(0, O.INF_NET, net)     # the net is read-only during inference
         ar.set_inferencer(1, O.INF_NET, net)
         ar.begin(g % 2)
-        for _ in range(int(rng.integers(0, int(0.6 * size * size) + 1))):
-            ar.random_move(1337, g)
+        if opening:
+            for _ in range(int(rng.integers(0, opening + 1))):
+                ar.random_move(1337, g)
         arenas.append(ar)
-    threads = [threading.Thread(target=ar.step, args=(True,)) for ar in arenas]
+    moves = [0] * T
+    done = [0] * T
+
+    def work(i):
+        ar = arenas[i]
+        while True:
+            alive = ar.step(True)
+            moves[i] += 1
+            if not alive:
+                done[i] += 1
+                break
+            if not complete and moves[i] >= moves_per_thread:
+                break
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(T)]
     t0 = time.perf_counter()
     for th in threads:
         th.start()
     for th in threads:
         th.join()
     dt = time.perf_counter() - t0
-    stats = [[ar.tree_stats(a) for a in (0, 1)] for ar in arenas]   # exactly one of the two agents searched
+    stats = [[ar.tree_stats(a) for a in (0, 1)] for ar in arenas]
     playouts = sum(st["playouts"] for pair in stats for st in pair)
     evals = sum(st["nn_evals"] for pair in stats for st in pair)
-    return {"value": playouts / dt, "unit": "sims/s", "cores": T, "kind": "port",
-            "sample": "oracle (C++ restatement, per-leaf inference): %d threads x (1 game from a random mid-game opening, 1 move, %d sims "
-                      "+ root eval) = %d evals in %.1f s on %d of the box's %d host cores" % (T, sims, evals, dt, T, os.cpu_count() or 0),
-            "evals_per_s": evals / dt, "per_core_sims_per_s": playouts / dt / T}
+    return {"sims_per_s": playouts / dt, "evals_per_s": evals / dt, "moves_per_s": sum(moves) / dt, "seconds": dt, "threads": T,
+            "sims": playouts, "moves": sum(moves), "games_finished": sum(done), "games_per_s": (sum(done) / dt) if complete else None}
+
+
+def cpu_baseline(size, K, L, budget_s=30.0, max_threads=64):
+    """The oracle (CPU restatement of the reference algorithm: per-leaf inference, sequential pipeline) timed on the box's host
+    cores, SURVEY 8(d) / BASELINE.md section 3: one independent game per thread (the way the reference would use its cores), threads
+    = min(host cores, 64).  Legs, ~30 s in total:
+      ttt           mnk.TicTacToe(), dual.DefaultConf(3, 3, 10), Budget 1000: COMPLETE games (configs[0])
+      c4            Connect-4 6x7, K=64, 6 blocks, 400 sims/move: two searched moves per thread (a complete game is ~1.5 min of CPU)
+      go9           9x9 Go, K=128, 10 blocks: one searched move of 24 sims per thread (400 sims/move = ~1 min of CPU per move)
+      g19_fair      19x19, K=256, 20 blocks, batch 1 per leaf: one move of a few sims per thread from a random mid-game opening
+      g19_faithful  the reference's Inferencer.Infer evaluates an ActionSpace-row batch per leaf (dualnet/meta.go:175-189): 362 rows;
+                    timed: one row per thread, all threads at once -> seconds per 362-row leaf on these cores
+    `value` is the g19_fair sims/s (the configuration the metric is quoted on)."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = os.cpu_count() or 2
+    T = max(1, min(max_threads, cores))
+    legs = {}
+    # --- ttt: complete games
+    net = _oracle_net(O, 3, 3, 6, 3, 3, 2, 10)
+    r = _oracle_selfplay_leg(O, T, O.MNK, 3, 3, 3, 0.0, O.ENC_TWOPLANE, net, 1000, 0, complete=True)
+    legs["ttt"] = dict(r, workload="mnk.TicTacToe(), dual.DefaultConf(3,3,10) (K=3, 3 blocks), Budget 1000, %d complete games" % T)
+    # --- c4
+    net = _oracle_net(O, 64, 6, 128, 7, 6, 2, 8)
+    r = _oracle_selfplay_leg(O, T, O.C4, 6, 7, 4, 0.0, O.ENC_TWOPLANE, net, 400, 2)
+    legs["c4"] = dict(r, workload="Connect-4 6x7, K=64, 6 blocks, 400 sims/move: %d games x 2 searched moves" % T,
+                      games_per_s_derived=r["moves_per_s"] / 21.0, derived_note="moves/s / 21 moves per game (what the GPU leg's games take)")
+    # --- go9
+    net = _oracle_net(O, 128, 10, 256, 9, 9, 18, 82)
+    r = _oracle_selfplay_leg(O, T, O.WQ, 9, 9, 0, 7.5, O.ENC_WQ, net, 24, 1)
+    legs["go9"] = dict(r, workload="9x9 Go (wq), K=128, 10 blocks: %d games x 1 searched move of 24 sims" % T,
+                       games_per_s_derived=r["sims_per_s"] / (400.0 * 64.0), derived_note="sims/s / (400 sims x 64 moves per game)")
+    # --- g19 fair
+    A_ = size * size + 1
+    net = _oracle_net(O, K, L, 2 * K, size, size, 18, A_)
+    x = np.zeros((1, 18, size, size), np.float32)
+    t0 = time.perf_counter()
+    net.infer(x)
+    t_eval = time.perf_counter() - t0
+    # under T concurrent evaluations one evaluation takes ~2.5x its solo time on this class of host (memory bandwidth)
+    sims = int(max(2, min(64, 9.0 / max(2.5 * t_eval, 1e-3) - 1)))
+    r = _oracle_selfplay_leg(O, T, O.WQ, size, size, 0, 7.5, O.ENC_WQ, net, sims, 1, opening=int(0.6 * size * size))
+    legs["g19_fair"] = dict(r, workload="19x19 Go, K=%d, %d blocks, batch 1 per leaf: %d games from random mid-game openings x 1 move of %d sims"
+                            % (K, L, T, sims), solo_eval_seconds=t_eval)
+    # --- g19 faithful: one row per thread, T rows at once; a leaf is A_ rows
+    xs = [np.zeros((1, 18, size, size), np.float32) for _ in range(T)]
+    threads = [threading.Thread(target=net.infer, args=(xs[i],)) for i in range(T)]
+    t0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    dt_rows = time.perf_counter() - t0
+    leaf_s = dt_rows * (A_ / float(T))
+    legs["g19_faithful"] = {"rows_timed": T, "seconds": dt_rows, "rows_per_leaf": A_, "seconds_per_leaf": leaf_s, "sims_per_s": 1.0 / leaf_s,
+                            "threads": T,
+                            "workload": "the reference evaluates an ActionSpace-row batch per leaf and keeps row 0 (dualnet/meta.go:175-189): "
+                                        "%d of a leaf's %d rows timed (one per thread, concurrently); seconds_per_leaf = that time x %d / %d — "
+                                        "a whole leaf on all %d threads" % (T, A_, A_, T, T)}
+    total = sum(v["seconds"] for v in legs.values())
+    return {"value": legs["g19_fair"]["sims_per_s"], "unit": "sims/s", "cores": T, "kind": "port",
+            "sample": "oracle (C++ restatement, per-leaf inference), %d threads on the box's %d host cores, one game per thread; legs ttt / c4 / go9 / "
+                      "g19_fair / g19_faithful, %.1f s in total; value = g19_fair (19x19, K=%d, %d blocks: %d sims in %.1f s)"
+                      % (T, cores, total, K, L, legs["g19_fair"]["sims"], legs["g19_fair"]["seconds"]),
+            "method": "round 3: threads = min(host cores, 64) (round 2: min(32, cores/2); round 1: min(32, cores)): aggregate values are not "
+                      "comparable across rounds, per_core_sims_per_s is the comparable figure",
+            "per_core_sims_per_s": legs["g19_fair"]["sims_per_s"] / T, "evals_per_s": legs["g19_fair"]["evals_per_s"],
+            "host_cores": cores, **legs}
 
 
 def games_leg(ctx, compute="bf16x3"):
