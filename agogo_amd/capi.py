@@ -109,6 +109,9 @@ def lib():
     sig("agz_net_commit", i32, vp)
     sig("agz_net_infer", i32, vp, pf, i32, pf, pf)
     sig("agz_net_infer_dev", i32, vp, vp, i32, vp, vp)
+    sig("agz_host_alloc", i32, vp, C.c_size_t, pvp)
+    sig("agz_host_free", i32, vp, vp)
+    sig("agz_mcts_to_dot", i32, vp, i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t))
     sig("agz_net_set_latency_mode", i32, vp, i32)
     sig("agz_net_set_tower_queues", i32, vp, i32)
     sig("agz_net_set_compute_mode", i32, vp, i32)
@@ -152,6 +155,7 @@ def lib():
     sig("agz_arena_tree_nodes", i32, vp, i32, i32, pi)
     sig("agz_arena_get_examples", i32, vp, pf, pf, pf, pi, i32, pi)
     sig("agz_arena_clear_examples", i32, vp)
+    sig("agz_arena_drop_labelled_examples", i32, vp)
     sig("agz_arena_examples_dev", i32, vp, pvp, pvp, pvp, pi)
     i64, pi64 = C.c_int64, C.POINTER(C.c_int64)
     sig("agz_train_dev", i32, vp, vp, vp, vp, i32, i32, u64, pf)
@@ -229,6 +233,9 @@ class Ctx:
             for k in sorted([k for k in kids if k is not None], key=lambda k: 0 if isinstance(k, Arena) else 1):  # arenas first
                 k.close()
             self._children = []
+            for p in list(getattr(self, "_pinned", {}).values()):
+                lib().agz_host_free(self.h, C.c_void_p(p))
+            self._pinned = {}
             lib().agz_ctx_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -237,6 +244,21 @@ class Ctx:
             self.close()
         except Exception:
             pass
+
+    def host_array(self, shape, dtype=np.float32):
+        """a numpy array over page-locked host memory (agz_host_alloc); freed when the ctx closes or by host_free(array)"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        _check(lib().agz_host_alloc(self.h, max(n, 1), C.byref(p)), "agz_host_alloc")
+        arr = np.ctypeslib.as_array((C.c_char * max(n, 1)).from_address(p.value)).view(dtype)[: int(np.prod(shape))].reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None and self.h:
+            _check(lib().agz_host_free(self.h, C.c_void_p(p)), "agz_host_free")
 
     def sync(self):
         _check(lib().agz_ctx_sync(self.h), "agz_ctx_sync")
@@ -679,6 +701,14 @@ class Mcts:
         _check(lib().agz_mcts_nodes(self.h, C.byref(n)), "agz_mcts_nodes")
         return n.value
 
+    def to_dot(self, max_nodes=0):
+        """(*MCTS).ToDot (mcts/graph.go:34): Graphviz text of the live tree"""
+        need = C.c_size_t(0)
+        _check(lib().agz_mcts_to_dot(self.h, int(max_nodes), None, 0, C.byref(need)), "agz_mcts_to_dot")
+        buf = C.create_string_buffer(need.value)
+        _check(lib().agz_mcts_to_dot(self.h, int(max_nodes), buf, need.value, C.byref(need)), "agz_mcts_to_dot")
+        return buf.value.decode("utf-8")
+
     def children(self, node=0):
         """(*MCTS).Children(of): ids, moves, visits, blackScores, priors of the children of any node (0 = root)"""
         cap = self.m * self.n + 2
@@ -692,20 +722,6 @@ class Mcts:
                                        _pf(pr), cap, C.byref(n)), "agz_mcts_children")
         k = n.value
         return ids[:k].copy(), mv[:k].copy(), vis[:k].copy(), bs[:k].copy(), pr[:k].copy()
-
-    def to_dot(self, max_nodes=200):
-        """(*MCTS).ToDot (mcts/graph.go:34) on the host: a Graphviz digraph of the most visited part of the tree"""
-        lines, todo, seen = ["digraph mcts {"], [0], 0
-        while todo and seen < max_nodes:
-            node = todo.pop(0)
-            ids, mv, vis, bs, pr = self.children(node)
-            for i, m_, v, b, p in zip(ids, mv, vis, bs, pr):
-                if v > 1:
-                    lines.append('  n%d -> n%d [label="%d"]; n%d [label="v=%d q=%.3f p=%.3f"];' % (node, i, m_, i, v, b / max(v, 1), p))
-                    todo.append(int(i))
-                    seen += 1
-        lines.append("}")
-        return "\n".join(lines)
 
     def stats(self):
         s = ArenaStats()

@@ -71,6 +71,24 @@ int agz_ctx_create(int device, agz_ctx** out) {
   *out = c;
   return AGZ_OK;
 }
+int agz_host_alloc(agz_ctx* ctx, size_t bytes, void** out) {
+  AGZ_REQUIRE(ctx && out && bytes > 0, AGZ_E_INVALID, "agz_host_alloc: bad argument");
+  AGZ_HIP_TRY(hipSetDevice(ctx->device));
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) { agz::set_error("agz_host_alloc: %zu bytes of pinned host memory: %s", bytes, hipGetErrorString(e)); return AGZ_E_NOMEM; }
+  *out = p;
+  return AGZ_OK;
+}
+
+int agz_host_free(agz_ctx* ctx, void* p) {
+  AGZ_REQUIRE(ctx, AGZ_E_INVALID, "agz_host_free: ctx is NULL");
+  if (!p) return AGZ_OK;
+  AGZ_HIP_TRY(hipSetDevice(ctx->device));
+  AGZ_HIP_TRY(hipHostFree(p));
+  return AGZ_OK;
+}
+
 void agz_ctx_destroy(agz_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);

@@ -1284,6 +1284,14 @@ int agz_arena::nn_step(int prep, int nl) {
   return AGZ_OK;
 }
 
+// rows kept[i] of src -> rows i of dst (rowlen floats / words each)
+__global__ void k_gather_rows(float* __restrict__ dst, const float* __restrict__ src, const int32_t* __restrict__ idx, int n, int rowlen) {
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (size_t)n * rowlen) return;
+  const int r = (int)(g / rowlen), c = (int)(g - (size_t)r * rowlen);
+  dst[(size_t)r * rowlen + c] = src[(size_t)idx[r] * rowlen + c];
+}
+
 extern "C" {
 
 int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_conf* mcts, int n_games, uint64_t seed,
@@ -1683,6 +1691,64 @@ int agz_arena_clear_examples(agz_arena* a) {
   return AGZ_OK;
 }
 
+int agz_arena_drop_labelled_examples(agz_arena* a) {
+  AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  hipStream_t s = a->ctx->stream;
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  const auto& c = a->gc;
+  int32_t cnt = 0;
+  AGZ_HIP_TRY(hipMemcpy(&cnt, a->d.ex_count, 4, hipMemcpyDeviceToHost));
+  cnt = std::min(cnt, a->d.ex_cap);
+  if (cnt == 0) return AGZ_OK;
+  std::vector<uint8_t> lab(cnt);
+  std::vector<int32_t> game(cnt), prev(cnt);
+  AGZ_HIP_TRY(hipMemcpy(lab.data(), a->d.ex_labelled, (size_t)cnt, hipMemcpyDeviceToHost));
+  AGZ_HIP_TRY(hipMemcpy(game.data(), a->d.ex_game, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+  AGZ_HIP_TRY(hipMemcpy(prev.data(), a->d.ex_prev, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+  std::vector<int32_t> kept, map(cnt, -1);
+  for (int i = 0; i < cnt; i++) if (!lab[i]) { map[i] = (int32_t)kept.size(); kept.push_back(i); }
+  const int k = (int)kept.size();
+  if (k == cnt) return AGZ_OK;                       // nothing labelled
+  std::vector<int32_t> last(a->G, -1);
+  if (k > 0) {
+    // the rows of games still in flight move to the front (through a scratch copy: source and target ranges overlap), their
+    // per-game chains (ex_prev, ex_last) are re-linked to the new row numbers
+    std::vector<int32_t> ngame(k), nprev(k);
+    for (int i = 0; i < k; i++) {
+      ngame[i] = game[kept[i]];
+      nprev[i] = prev[kept[i]] >= 0 ? map[prev[kept[i]]] : -1;
+      last[ngame[i]] = i;                            // rows of a game are recorded in increasing row order
+    }
+    const size_t xs = (size_t)c.F * c.cells, ps = (size_t)c.A + 1;
+    int32_t* d_idx = nullptr;
+    float* tmp = nullptr;
+    AGZ_HIP_TRY(hipMalloc(&d_idx, (size_t)k * 4));
+    hipError_t e = hipMalloc(&tmp, (size_t)k * std::max(xs, ps) * 4);
+    if (e != hipSuccess) { hipFree(d_idx); AGZ_HIP_TRY(e); }
+    e = hipMemcpyAsync(d_idx, kept.data(), (size_t)k * 4, hipMemcpyHostToDevice, s);
+    auto move = [&](float* buf, size_t rowlen) {
+      if (e != hipSuccess) return;
+      hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)(((size_t)k * rowlen + 255) / 256)), dim3(256), 0, s, tmp, (const float*)buf, (const int32_t*)d_idx, k, (int)rowlen);
+      e = hipMemcpyAsync(buf, tmp, (size_t)k * rowlen * 4, hipMemcpyDeviceToDevice, s);
+    };
+    move(a->d.ex_planes, xs);
+    move(a->d.ex_policy, ps);
+    move(a->d.ex_value, 1);
+    if (e == hipSuccess) e = hipMemcpyAsync(a->d.ex_game, ngame.data(), (size_t)k * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(a->d.ex_prev, nprev.data(), (size_t)k * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(a->d.ex_labelled, 0, (size_t)k, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(d_idx); hipFree(tmp);
+    AGZ_HIP_TRY(e);
+  }
+  const int32_t kk = k;
+  AGZ_HIP_TRY(hipMemcpyAsync(a->d.ex_last, last.data(), (size_t)a->G * 4, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(a->d.ex_count, &kk, 4, hipMemcpyHostToDevice, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  return AGZ_OK;
+}
+
 int agz_arena_examples_dev(agz_arena* a, float** planes, float** policy, float** value, int* n) {
   AGZ_REQUIRE(a && n, AGZ_E_INVALID, "bad argument");
   AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
@@ -1847,8 +1913,13 @@ int agz_mcts_search(agz_mcts* m, int player, int32_t* best) {
   AGZ_REQUIRE(player == AGZ_BLACK || player == AGZ_WHITE, AGZ_E_INVALID, "agz_mcts_search: player %d", player);
   agz_arena* a = m->arena;
   AGZ_REQUIRE(!a->in_move, AGZ_E_STATE, "agz_mcts_search: a search is in progress");
+  // (t.current is nil before SetGame in the reference, tree.go:107-111: Search would dereference it)
+  AGZ_REQUIRE(m->have_game, AGZ_E_STATE, "agz_mcts_search: no game — call agz_mcts_set_game first (mcts.SetGame, tree.go:107)");
   AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
   hipStream_t s = a->ctx->stream;
+  // the overflow counter is cumulative over the handle's life: this search is judged by what IT adds
+  unsigned long long full0 = 0;
+  AGZ_HIP_TRY(hipMemcpyAsync(&full0, a->d.counters + CNT_FULL, 8, hipMemcpyDeviceToHost, s));
   // t.current.SetToMove(player) (search.go:95); the tree of this handle is agent A's: A holds the colour that searches
   const int32_t tm = player, ab = player == AGZ_BLACK ? 1 : 0, zero = 0;
   AGZ_HIP_TRY(hipMemcpyAsync(a->d.to_move, &tm, 4, hipMemcpyHostToDevice, s));
@@ -1872,7 +1943,7 @@ int agz_mcts_search(agz_mcts* m, int player, int32_t* best) {
   AGZ_HIP_TRY(hipMemcpyAsync(&full, a->d.counters + CNT_FULL, 8, hipMemcpyDeviceToHost, s));
   AGZ_HIP_TRY(hipStreamSynchronize(s));
   *best = out[0];
-  AGZ_REQUIRE(full == 0, AGZ_E_TREE_FULL, "agz_mcts_search: the node pool overflowed (max_nodes too small); the move is the best of the truncated search");
+  AGZ_REQUIRE(full == full0, AGZ_E_TREE_FULL, "agz_mcts_search: the node pool overflowed (max_nodes too small); the move is the best of the truncated search");
   return AGZ_OK;
 }
 
@@ -1933,6 +2004,78 @@ int agz_mcts_children(agz_mcts* m, int node, int32_t* child_ids, int32_t* moves,
   return AGZ_OK;
 }
 
+// (*MCTS).ToDot (mcts/graph.go:34-90): the live tree as a Graphviz digraph "G", one HTML-table node per tree node (ID, Move,
+// Player, Visits, Score, State — the reference's rows; its "Value" row prints the evaluation a node was created with, which the
+// device pool does not keep: rendered as "-"), children in move order, the board of a node = its parent's board plus its own move
+// (graph.go:57-60,80-82: captures are not applied there either).  The whole pool is copied to the host once.
+int agz_mcts_to_dot(agz_mcts* m, int max_nodes, char* buf, size_t cap, size_t* needed) {
+  AGZ_REQUIRE(m && needed && (buf || cap == 0), AGZ_E_INVALID, "agz_mcts_to_dot: bad argument");
+  agz_arena* a = m->arena;
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  int32_t pool = 0, n_nodes = 0, hr = 0;
+  AGZ_HIP_TRY(hipMemcpy(&hr, a->d.has_root, 4, hipMemcpyDeviceToHost));
+  if (hr) {
+    AGZ_HIP_TRY(hipMemcpy(&pool, a->d.cur_pool, 4, hipMemcpyDeviceToHost));
+    AGZ_HIP_TRY(hipMemcpy(&n_nodes, a->d.n_nodes, 4, hipMemcpyDeviceToHost));
+  }
+  if (max_nodes > 0 && n_nodes > max_nodes) n_nodes = max_nodes;       // BFS block order: a prefix of the pool is a top of the tree
+  const size_t base = (size_t)pool * a->d.cap;
+  std::vector<int32_t> off(n_nodes);
+  std::vector<int16_t> kn(n_nodes), mv(n_nodes);
+  std::vector<uint32_t> vis(n_nodes);
+  std::vector<float> pri(n_nodes);
+  if (n_nodes) {
+    AGZ_HIP_TRY(hipMemcpy(off.data(), a->d.kids_off + base, (size_t)n_nodes * 4, hipMemcpyDeviceToHost));
+    AGZ_HIP_TRY(hipMemcpy(kn.data(), a->d.kids_n + base, (size_t)n_nodes * 2, hipMemcpyDeviceToHost));
+    AGZ_HIP_TRY(hipMemcpy(mv.data(), a->d.nmove + base, (size_t)n_nodes * 2, hipMemcpyDeviceToHost));
+    AGZ_HIP_TRY(hipMemcpy(vis.data(), a->d.visits + base, (size_t)n_nodes * 4, hipMemcpyDeviceToHost));
+    AGZ_HIP_TRY(hipMemcpy(pri.data(), a->d.prior + base, (size_t)n_nodes * 4, hipMemcpyDeviceToHost));
+  }
+  const int cells = a->gc.cells, stride = a->gc.m;
+  std::vector<int> parent(n_nodes, -1), player(n_nodes, AGZ_BLACK);
+  std::string out = "digraph G {\n";
+  std::string edges, nodes;
+  std::vector<int8_t> board(cells);
+  char tmp[160];
+  for (int i = 0; i < n_nodes; i++) {
+    // this node's board: the moves on the path from the root, each with the colour of its node
+    std::fill(board.begin(), board.end(), 0);
+    for (int j = i; j >= 0; j = parent[j])
+      if (mv[j] >= 0 && mv[j] < cells) board[mv[j]] = (int8_t)player[j];
+    nodes += "\t" + std::to_string(i) + " [ fontname=\"Monaco\", shape=none, label=<\n<TABLE BORDER=\"0\" CELLBORDER=\"1\" CELLSPACING=\"0\">\n";
+    snprintf(tmp, sizeof tmp, "<TR><TD>Node ID</TD><TD>xx%d</TD></TR>\n<TR><TD>Move</TD><TD>%d</TD></TR>\n", i, (int)mv[i]);
+    nodes += tmp;
+    snprintf(tmp, sizeof tmp, "<TR><TD>Player</TD><TD>%s</TD></TR>\n<TR><TD>Visits</TD><TD>%u</TD></TR>\n", player[i] == AGZ_BLACK ? "Black" : "White", vis[i]);
+    nodes += tmp;
+    snprintf(tmp, sizeof tmp, "<TR><TD>Score</TD><TD>%g</TD></TR>\n<TR><TD>Value</TD><TD>-</TD></TR>\n<TR><TD>State</TD><TD>", (double)pri[i]);
+    nodes += tmp;
+    for (int q = 0; q < cells; q++) {
+      if (q % stride == 0) nodes += "\xe2\x8e\xa2 ";                                    // "⎢ "
+      nodes += board[q] == AGZ_BLACK ? "X " : (board[q] == AGZ_WHITE ? "O " : "\xc2\xb7 ");  // "·"
+      if ((q + 1) % stride == 0 && q != 0) nodes += "\xe2\x8e\xa5<BR />";                // "⎥"
+    }
+    nodes += "</TD></TR>\n</TABLE>\n> ];\n";
+    if (off[i] < 0) continue;
+    std::vector<int> kids;
+    for (int k = 0; k < kn[i]; k++) if (off[i] + k < n_nodes) kids.push_back(off[i] + k);
+    std::sort(kids.begin(), kids.end(), [&](int x, int y) { return mv[x] < mv[y]; });            // sort.Sort(byMove) (graph.go:74)
+    for (int c : kids) {
+      parent[c] = i;
+      player[c] = player[i] == AGZ_BLACK ? AGZ_WHITE : AGZ_BLACK;
+      edges += "\t" + std::to_string(i) + "->" + std::to_string(c) + ";\n";
+    }
+  }
+  out += edges + nodes + "}\n";
+  *needed = out.size() + 1;
+  if (cap) {
+    const size_t k = std::min(cap - 1, out.size());
+    memcpy(buf, out.data(), k);
+    buf[k] = 0;
+  }
+  return AGZ_OK;
+}
+
 int agz_mcts_nodes(agz_mcts* m, int* n_nodes) {
   AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
   return agz_arena_tree_nodes(m->arena, 0, 0, n_nodes);
@@ -1958,6 +2101,7 @@ int agz_mcts_reset(agz_mcts* m) {
   AGZ_HIP_TRY(hipMemsetAsync(a->d.counters, 0, CNT_N * sizeof(unsigned long long), s));
   AGZ_HIP_TRY(hipStreamSynchronize(s));
   a->prep_expand_seen = 0;
+  m->have_game = false;      // a fresh mcts.New has no game: SetGame comes first
   return AGZ_OK;
 }
 

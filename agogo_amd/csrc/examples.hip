@@ -170,7 +170,8 @@ int agz_examples_append_arena(agz_examples* e, agz_arena* arena) {
   if (r != AGZ_OK) return r;
   // only examples of FINISHED games carry a training target: SelfPlay returns after the game has ended and been labelled
   // (arena.go:140-155); rows of games still running (agz_arena_selfplay stopped at its target, agz_arena_play(n_moves > 0))
-  // hold the raw mover colour and stay in the arena until their game ends
+  // hold the raw mover colour and stay in the arena until their game ends (agz_arena_clear_examples would discard them with
+  // their games' earlier plies: do not clear an arena in mid-game)
   const uint8_t* lab_dev = nullptr;
   r = agz_arena_examples_labelled_dev(arena, &lab_dev);
   if (r != AGZ_OK) return r;
@@ -181,7 +182,11 @@ int agz_examples_append_arena(agz_examples* e, agz_arena* arena) {
   for (int i = 0; i < cnt; i++) if (lab[i]) order.push_back(i);
   if (order.empty()) return AGZ_OK;
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return game[a] < game[b]; });
-  return e->append(p, q, v, order.size(), &order);
+  r = e->append(p, q, v, order.size(), &order);
+  if (r != AGZ_OK) return r;
+  // TAKE semantics: what was appended leaves the arena (a second append does not duplicate it), the rows of games still in
+  // flight stay — compacted to the front with their per-game chains re-linked — and are labelled and handed over once their game ends
+  return agz_arena_drop_labelled_examples(arena);
 }
 
 int agz_examples_append_dev(agz_examples* e, const float* planes_dev, const float* policy_dev, const float* value_dev, int64_t n) {

@@ -239,6 +239,22 @@ def go9_leg(ctx, compute="wino_h2"):
     return out
 
 
+def config0_leg():
+    """BASELINE configs[0] exactly as the reference's README runs it — AZ.Learn(5, 50, 100, 100) on mnk.TicTacToe() with
+    dual.DefaultConf(3, 3, 10), MCTS Budget 1000 — through the C++ host mirror over the C ABI (tests/cpp/az_learn_ttt, its own
+    process): wall time incl. process start."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "az_learn_ttt")
+    if not os.path.exists(exe):
+        return {"error": "tests/cpp/az_learn_ttt not built"}
+    t0 = time.perf_counter()
+    out = subprocess.run([exe, "5", "50", "100", "100", "1000"], capture_output=True, text=True, timeout=120)
+    wall = time.perf_counter() - t0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("epoch")]
+    return {"workload": "configs[0]: AZ.Learn(5, 50, 100, 100), TicTacToe, DefaultConf(3,3,10), Budget 1000 (C++ host mirror over the C ABI)",
+            "seconds": wall, "ok": "AZ_LEARN OK" in out.stdout, "epochs": lines}
+
+
 def latency_leg(ctx, lanes_list=(1, 16), moves=3, sims=1600):
     """BASELINE config #5 (tournament Agent.Search): 19x19, K=256, 40 blocks, 1600 sims/move, ONE tree through the single-tree
     boundary's engine; p50 wall time of a move (begin_move + simulate(Budget) + end_move + sync) on a short sample: the
@@ -670,6 +686,11 @@ def main():
                 out["extra"]["latency_leg"] = latency_leg(ctx)
             except Exception as e:
                 out["extra"]["latency_leg"] = {"error": repr(e)}
+        if world == 1 and not args.no_games_leg:
+            try:
+                out["extra"]["config0_leg"] = config0_leg()
+            except Exception as e:
+                out["extra"]["config0_leg"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(S, K, L)

@@ -115,19 +115,53 @@ const (
 
 func (n *Net) Close() error { defer n.ctx.enter()(); C.agz_net_destroy(n.h); n.h = nil; return nil }
 
-// Inferencer implements agogo.Inferer over a Net (the batch-1 path; the batched path is BatchedArena).
-type Inferencer struct{ *Net }
+// Inferencer implements agogo.Inferer over a Net (the batch-1 path; the batched path is BatchedArena).  The board, policy and
+// value of a call travel through page-locked staging buffers (agz_host_alloc): Go memory cannot be pinned, a pageable buffer
+// costs a driver bounce copy per direction on the one-board-per-call path (agent.go:60-74).
+type Inferencer struct {
+	*Net
+	in, pol, val unsafe.Pointer // pinned: [Features*H*W], [ActionSpace], [1] floats
+}
 
-var _ agogo.Inferer = Inferencer{}
+var _ agogo.Inferer = (*Inferencer)(nil)
+
+// NewInferencer is dual.Infer's role (dualnet/meta.go:125): an inference handle over committed weights.
+func NewInferencer(n *Net) (*Inferencer, error) {
+	defer n.ctx.enter()()
+	m := &Inferencer{Net: n}
+	nin := C.size_t(n.conf.Features * n.conf.Height * n.conf.Width * 4)
+	if err := lastErr(C.agz_host_alloc(n.ctx.h, nin, &m.in)); err != nil {
+		return nil, err
+	}
+	if err := lastErr(C.agz_host_alloc(n.ctx.h, C.size_t(n.conf.ActionSpace*4), &m.pol)); err != nil {
+		return nil, err
+	}
+	if err := lastErr(C.agz_host_alloc(n.ctx.h, 4, &m.val)); err != nil {
+		return nil, err
+	}
+	return m, nil
+}
 
 // Infer evaluates one encoded board (dualnet/meta.go:168-190).  The returned slice is freshly allocated —
 // the reference returns a slice aliasing the VM output (meta.go:186-189), a latent race not reproduced here.
-func (m Inferencer) Infer(board []float32) (policy []float32, value float32, err error) {
+func (m *Inferencer) Infer(board []float32) (policy []float32, value float32, err error) {
 	defer m.ctx.enter()()
+	nin := m.conf.Features * m.conf.Height * m.conf.Width
+	copy(unsafe.Slice((*float32)(m.in), nin), board)
+	err = lastErr(C.agz_net_infer(m.h, (*C.float)(m.in), 1, (*C.float)(m.pol), (*C.float)(m.val)))
 	policy = make([]float32, m.conf.ActionSpace)
-	var v C.float
-	err = lastErr(C.agz_net_infer(m.h, (*C.float)(unsafe.Pointer(&board[0])), 1, (*C.float)(unsafe.Pointer(&policy[0])), &v))
-	return policy, float32(v), err // Agent.Infer panics on err (agent.go:66-71): behaviour preserved by the caller
+	copy(policy, unsafe.Slice((*float32)(m.pol), m.conf.ActionSpace))
+	return policy, *(*float32)(m.val), err // Agent.Infer panics on err (agent.go:66-71): behaviour preserved by the caller
+}
+
+// Close releases the staging buffers (agogo.Inferer.Close); the Net stays with its owner.
+func (m *Inferencer) Close() error {
+	defer m.ctx.enter()()
+	for _, p := range []unsafe.Pointer{m.in, m.pol, m.val} {
+		C.agz_host_free(m.ctx.h, p)
+	}
+	m.in, m.pol, m.val = nil, nil, nil
+	return nil
 }
 
 // GameKind maps an in-tree game.State to its device implementation; arbitrary user games are not supported.
@@ -439,6 +473,20 @@ func (t *MCTS) Nodes() int {
 	var n C.int
 	C.agz_mcts_nodes(t.h, &n)
 	return int(n)
+}
+
+// ToDot renders the live tree as Graphviz text (mcts/graph.go:34-90).
+func (t *MCTS) ToDot() string {
+	defer t.ctx.enter()()
+	var need C.size_t
+	if C.agz_mcts_to_dot(t.h, 0, nil, 0, &need) != 0 || need == 0 {
+		return ""
+	}
+	buf := make([]byte, int(need))
+	if C.agz_mcts_to_dot(t.h, 0, (*C.char)(unsafe.Pointer(&buf[0])), need, &need) != 0 {
+		return ""
+	}
+	return string(buf[:len(buf)-1])
 }
 
 // Child is one entry of Children: what (*MCTS).Log / ToDot print per node (node.go:56-68).

@@ -54,6 +54,12 @@ const char* agz_version(void);
 /* One HIP device + stream.  Replaces the implicit gorgonia VM/engine an Agent owns (agent.go:44-53). */
 int agz_ctx_create(int device, agz_ctx** out);
 void agz_ctx_destroy(agz_ctx* ctx);
+/* Page-locked host memory for the buffers handed to the host-pointer entry points (agz_net_infer, agz_arena_get_*, ...):
+ * the library stages pageable memory through the driver's bounce buffer; a buffer from agz_host_alloc is DMA-ed directly
+ * (the batch-1 agogo.Inferer path — agent.go:60-74 hands one board per call — is pure latency otherwise).  Plain host
+ * memory as far as the caller is concerned; free with agz_host_free before the ctx goes. */
+int agz_host_alloc(agz_ctx* ctx, size_t bytes, void** out);
+int agz_host_free(agz_ctx* ctx, void* p);
 int agz_ctx_sync(agz_ctx* ctx);
 /* raw hipStream_t the ctx launches on (for callers that want to record their own events) */
 void* agz_ctx_stream(agz_ctx* ctx);
@@ -346,6 +352,11 @@ int agz_arena_tree_nodes(agz_arena* arena, int g, int agent, int* n_nodes);
 int agz_arena_get_examples(agz_arena* arena, float* planes, float* policy, float* value, int32_t* game_idx,
                            int cap, int* n);
 int agz_arena_clear_examples(agz_arena* arena);
+/* Removes the examples of FINISHED games (labelled rows) from the arena's buffer and keeps the rows of games still in flight
+ * (compacted, their per-game chains re-linked), so that continuous self-play can be harvested repeatedly without duplicates
+ * and without losing the earlier plies of running games.  agz_examples_append_arena calls it (take semantics);
+ * agz_arena_clear_examples, in contrast, discards everything — including the rows of running games. */
+int agz_arena_drop_labelled_examples(agz_arena* arena);
 /* device pointers of the example buffers (for an RCCL all-gather before dual.Train) */
 int agz_arena_examples_dev(agz_arena* arena, float** planes, float** policy, float** value, int* n);
 /* device flags [n]: 1 = the example's game has ended and Value is the +1/-1/0 label; 0 = still the raw mover colour */
@@ -376,6 +387,12 @@ int agz_mcts_root_children(agz_mcts* mcts, int32_t* moves, uint32_t* visits, flo
  * node of the live tree — node 0 is the root, child_ids feed further calls; *n = number of children (0: not expanded) */
 int agz_mcts_children(agz_mcts* mcts, int node, int32_t* child_ids, int32_t* moves, uint32_t* visits, float* black_scores,
                       float* priors, int cap, int* n);
+/* (*MCTS).ToDot() (mcts/graph.go:34-90): the live tree as Graphviz text — digraph "G", one HTML-table node per tree node with the
+ * reference's rows (Node ID, Move, Player, Visits, Score = prior, State = the moves of its path on an empty board; "Value", the
+ * evaluation a node was created with, is not kept on the device and prints as "-"), children in move order.  max_nodes > 0 limits
+ * the output to the first max_nodes nodes of the pool (a top of the tree); *needed = bytes incl. the terminating 0 — call with
+ * cap = 0 to size the buffer. */
+int agz_mcts_to_dot(agz_mcts* mcts, int max_nodes, char* buf, size_t cap, size_t* needed);
 /* (*MCTS).Nodes() (tree.go:126): nodes of the live tree (the reference counts its arena slots, freed ones included) */
 int agz_mcts_nodes(agz_mcts* mcts, int* n_nodes);
 int agz_mcts_get_stats(agz_mcts* mcts, agz_arena_stats* out);
@@ -391,8 +408,9 @@ int agz_examples_create(agz_ctx* ctx, int Features, int Height, int Width, int P
 void agz_examples_destroy(agz_examples* ex);
 int agz_examples_count(const agz_examples* ex, int64_t* n);
 int agz_examples_clear(agz_examples* ex);
-/* `ex = append(ex, a.SelfPlay()...)` (agogo.go:110-114) for all games of a batched arena, in the reference's order:
- * game after game, each in ply order. Device-to-device. */
+/* `ex = append(ex, a.SelfPlay()...)` (agogo.go:110-114) for all FINISHED games of a batched arena, in the reference's order:
+ * game after game, each in ply order. Device-to-device.  The appended rows are TAKEN out of the arena
+ * (agz_arena_drop_labelled_examples): calling it again appends only games that finished since. */
 int agz_examples_append_arena(agz_examples* ex, agz_arena* arena);
 /* append n rows from device buffers (e.g. the RCCL all-gathered examples of the other ranks) / host buffers */
 int agz_examples_append_dev(agz_examples* ex, const float* planes_dev, const float* policy_dev, const float* value_dev, int64_t n);

@@ -115,3 +115,50 @@ def test_train_dev_matches_host_train(ctx):
     # device tensors are left in place
     X2, P2, V2 = ex2.tensors()
     np.testing.assert_array_equal(X2, Xp)
+
+
+def test_append_arena_takes_the_finished_games_and_keeps_the_running_ones(ctx):
+    """continuous self-play harvested repeatedly.  agz_examples_append_arena TAKES the rows of finished games
+    out of the arena (a second call appends nothing new), the rows of games still in flight stay — with their earlier plies — and
+    come out labelled once their game ends.  Checked against a twin arena (same seed, same calls) that is never harvested: after
+    every harvest, rows appended so far + rows left in the arena are exactly the twin's rows — same planes, policies AND labels,
+    i.e. the per-game chains survived the compaction and every game was labelled as a whole."""
+    G = 16
+
+    def make():
+        a = A.Arena(ctx, capi.GAME_MNK, 3, 3, 3, encoder=capi.ENC_TWOPLANE, n_games=G, seed=9, Budget=20)
+        a.set_inferencer(0, capi.INF_HASH)
+        a.set_inferencer(1, capi.INF_HASH)
+        a.reset()
+        return a
+
+    def rows(p, q, v):
+        m = np.concatenate([np.asarray(p).reshape(len(v), 18), np.asarray(q).reshape(len(v), 10), np.asarray(v).reshape(-1, 1)], axis=1)
+        return m[np.lexsort(m.T[::-1])] if len(v) else m
+
+    arena, twin = make(), make()
+    ex = A.Examples(ctx, 2, 3, 3, 10)
+    for a in (arena, twin):
+        a.play(4, True)                       # four plies of every game: nothing has ended, nothing to take
+    ex.append_arena(arena)
+    assert len(ex) == 0 and len(arena.examples()[2]) == 4 * G
+    for more in (5, 11, 30):
+        for a in (arena, twin):
+            a.selfplay(a.stats()["games_finished"] + more, record=True)   # finished games restart at once: some are always mid-way
+        before = len(ex)
+        ex.append_arena(arena)
+        assert len(ex) > before
+        again = len(ex)
+        ex.append_arena(arena)                # nothing finished in between: no duplicates
+        assert len(ex) == again
+        left = arena.examples()
+        st = arena.stats()
+        assert st["examples_dropped"] == 0 and st == twin.stats()
+        assert len(ex) + len(left[2]) == st["examples"]
+        assert set(np.unique(left[2])) <= {1.0, 2.0}          # what stays is unlabelled (the raw mover colour)
+        p, q, v = ex.get()
+        assert set(np.unique(v)) <= {-1.0, 0.0, 1.0}
+        tp, tq, tv, _ = twin.examples()
+        mine = rows(np.concatenate([p.reshape(len(v), 18), left[0].reshape(len(left[2]), 18)]),
+                    np.concatenate([q, left[1]]), np.concatenate([v, left[2]]))
+        np.testing.assert_array_equal(mine, rows(tp, tq, tv))

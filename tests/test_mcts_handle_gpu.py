@@ -185,7 +185,7 @@ def test_children_walk_the_whole_tree(ctx):
         for i, v in zip(ids, vis):
             todo.append((int(i), int(v)))
     assert count == dev.nodes()
-    assert dev.to_dot().startswith("digraph mcts {")
+    assert dev.to_dot().startswith("digraph G {")
     with pytest.raises(A.AgzError, match="outside the tree"):
         dev.children(10 ** 6)
 
@@ -227,3 +227,79 @@ def test_single_tree_search_with_the_hip_network(ctx):
         best = dev.root_children()[0][0]
         host.apply(player, int(best) if best >= 0 else host.legal(player)[0])
         player = O.WHITE if player == O.BLACK else O.BLACK
+
+
+def test_search_needs_a_game_and_judges_overflow_per_search(ctx):
+    """Search before SetGame is an error (the reference would dereference a nil t.current, tree.go:107-111), also
+    after Reset; and AGZ_E_TREE_FULL is reported by the search that overflowed only — the next search that fits succeeds."""
+    host = Host(O.MNK, 5, 5, 4, 0.0)
+    dev = A.Mcts(ctx, capi.GAME_MNK, 5, 5, 4, Budget=200, max_nodes=600)
+    dev.set_inferencer(capi.INF_HASH)
+    with pytest.raises(A.AgzError, match="set_game"):
+        dev.search(O.BLACK)
+    dev.set_game(**host.state_kw())
+    with pytest.raises(A.AgzError, match="overflowed"):
+        dev.search(O.BLACK)                      # 200 simulations x up to 25 children do not fit 600 nodes
+    # a position near the end of the game: few legal moves, the same pool is plenty
+    for i, mv in enumerate([0, 1, 2, 3, 5, 4, 6, 8, 7, 9, 10, 12, 11, 13, 14, 16, 15, 17, 18, 20]):
+        host.apply(O.BLACK if i % 2 == 0 else O.WHITE, mv)
+    dev.set_game(**host.state_kw(n_last=0))
+    best = dev.search(O.BLACK)                   # must not raise: the earlier overflow is not this search's
+    assert best in host.legal(O.BLACK)
+    dev.reset()
+    with pytest.raises(A.AgzError, match="set_game"):
+        dev.search(O.BLACK)
+
+
+def test_to_dot_renders_the_live_tree(ctx):
+    """(*MCTS).ToDot (mcts/graph.go:34-90) over the device tree: one node per tree node with the reference's rows, one edge per
+    parent/child pair, children in move order, a node's board = the moves of its path (root: Black, then alternating)."""
+    import re
+    host = Host(O.MNK, 3, 3, 3, 0.0)
+    dev = A.Mcts(ctx, capi.GAME_MNK, 3, 3, 3, Budget=40)
+    dev.set_inferencer(capi.INF_HASH)
+    dev.set_game(**host.state_kw())
+    dev.search(O.BLACK)
+    dot = dev.to_dot()
+    assert dot.startswith("digraph G {") and dot.rstrip().endswith("}")
+    n = dev.nodes()
+    ids = [int(x) for x in re.findall(r"^\t(\d+) \[ fontname", dot, flags=re.M)]
+    assert ids == list(range(n))
+    edges = [(int(a), int(b)) for a, b in re.findall(r"^\t(\d+)->(\d+);", dot, flags=re.M)]
+    assert len(edges) == n - 1 and sorted(b for _, b in edges) == list(range(1, n))       # a tree: every non-root node has one parent
+    kid_ids, moves, visits, _, priors = dev.children(0)
+    root_edges = [b for a, b in edges if a == 0]
+    assert sorted(root_edges) == sorted(int(k) for k in kid_ids)
+    assert [int(moves[list(kid_ids).index(b)]) for b in root_edges] == sorted(int(m) for m in moves)   # byMove order
+    for row in ("Node ID", "Move", "Player", "Visits", "Score", "Value", "State"):
+        assert dot.count("<TD>%s</TD>" % row) == n
+    first = int(kid_ids[0])
+    blk = dot[dot.index("\t%d [ fontname" % first):]
+    blk = blk[:blk.index("];")]
+    assert "<TD>Player</TD><TD>White</TD>" in blk and "<TD>Visits</TD><TD>%d</TD>" % int(visits[0]) in blk
+    # the child's own move in its colour on top of the root's: a fresh mnk root carries the first legal move (no Pass in mnk:
+    # search.go:476-487), rendered as Black's like the reference does (graph.go:57-60)
+    assert blk.count("O ") == 1 and blk.count("X ") == 1
+    short = dev.to_dot(max_nodes=5)
+    assert short.count("[ fontname") == 5
+
+
+def test_pinned_host_buffers_for_the_batch_one_inferer_path(ctx):
+    """agz_host_alloc: page-locked buffers behave like any host memory at the boundary (same bits as pageable ones)"""
+    net = A.Net(ctx, 32, 1, 16, 3, 3, 2, 10)
+    net.init_random(3)
+    net.commit()
+    x = np.random.default_rng(1).choice(np.array([0.0, 1.0], np.float32), size=(1, 2, 3, 3)).astype(np.float32)
+    p0, v0 = net.infer(x)
+    xin = ctx.host_array((1, 2, 3, 3))
+    pol = ctx.host_array((1, 10))
+    val = ctx.host_array((1,))
+    xin[...] = x
+    import ctypes as C
+    capi._check(capi.lib().agz_net_infer(net.h, xin.ctypes.data_as(C.POINTER(C.c_float)), 1, pol.ctypes.data_as(C.POINTER(C.c_float)),
+                                         val.ctypes.data_as(C.POINTER(C.c_float))), "agz_net_infer")
+    np.testing.assert_array_equal(pol, p0)
+    np.testing.assert_array_equal(val, v0)
+    ctx.host_free(xin)
+    with pytest.raises(A.AgzError):
+        capi._check(capi.lib().agz_host_alloc(ctx.h, 0, C.byref(C.c_void_p())), "agz_host_alloc")
