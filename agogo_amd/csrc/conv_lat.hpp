@@ -1,0 +1,277 @@
+// Small-batch ("latency regime") dual block: tournament Agent.Search evaluates ONE board per simulation (agent.go:77-80,
+// dualnet/meta.go:168-190), so a 19x19 / K=256 layer is a 361 x 512 x 2304 GEMM over 7 MB of weights — bound by how fast the
+// weights stream and by launch / dependency latency, not by tiles.  Round 2 ran it as a 9-way split-K fp32-MFMA convolution plus a
+// reduction kernel (22.7 us per layer: two launches, 7 MB of partial sums written and read back, ~1.2 us per K iteration of load ->
+// LDS -> barrier -> MFMA chain).  This kernel is ONE launch per layer with no partial sums in memory:
+//   * workgroup = (8 output channels x both branches = 16 GEMM columns) x (a slot of 48-pixel row groups); NW = C/32 waves, wave w
+//     owns input channels [32 w, 32 w + 32) — the K split is INSIDE the workgroup;
+//   * every wave issues the loads of its whole weight slice up front: 9 taps x 3 bf16 pieces x one 16-byte MFMA B fragment =
+//     27 registers-quads straight from the committed bf16x3 image (w3[cc16][tap][piece][n][16], conv_x3.hpp), kept for all row
+//     groups of the workgroup — every weight byte is read by exactly the workgroups of one column tile, which share an XCD's L2;
+//   * the wave's activation slice (the pixels of the row group plus its 3x3 halo, 32 channels) is split ONCE into the three
+//     exact bf16 pieces on its way into LDS ([piece][pixel][32] bf16, wave-private); the nine taps read their A fragments from
+//     there (no barrier: a wave reads only what it wrote);
+//   * 9 taps x 6 piece products (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi — conv_x3.hpp's fp32-grade product) of
+//     v_mfma_f32_16x16x32_bf16 per 16-row tile; the NW partial tiles are summed through LDS in wave order (deterministic, the same
+//     for every batch size of the regime) and the BN / ReLU / dual-add epilogue is applied by the same workgroup.
+// Per 19x19 K=256 layer: 256 workgroups (32 column tiles x 8 row groups) of 512 threads, 331,776 MFMAs = 2.5 us of matrix pipe at
+// the 16x16x32 rate, 7 MB from HBM.
+#pragma once
+// (included by net.hip INSIDE namespace agz, after conv_x3.hpp)
+
+typedef float f32x4_lat __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_lat __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lat_lds_ptr_t;
+constexpr int LAT_ROWS = 48;         // pixels per row group (3 MFMA row tiles)
+constexpr int LAT_NPIX = 100;        // pixels of a row group incl. halo: 48 + up to 3 board-row seams * 2 + 2 * (Wp + 1) <= 98 at Wp = 21
+constexpr int LAT_SLOTS = 8;         // row-group slots (grid.y)
+
+struct LatArgs {
+  const float* x;            // [B][Hp][Wp][C] padded NHWC fp32 (PRE = false: split in the kernel)
+  const unsigned short* x3;  // [B][3][Hp*Wp][C] the same activations as three bf16 pieces, written by the previous layer (PRE = true)
+  const unsigned short* w3;  // [C/16][9][3][Ntot][16] bf16 pieces, columns in block-tile order (tile*128 + branch*64 + c%64)
+  const void* ep;            // float4 {sa,ta,sb,tb} [HW][Cout_p]
+  float* y;                  // [B][Hp][Wp][Cout_p]
+  unsigned short* y3;        // [B][3][Hp*Wp][Cout_p] pieces of y for the next layer (nullptr: not written)
+  int B, H, W, Hp, Wp, C, Cout_p, Ntot;
+  int groups_per_board;      // ceil(HW / 48)
+#ifdef LAT_PROBE
+  long long* dbg;            // scripts/probes/lat_probe.hip: s_memrealtime stamps of one wave
+#endif
+};
+#ifdef LAT_PROBE
+#define LAT_STAMP(i, waitasm) do { if (a.dbg) { asm volatile(waitasm ::: "memory"); if (blockIdx.x == LAT_PROBE_X && blockIdx.y == 0 && w == LAT_PROBE_W) { long long t_ = __builtin_amdgcn_s_memrealtime(); if (lane == 0) a.dbg[i] = t_; } } } while (0)
+#else
+#define LAT_STAMP(i, waitasm) do { } while (0)
+#endif
+
+template <int NW, bool PRE>
+__global__ __launch_bounds__(NW * 64) void conv3x3_lat_x3_kernel(LatArgs a) {
+  constexpr int PIECE = LAT_NPIX * 64;                 // bytes of one piece image of one wave (32 bf16 per pixel)
+  constexpr int WAVE_LDS = 3 * PIECE;                  // 19,200 B
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NW * WAVE_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = blockIdx.x;                           // column tile: channels ct*8 .. ct*8+7, both branches
+  const int HW = a.H * a.W, HpWp = a.Hp * a.Wp;
+  const int r16 = lane & 15, q = lane >> 4;
+
+  LAT_STAMP(0, "");
+  unsigned char* my = lds + w * WAVE_LDS;
+  const int n_groups = a.B * a.groups_per_board;
+  const int sub = lane >> 3, c4 = (lane & 7) * 4;     // fp32 staging: lane = (pixel l/8 of 8, 4 channels (l%8)*4 ..) per instruction
+  constexpr int NIT = PRE ? 1 : (LAT_NPIX + 7) / 8;
+  constexpr int NE = (LAT_ROWS * 8 + NW * 64 - 1) / (NW * 64);      // epilogue items per thread
+  float4 v[NIT];
+  float4 E[NE];
+  // the epilogue parameters of a group's outputs
+  auto issue_params = [&](int grp) {
+    const int b = grp / a.groups_per_board, gi = grp - b * a.groups_per_board;
+    const int p0 = gi * LAT_ROWS;
+#pragma unroll
+    for (int k = 0; k < NE; k++) {
+      const int o = tid + k * NW * 64;
+      int p = p0 + (o >> 3);
+      p = p < HW ? p : HW - 1;
+      E[k] = reinterpret_cast<const float4*>(a.ep)[(size_t)p * a.Cout_p + ct * 8 + (o & 7)];
+    }
+  };
+  // the wave's activation slice of a row group (its pixels plus the 3x3 halo, 32 channels).  Buffer loads: one lane-offset register
+  // for the whole batch (global_load needs an address pair per load — registers the allocator then recycles by WAITING for early
+  // loads before the weight loads are out), and a window that runs past the last board reads zeros instead of faulting.
+  auto issue_group = [&](int grp) {
+    const int b = grp / a.groups_per_board, gi = grp - b * a.groups_per_board;
+    const int p0 = gi * LAT_ROWS;
+    const int pix0 = p0 + 2 * (p0 / a.W);
+    if constexpr (PRE) {
+      // pieces written by the previous layer: DMA straight into the LDS image, 16 pixels x 64 B per instruction, no registers, no VALU
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x3), 0, a.B * 3 * HpWp * a.C * 2, 0x00020000);
+      const unsigned vo = (unsigned)((((b * 3) * HpWp + pix0 + (lane >> 2)) * a.C + 32 * w + (lane & 3) * 8) * 2);
+      const unsigned pl = (unsigned)(HpWp * a.C * 2), step = (unsigned)(a.C * 32);
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+#pragma unroll
+        for (int it = 0; it < LAT_NPIX / 16; it++)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lat_lds_ptr_t)(my + p * PIECE + it * 1024), 16, vo + p * pl + it * step, 0, 0, 0);
+        if (lane < (LAT_NPIX % 16) * 4)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lat_lds_ptr_t)(my + p * PIECE + (LAT_NPIX / 16) * 1024), 16, vo + p * pl + (LAT_NPIX / 16) * step, 0, 0, 0);
+      }
+    } else {
+      const float* xb = a.x + ((size_t)b * HpWp + pix0) * a.C + 32 * w;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, ((a.B - b) * HpWp - pix0) * a.C * 4 - 128 * w, 0x00020000);
+      const unsigned vo = (unsigned)(sub * a.C + c4) * 4u, step = (unsigned)a.C * 32u;
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const u32x4_lat r = __builtin_amdgcn_raw_buffer_load_b128(rx, vo + it * step, 0, 0);
+        v[it] = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+      }
+    }
+  };
+  // Issue order (loads return in order): parameters, the first group's activations, [workgroup barrier: every wave's activation loads
+  // are queued before any wave's weight loads], the weights.  The activations are consumed while the weights are still in flight.
+  issue_params(blockIdx.y);                          // (grid.y <= n_groups: conv_lat_launch)
+  issue_group(blockIdx.y);
+  __builtin_amdgcn_sched_barrier(0);                 // (the compiler otherwise hoists the weight loads above these)
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- the wave's weight slice, all of it: B fragment of (tap, piece): column j = lane % 16 (branch j / 8, channel ct*8 + j % 8),
+  // k octet q of the wave's 32 channels = chunk 2w + q/2, elements (q%2)*8 .. +7
+  bf16x8_t Bf[9][3];
+  {
+    const int j = r16, c = ct * 8 + (j & 7);
+    const int n = (c >> 6) * 128 + (j >> 3) * 64 + (c & 63);
+    const int cc = 2 * w + (q >> 1);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w3), 0, (a.C / 16) * 27 * a.Ntot * 32, 0x00020000);
+    const unsigned vo = (unsigned)((cc * 27 * a.Ntot + n) * 16 + (q & 1) * 8) * 2u;
+    const unsigned pstride = (unsigned)a.Ntot * 32u;    // bytes between (tap, piece) planes: a scalar offset per load
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+        const u32x4_lat r = __builtin_amdgcn_raw_buffer_load_b128(rw, vo, (t * 3 + p) * pstride, 0);
+        Bf[t][p] = __builtin_bit_cast(bf16x8_t, r);
+      }
+  }
+
+  // (a lambda instantiated twice, not a loop entered with the weights in flight: the wait counts the compiler inserts at a loop
+  // header must hold for every way of reaching it, so a shared body would wait for the WEIGHTS before it touches the first group)
+  auto process = [&](const int grp, auto first_c) __attribute__((always_inline)) {
+    constexpr bool first = decltype(first_c)::value;
+    const int b = grp / a.groups_per_board, gi = grp - b * a.groups_per_board;
+    const int p0 = gi * LAT_ROWS;                       // first pixel (row-major interior index) of the group
+    // pixel window of the group in the padded board: centre of p = p + 2 (p / W) + Wp + 1
+    const int pix0 = p0 + 2 * (p0 / a.W);               // = centre(p0) - Wp - 1
+    LAT_STAMP(1, "s_waitcnt vmcnt(27)");              // (probe: activations + parameters arrived, weights in flight)
+    if constexpr (PRE) {
+      // the DMA writes LDS behind the compiler's back: wait for it by hand (first group: the 27 weight loads stay in flight)
+      if constexpr (first) asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      // ---- split into the three bf16 pieces, once per element, on the way into the wave's LDS image
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int px = it * 8 + sub;
+        unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+        x3_split(v[it].x, h0, m0, l0); x3_split(v[it].y, h1, m1, l1); x3_split(v[it].z, h2, m2, l2); x3_split(v[it].w, h3, m3, l3);
+        if (px < LAT_NPIX) {
+          unsigned char* dst = my + px * 64 + c4 * 2;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(x3_pack(h0, h1), x3_pack(h2, h3));
+          *reinterpret_cast<uint2*>(dst + PIECE) = make_uint2(x3_pack(m0, m1), x3_pack(m2, m3));
+          *reinterpret_cast<uint2*>(dst + 2 * PIECE) = make_uint2(x3_pack(l0, l1), x3_pack(l2, l3));
+        }
+      }
+      // (wave-private LDS: the wave's own writes are visible to its own reads once they have completed)
+      __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0)
+    }
+    __builtin_amdgcn_wave_barrier();
+    LAT_STAMP(2, "");
+    LAT_STAMP(3, "s_waitcnt vmcnt(0)");
+
+    // ---- 3 row tiles x 9 taps x 6 piece products
+    f32x4_lat acc[3];
+    unsigned loc[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      acc[i] = f32x4_lat{0.f, 0.f, 0.f, 0.f};
+      int p = p0 + i * 16 + r16;
+      if (p >= HW) p = HW - 1;                          // (rows past the board: computed on a valid pixel, never stored)
+      loc[i] = (unsigned)((p + 2 * (p / a.W) + a.Wp + 1 - pix0) * 64 + q * 16);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int toff = ((t / 3 - 1) * a.Wp + (t % 3 - 1)) * 64;
+      bf16x8_t A_[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const unsigned char* src = my + (int)loc[i] + toff;
+#pragma unroll
+        for (int p = 0; p < 3; p++) A_[i][p] = *reinterpret_cast<const bf16x8_t*>(src + p * PIECE);
+      }
+      // small terms first (conv_x3.hpp): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi; the three row tiles interleaved so that
+      // consecutive MFMAs never wait on each other's accumulator
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int pa = k == 0 ? 2 : (k == 2 || k == 3) ? 1 : 0, pb = k == 1 ? 2 : (k == 2 || k == 4) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[i][pa], Bf[t][pb], acc[i], 0, 0, 0);
+      }
+    }
+
+    LAT_STAMP(4, "");
+    // ---- sum the NW channel slices through LDS (wave order), epilogue
+    __syncthreads();                                    // every wave is done with its activation image
+    float* red = reinterpret_cast<float*>(lds);         // [NW][48 rows][16 columns]
+    {
+      // C/D layout of 16x16: column = lane % 16, rows 4 * (lane / 16) + reg
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[((size_t)w * LAT_ROWS + i * 16 + 4 * q + r) * 16 + r16] = acc[i][r];
+    }
+    __syncthreads();
+    LAT_STAMP(5, "");
+#pragma unroll
+    for (int k = 0; k < NE; k++) {
+      const int o = tid + k * NW * 64;
+      const int row = o >> 3, ch = o & 7;
+      const int p = p0 + row;
+      if (o < LAT_ROWS * 8 && p < HW) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int u = 0; u < NW; u++) {
+          sa += red[((size_t)u * LAT_ROWS + row) * 16 + ch];
+          sb += red[((size_t)u * LAT_ROWS + row) * 16 + 8 + ch];
+        }
+        const int c = ct * 8 + ch;
+        const float4 e = E[k];
+        float va = sa * e.x + e.y, vb = sb * e.z + e.w;
+        va = va > 0.f ? va : 0.f;
+        vb = vb > 0.f ? vb : 0.f;
+        const float s_ = va + vb;
+        const float out = s_ > 0.f ? s_ : 0.f;
+        const int h = p / a.W, ww = p - h * a.W;
+        const size_t pix = (size_t)(h + 1) * a.Wp + (ww + 1);
+        a.y[((size_t)b * HpWp + pix) * a.Cout_p + c] = out;
+        if (a.y3) {                                     // the next layer's operand, split here once instead of by 32 column tiles
+          unsigned hh, mm, ll;
+          x3_split(out, hh, mm, ll);
+          unsigned short* d3 = a.y3 + ((size_t)(b * 3) * HpWp + pix) * a.Cout_p + c;
+          const size_t pl = (size_t)HpWp * a.Cout_p;
+          d3[0] = (unsigned short)(hh >> 16); d3[pl] = (unsigned short)(mm >> 16); d3[2 * pl] = (unsigned short)(ll >> 16);
+        }
+      }
+    }
+    LAT_STAMP(6, "s_waitcnt vmcnt(0)");
+  };
+  process((int)blockIdx.y, std::integral_constant<bool, true>{});
+  for (int grp = blockIdx.y + LAT_SLOTS; grp < n_groups; grp += LAT_SLOTS) {   // (batches of more than one board)
+    __syncthreads();                                    // the reduction buffer is the next group's activation image
+    issue_params(grp);
+    issue_group(grp);
+    process(grp, std::integral_constant<bool, false>{});
+  }
+}
+
+// shapes the kernel is instantiated for: C = Cout_p in {64, 128, 256} (NW = C / 32 waves; 512 would need 300 KB of LDS), boards whose
+// row groups fit the window
+static inline bool conv_lat_ok(int C, int Cout_p, int Wp) {
+  return C == Cout_p && (C == 64 || C == 128 || C == 256) && LAT_ROWS + 2 * ((LAT_ROWS - 1) / (Wp - 2) + 1) + 2 * (Wp + 1) <= LAT_NPIX;
+}
+
+static void conv_lat_launch(agz_ctx* ctx, const LatArgs& a) {
+  const dim3 grid((unsigned)(a.Cout_p / 8), (unsigned)std::min(LAT_SLOTS, a.B * a.groups_per_board));
+  if (a.x3) {
+    switch (a.C / 32) {
+      case 2: hipLaunchKernelGGL((conv3x3_lat_x3_kernel<2, true>), grid, dim3(128), 0, ctx->stream, a); break;
+      case 4: hipLaunchKernelGGL((conv3x3_lat_x3_kernel<4, true>), grid, dim3(256), 0, ctx->stream, a); break;
+      default: hipLaunchKernelGGL((conv3x3_lat_x3_kernel<8, true>), grid, dim3(512), 0, ctx->stream, a); break;
+    }
+  } else {
+    switch (a.C / 32) {
+      case 2: hipLaunchKernelGGL((conv3x3_lat_x3_kernel<2, false>), grid, dim3(128), 0, ctx->stream, a); break;
+      case 4: hipLaunchKernelGGL((conv3x3_lat_x3_kernel<4, false>), grid, dim3(256), 0, ctx->stream, a); break;
+      default: hipLaunchKernelGGL((conv3x3_lat_x3_kernel<8, false>), grid, dim3(512), 0, ctx->stream, a); break;
+    }
+  }
+}

@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 #include "conv_wino.hpp"
 #include "conv_h2.hpp"
 #include "conv_wino_h2.hpp"
+#include "conv_lat.hpp"
 
 
 // device-side weight split for the trainer (weights change every step): one thread per (tap, n, ci)
@@ -590,6 +592,8 @@ void agz_net::free_device() {
   d_w_dual.clear(); d_ep_dual.clear(); d_w3_dual.clear(); d_w2_dual.clear(); d_u3_dual.clear();
   f(d_head_conv); f(d_head_bn); f(d_Wp); f(d_bp); f(d_W1); f(d_b1); f(d_W2); f(d_b2);
   f(d_act_in); f(d_actA); f(d_actB); f(d_planes); f(d_policy); f(d_value); f(d_ws); f(d_hs);
+  for (auto& p3 : d_lat3) { if (p3) hipFree(p3); p3 = nullptr; }
+  lat3_cap = 0;
   ws_cap = 0; hs_cap = 0;
   max_batch = 0;
 }
@@ -1065,6 +1069,27 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       a.splits = 1; a.per = 0; a.ws = nullptr; a.raw = 0;
       ProfScope ps(ctx, AGZ_PROF_CONV);
       hipLaunchKernelGGL((conv3x3_x3_kernel<true>), dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, a, d_w3_dual[l]);
+      rc = AGZ_OK;
+    }
+    else if (latency && cfg == 0 && (int)d_w3_dual.size() == conf.SharedLayers && d_w3_dual[l] && agz::conv_lat_ok(Kp, Kp, Wp)) {
+      // latency regime, one launch per layer: K split inside the workgroup, weights up front, no partial sums in memory (conv_lat.hpp)
+      // From the second layer on the activations arrive as the three bf16 pieces the previous layer's epilogue wrote (split once
+      // by the producer instead of by each of the 32 column tiles that read them; DMA'd straight into LDS).
+      const size_t need3 = (size_t)B * 3 * Hp * Wp * Kp * sizeof(unsigned short);
+      if (lat3_cap < need3) {
+        for (auto& p3 : d_lat3) { if (p3) hipFree(p3); p3 = nullptr; }
+        lat3_cap = 0;
+        for (auto& p3 : d_lat3) { AGZ_HIP_TRY(hipMalloc(&p3, need3)); AGZ_HIP_TRY(hipMemsetAsync(p3, 0, need3, ctx->stream)); }   // (borders stay zero)
+        lat3_cap = need3;
+      }
+      agz::LatArgs la{};
+      la.x = cur; la.w3 = d_w3_dual[l]; la.ep = d_ep_dual[l]; la.y = nxt;
+      la.x3 = l > 0 ? d_lat3[(l - 1) & 1] : nullptr;
+      la.y3 = l + 1 < conf.SharedLayers ? d_lat3[l & 1] : nullptr;
+      la.B = B; la.H = H; la.W = W; la.Hp = Hp; la.Wp = Wp; la.C = Kp; la.Cout_p = Kp; la.Ntot = 2 * Kp;
+      la.groups_per_board = ceil_div(HW, agz::LAT_ROWS);
+      ProfScope ps(ctx, AGZ_PROF_CONV);
+      agz::conv_lat_launch(ctx, la);
       rc = AGZ_OK;
     }
     else if (cfg != 0) rc = launch_conv<4, 1, 1, true>(ctx, a, wsp, &ws_cap);

@@ -88,6 +88,8 @@ struct agz_net {
   float* d_policy = nullptr;  // [B][A]
   float* d_value = nullptr;   // [B]
   float* d_ws = nullptr;      // split-K workspace (small batches)
+  unsigned short* d_lat3[2] = {nullptr, nullptr};   // latency regime: the tower's activations as bf16x3 pieces, ping-pong (conv_lat.hpp)
+  size_t lat3_cap = 0;        // bytes of each
   size_t ws_cap = 0;
   float* d_hs = nullptr;      // latency-regime head scratch: [B][3][HW] features + [B][A+FC] columns
   size_t hs_cap = 0;
