@@ -175,118 +175,6 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_kernel(WinoArgs a) {
     }
   }
 }
-// Continuous-pipeline form: a workgroup owns a strided list of tiles of its XCD's range and runs them as ONE K loop — the fetch
-// cursor rolls over into the next tile while the matrix pipe is still on the current one, so the load -> split -> LDS pipeline
-// never drains at a tile boundary (the plain kernel pays a first-load bubble of ~2-3 K steps on every 16-step tile); every NK
-// steps the accumulators are stored and cleared.  Needs an even NK (LDS stages alternate with the step parity).
-__global__ __launch_bounds__(256, 3) void wino_gemm_stream_kernel(WinoArgs a) {
-  constexpr int PIECE = 128 * 32;
-  constexpr int STAGE = 6 * PIECE;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
-
-  const int per_pos = a.n_mtiles * a.n_ntiles;
-  const int nblk = 36 * per_pos;
-  const int id = blockIdx.x;
-  const int q = nblk >> 3, rr = nblk & 7, xcd = id & 7;
-  const int first = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
-  const int count = q + (xcd < rr ? 1 : 0);
-  const int stride = ((int)gridDim.x - xcd + 7) >> 3;      // workgroups whose id & 7 == xcd
-  const int lslot = id >> 3;
-  if (lslot >= count) return;                              // uniform: no tile for this workgroup
-  const int n_my = (count - lslot + stride - 1) / stride;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int srow = tid >> 1, shalf = tid & 1;
-  const int NK = a.C >> 4;
-  const unsigned piece_bytes = (unsigned)a.Ntot * 32u;
-  const unsigned s_off = x3_lds_off(srow, shalf);
-
-#define W_TILE_ADDR(TILE_, AOUT, BOUT)                                                                   \
-  {                                                                                                      \
-    const int pos_ = (TILE_) / per_pos;                                                                  \
-    const int rem_ = (TILE_) - pos_ * per_pos;                                                           \
-    const int mt_ = rem_ / a.n_ntiles, nt_ = rem_ - mt_ * a.n_ntiles;                                    \
-    int mr_ = mt_ * 128 + srow;                                                                          \
-    if (mr_ >= a.T) mr_ = a.T - 1;                                                                       \
-    int nr_ = nt_ * 128 + srow;                                                                          \
-    if (nr_ >= a.Ntot) nr_ = a.Ntot - 1;                                                                 \
-    AOUT = (unsigned)((((size_t)pos_ * a.T + mr_) * a.C + shalf * 8) * 4);                               \
-    BOUT = (unsigned)pos_ * (unsigned)NK * 3u * piece_bytes + (unsigned)nr_ * 32u + (unsigned)shalf * 16u; \
-  }
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  unsigned fa[2], fb[2];
-#pragma unroll
-  for (int i = 0; i < 2; i++) fa[i] = x3_lds_off((wm * 2 + i) * 32 + (lane & 31), lane >> 5);
-#pragma unroll
-  for (int j = 0; j < 2; j++) fb[j] = x3_lds_off((wn * 2 + j) * 32 + (lane & 31), lane >> 5);
-
-  float4 xa0, xa1, ya0, ya1;
-  u32x4_t xb0, xb1, xb2, yb0, yb1, yb2;
-  const char* xbase = reinterpret_cast<const char*>(a.V);
-  const char* wbase = reinterpret_cast<const char*>(a.U3);
-  int f_t = lslot, f_k = 0;            // fetch cursor: tile slot inside the XCD range, K step inside the tile
-  unsigned xo_, wo_;
-  W_TILE_ADDR(first + f_t, xo_, wo_)
-#undef X3_ADVANCE
-#define X3_ADVANCE()                                                                          \
-  if (f_k + 1 < NK) { f_k++; xo_ += 64u; wo_ += 3u * piece_bytes; }                           \
-  else if (f_t + stride < count) { f_t += stride; f_k = 0; W_TILE_ADDR(first + f_t, xo_, wo_) }
-  // (past the last tile the cursor stays where it is: the extra loads re-read valid data and are never consumed)
-
-  X3_GLOAD(ya0, ya1, yb0, yb1, yb2)
-  X3_GLOAD(xa0, xa1, xb0, xb1, xb2)
-  X3_STORE_A(ya0, ya1, 0)
-  X3_STORE_B(yb0, yb1, yb2, 0)
-  __syncthreads();
-  int c_t = lslot, c_k = 0;            // compute cursor
-  const int total = n_my * NK;
-  for (int s = 0; s < total; s += 2) {
-    X3_ITER(0, xa0, xa1, xb0, xb1, xb2, ya0, ya1, yb0, yb1, yb2)
-    X3_ITER(1, ya0, ya1, yb0, yb1, yb2, xa0, xa1, xb0, xb1, xb2)
-    c_k += 2;
-    if (c_k == NK) {                   // tile finished: store, clear, next
-      const int tile = first + c_t;
-      const int pos = tile / per_pos;
-      const int rem = tile - pos * per_pos;
-      const int m_tile = rem / a.n_ntiles, n_tile = rem - m_tile * a.n_ntiles;
-      const int m0 = m_tile * 128, n0 = n_tile * 128;
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int m = m0 + row;
-          if (m < a.T) {
-            float* dst = a.Mb + ((size_t)pos * a.T + m) * a.Ntot;
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-              const int c = n0 + (wn * 2 + j) * 32 + (lane & 31);
-              if (c < a.Ntot) dst[c] = acc[i][j][r];
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-      c_k = 0;
-      c_t += stride;
-    }
-  }
-#undef W_TILE_ADDR
-}
 // the shared X3_* staging / pipeline macros of conv_x3.hpp end here
 #undef X3_ITER
 #undef X3_QUAD
@@ -343,98 +231,6 @@ __global__ __launch_bounds__(256) void wino_out_kernel(WinoArgs a) {
   }
 }
 
-// Fused boundary between two Winograd blocks: the output transform + epilogue of block l and the input transform of block
-// l+1 in one kernel — a workgroup owns one board and WINO_CG channels, builds that slice of the block output in LDS
-// (padded board, zero halo) and transforms it straight into V of the next block; the activation never goes to HBM
-// (saves its 0.19 GB write and the re-read).  Mb / ep: block l;  V: input of block l+1 (same T);  y != nullptr: also store
-// the activation (not needed between blocks).
-constexpr int WINO_CG = 32;
-__global__ __launch_bounds__(256) void wino_mid_kernel(WinoArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float yb[];     // [Hp*Wp][WINO_CG]
-  const int ngrp = a.Cout_p / WINO_CG;
-  const int b = blockIdx.x / ngrp, cg = blockIdx.x - b * ngrp;
-  const int tid = threadIdx.x;
-  const int cells = a.Hp * a.Wp * WINO_CG;
-  for (int i = tid; i < cells; i += 256) yb[i] = 0.f;
-  __syncthreads();
-  const float4* ep = reinterpret_cast<const float4*>(a.ep);
-  // ---- phase 1: At M A + epilogue of this board's tiles for channels [cg*CG, cg*CG + CG)
-  for (int it = tid; it < a.TPB * WINO_CG; it += 256) {
-    const int cl = it % WINO_CG, tt = it / WINO_CG;
-    const int c = cg * WINO_CG + cl;
-    const int t = b * a.TPB + tt;
-    const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
-    float Y[2][4][4];
-#pragma unroll
-    for (int br = 0; br < 2; br++) {
-      float tm[4][6];
-#pragma unroll
-      for (int nu = 0; nu < 6; nu++) {
-        float m[6], o[4];
-#pragma unroll
-        for (int xi = 0; xi < 6; xi++) m[xi] = a.Mb[((size_t)(xi * 6 + nu) * a.T + t) * a.Ntot + br * a.Cout_p + c];
-        wino_at4(m, o);
-#pragma unroll
-        for (int k = 0; k < 4; k++) tm[k][nu] = o[k];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; k++) wino_at4(tm[k], Y[br][k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int h = 4 * ty + k;
-#pragma unroll
-      for (int l = 0; l < 4; l++) {
-        const int w = 4 * tx + l;
-        if (h < a.H && w < a.W) {
-          const float4 e = ep[(size_t)(h * a.W + w) * a.Cout_p + c];
-          float va = Y[0][k][l] * e.x + e.y;
-          float vb = Y[1][k][l] * e.z + e.w;
-          va = va > 0.f ? va : 0.f;
-          vb = vb > 0.f ? vb : 0.f;
-          float sv = va + vb;
-          sv = sv > 0.f ? sv : 0.f;
-          yb[((h + 1) * a.Wp + (w + 1)) * WINO_CG + cl] = sv;
-          if (a.y) a.y[(size_t)b * a.Hp * a.Wp * a.Cout_p + ((size_t)(h + 1) * a.Wp + (w + 1)) * a.Cout_p + c] = sv;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // ---- phase 2: Bt d B of the same board slice -> V of the next block
-  for (int it = tid; it < a.TPB * (WINO_CG / 2); it += 256) {
-    const int c2 = it % (WINO_CG / 2), tt = it / (WINO_CG / 2);
-    const int t = b * a.TPB + tt;
-    const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
-    float tmx[6][6], tmy[6][6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      const int px = 4 * tx + j;
-      float dx[6], dy[6], ox[6], oy[6];
-#pragma unroll
-      for (int i = 0; i < 6; i++) {
-        const int py = 4 * ty + i;
-        float2 v = make_float2(0.f, 0.f);
-        if (py < a.Hp && px < a.Wp) v = *reinterpret_cast<const float2*>(&yb[(py * a.Wp + px) * WINO_CG + 2 * c2]);
-        dx[i] = v.x; dy[i] = v.y;
-      }
-      wino_bt6(dx, ox);
-      wino_bt6(dy, oy);
-#pragma unroll
-      for (int i = 0; i < 6; i++) { tmx[i][j] = ox[i]; tmy[i][j] = oy[i]; }
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      float ox[6], oy[6];
-      wino_bt6(tmx[i], ox);
-      wino_bt6(tmy[i], oy);
-#pragma unroll
-      for (int j = 0; j < 6; j++)
-        *reinterpret_cast<float2*>(a.V + ((size_t)(i * 6 + j) * a.T + t) * a.C + cg * WINO_CG + 2 * c2) = make_float2(ox[j], oy[j]);
-    }
-  }
-}
-
 // Host: U[pos][n][ci] = (G g Gt)[xi][nu] of filter g = w[n][ci][3][3] (double, rounded once to fp32), split exactly into
 // three bf16 pieces: u3[pos][ci/16][piece][n][ci%16].  get(n, ci, tap) returns the filter value (0 for padding).
 template <typename Get>
@@ -467,15 +263,10 @@ static void wino_build_u3(std::vector<unsigned short>& u3, int Ntot, int C, Get 
 }
 
 // launches the selected stages for one chunk of boards; V / Mb sized by the caller
-enum { WINO_IN = 1, WINO_GEMM = 2, WINO_OUT = 4, WINO_MID = 8 };
+enum { WINO_IN = 1, WINO_GEMM = 2, WINO_OUT = 4 };
 static void wino_launch(agz_ctx* ctx, WinoArgs& a, int stages) {
   a.nty = ceil_div(a.H, 4); a.ntx = ceil_div(a.W, 4); a.TPB = a.nty * a.ntx; a.T = a.B * a.TPB;
   a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
-  if (stages & WINO_MID) {   // output transform of the previous block (a.Mb, a.ep) fused with this block's input transform (a.V)
-    ProfScope ps(ctx, AGZ_PROF_WINO_OUT);
-    const size_t smem = (size_t)a.Hp * a.Wp * WINO_CG * sizeof(float);
-    hipLaunchKernelGGL(wino_mid_kernel, dim3(a.B * (a.Cout_p / WINO_CG)), dim3(256), smem, ctx->stream, a);
-  }
   if (stages & WINO_IN) {
     ProfScope ps(ctx, AGZ_PROF_WINO_IN);
     const size_t n_in = (size_t)a.T * (a.C / 2);
@@ -483,13 +274,8 @@ static void wino_launch(agz_ctx* ctx, WinoArgs& a, int stages) {
   }
   if (stages & WINO_GEMM) {
     ProfScope ps(ctx, AGZ_PROF_WINO_GEMM);
-    static const int stream_wgs = [] { const char* e = getenv("AGZ_WINO_STREAM"); return e ? atoi(e) : 0; }();   // tuning knob: workgroups per CU
     const int nblk = 36 * a.n_mtiles * a.n_ntiles;
-    if (stream_wgs > 0 && ((a.C >> 4) & 1) == 0)
-      // (at least 8 workgroups when there are 8 tiles: every XCD range needs an owner)
-      hipLaunchKernelGGL(wino_gemm_stream_kernel, dim3(std::min(nblk, std::max(8, stream_wgs * ctx->num_cus))), dim3(256), 0, ctx->stream, a);
-    else
-      hipLaunchKernelGGL(wino_gemm_kernel, dim3(nblk), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(wino_gemm_kernel, dim3(nblk), dim3(256), 0, ctx->stream, a);
   }
   if (stages & WINO_OUT) {
     ProfScope ps(ctx, AGZ_PROF_WINO_OUT);

@@ -1057,47 +1057,33 @@ static void wino_build_u2(std::vector<_Float16>& u2, int Ntot, int C, Get get, s
 
 // tile size with the fewest transform-domain rows for an H x W board
 static inline int wino_h2_pick_tm(int H, int W) {
-  static const int force = [] { const char* e = getenv("AGZ_WINO_H2_TM"); return e ? atoi(e) : 0; }();   // tuning knob
+  static const int force = [] { const char* e = getenv("AGZ_WINO_H2_TM"); return e ? atoi(e) : 0; }();   // environment switch (agz.h)
   if (force == 4 || force == 5) return force;
   const int r4 = 36 * ceil_div(H, 4) * ceil_div(W, 4), r5 = 49 * ceil_div(H, 5) * ceil_div(W, 5);
   return r5 < r4 ? 5 : 4;
 }
 
-// Layout of V and M (tuning knob AGZ_WINO_H2_LAYOUT = blocked (default) | plain, AGZ_WINO_H2_PAD = rows of padding between the
-// positions of the plain layout; measured: no effect, the HBM address hash already spreads the power-of-two stride).
-static inline bool wino_h2_blocked() {
-  static const bool v = [] { const char* e = getenv("AGZ_WINO_H2_LAYOUT"); return !(e && !strcmp(e, "plain")); }();
-  return v;
-}
-static inline int wino_h2_pos_pad() {
-  static const int v = [] { const char* e = getenv("AGZ_WINO_H2_PAD"); return e ? atoi(e) : 0; }();
-  return v < 0 ? 0 : v;
-}
 // rows of V (and of M) the launch below addresses for `tiles` tiles: what the caller sizes the buffers by
-static inline size_t wino_h2_rows(int npos, size_t tiles) { return (size_t)npos * (((tiles + 127) / 128) * 128 + wino_h2_pos_pad()); }
+static inline size_t wino_h2_rows(int npos, size_t tiles) { return (size_t)npos * (((tiles + 127) / 128) * 128); }
 
 // launches the stages of one block for a chunk of boards (h.w.V / Mb sized by the caller: wino_h2_rows())
-static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, hipStream_t st = nullptr) {
+static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, hipStream_t st = nullptr) {
   if (!st) st = ctx->stream;
   WinoArgs& a = h.w;
   const int tm = h.tm == 5 ? 5 : 4;
   h.tm = tm; h.npos = (tm + 2) * (tm + 2);
   a.nty = ceil_div(a.H, tm); a.ntx = ceil_div(a.W, tm); a.TPB = a.nty * a.ntx; a.T = a.B * a.TPB;
-  if (wino_h2_blocked()) { h.rsh = 7; h.rmask = 127; h.rA = (unsigned)h.npos * 128u; h.rB = 128u; }
-  else { h.rsh = 31; h.rmask = 0x7fffffff; h.rA = 0; h.rB = (unsigned)(a.T + wino_h2_pos_pad()); }
+  h.rsh = 7; h.rmask = 127; h.rA = (unsigned)h.npos * 128u; h.rB = 128u;   // V and M in blocks of 128 tiles: [tile / 128][position][tile % 128]
   a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
-  static const int in_swap_env = [] { const char* e = getenv("AGZ_WINO_H2_IN_SWAP"); return e ? atoi(e) : 1; }();
-  h.in_swap = (in_swap_env && a.C % 128 == 0) ? 1 : 0;   // a wave = 64 channel pairs of ONE tile
-  // Forms of the output transform (tuning knob AGZ_WINO_H2_OUT_PAIR): 0 = thread per (tile, channel), both branches at once;
+  h.in_swap = a.C % 128 == 0 ? 1 : 0;   // a wave = 64 channel pairs of ONE tile
+  // Forms of the output transform: 0 = thread per (tile, channel), both branches at once;
   // 3 = block per tile, thread per channel, branch after branch.  Default: 3 for F(5x5,3x3) (0.237 ms against 0.30 for form 0 on
   // the headline block), 0 for F(4x4,3x3) (0.231 against 0.255 for form 3).  (1 and 2 were the removed lane-pair forms.)
-  static const int form_env = [] { const char* e = getenv("AGZ_WINO_H2_OUT_PAIR"); return e ? atoi(e) : -1; }();
   const bool fits32 = (size_t)h.npos * h.rB * a.Ntot * 4 < ((size_t)1 << 32);   // scalar position offsets of the tile form
-  int form = (form_env == 0 || form_env == 3) ? form_env : (tm == 5 ? 3 : 0);
+  int form = tm == 5 ? 3 : 0;
   if (form == 3 && !fits32) form = 0;
-  // the board-range reduction between two blocks rides in the next block's input transform (tuning knob AGZ_WINO_H2_FUSE_MAX)
-  static const int fuse_env = [] { const char* e = getenv("AGZ_WINO_H2_FUSE_MAX"); return e ? atoi(e) : 1; }();
-  const bool fuse = fuse_env && a.C % 128 == 0 && h.wave_max != nullptr;
+  // the board-range reduction between two blocks rides in the next block's input transform
+  const bool fuse = a.C % 128 == 0 && h.wave_max != nullptr;
   h.wm_per_board = a.TPB * (a.Cout_p >> 6);             // wave_max: one word per tile and 64 channels
   h.fuse_prev = (h.fuse_prev && fuse) ? 1 : 0;
   h.amax_self = const_cast<unsigned*>(h.amax_in);
@@ -1110,16 +1096,14 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, int pfa = 0, 
   {
     ProfScopeOn ps(ctx, AGZ_PROF_WINO_GEMM, st == ctx->stream);
     const dim3 gw(h.npos * a.n_mtiles * ceil_div(a.Ntot, 256)), gn(h.npos * a.n_mtiles * a.n_ntiles);
-    // the unrolled deep-prefetch form is instantiated per K extent (32-channel steps); K = 256 with every prefetch depth (tuning)
+    // the unrolled form with the A operand fetched two steps ahead, instantiated per K extent (32-channel steps); other extents take
+    // the plain single-prefetch kernels
     const int nk = a.C >> 5;
     bool done = true;
 #define AGZ_H2D(NK_, PF_, NT_, G_) hipLaunchKernelGGL((wino_gemm_h2d_kernel<NK_, PF_, NT_>), G_, dim3(256), 0, st, h)
 #define AGZ_H2D_NK(NK_) { if (wide) AGZ_H2D(NK_, 2, 2, gw); else AGZ_H2D(NK_, 2, 1, gn); }
-    if (pfa < 1 || (a.C & 31)) done = false;
-    else if (nk == 8) {
-      if (wide) { if (pfa == 1) AGZ_H2D(8, 1, 2, gw); else if (pfa == 2) AGZ_H2D(8, 2, 2, gw); else if (pfa == 3) AGZ_H2D(8, 3, 2, gw); else AGZ_H2D(8, 4, 2, gw); }
-      else { if (pfa == 1) AGZ_H2D(8, 1, 1, gn); else if (pfa == 2) AGZ_H2D(8, 2, 1, gn); else if (pfa == 3) AGZ_H2D(8, 3, 1, gn); else AGZ_H2D(8, 4, 1, gn); }
-    }
+    if (a.C & 31) done = false;
+    else if (nk == 8) AGZ_H2D_NK(8)
     else if (nk == 2) AGZ_H2D_NK(2)
     else if (nk == 4) AGZ_H2D_NK(4)
     else if (nk == 6) AGZ_H2D_NK(6)

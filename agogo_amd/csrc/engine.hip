@@ -1215,8 +1215,7 @@ int agz_arena::nn_step(int prep, int nl) {
   if (inf_kind[0] == AGZ_INF_NET) act0 = net[0]->d_act_in;
   if (inf_kind[1] == AGZ_INF_NET) act1 = split_nets() ? net[1]->d_act_in : (net[1]->d_act_in);
   if (split_nets()) { /* both nets see global slot indices; net B's sub-batch starts at slot nA */ }
-  static const int fused_env = [] { const char* e = getenv("AGZ_LANES_FUSED"); return e ? atoi(e) : 0; }();   // tests: the one-kernel lane loop
-  const bool split_lanes = d.V > 1 && !fused_env;
+  const bool split_lanes = d.V > 1;
   {
     ProfScope ps(ctx, AGZ_PROF_SELECT);
     if (split_lanes) {

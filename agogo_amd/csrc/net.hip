@@ -625,10 +625,7 @@ int agz_net::ensure_batch(int B) {
 // go to a workspace and a second kernel reduces them (in split order) and applies the epilogue.  `per` (measured at
 // K=256, batch 1: 4 -> 1.19, 8 -> 1.05, 12 -> 1.15 ms/simulation) depends on the layer shape only, never on the batch, so within the split regime results are bit-identical for every batch size.
 // ws/ws_cap: caller-owned workspace (grown on demand); ws == nullptr: never split.
-static int splitk_per(int NC) {  // default: one filter tap (NC = Cin/32 iterations) per workgroup -> 9 splits
-  static int over = [] { const char* e = getenv("AGZ_SPLITK_PER"); return e ? atoi(e) : 0; }();  // tuning knob
-  return over >= 1 ? over : NC;
-}
+static int splitk_per(int NC) { return NC; }  // one filter tap (NC = Cin/32 iterations) per workgroup -> 9 splits
 template <int WM, int WN, int MT, bool DUAL>
 static int launch_conv(agz_ctx* ctx, ConvArgs& a, float** ws = nullptr, size_t* ws_cap = nullptr) {
   const int klass = DUAL ? AGZ_PROF_CONV : AGZ_PROF_CONV_INIT;
@@ -744,7 +741,7 @@ int agz::conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float
   wa.B = B; wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Cin_p; wa.Cout_p = Cout_p; wa.Ntot = Cout_p;
   hh.U2 = (const _Float16*)sc->U2; hh.w_unscale = 1.f; hh.w_unscale_dev = unscale; hh.raw = 1; hh.tm = tm;
   hh.amax_in = sc->words; hh.amax_out = nullptr; hh.wave_max = nullptr; hh.fuse_prev = 0;
-  wino_h2_launch(ctx, hh, Cout_p % 256 == 0, 2, s);
+  wino_h2_launch(ctx, hh, Cout_p % 256 == 0, s);
   AGZ_HIP_TRY(hipGetLastError());
   return AGZ_OK;
 }
@@ -845,7 +842,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
                             (this->compute_mode == AGZ_COMPUTE_WINO_H2 || this->compute_mode == AGZ_COMPUTE_WINO ||
                              this->compute_mode == AGZ_COMPUTE_BF16X3 || this->compute_mode == AGZ_COMPUTE_FP16X2);
   const bool latency = small && !forced_split;          // split-K convolutions
-  static const int spread_max = [] { const char* e = getenv("AGZ_HEADS_SPREAD_MAX"); return e ? atoi(e) : 64; }();   // tuning knob
+  const int spread_max = 64;
   // (wide towers: the spread form also wins at 512 boards — 0.17 vs 0.35 ms at 19x19 / K=256, profiles/r02/init_heads_ab.log)
   const bool heads_spread = small || (latency_mode && (B <= spread_max || Kp >= 256));
   float** wsp = latency ? &d_ws : nullptr;
@@ -862,14 +859,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     compute_mode = (Kp >= 192 && cover * 4 <= HW * 5) ? AGZ_COMPUTE_WINO : AGZ_COMPUTE_BF16X3;
   }
   const bool use_h2 = split_ok && compute_mode == AGZ_COMPUTE_FP16X2;
-  // Winograd in the latency regime (AGZ_WINO_LATENCY_TILES=<min tiles>, tuning knob): a round of 8-16 lanes of one tree is
-  // 200-400 tiles = 2-4 row tiles x 4 column tiles x 36 positions — a few hundred workgroups of 16 K steps, where the
-  // split-K fp32 path runs 9 x fewer-but-longer workgroups plus a reduction kernel.  The init conv and the heads keep
-  // their latency-regime kernels.
-  static const int wino_lat_tiles = [] { const char* e = getenv("AGZ_WINO_LATENCY_TILES"); return e ? atoi(e) : 0; }();
-  const bool wino_lat = latency && cfg == 0 && conf.SharedLayers > 0 && wino_lat_tiles > 0 &&
-                        B * ceil_div(H, 4) * ceil_div(W, 4) >= wino_lat_tiles;
-  const bool wino_ok = (split_ok || wino_lat) && compute_mode == AGZ_COMPUTE_WINO;
+  const bool wino_ok = split_ok && compute_mode == AGZ_COMPUTE_WINO;
   const bool wino_h2_ok = split_ok && compute_mode == AGZ_COMPUTE_WINO_H2;
   if (use_h2 && (size_t)B > amax_cap) {
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -879,8 +869,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     amax_cap = (size_t)B;
   }
   int rc;
-  static const int init_x3_env = [] { const char* e = getenv("AGZ_INIT_X3"); return e ? atoi(e) : 1; }();   // tuning knob
-  if (split_ok && compute_mode != AGZ_COMPUTE_F32_MFMA && d_w3_init && Kp % 128 == 0 && init_x3_env &&
+  if (split_ok && compute_mode != AGZ_COMPUTE_F32_MFMA && d_w3_init && Kp % 128 == 0 &&
       (size_t)B * Hp * Wp * Fp * sizeof(float) < ((size_t)1 << 32)) {
     // the split modes: input convolution with bf16x3 products too (same fp32-grade arithmetic as AGZ_COMPUTE_BF16X3)
     a.n_ntiles = ceil_div(a.Ntot, 128); a.n_mtiles = ceil_div(a.M, 128);
@@ -897,56 +886,16 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   float* cur = d_actA;
   float* nxt = d_actB;
   bool tower_done = false;
-  {
-    // Winograd tower with fused block boundaries (AGZ_WINO_FUSE=1, tuning knob): input transform once, then per block
-    // GEMMs + [output transform of block l | input transform of block l+1] in one kernel, the activation staying on chip
-    static const int fuse_env = [] { const char* e = getenv("AGZ_WINO_FUSE"); return e ? atoi(e) : 0; }();
-    const int tpb = ceil_div(H, 4) * ceil_div(W, 4);
-    const size_t v_bytes = (size_t)36 * B * tpb * Kp * 4;
-    if (fuse_env && wino_ok && v_bytes < ((size_t)1 << 32) && Kp % WINO_CG == 0 &&
-        (size_t)Hp * Wp * WINO_CG * sizeof(float) <= 64 * 1024) {
-      AGZ_REQUIRE((int)d_u3_dual.size() == conf.SharedLayers, AGZ_E_STATE, "agz_net: Winograd weights not built");
-      if (B > wino_chunk_cap) {
-        AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (d_wV) hipFree(d_wV);
-        if (d_wM) hipFree(d_wM);
-        d_wV = d_wM = nullptr; wino_chunk_cap = 0;
-        AGZ_HIP_TRY(hipMalloc(&d_wV, (size_t)36 * B * tpb * Kp * sizeof(float)));
-        AGZ_HIP_TRY(hipMalloc(&d_wM, (size_t)36 * B * tpb * 2 * Kp * sizeof(float)));
-        wino_chunk_cap = B; wino_v_cap = 0;
-      }
-      WinoArgs wa{};
-      wa.V = d_wV; wa.Mb = d_wM;
-      wa.B = B; wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
-      for (int l = 0; l < conf.SharedLayers; l++) {
-        ProfScope ps(ctx, AGZ_PROF_CONV);
-        wa.U3 = d_u3_dual[l];
-        if (l == 0) { wa.x = cur; wino_launch(ctx, wa, WINO_IN | WINO_GEMM); }
-        else { wa.ep = d_ep_dual[l - 1]; wa.y = nullptr; wino_launch(ctx, wa, WINO_MID | WINO_GEMM); }
-      }
-      {
-        ProfScope ps(ctx, AGZ_PROF_CONV);
-        wa.ep = d_ep_dual[conf.SharedLayers - 1]; wa.y = nxt;
-        wino_launch(ctx, wa, WINO_OUT);
-      }
-      cur = nxt;
-      tower_done = true;
-    }
-  }
   if (!tower_done && wino_h2_ok) {
     // Winograd with fp16x2 transform-domain products (conv_wino_h2.hpp): per-board ranges in d_amax[block][board]
     AGZ_REQUIRE((int)d_u2_dual.size() == conf.SharedLayers, AGZ_E_STATE, "agz_net: Winograd fp16x2 weights not built");
     // GEMM form (measured on G19/B=512, profiles/r02/wino_h2_gemm_variants.log): 128x256 tile with the A operand fetched two
-    // steps ahead 0.385 ms, 128x128 0.40 ms, the plain single-prefetch kernels 0.47-0.50 ms.  Tuning knobs override.
-    static const int wide_env = [] { const char* e = getenv("AGZ_WINO_H2_WIDE"); return e ? atoi(e) : -1; }();
-    static const int pfa_env = [] { const char* e = getenv("AGZ_WINO_H2_PFA"); return e ? atoi(e) : -1; }();
-    const int pfa = pfa_env >= 0 ? pfa_env : 2;
+    // steps ahead 0.385 ms, 128x128 0.40 ms, the plain single-prefetch kernels 0.47-0.50 ms.
     const int npos = (wino_tm + 2) * (wino_tm + 2);
     const int tpb = ceil_div(H, wino_tm) * ceil_div(W, wino_tm);
     // ... and the 128-column tile when the 256-column grid would leave CUs without a workgroup (a lane round of 16 boards: 196
     // against 392 workgroups, 0.0747 -> 0.0726 ms per block, p50 move 0.250 -> 0.241 s)
-    const bool wide = wide_env >= 0 ? wide_env != 0
-                                    : ((2 * Kp) % 256 == 0 && (size_t)npos * ceil_div(B * tpb, 128) * ((2 * Kp) / 256) >= (size_t)ctx->num_cus);
+    const bool wide = (2 * Kp) % 256 == 0 && (size_t)npos * ceil_div(B * tpb, 128) * ((2 * Kp) / 256) >= (size_t)ctx->num_cus;
     // Board chunks and queues (agz_net_set_tower_queues; AGZ_WINO_H2_CHUNK = boards per chunk, AGZ_WINO_H2_QUEUES = 1 | 2 override):
     // chunk i runs its block chain on queue i % queues with that queue's scratch — chains of different boards are independent
     // (per-board ranges, bit-identical results), so one half-batch's HBM-bound transform kernels run under the other's GEMM and
@@ -955,7 +904,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     static const int queues_env = [] { const char* e = getenv("AGZ_WINO_H2_QUEUES"); return e ? atoi(e) : 0; }();
     const int queues_want = queues_env > 0 ? queues_env : (tower_queues > 0 ? tower_queues : (B >= 256 ? 2 : 1));
     // 32-bit byte offsets into V: npos * (tiles rounded up to 128 + pad) * Kp * 4 < 2^32
-    const int chunk_max = (int)std::min<size_t>((size_t)B, ((((size_t)1 << 32) - 1) / ((size_t)npos * Kp * 4) - 127 - wino_h2_pos_pad()) / tpb);
+    const int chunk_max = (int)std::min<size_t>((size_t)B, ((((size_t)1 << 32) - 1) / ((size_t)npos * Kp * 4) - 127) / tpb);
     int chunk = chunk_env >= 1 ? std::min(chunk_env, chunk_max) : chunk_max;
     const int ns = (queues_want == 2 && B >= 64) ? 2 : 1;
     if (ns == 2 && chunk >= B) chunk = (B + 1) / 2;
@@ -1009,7 +958,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         hh.amax_in = d_amax + (size_t)l * B + b0; hh.amax_out = d_amax + (size_t)(l + 1) * B + b0;
         hh.wave_max = d_wave_max + (size_t)b0 * wm_board;
         hh.fuse_prev = l > 0;   // block 0's input range comes from board_amax_kernel above
-        wino_h2_launch(ctx, hh, wide, pfa, q ? ctx->stream2 : ctx->stream);
+        wino_h2_launch(ctx, hh, wide, q ? ctx->stream2 : ctx->stream);
       }
       std::swap(cur, nxt);
     }

@@ -632,14 +632,12 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     hipLaunchKernelGGL(k_bn_bwd2, dim3(nblk((size_t)g.M * C)), dim3(256), 0, s, g, ly.z, ly.mean, ly.inv, dz, s1, s2, C);
     AGZ_HIP_TRY(hipMemsetAsync(acc, 0, 2048 * sizeof(double), s));
     // weight gradient
-    static const int wg_rows_env = [] { const char* e = getenv("AGZ_WGRAD_ROWS"); return e ? atoi(e) : 0; }();   // tuning knob: rows of the reduction per workgroup
     WgArgs wa{};
-    wa.dz = dz; wa.x = xin; wa.dw = G + ly.o_wf; wa.g = g; wa.N = C; wa.Cin = ly.Cin_p; wa.rows_per_block = wg_rows_env > 0 ? wg_rows_env : 2048;
+    wa.dz = dz; wa.x = xin; wa.dw = G + ly.o_wf; wa.g = g; wa.N = C; wa.Cin = ly.Cin_p; wa.rows_per_block = 2048;   // rows of the reduction per workgroup
     wa.n_tiles = ceil_div(C, 128); wa.c_tiles = ceil_div(ly.Cin_p, 128);
     int chunks = ceil_div(g.M, wa.rows_per_block);
-    // bf16x3 mode: the weight gradient runs on the bf16 pipe as well (tuning knob AGZ_WGRAD_X3=0 keeps the fp32-MFMA kernel)
-    static const int wg_x3_env = [] { const char* e = getenv("AGZ_WGRAD_X3"); return e ? atoi(e) : 1; }();
-    if (x3 && wg_x3_env && (x3_force || (size_t)wa.n_tiles * wa.c_tiles * 9 * chunks >= (size_t)ctx->num_cus))
+    // bf16x3 mode: the weight gradient runs on the bf16 pipe as well
+    if (x3 && (x3_force || (size_t)wa.n_tiles * wa.c_tiles * 9 * chunks >= (size_t)ctx->num_cus))
       hipLaunchKernelGGL(k_wgrad_x3, dim3(wa.n_tiles * wa.c_tiles * 9 * chunks), dim3(256), 0, s, wa);
     else
       hipLaunchKernelGGL(k_wgrad, dim3(wa.n_tiles * wa.c_tiles * 9 * chunks), dim3(256), 0, s, wa);

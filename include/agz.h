@@ -15,6 +15,18 @@
  * dualnet/meta.go:186-189 — a latent race this ABI does not reproduce).
  *
  * Errors: 0 = ok, <0 = AGZ_E_*; agz_last_error() returns a thread-local message.
+ *
+ * Environment switches (ALL of them; each is read once per process, the API default applies when unset, and
+ * each has a test that runs it against the default — named in brackets):
+ *   AGZ_RCCL_LIB=<path>       library dlopen'ed for the ncclXxx symbols instead of librccl.so (agz_comm_*)
+ *                             [tests/test_comm_fake_gpu.py, tests/test_train_gpu.py: the in-tree fake RCCL]
+ *   AGZ_WINO_H2_TM=4|5        Winograd tile of AGZ_COMPUTE_WINO_H2: F(4x4,3x3) / F(5x5,3x3); default: the one with
+ *                             fewer transform-domain rows for the board   [tests/test_wino_gpu.py knobs test]
+ *   AGZ_WINO_H2_CHUNK=<n>     boards per chunk of the AGZ_COMPUTE_WINO_H2 tower (default: as many as 32-bit
+ *                             offsets allow); results are bit-identical  [tests/test_wino_gpu.py knobs test]
+ *   AGZ_WINO_H2_QUEUES=1|2    overrides agz_net_set_tower_queues         [tests/test_wino_gpu.py knobs test]
+ *   AGZ_WINO_CHUNK=<n>        boards per chunk of the AGZ_COMPUTE_WINO tower; bit-identical
+ *                             [tests/test_wino_gpu.py::test_wino_board_chunks_in_a_subprocess]
  */
 #ifndef AGZ_H
 #define AGZ_H

@@ -27,7 +27,7 @@ ap.add_argument("--games", type=int, default=1)
 ap.add_argument("--lanes", type=int, default=1, help="agz_arena_set_parallel: simulations per tree and round")
 ap.add_argument("--compute", choices=["f32", "bf16x3", "wino", "wino_h2"], default="f32",
                 help="wino_h2: AGZ_COMPUTE_WINO_H2 | AGZ_COMPUTE_FORCE (the Winograd fp16x2 tower at every batch size: lane rounds); "
-                     "wino: AGZ_COMPUTE_WINO (with AGZ_WINO_LATENCY_TILES=<n> in the environment it also serves small lane rounds)")
+                     "wino: AGZ_COMPUTE_WINO")
 ap.add_argument("--open", type=int, default=0, help="random opening moves before the timed moves (mid-game trees)")
 args = ap.parse_args()
 

@@ -20,7 +20,7 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--x3", action="store_true")
 ap.add_argument("--h2", action="store_true", help="AGZ_COMPUTE_FP16X2")
 ap.add_argument("--wino", action="store_true", help="AGZ_COMPUTE_WINO (AGZ_WINO_CHUNK=n in the environment: boards per chunk)")
-ap.add_argument("--wino-h2", action="store_true", help="AGZ_COMPUTE_WINO_H2 (AGZ_WINO_H2_WIDE=1: 128x256 GEMM tile)")
+ap.add_argument("--wino-h2", action="store_true", help="AGZ_COMPUTE_WINO_H2")
 ap.add_argument("--force", action="store_true", help="AGZ_COMPUTE_FORCE: take the split kernels below the chip-filling threshold")
 ap.add_argument("--no-latency", action="store_true", help="agz_net_set_latency_mode(0)")
 ap.add_argument("--zero", action="store_true", help="all-zero weights (DVFS probe: same instruction stream, low toggle power)")

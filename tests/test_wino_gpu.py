@@ -192,23 +192,18 @@ def test_wino_h2_two_queue_tower_is_bit_identical(ctx):
 
 H2_KNOBS = [
     {"AGZ_WINO_H2_TM": "4"},                                       # F(4x4,3x3) on boards where F(5x5,3x3) is the default
-    {"AGZ_WINO_H2_TM": "5", "AGZ_WINO_H2_OUT_PAIR": "0"},          # F(5x5,3x3) with the one-thread-per-channel output transform
-    {"AGZ_WINO_H2_TM": "4", "AGZ_WINO_H2_OUT_PAIR": "3"},          # block-per-tile branch-after-branch form on F(4x4,3x3)
-    {"AGZ_WINO_H2_IN_SWAP": "0"},                                  # input transform stores without the lane swaps
-    {"AGZ_WINO_H2_FUSE_MAX": "0"},                                 # board ranges by the separate one-wave-per-board kernel
-    {"AGZ_WINO_H2_FUSE_MAX": "0", "AGZ_WINO_H2_CHUNK": "16"},
-    {"AGZ_WINO_H2_LAYOUT": "plain", "AGZ_WINO_H2_PAD": "9"},       # [position][tile] layout of V and M, padded
+    {"AGZ_WINO_H2_TM": "5"},                                       # F(5x5,3x3) on boards where F(4x4,3x3) is the default (9x9)
     {"AGZ_WINO_H2_CHUNK": "16"},                                   # board chunks
     {"AGZ_WINO_H2_CHUNK": "16", "AGZ_WINO_H2_QUEUES": "2"},        # board chunks on two queues
-    {"AGZ_WINO_H2_WIDE": "0", "AGZ_WINO_H2_PFA": "0"},             # 128x128 GEMM tile, no operand prefetch
+    {"AGZ_WINO_H2_QUEUES": "1"},                                   # one queue whatever the batch
 ]
 
 
 @pytest.mark.parametrize("knobs", H2_KNOBS, ids=lambda k: ",".join("%s=%s" % (a[12:], b) for a, b in k.items()))
 def test_wino_h2_tuning_knobs_in_a_subprocess(knobs):
-    """The AGZ_WINO_H2_* tuning knobs (read once per process) select other tile sizes, layouts and schedules of the same
-    arithmetic: every one of them stays inside the network tolerance against the fp32-MFMA path, and the ones that only move
-    data (layout, chunks, queues, GEMM tile) reproduce the default bit for bit."""
+    """The AGZ_WINO_H2_* environment switches (include/agz.h, read once per process) select the other tile size and other
+    schedules of the same arithmetic: every one of them stays inside the network tolerance against the fp32-MFMA path, and the
+    ones that only move data (chunks, queues) reproduce the default bit for bit."""
     import os
     import subprocess
     import sys
