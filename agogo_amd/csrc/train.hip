@@ -121,7 +121,7 @@ __global__ void k_bn_bwd2(TGeo g, const float* __restrict__ z, const float* __re
 // results are added with float atomics (one wgrad launch per layer; order-dependent rounding is within tolerance).
 struct WgArgs {
   const float* dz; const float* x; float* dw;
-  TGeo g; int N, Cin, rows_per_block, n_tiles, c_tiles;
+  TGeo g; int N, Cin, rows_per_block, n_tiles, c_tiles, n_chunks;
 };
 __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
   __shared__ float As[32][132];  // [k row][n]   (+4 pad: conflict-free ds_read_b32 across the two lane halves)
@@ -202,10 +202,16 @@ __device__ __forceinline__ unsigned wg_lds_off(int col, int kg) { return (unsign
 __global__ __launch_bounds__(256, 2) void k_wgrad_x3(WgArgs a) {
   constexpr int PIECE = 128 * 64;                 // one piece image of one operand: 128 columns x 32 k x 2 B
   __shared__ __attribute__((aligned(16))) unsigned char lds[6 * PIECE];   // A (dz) pieces 0..2, B (x) pieces 3..5
-  int bid = blockIdx.x;
+  // XCD-aware order: the 9 taps x tiles of one row chunk re-read the same dz / x rows (6 MB per 2048 rows at K = 256); workgroup ids
+  // go round-robin over the 8 XCDs, so chunk c runs entirely on XCD c % 8 and its re-reads hit that XCD's L2 instead of missing in 8
+  const int per_chunk = a.n_tiles * a.c_tiles * 9;
+  const int local = (int)(blockIdx.x >> 3);
+  const int chunk = (local / per_chunk) * 8 + (int)(blockIdx.x & 7);
+  if (chunk >= a.n_chunks) return;
+  int bid = local % per_chunk;
   const int ct = bid % a.c_tiles; bid /= a.c_tiles;
   const int nt = bid % a.n_tiles; bid /= a.n_tiles;
-  const int tap = bid % 9, chunk = bid / 9;
+  const int tap = bid;
   const int n0 = nt * 128, c0 = ct * 128;
   const int ky = tap / 3, kx = tap - ky * 3;
   const long tapoff = (long)(ky - 1) * a.g.Wp + (kx - 1);
@@ -215,8 +221,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_x3(WgArgs a) {
   const int kg = wid;                             // staging: this wave's k group = rows rb + 8 kg .. + 7
   const bool na0 = n0 + lane < a.N, na1 = n0 + 64 + lane < a.N;
   const bool cb0 = c0 + lane < a.Cin, cb1 = c0 + 64 + lane < a.Cin;
-  const float* dzp = a.dz + n0 + lane;
-  const float* xp = a.x + c0 + lane;
+  // (buffer loads, masked lanes and rows past the chunk read zero through an out-of-range offset: see k_wgrad_h2)
+  const size_t n_pix = (size_t)a.g.B * a.g.Hp * a.g.Wp;
+  const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz), 0, (int)(n_pix * a.N * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)(n_pix * a.Cin * 4), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -231,15 +240,18 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_x3(WgArgs a) {
     int h = p / a.g.W, w = p - h * a.g.W;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-      const bool ok = r0 + q < r_end;             // uniform
-      const size_t po = ((size_t)b * a.g.Hp + h + 1) * a.g.Wp + w + 1;
-      const float* dr = dzp + po * a.N;
-      const float* xr = xp + (size_t)((long)po + tapoff) * a.Cin;
-      va0[q] = ok && na0 ? dr[0] : 0.f;
-      va1[q] = ok && na1 ? dr[64] : 0.f;
-      vb0[q] = ok && cb0 ? xr[0] : 0.f;
-      vb1[q] = ok && cb1 ? xr[64] : 0.f;
-      if (++w == a.g.W) { w = 0; if (++h == a.g.H) { h = 0; ++b; } }
+      // (rows past the last board lie past the end of both buffers and read zero; chunk ends are multiples of the 32-row K step)
+      const int po = (b * a.g.Hp + h + 1) * a.g.Wp + w + 1;
+      const unsigned oa = (unsigned)(po * a.N + n0 + lane) * 4u;
+      const unsigned ob = (unsigned)((po + (int)tapoff) * a.Cin + c0 + lane) * 4u;
+      va0[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdz, na0 ? oa : OOB, 0, 0));
+      va1[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdz, na1 ? oa + 256u : OOB, 0, 0));
+      vb0[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, cb0 ? ob : OOB, 0, 0));
+      vb1[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, cb1 ? ob + 256u : OOB, 0, 0));
+      const bool we = ++w == a.g.W;                 // (selects, not branches)
+      w = we ? 0 : w; h += we ? 1 : 0;
+      const bool he = h == a.g.H;
+      h = he ? 0 : h; b += he ? 1 : 0;
     }
   };
   auto stage = [&](const float* v, int piece0, int col) {   // split eight k of one column, one 16-byte word per piece
@@ -294,6 +306,168 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_x3(WgArgs a) {
         int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         int c = c0 + wn * 64 + j * 32 + (lane & 31);
         if (n < a.N && c < a.Cin) atomicAdd(&a.dw[((size_t)tap * a.N + n) * a.Cin + c], acc[i][j][r]);
+      }
+}
+
+// ---- the weight gradient with fp16x2 products (AGZ_COMPUTE_WINO_H2) --------------------------------------------------------
+// k_wgrad_x3 spends as many cycles splitting as multiplying: every element of dz and x is split (4 VALU ops + packing) by each of the
+// 9 tap workgroups that read it, and a product costs six MFMAs.  Here both operands are split ONCE per layer by an elementwise pass
+// (k_absmax -> power-of-two scale putting the tensor's maximum into [2^13, 2^14); k_split_h2 writes hi = RN16(v s), lo = RN16(v s - hi)
+// as one 32-bit word per element, 4 bytes like the fp32 it replaces), the GEMM's staging only regroups eight rows of a column into
+// 16-byte words (one v_perm per two halves), and a product is three v_mfma_f32_32x32x16_f16 (hi hi, hi lo, lo hi; the dropped
+// lo lo <= 2^-22 relative).  hi + lo carries v s to an absolute error <= 2^-25 (scaled units) = 2^-38 of the tensor's range.
+// The sums come out scaled by s_dz s_x and are un-scaled (exact powers of two) before the atomic add.
+typedef _Float16 wg_f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float wg_h2_scale(unsigned amax_bits) {   // 2^(13 - E(amax)); 1 for an all-zero (or non-finite) tensor
+  const int e = (int)((amax_bits >> 23) & 0xff);
+  if (e == 0 || e == 255) return 1.f;
+  int se = 127 + 13 - (e - 127);
+  se = se < 1 ? 1 : (se > 254 ? 254 : se);
+  return __uint_as_float((unsigned)se << 23);
+}
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, size_t n4, unsigned* __restrict__ out_bits) {
+  unsigned m = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const unsigned a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
+    const unsigned c = __float_as_uint(v.z) & 0x7fffffffu, d = __float_as_uint(v.w) & 0x7fffffffu;
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d, q = ab > cd ? ab : cd;
+    m = q > m ? q : m;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+  __shared__ unsigned sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned a = sm[0] > sm[1] ? sm[0] : sm[1], b = sm[2] > sm[3] ? sm[2] : sm[3];
+    atomicMax(out_bits, a > b ? a : b);
+  }
+}
+__global__ __launch_bounds__(256) void k_split_h2(const float* __restrict__ x, unsigned* __restrict__ y, size_t n4, const unsigned* __restrict__ amax_bits) {
+  const float s = wg_h2_scale(*amax_bits);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float in[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+    unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const _Float16 hi = (_Float16)in[k];
+      const _Float16 lo = (_Float16)(in[k] - (float)hi);
+      o[k] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+    }
+    reinterpret_cast<uint4*>(y)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+struct WgH2Args {
+  const unsigned* dz2; const unsigned* x2;   // (hi | lo << 16) per element, the layouts of dz and x
+  const unsigned* amax;                      // [0] dz, [1] x: bits of max|.|
+  float* dw;
+  TGeo g; int N, Cin, rows_per_block, n_tiles, c_tiles, n_chunks;
+};
+__global__ __launch_bounds__(256, 2) void k_wgrad_h2(WgH2Args a) {
+  constexpr int PIECE = 128 * 64;                 // one piece image of one operand: 128 columns x 32 k x 2 B
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * PIECE];   // A (dz) hi, lo; B (x) hi, lo
+  // XCD-aware order: the 9 taps x tiles of one row chunk re-read the same dz / x rows (6 MB per 2048 rows at K = 256); workgroup ids
+  // go round-robin over the 8 XCDs, so chunk c runs entirely on XCD c % 8 and its re-reads hit that XCD's L2 instead of missing in 8
+  const int per_chunk = a.n_tiles * a.c_tiles * 9;
+  const int local = (int)(blockIdx.x >> 3);
+  const int chunk = (local / per_chunk) * 8 + (int)(blockIdx.x & 7);
+  if (chunk >= a.n_chunks) return;
+  int bid = local % per_chunk;
+  const int ct = bid % a.c_tiles; bid /= a.c_tiles;
+  const int nt = bid % a.n_tiles; bid /= a.n_tiles;
+  const int tap = bid;
+  const int n0 = nt * 128, c0 = ct * 128;
+  const int ky = tap / 3, kx = tap - ky * 3;
+  const long tapoff = (long)(ky - 1) * a.g.Wp + (kx - 1);
+  const int r_begin = chunk * a.rows_per_block, r_end = min(r_begin + a.rows_per_block, a.g.M);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
+  const int kg = wid;                             // staging: this wave's k group = rows rb + 8 kg .. + 7
+  const bool na0 = n0 + lane < a.N, na1 = n0 + 64 + lane < a.N;
+  const bool cb0 = c0 + lane < a.Cin, cb1 = c0 + 64 + lane < a.Cin;
+  // buffer loads with a per-lane byte offset: masked lanes and rows past the chunk get an out-of-range offset and read zero — a
+  // conditional global_load costs a saveexec + two branches per load (32 loads per thread and K step: more cycles than the MFMAs)
+  const size_t n_pix = (size_t)a.g.B * a.g.Hp * a.g.Wp;
+  const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.dz2), 0, (int)(n_pix * a.N * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.x2), 0, (int)(n_pix * a.Cin * 4), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  unsigned va0[8], va1[8], vb0[8], vb1[8];
+  auto fetch = [&](int rb) {
+    const int r0 = rb + kg * 8;                   // wave-uniform
+    int b = r0 / a.g.HW, p = r0 - b * a.g.HW;
+    int h = p / a.g.W, w = p - h * a.g.W;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      // (rows past the last board lie past the end of both buffers and read zero; chunk ends are multiples of the 32-row K step)
+      const int po = (b * a.g.Hp + h + 1) * a.g.Wp + w + 1;
+      const unsigned oa = (unsigned)(po * a.N + n0 + lane) * 4u;
+      const unsigned ob = (unsigned)((po + (int)tapoff) * a.Cin + c0 + lane) * 4u;
+      va0[q] = __builtin_amdgcn_raw_buffer_load_b32(rdz, na0 ? oa : OOB, 0, 0);
+      va1[q] = __builtin_amdgcn_raw_buffer_load_b32(rdz, na1 ? oa + 256u : OOB, 0, 0);
+      vb0[q] = __builtin_amdgcn_raw_buffer_load_b32(rx, cb0 ? ob : OOB, 0, 0);
+      vb1[q] = __builtin_amdgcn_raw_buffer_load_b32(rx, cb1 ? ob + 256u : OOB, 0, 0);
+      const bool we = ++w == a.g.W;                 // (selects, not branches)
+      w = we ? 0 : w; h += we ? 1 : 0;
+      const bool he = h == a.g.H;
+      h = he ? 0 : h; b += he ? 1 : 0;
+    }
+  };
+  auto stage = [&](const unsigned* v, int piece0, int col) {   // eight k of one column: one 16-byte word of hi halves, one of lo halves
+    wg_u32x4_t ph, pl;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      ph[q] = __builtin_amdgcn_perm(v[2 * q + 1], v[2 * q], 0x05040100u);
+      pl[q] = __builtin_amdgcn_perm(v[2 * q + 1], v[2 * q], 0x07060302u);
+    }
+    const unsigned off = wg_lds_off(col, kg);
+    *reinterpret_cast<wg_u32x4_t*>(lds + (piece0 + 0) * PIECE + off) = ph;
+    *reinterpret_cast<wg_u32x4_t*>(lds + (piece0 + 1) * PIECE + off) = pl;
+  };
+  fetch(r_begin);
+  for (int rb = r_begin; rb < r_end; rb += 32) {
+    stage(va0, 0, lane); stage(va1, 0, 64 + lane);
+    stage(vb0, 2, lane); stage(vb1, 2, 64 + lane);
+    __syncthreads();
+    if (rb + 32 < r_end) fetch(rb + 32);          // in flight under the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const int kgr = ks * 2 + (lane >> 5);
+      wg_f16x8_t A_[2][2], B_[2][2];
+#pragma unroll
+      for (int pz = 0; pz < 2; pz++) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+          A_[i][pz] = *reinterpret_cast<const wg_f16x8_t*>(lds + pz * PIECE + wg_lds_off(wm * 64 + i * 32 + (lane & 31), kgr));
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          B_[j][pz] = *reinterpret_cast<const wg_f16x8_t*>(lds + (2 + pz) * PIECE + wg_lds_off(wn * 64 + j * 32 + (lane & 31), kgr));
+      }
+#define WG_MF(I, J, PA, PB) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[I][PA], B_[J][PB], acc[I][J], 0, 0, 0);
+#define WG_QUAD(PA, PB) WG_MF(0, 0, PA, PB) WG_MF(0, 1, PA, PB) WG_MF(1, 0, PA, PB) WG_MF(1, 1, PA, PB)
+      WG_QUAD(1, 0) WG_QUAD(0, 1) WG_QUAD(0, 0)   // smaller terms first
+#undef WG_QUAD
+#undef WG_MF
+    }
+    __syncthreads();
+  }
+  const float un = 1.f / (wg_h2_scale(a.amax[0]) * wg_h2_scale(a.amax[1]));   // exact: a power of two
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int c = c0 + wn * 64 + j * 32 + (lane & 31);
+        if (n < a.N && c < a.Cin) atomicAdd(&a.dw[((size_t)tap * a.N + n) * a.Cin + c], acc[i][j][r] * un);
       }
 }
 
@@ -554,6 +728,9 @@ struct agz_trainer {
   // other data draw at K = 256 / 19x19, which moves that unit's gradients by percent: outside the stated tolerance, removed.)
   bool wino = false;
   WinoRawScratch wsc;
+  // ... and the weight gradient with fp16x2 products: both operands split once per layer (k_wgrad_h2)
+  unsigned *dz_h2 = nullptr, *x_h2 = nullptr, *wg_amax = nullptr;
+  size_t dz_h2_cap = 0, x_h2_cap = 0;
   bool use_wino(int cin, int cout) const {
     return wino && cin % 32 == 0 && cin >= 64 && conv3x3_raw_wino_h2_fits(B, g.H, g.W, cin, cout) &&
            (x3_force || (size_t)((g.M + 127) / 128) * ((cout + 127) / 128) >= (size_t)ctx->num_cus);
@@ -636,9 +813,30 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     wa.dz = dz; wa.x = xin; wa.dw = G + ly.o_wf; wa.g = g; wa.N = C; wa.Cin = ly.Cin_p; wa.rows_per_block = 2048;   // rows of the reduction per workgroup
     wa.n_tiles = ceil_div(C, 128); wa.c_tiles = ceil_div(ly.Cin_p, 128);
     int chunks = ceil_div(g.M, wa.rows_per_block);
+    wa.n_chunks = chunks;
+    const unsigned wg_grid = (unsigned)(wa.n_tiles * wa.c_tiles * 9 * round_up(chunks, 8));   // k_wgrad_x3 / _h2: XCD-aware order
+    const bool chip_full = x3_force || (size_t)wa.n_tiles * wa.c_tiles * 9 * chunks >= (size_t)ctx->num_cus;
+    const bool off31 = (size_t)B * g.Hp * g.Wp * (size_t)std::max(C, ly.Cin_p) * 4 < ((size_t)1 << 31);   // byte offsets of the buffer loads
+    if (wino && chip_full && off31 && C % 4 == 0 && ly.Cin_p % 4 == 0) {
+      // fp16x2 products: range + split pass over dz and x (once per layer, not once per tap workgroup), then the GEMM
+      const size_t n_dz = (size_t)B * g.Hp * g.Wp * C, n_x = (size_t)B * g.Hp * g.Wp * ly.Cin_p;
+      if (dz_h2_cap < n_dz) { if (dz_h2) hipFree(dz_h2); dz_h2 = nullptr; dz_h2_cap = 0; AGZ_HIP_TRY(hipMalloc(&dz_h2, n_dz * 4)); dz_h2_cap = n_dz; }
+      if (x_h2_cap < n_x) { if (x_h2) hipFree(x_h2); x_h2 = nullptr; x_h2_cap = 0; AGZ_HIP_TRY(hipMalloc(&x_h2, n_x * 4)); x_h2_cap = n_x; }
+      if (!wg_amax) AGZ_HIP_TRY(hipMalloc(&wg_amax, 2 * sizeof(unsigned)));
+      AGZ_HIP_TRY(hipMemsetAsync(wg_amax, 0, 2 * sizeof(unsigned), s));
+      const unsigned gs = (unsigned)std::min<size_t>(nblk(n_dz / 4), (size_t)ctx->num_cus * 8);
+      hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, s, dz, n_dz / 4, wg_amax);
+      hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, s, xin, n_x / 4, wg_amax + 1);
+      hipLaunchKernelGGL(k_split_h2, dim3(gs), dim3(256), 0, s, dz, dz_h2, n_dz / 4, wg_amax);
+      hipLaunchKernelGGL(k_split_h2, dim3(gs), dim3(256), 0, s, xin, x_h2, n_x / 4, wg_amax + 1);
+      WgH2Args wh{};
+      wh.dz2 = dz_h2; wh.x2 = x_h2; wh.amax = wg_amax; wh.dw = wa.dw; wh.g = g; wh.N = wa.N; wh.Cin = wa.Cin;
+      wh.rows_per_block = wa.rows_per_block; wh.n_tiles = wa.n_tiles; wh.c_tiles = wa.c_tiles; wh.n_chunks = chunks;
+      hipLaunchKernelGGL(k_wgrad_h2, dim3(wg_grid), dim3(256), 0, s, wh);
+    }
     // bf16x3 mode: the weight gradient runs on the bf16 pipe as well
-    if (x3 && (x3_force || (size_t)wa.n_tiles * wa.c_tiles * 9 * chunks >= (size_t)ctx->num_cus))
-      hipLaunchKernelGGL(k_wgrad_x3, dim3(wa.n_tiles * wa.c_tiles * 9 * chunks), dim3(256), 0, s, wa);
+    else if (x3 && off31 && chip_full)
+      hipLaunchKernelGGL(k_wgrad_x3, dim3(wg_grid), dim3(256), 0, s, wa);
     else
       hipLaunchKernelGGL(k_wgrad, dim3(wa.n_tiles * wa.c_tiles * 9 * chunks), dim3(256), 0, s, wa);
     if (l > 0) {  // data gradient: the forward GEMM with flipped/transposed weights over the [a|b] channels of dz
@@ -731,6 +929,9 @@ void agz_trainer_destroy(agz_trainer* t) {
   hipStreamSynchronize(t->ctx->stream);
   for (void* p : t->allocs) hipFree(p);
   wino_raw_scratch_free(&t->wsc);
+  if (t->dz_h2) hipFree(t->dz_h2);
+  if (t->x_h2) hipFree(t->x_h2);
+  if (t->wg_amax) hipFree(t->wg_amax);
   delete t;
 }
 
