@@ -58,6 +58,28 @@ __global__ __launch_bounds__(256) void board_amax_kernel(const float* __restrict
   if (tid == 0) amax[b] = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
+// the same reduction spread over `parts` workgroups per board (grid = B * parts, amax zeroed by the caller): the trainer's
+// 256-board passes, where one workgroup per board leaves the chip reading at 0.9 TB/s.  max is order-independent: same words.
+__global__ __launch_bounds__(256) void board_amax_parts_kernel(const float* __restrict__ x, unsigned* __restrict__ amax, int HW, int W, int Wp,
+                                                               int HpWp, int C, int parts) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / parts, part = blockIdx.x - b * parts, tid = threadIdx.x;
+  const int c4 = C >> 2;
+  const int n = HW * c4, lo = (int)((long)n * part / parts), hi = (int)((long)n * (part + 1) / parts);
+  float m = 0.f;
+  for (int i = lo + tid; i < hi; i += 256) {
+    int p = i / c4, c = (i - p * c4) << 2;
+    int h = p / W, w = p - h * W;
+    const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * HpWp + (h + 1) * Wp + (w + 1)) * C + c);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) atomicMax(&amax[b], __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
 __global__ __launch_bounds__(256, 3) void conv3x3_h2_kernel(ConvArgs a, const _Float16* __restrict__ w2) {
   constexpr int BM = 128, BNT = 128;
   constexpr int PIECE = 128 * 64;            // bytes of one piece image (128 rows x 32 fp16)
@@ -383,6 +405,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h2w_kernel(ConvArgs a, const _
       float s_, unscale;
       h2_scales(a.amax_in[b], &s_, &unscale);
       unscale *= a.w_unscale;
+      if (a.raw) {
+        // training forward (conv3x3_raw_h2): the GEMM result as is, columns in the weight image's own order; the weights' scale is a
+        // device word (they change every step)
+        float sw_, unw_;
+        h2_scales(*a.w_amax_dev, &sw_, &unw_);
+        unscale *= unw_;
+        float* yr = a.y + ((size_t)b * a.HpWp + (h + 1) * a.Wp + (w + 1)) * a.Ntot;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int c = n0 + rb[j];
+          if (mvalid && c < a.Ntot) yr[c] = acc[i][j][r] * unscale;
+        }
+        continue;
+      }
 #pragma unroll
       for (int jj = 0; jj < 2; jj++) {
         int c = n_tile * 128 + wn * 64 + jj * 32 + (lane & 31);

@@ -47,6 +47,7 @@ struct ConvArgs {
   // w_unscale = 2^-eb of the pre-scaled weights
   const unsigned* amax_in;
   float w_unscale;
+  const unsigned* w_amax_dev;   // raw fp16x2 form (conv3x3_raw_h2): bits of max|w|, the scale of the device-built weight image
 };
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -689,6 +690,68 @@ int agz::conv3x3_raw_x3(agz_ctx* ctx, const float* x, const unsigned short* w3, 
   return AGZ_OK;
 }
 
+// ---- raw convolution with fp16x2 products (the trainer's forward in AGZ_COMPUTE_WINO_H2): conv_h2.hpp's 128x256 kernel with a raw
+// store, on a weight image built on the device from the current filter (range word + hi/lo split; the weights change every step)
+__global__ __launch_bounds__(256) void w_absmax_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ out_bits) {
+  unsigned m = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned a = __float_as_uint(w[i]) & 0x7fffffffu;
+    m = a > m ? a : m;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, m);
+}
+__global__ __launch_bounds__(256) void split_w2_kernel(const float* __restrict__ w, _Float16* __restrict__ w2, int N, int Cin_p, const unsigned* __restrict__ wmax) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)9 * N * Cin_p) return;
+  const int ci = (int)(idx % Cin_p);
+  const size_t r = idx / Cin_p;
+  const int n = (int)(r % N), t = (int)(r / N);
+  float s, inv;
+  h2_scales(*wmax, &s, &inv);
+  const float xs = w[idx] * s;
+  const _Float16 hi = (_Float16)xs;
+  const _Float16 lo = (_Float16)(xs - (float)hi);
+  const size_t base = (((size_t)((ci >> 5) * 9 + t) * 2) * N + n) * 32 + (ci & 31);
+  w2[base] = hi;
+  w2[base + (size_t)N * 32] = lo;
+}
+bool agz::conv3x3_raw_h2_fits(int B, int H, int W, int Cin_p, int Cout_p) {
+  return Cin_p % 32 == 0 && Cout_p % 256 == 0 && (size_t)B * (H + 2) * (W + 2) * (size_t)std::max(Cin_p, Cout_p) * sizeof(float) < ((size_t)1 << 32);
+}
+int agz::conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc) {
+  AGZ_REQUIRE(conv3x3_raw_h2_fits(B, H, W, Cin_p, Cout_p), AGZ_E_UNSUPPORTED, "conv3x3_raw_h2: shape %d x %dx%d, %d -> %d not supported", B, H, W, Cin_p, Cout_p);
+  hipStream_t s = ctx->stream;
+  const size_t w_elems = (size_t)9 * Cout_p * Cin_p;
+  if (sc->w2_cap < w_elems * 2) {
+    if (sc->w2) hipFree(sc->w2);
+    sc->w2 = nullptr; sc->w2_cap = 0;
+    AGZ_HIP_TRY(hipMalloc(&sc->w2, w_elems * 2 * sizeof(_Float16)));
+    sc->w2_cap = w_elems * 2;
+  }
+  if (sc->h2_b_cap < B) {
+    if (sc->h2_words) hipFree(sc->h2_words);
+    sc->h2_words = nullptr; sc->h2_b_cap = 0;
+    AGZ_HIP_TRY(hipMalloc(&sc->h2_words, ((size_t)B + 1) * sizeof(unsigned)));
+    sc->h2_b_cap = B;
+  }
+  unsigned* wmax = sc->h2_words + B;
+  AGZ_HIP_TRY(hipMemsetAsync(wmax, 0, sizeof(unsigned), s));
+  hipLaunchKernelGGL(w_absmax_kernel, dim3((unsigned)std::min<size_t>((w_elems + 255) / 256, 1024)), dim3(256), 0, s, w, w_elems, wmax);
+  hipLaunchKernelGGL(split_w2_kernel, dim3((unsigned)((w_elems + 255) / 256)), dim3(256), 0, s, w, (_Float16*)sc->w2, Cout_p, Cin_p, wmax);
+  AGZ_HIP_TRY(hipMemsetAsync(sc->h2_words, 0, (size_t)B * sizeof(unsigned), s));
+  hipLaunchKernelGGL(board_amax_parts_kernel, dim3(B * 8), dim3(256), 0, s, x, sc->h2_words, H * W, W, W + 2, (H + 2) * (W + 2), Cin_p, 8);
+  ConvArgs a{};
+  a.M = B * H * W; a.HW = H * W; a.W = W; a.Wp = W + 2; a.HpWp = (H + 2) * (W + 2);
+  a.x = x; a.w = nullptr; a.ep = nullptr; a.y = y; a.Cin_p = Cin_p; a.Cout_p = Cout_p; a.Ntot = Cout_p; a.raw = 1;
+  a.n_ntiles = Cout_p / 256; a.n_mtiles = ceil_div(a.M, 128); a.splits = 1;
+  a.amax_in = sc->h2_words; a.w_unscale = 1.f; a.w_amax_dev = wmax;
+  ProfScope ps(ctx, AGZ_PROF_CONV_INIT);
+  hipLaunchKernelGGL(conv3x3_h2w_kernel, dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, s, a, (const _Float16*)sc->w2);
+  AGZ_HIP_TRY(hipGetLastError());
+  return AGZ_OK;
+}
+
 bool agz::conv3x3_raw_wino_h2_fits(int B, int H, int W, int Cin_p, int Cout_p) {
   const int tm = wino_h2_pick_tm(H, W), npos = (tm + 2) * (tm + 2);
   const size_t tiles = (size_t)B * ceil_div(H, tm) * ceil_div(W, tm);
@@ -703,6 +766,8 @@ void agz::wino_raw_scratch_free(WinoRawScratch* sc) {
   if (sc->M) hipFree(sc->M);
   if (sc->U2) hipFree(sc->U2);
   if (sc->words) hipFree(sc->words);
+  if (sc->w2) hipFree(sc->w2);
+  if (sc->h2_words) hipFree(sc->h2_words);
   *sc = WinoRawScratch{};
 }
 
@@ -734,7 +799,8 @@ int agz::conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float
     hipLaunchKernelGGL(wino_u_build_kernel<4>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax, (_Float16*)sc->U2, unscale);
   }
   // per-board range of the input (training activations are signed: the kernel takes |x|)
-  hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, s, x, sc->words, H * W, W, Wp, Hp * Wp, Cin_p);
+  AGZ_HIP_TRY(hipMemsetAsync(sc->words, 0, (size_t)B * sizeof(unsigned), s));
+  hipLaunchKernelGGL(board_amax_parts_kernel, dim3(B * 8), dim3(256), 0, s, x, sc->words, H * W, W, Wp, Hp * Wp, Cin_p, 8);
   WinoH2Args hh{};
   WinoArgs& wa = hh.w;
   wa.x = x; wa.y = y; wa.V = sc->V; wa.Mb = sc->M; wa.ep = nullptr;

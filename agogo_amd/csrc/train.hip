@@ -57,6 +57,43 @@ __global__ void k_bn_fin(double* acc, int C, double m, float eps, float* mean, f
   acc[c] = 0;
 }
 
+// One pass for both statistics (C % 4 == 0, C <= 1024): sum(z) -> acc[c], sum(z^2) -> acc[1024 + c], both in double (a product of
+// two fp32 values is exact in double, so E[z^2] - mean^2 loses nothing against the two-pass form above at these row counts); float4
+// loads, 256 / (C/4) row slices per workgroup reduced through LDS, one double atomic per channel and workgroup.
+__global__ __launch_bounds__(256) void k_bn_stats(TGeo g, const float* __restrict__ z, int C, double* __restrict__ acc, int rows_per_block) {
+  __shared__ double red[2][1024];
+  const int c4n = C >> 2, slices = 256 / c4n;
+  const int tid = threadIdx.x, cg = tid % c4n, rs = tid / c4n;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, g.M);
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (rs < slices)
+    for (int r = r0 + rs; r < r1; r += slices) {
+      const float4 v = *reinterpret_cast<const float4*>(z + pix_off(g, r) * C + 4 * cg);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+    }
+  for (int c = tid; c < C; c += 256) { red[0][c] = 0; red[1][c] = 0; }
+  __syncthreads();
+  for (int k = 0; k < slices; k++) {          // slice after slice: a fixed summation order inside the workgroup
+    if (rs == k) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) { red[0][4 * cg + e] += s[e]; red[1][4 * cg + e] += q[e]; }
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < C; c += 256) { atomicAdd(&acc[c], red[0][c]); atomicAdd(&acc[1024 + c], red[1][c]); }
+}
+__global__ void k_bn_fin2(double* acc, int C, double m, float eps, float* mean, float* inv) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = acc[c] / m;
+  double var = acc[1024 + c] / m - mu * mu;
+  var = var > 0 ? var : 0;
+  mean[c] = (float)mu;
+  inv[c] = 1.0f / sqrtf((float)var + eps);
+  acc[c] = 0; acc[1024 + c] = 0;
+}
+
 // ---- tower BN apply (+ReLU, + dual add + ReLU).  z [pix][nbr*Kp]; gamma/beta [M][nbr*Kp]; out [pix][Kp] --------
 __global__ void k_bn_apply(TGeo g, const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
                            const float* __restrict__ mean, const float* __restrict__ inv, float* __restrict__ out, int Kp, int nbr) {
@@ -735,6 +772,13 @@ struct agz_trainer {
     return wino && cin % 32 == 0 && cin >= 64 && conv3x3_raw_wino_h2_fits(B, g.H, g.W, cin, cout) &&
            (x3_force || (size_t)((g.M + 127) / 128) * ((cout + 127) / 128) >= (size_t)ctx->num_cus);
   }
+  // AGZ_COMPUTE_WINO_H2 forward: the DIRECT convolution with fp16x2 products (conv_h2.hpp's kernel with a raw store) — no transform in
+  // front of the products, so its rounding is that of fp32 accumulation (3e-7 of the output rms, the same as bf16x3), unlike the
+  // Winograd forward that was removed
+  bool use_h2_fwd(int cin, int cout) const {
+    return wino && cin >= 64 && conv3x3_raw_h2_fits(B, g.H, g.W, cin, cout) &&
+           (x3_force || (size_t)((g.M + 127) / 128) * (cout / 256) >= (size_t)ctx->num_cus);
+  }
   // bf16x3 only where the 128-row tiles fill the chip (same rule as inference) and the filter has whole 16-channel chunks
   bool use_x3(const TLayer& ly, int cin, int cout) const {
     return x3 && ly.w3f && cin % 16 == 0 && cin >= 64 &&
@@ -762,7 +806,9 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   for (int l = 0; l <= L; l++) {
     TLayer& ly = layers[l];
     int r;
-    if (use_x3(ly, ly.Cin_p, ly.Cout_p)) {
+    if (use_h2_fwd(ly.Cin_p, ly.Cout_p)) {
+      r = conv3x3_raw_h2(ctx, cur, P + ly.o_wf, ly.z, B, g.H, g.W, ly.Cin_p, ly.Cout_p, &wsc);
+    } else if (use_x3(ly, ly.Cin_p, ly.Cout_p)) {
       if ((r = split_w3(ctx, P + ly.o_wf, ly.w3f, ly.Cout_p, ly.Cin_p)) != AGZ_OK) return r;
       r = conv3x3_raw_x3(ctx, cur, ly.w3f, ly.z, B, g.H, g.W, ly.Cin_p, ly.Cout_p);
     } else {
@@ -770,10 +816,15 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     }
     if (r != AGZ_OK) return r;
     int C = ly.Cout_p;
-    hipLaunchKernelGGL(k_bn_sum, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, C, (const float*)nullptr, acc, RPB);
-    hipLaunchKernelGGL(k_bn_fin, dim3(nblk(C)), dim3(256), 0, s, acc, C, (double)g.M, conf.bn_eps, ly.mean, ly.inv, 0);
-    hipLaunchKernelGGL(k_bn_sum, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, C, (const float*)ly.mean, acc, RPB);
-    hipLaunchKernelGGL(k_bn_fin, dim3(nblk(C)), dim3(256), 0, s, acc, C, (double)g.M, conf.bn_eps, ly.mean, ly.inv, 1);
+    if (C % 4 == 0 && C <= 1024 && g.M >= 4096) {   // (small problems keep the two-pass form: nothing to gain, and it is the oracle's order)
+      hipLaunchKernelGGL(k_bn_stats, dim3(nblk(g.M, 256)), dim3(256), 0, s, g, ly.z, C, acc, 256);
+      hipLaunchKernelGGL(k_bn_fin2, dim3(nblk(C)), dim3(256), 0, s, acc, C, (double)g.M, conf.bn_eps, ly.mean, ly.inv);
+    } else {
+      hipLaunchKernelGGL(k_bn_sum, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, C, (const float*)nullptr, acc, RPB);
+      hipLaunchKernelGGL(k_bn_fin, dim3(nblk(C)), dim3(256), 0, s, acc, C, (double)g.M, conf.bn_eps, ly.mean, ly.inv, 0);
+      hipLaunchKernelGGL(k_bn_sum, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, C, (const float*)ly.mean, acc, RPB);
+      hipLaunchKernelGGL(k_bn_fin, dim3(nblk(C)), dim3(256), 0, s, acc, C, (double)g.M, conf.bn_eps, ly.mean, ly.inv, 1);
+    }
     hipLaunchKernelGGL(k_bn_apply, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean,
                        ly.inv, ly.out, Kp, ly.nbr);
     cur = ly.out;
