@@ -693,16 +693,29 @@ int agz::conv3x3_raw_x3(agz_ctx* ctx, const float* x, const unsigned short* w3, 
 // ---- raw convolution with fp16x2 products (the trainer's forward in AGZ_COMPUTE_WINO_H2): conv_h2.hpp's 128x256 kernel with a raw
 // store, on a weight image built on the device from the current filter (range word + hi/lo split; the weights change every step)
 __global__ __launch_bounds__(256) void w_absmax_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ out_bits) {
+  __shared__ unsigned sm[4];
   unsigned m = 0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const unsigned a = __float_as_uint(w[i]) & 0x7fffffffu;
     m = a > m ? a : m;
   }
   for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
-  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned a = sm[0] > sm[1] ? sm[0] : sm[1], b = sm[2] > sm[3] ? sm[2] : sm[3];
+    atomicMax(out_bits, a > b ? a : b);
+  }
 }
-__global__ __launch_bounds__(256) void split_w2_kernel(const float* __restrict__ w, _Float16* __restrict__ w2, int N, int Cin_p, const unsigned* __restrict__ wmax) {
+// (also clears what the NEXT kernels accumulate into: the board range words of this call and the weight range word of the next call —
+// two words used alternately, so no memset launches between the kernels)
+__global__ __launch_bounds__(256) void split_w2_kernel(const float* __restrict__ w, _Float16* __restrict__ w2, int N, int Cin_p, const unsigned* __restrict__ wmax,
+                                                       unsigned* __restrict__ board_words, int B, unsigned* __restrict__ wmax_next) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0) {
+    for (int b = threadIdx.x; b < B; b += 256) board_words[b] = 0u;
+    if (threadIdx.x == 0) *wmax_next = 0u;
+  }
   if (idx >= (size_t)9 * N * Cin_p) return;
   const int ci = (int)(idx % Cin_p);
   const size_t r = idx / Cin_p;
@@ -732,14 +745,15 @@ int agz::conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, 
   if (sc->h2_b_cap < B) {
     if (sc->h2_words) hipFree(sc->h2_words);
     sc->h2_words = nullptr; sc->h2_b_cap = 0;
-    AGZ_HIP_TRY(hipMalloc(&sc->h2_words, ((size_t)B + 1) * sizeof(unsigned)));
-    sc->h2_b_cap = B;
+    AGZ_HIP_TRY(hipMalloc(&sc->h2_words, ((size_t)B + 2) * sizeof(unsigned)));
+    AGZ_HIP_TRY(hipMemsetAsync(sc->h2_words, 0, ((size_t)B + 2) * sizeof(unsigned), s));
+    sc->h2_b_cap = B; sc->h2_flip = 0;
   }
-  unsigned* wmax = sc->h2_words + B;
-  AGZ_HIP_TRY(hipMemsetAsync(wmax, 0, sizeof(unsigned), s));
-  hipLaunchKernelGGL(w_absmax_kernel, dim3((unsigned)std::min<size_t>((w_elems + 255) / 256, 1024)), dim3(256), 0, s, w, w_elems, wmax);
-  hipLaunchKernelGGL(split_w2_kernel, dim3((unsigned)((w_elems + 255) / 256)), dim3(256), 0, s, w, (_Float16*)sc->w2, Cout_p, Cin_p, wmax);
-  AGZ_HIP_TRY(hipMemsetAsync(sc->h2_words, 0, (size_t)B * sizeof(unsigned), s));
+  unsigned* wmax = sc->h2_words + sc->h2_b_cap + sc->h2_flip;          // zero: cleared at allocation / by the previous call's split kernel
+  unsigned* wmax_next = sc->h2_words + sc->h2_b_cap + (sc->h2_flip ^ 1);
+  sc->h2_flip ^= 1;
+  hipLaunchKernelGGL(w_absmax_kernel, dim3((unsigned)std::min<size_t>((w_elems + 255) / 256, 256)), dim3(256), 0, s, w, w_elems, wmax);
+  hipLaunchKernelGGL(split_w2_kernel, dim3((unsigned)((w_elems + 255) / 256)), dim3(256), 0, s, w, (_Float16*)sc->w2, Cout_p, Cin_p, wmax, sc->h2_words, B, wmax_next);
   hipLaunchKernelGGL(board_amax_parts_kernel, dim3(B * 8), dim3(256), 0, s, x, sc->h2_words, H * W, W, W + 2, (H + 2) * (W + 2), Cin_p, 8);
   ConvArgs a{};
   a.M = B * H * W; a.HW = H * W; a.W = W; a.Wp = W + 2; a.HpWp = (H + 2) * (W + 2);

@@ -26,7 +26,7 @@ struct WinoRawScratch {
   float* V = nullptr; float* M = nullptr; void* U2 = nullptr; unsigned* words = nullptr;   // words: [B] board ranges, max|U| bits, 1/su
   size_t v_cap = 0, m_cap = 0, u_cap = 0; int b_cap = 0;
   void* w2 = nullptr; unsigned* h2_words = nullptr;   // conv3x3_raw_h2: fp16x2 weight image, [B] board ranges + max|w| bits
-  size_t w2_cap = 0; int h2_b_cap = 0;
+  size_t w2_cap = 0; int h2_b_cap = 0, h2_flip = 0;
 };
 // raw 3x3 convolution with fp16x2 products (direct form; weights split on the device every call)
 int conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc);
