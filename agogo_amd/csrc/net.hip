@@ -931,13 +931,11 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   // (the split kernels use 32-bit BYTE offsets: activation tensor below 4 GiB)
   const bool split_ok = cfg == 0 && !latency && (!half_dual || compute_force) && conf.SharedLayers > 0 &&
                         (size_t)B * Hp * Wp * Kp * sizeof(float) < ((size_t)1 << 32);
-  // AGZ_COMPUTE_AUTO: the measured per-shape choice (19x19 K=256: Winograd 1.07 vs bf16x3 2.03 ms per block; 9x9 K=128: bf16x3
-  // 13.4 vs Winograd 12.6 games/s; shapes below the chip-filling threshold: fp32 kernels)
+  // AGZ_COMPUTE_AUTO: the measured choice — the Winograd fp16x2 tower wherever its weights exist (K a multiple of 64; 19x19 K=256:
+  // 0.72 vs 2.03 ms per block for bf16x3, 9x9 K=128: 21.4 vs 13.5 games/s), else bf16x3; shapes below the chip-filling threshold
+  // keep the fp32 kernels either way
   int compute_mode = this->compute_mode;
-  if (compute_mode == AGZ_COMPUTE_AUTO) {
-    const int cover = ceil_div(H, 4) * 4 * ceil_div(W, 4) * 4;
-    compute_mode = (Kp >= 192 && cover * 4 <= HW * 5) ? AGZ_COMPUTE_WINO : AGZ_COMPUTE_BF16X3;
-  }
+  if (compute_mode == AGZ_COMPUTE_AUTO) compute_mode = !d_u2_dual.empty() ? AGZ_COMPUTE_WINO_H2 : AGZ_COMPUTE_BF16X3;
   const bool use_h2 = split_ok && compute_mode == AGZ_COMPUTE_FP16X2;
   const bool wino_ok = split_ok && compute_mode == AGZ_COMPUTE_WINO;
   const bool wino_h2_ok = split_ok && compute_mode == AGZ_COMPUTE_WINO_H2;
@@ -1466,8 +1464,8 @@ int agz_net_commit(agz_net* n) {
   n->d_u2_tin.clear();
   for (auto& p : n->d_u2_colun) if (p) hipFree(p);
   n->d_u2_colun.clear();
-  if ((n->compute_mode == AGZ_COMPUTE_WINO || n->compute_mode == AGZ_COMPUTE_AUTO) && n->cfg == 0) return n->build_wino_weights();
-  if (n->compute_mode == AGZ_COMPUTE_WINO_H2 && n->cfg == 0) return n->build_wino_h2_weights();
+  if (n->compute_mode == AGZ_COMPUTE_WINO && n->cfg == 0) return n->build_wino_weights();
+  if ((n->compute_mode == AGZ_COMPUTE_WINO_H2 || n->compute_mode == AGZ_COMPUTE_AUTO) && n->cfg == 0) return n->build_wino_h2_weights();
   return AGZ_OK;
 }
 
@@ -1520,8 +1518,8 @@ int agz_net_set_compute_mode(agz_net* n, int mode) {
               AGZ_E_INVALID, "agz_net_set_compute_mode: unknown mode %d", mode);
   n->compute_mode = base;
   n->compute_force = (mode & AGZ_COMPUTE_FORCE) != 0;
-  if ((base == AGZ_COMPUTE_WINO || base == AGZ_COMPUTE_AUTO) && n->committed && n->cfg == 0 && n->d_u3_dual.empty()) return n->build_wino_weights();
-  if (base == AGZ_COMPUTE_WINO_H2 && n->committed && n->cfg == 0 && n->d_u2_dual.empty()) return n->build_wino_h2_weights();
+  if (base == AGZ_COMPUTE_WINO && n->committed && n->cfg == 0 && n->d_u3_dual.empty()) return n->build_wino_weights();
+  if ((base == AGZ_COMPUTE_WINO_H2 || base == AGZ_COMPUTE_AUTO) && n->committed && n->cfg == 0 && n->d_u2_dual.empty()) return n->build_wino_h2_weights();
   return AGZ_OK;
 }
 

@@ -152,8 +152,8 @@ int agz_net_set_tower_queues(agz_net* net, int queues);
 #define AGZ_COMPUTE_WINO 3 /* Winograd F(4x4,3x3): transforms in fp32, the 36 transform-domain GEMMs with BF16X3 products — 3.6x
                             * fewer matrix instructions on 19x19; rounding error ~5x a direct fp32 convolution's (still inside
                             * the stated tolerance); opt-in, same shape conditions as the split modes */
-#define AGZ_COMPUTE_AUTO 4 /* per forward: Winograd where it measured fastest (K >= 192 and the 4x4 tiles overhang the board by at most
-                            * 25 %), else BF16X3 where the split kernels apply, else F32_MFMA */
+#define AGZ_COMPUTE_AUTO 4 /* the measured choice: WINO_H2 where its weight image exists (K a multiple of 64), else BF16X3 where the
+                            * split kernels apply, else F32_MFMA   [tests/test_wino_gpu.py::test_compute_auto_takes_the_measured_mode] */
 #define AGZ_COMPUTE_WINO_H2 5 /* Winograd F(4x4,3x3) with FP16X2 products in the transform domain: the input transform writes the
                             * operand already split into two fp16 pieces (scaled per board by a power of two from a proven bound,
                             * overflow impossible), three fp16 MFMAs per product — half the matrix instructions of AGZ_COMPUTE_WINO */

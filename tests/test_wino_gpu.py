@@ -118,6 +118,31 @@ def test_wino_h2_range_management_and_batch_independence(ctx, scale):
     assert np.all(np.isfinite(pol_h))
 
 
+def test_compute_auto_takes_the_measured_mode(ctx):
+    """AGZ_COMPUTE_AUTO: the Winograd fp16x2 tower where its weights exist (K a multiple of 64), else the bf16x3 split kernels —
+    each branch bit-identical to the explicitly chosen mode and inside the oracle tolerance."""
+    for (K, S, B, explicit) in ((128, 9, 300, A.capi.COMPUTE_WINO_H2), (32, 9, 600, A.capi.COMPUTE_BF16X3)):
+        onet, gnet = make_pair(ctx, K, 2, 32, S, S, 18, S * S + 1, 2)
+        x = rand_planes(B, 18, S, S, seed=K)
+        gnet.set_compute_mode(explicit)
+        pe, ve = gnet.infer(x)
+        gnet.set_compute_mode(A.capi.COMPUTE_F32_MFMA)
+        pf, vf = gnet.infer(x)
+        gnet.set_compute_mode(A.capi.COMPUTE_AUTO)
+        pa, va = gnet.infer(x)
+        np.testing.assert_array_equal(pa, pe)
+        np.testing.assert_array_equal(va, ve)
+        if K == 128:
+            assert not np.array_equal(pa, pf)        # the batch fills the chip: really the Winograd arithmetic
+        idx = [0, B // 2, B - 1]
+        po, vo = onet.infer(x[idx])
+        np.testing.assert_allclose(pa[idx], po, atol=POL_ATOL, rtol=POL_RTOL)
+        np.testing.assert_allclose(va[idx], vo, atol=VAL_ATOL)
+        gnet.commit()                                 # a re-commit under AUTO rebuilds what AUTO needs
+        pc, vc = gnet.infer(x)
+        np.testing.assert_array_equal(pc, pa)
+
+
 def test_wino_recommit_and_mode_round_trip(ctx):
     """weights are rebuilt on commit; switching modes back and forth keeps every mode's own result"""
     onet, gnet = make_pair(ctx, 64, 1, 32, 9, 9, 18, 82, 2)
