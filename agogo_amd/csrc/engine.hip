@@ -86,8 +86,29 @@ __device__ int apply_move(const GameCfg& c, const Dev& d, Sh& s, St& st, int mv,
     }
   } else {  // komi/game.go:104-130,277-313 ; wq/game.go:81-92 (+pass completion)
     if (mv != AGZ_PASS) {
-      analyse(c, s, d.ztable, lane, false);
-      taken = go_apply(c, s, d.ztable, mv, player, &st.hash, lane);
+      // A capture needs an opponent group whose ONLY liberty is mv.  If every opponent stone next to mv has another empty neighbour
+      // of its own, no group can be in that state and Apply is "place the stone" — no component labelling of the whole board (the
+      // common case inside the tree; the batch-1 descent spent most of its time labelling).  Otherwise: the full analysis, as before.
+      const int o = opp(player);
+      bool maybe = false;
+#pragma unroll
+      for (int dd = 0; dd < 4; dd++) {
+        const int a = nbr(c, mv, dd);
+        if (a >= 0 && s.board[a] == o) {
+          bool other = false;
+#pragma unroll
+          for (int e = 0; e < 4; e++) { const int b2 = nbr(c, a, e); other |= (b2 >= 0 && b2 != mv && s.board[b2] == AGZ_NONE); }
+          maybe |= !other;
+        }
+      }
+      if (maybe) {
+        analyse(c, s, d.ztable, lane, false);
+        taken = go_apply(c, s, d.ztable, mv, player, &st.hash, lane);
+      } else {
+        __syncthreads();                       // every lane has read the board
+        if (lane == 0) s.board[mv] = (int8_t)player;
+        if (d.ztable) st.hash ^= (uint32_t)d.ztable[2 * mv + (player == AGZ_BLACK ? 0 : 1)];
+      }
       st.passes = 0;
     } else {
       st.passes++;
@@ -131,18 +152,26 @@ __device__ void encode_nhwc(const GameCfg& c, const Sh& s, const St& st, float* 
     } else {  // WQEncoder, encoding_helper.go:29-68
       int mn = move_number(c, st.ply);
       bool nb = st.to_move == AGZ_BLACK;
-      int blackStart = nb ? 0 : 8, whiteStart = nb ? 8 : 0;
+      float vb[8], vw[8];                       // the mover's planes 0..7 and the opponent's
 #pragma unroll
       for (int k = 1; k < 8; k++) {
         int j = mn - k;  // board after move j (Historical(h), h = mn-1-k, needs h > 0)
         float e = 0.f;
         if (j >= 2) { int v = s.ring[j % RING][i]; e = v == AGZ_BLACK ? 1.f : (v == AGZ_WHITE ? -1.f : 0.f); }
-        o[blackStart + k - 1] = e;
-        o[whiteStart + k - 1] = j >= 2 ? -e : 0.f;  // vecf32.Scale(retVal, -1): empty cells become -0.0
+        vb[k - 1] = e;
+        vw[k - 1] = j >= 2 ? -e : 0.f;  // vecf32.Scale(retVal, -1): empty cells become -0.0
       }
-      o[7] = 0.f; o[15] = 0.f;
-      o[16] = nb ? 1.f : 0.f;
-      o[17] = nb ? 0.f : -1.f;
+      vb[7] = 0.f; vw[7] = 0.f;
+      // channels 0..7 = black planes, 8..15 = white planes when Black is to move (swapped otherwise), 16 / 17 the colour planes,
+      // 18..19 padding (zero like the rest of the 32-channel slot): five 16-byte stores per cell instead of 18 scalar ones
+      float4* o4 = reinterpret_cast<float4*>(o);
+      const float* lo8 = nb ? vb : vw;
+      const float* hi8 = nb ? vw : vb;
+      o4[0] = make_float4(lo8[0], lo8[1], lo8[2], lo8[3]);
+      o4[1] = make_float4(lo8[4], lo8[5], lo8[6], lo8[7]);
+      o4[2] = make_float4(hi8[0], hi8[1], hi8[2], hi8[3]);
+      o4[3] = make_float4(hi8[4], hi8[5], hi8[6], hi8[7]);
+      o4[4] = make_float4(nb ? 1.f : 0.f, nb ? 0.f : -1.f, 0.f, 0.f);
     }
   }
 }
@@ -172,10 +201,17 @@ __device__ void encode_nchw(const GameCfg& c, const Sh& s, const St& st, float* 
 }
 
 __device__ void load_state(const GameCfg& c, const Dev& d, int g, Sh& s, St& st, bool use_ring, int lane) {
-  for (int i = lane; i < c.cells; i += WAVE) s.board[i] = d.board[(size_t)g * CELLS_PAD + i];
-  if (use_ring)
-    for (int r = 0; r < RING; r++)
-      for (int i = lane; i < c.cells; i += WAVE) s.ring[r][i] = d.ring[((size_t)g * RING + r) * CELLS_PAD + i];
+  // whole padded rows in 16-byte words (the pad cells are zero on both sides): 4 loads per lane instead of 54 byte loads
+  {
+    const uint4* gb = reinterpret_cast<const uint4*>(d.board + (size_t)g * CELLS_PAD);
+    uint4* sb = reinterpret_cast<uint4*>(s.board);
+    for (int i = lane; i < CELLS_PAD / 16; i += WAVE) sb[i] = gb[i];
+    if (use_ring) {
+      const uint4* gr = reinterpret_cast<const uint4*>(d.ring + (size_t)g * RING * CELLS_PAD);
+      uint4* sr = reinterpret_cast<uint4*>(&s.ring[0][0]);
+      for (int i = lane; i < RING * CELLS_PAD / 16; i += WAVE) sr[i] = gr[i];
+    }
+  }
   st.to_move = d.to_move[g];
   st.ply = d.ply[g];
   st.passes = d.passes[g];
@@ -752,7 +788,14 @@ __global__ __launch_bounds__(64) void k_expand(Dev d, GameCfg c, MctsCfg mc, Inf
       __syncthreads();
       // legalSum: sequential float32 sum in list order, as the reference accumulates it
       float legalSum = 0.f;
-      if (lane == 0) { for (int i = 0; i < n; i++) legalSum = __fadd_rn(legalSum, s.fscore[i]); }
+      if (lane == 0) {   // (four list entries per LDS read; the additions stay one after the other, in list order)
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+          const float4 v4 = *reinterpret_cast<const float4*>(&s.fscore[i]);
+          legalSum = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(legalSum, v4.x), v4.y), v4.z), v4.w);
+        }
+        for (; i < n; i++) legalSum = __fadd_rn(legalSum, s.fscore[i]);
+      }
       legalSum = __shfl(legalSum, 0, 64);
       if (legalSum > 1.401298464e-45f) {
         for (int i = lane; i < n; i += WAVE) s.fscore[i] = __fdiv_rn(s.fscore[i], legalSum);
@@ -772,7 +815,15 @@ __global__ __launch_bounds__(64) void k_expand(Dev d, GameCfg c, MctsCfg mc, Inf
           for (int i = lane; i < n; i += WAVE) {
             float si = s.fscore[i];
             int rank = 0;
-            for (int j = 0; j < n; j++) { float sj = s.fscore[j]; rank += (sj > si) || (sj == si && j < i); }
+            int j = 0;
+            for (; j + 4 <= n; j += 4) {   // (broadcast reads, four entries each)
+              const float4 v4 = *reinterpret_cast<const float4*>(&s.fscore[j]);
+              rank += (v4.x > si) || (v4.x == si && j < i);
+              rank += (v4.y > si) || (v4.y == si && j + 1 < i);
+              rank += (v4.z > si) || (v4.z == si && j + 2 < i);
+              rank += (v4.w > si) || (v4.w == si && j + 3 < i);
+            }
+            for (; j < n; j++) { float sj = s.fscore[j]; rank += (sj > si) || (sj == si && j < i); }
             size_t o = base + off + rank;
             d.prior[o] = si; d.visits[o] = 1; d.bsum[o] = 0.f; d.kids_off[o] = -1; d.kids_n[o] = 0;  // tree.go:106-117
             d.nmove[o] = (int16_t)s.fmove[i];

@@ -154,7 +154,7 @@ struct Sh {
   int32_t gsize[CELLS_PAD];   // component size (indexed by label)
   int32_t ghash[CELLS_PAD];   // stone groups: xor of zobrist keys
   int32_t touch[CELLS_PAD];   // empty components: bit0 touches black, bit1 touches white
-  float fscore[CELLS_PAD];    // expansion: scores
+  alignas(16) float fscore[CELLS_PAD];    // expansion: scores (read four at a time)
   int32_t fmove[CELLS_PAD];
   int32_t misc[16];
 };
