@@ -37,32 +37,54 @@ __device__ __forceinline__ float evaluate(float bs, uint32_t visits, int player)
 }
 
 // Node.Select: mcts/node.go:170-237.  64 lanes over the contiguous child block; strict '>' keeps the first maximum.
-__device__ int select_child(const Dev& d, size_t base, int off, int n, int player, float PUCT, int lane, bool use_vl) {
+__device__ int select_child(const Dev& d, size_t base, int off, int n, int player, float PUCT, int lane, bool use_vl, int* move_out = nullptr) {
+  // The whole child block goes to registers in ONE batch of loads (n <= CELLS_PAD: six children per lane): visits, sums, priors,
+  // virtual-loss marks and the children's moves — the parent-visit sum and the argmax then run without touching memory again, and the
+  // caller gets the chosen child's move with it (the descent was four dependent memory round trips per level; now two).
+  constexpr int PER = CELLS_PAD / WAVE;
+  uint32_t cv[PER]; float cb[PER], cp[PER]; int cm[PER]; uint8_t cl[PER];
+  const size_t cb0 = base + off;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int i = lane + k * WAVE;
+    const bool ok = i < n;
+    const size_t o = cb0 + (ok ? i : 0);
+    cv[k] = d.visits[o]; cb[k] = d.bsum[o]; cp[k] = d.prior[o]; cm[k] = d.nmove[o];
+    cl[k] = use_vl ? d.vl[o] : 0;
+    if (!ok) cv[k] = 0;
+  }
   uint32_t pv = 0;
-  for (int i = lane; i < n; i += WAVE) pv += d.visits[base + off + i];
+#pragma unroll
+  for (int k = 0; k < PER; k++) pv += cv[k];
   for (int o = 32; o > 0; o >>= 1) pv += __shfl_xor(pv, o, 64);
   float numerator = __fsqrt_rn((float)pv);
   float best = -INFINITY;
-  int idx = -1;
-  for (int i = lane; i < n; i += WAVE) {
-    uint32_t v = d.visits[base + off + i];
-    float bs = d.bsum[base + off + i];
-    // Evaluate (node.go:147-159): only White's view includes the stored virtual loss (3.0 while a lane of this round is below)
-    if (use_vl && player == AGZ_WHITE) bs = __fadd_rn(bs, d.vl[base + off + i] ? 3.0f : 0.0f);
-    float psa = d.prior[base + off + i];
-    float qsa = evaluate(bs, v, player);
-    float denominator = __fadd_rn(1.0f, (float)v);
-    float lastTerm = __fdiv_rn(numerator, denominator);
-    float puct = __fmul_rn(__fmul_rn(PUCT, psa), lastTerm);
-    float usa = __fadd_rn(qsa, puct);
-    if (usa > best) { best = usa; idx = i; }
+  int idx = -1, mv = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int i = lane + k * WAVE;
+    if (i < n) {
+      uint32_t v = cv[k];
+      float bs = cb[k];
+      // Evaluate (node.go:147-159): only White's view includes the stored virtual loss (3.0 while a lane of this round is below)
+      if (use_vl && player == AGZ_WHITE) bs = __fadd_rn(bs, cl[k] ? 3.0f : 0.0f);
+      float psa = cp[k];
+      float qsa = evaluate(bs, v, player);
+      float denominator = __fadd_rn(1.0f, (float)v);
+      float lastTerm = __fdiv_rn(numerator, denominator);
+      float puct = __fmul_rn(__fmul_rn(PUCT, psa), lastTerm);
+      float usa = __fadd_rn(qsa, puct);
+      if (usa > best) { best = usa; idx = i; mv = cm[k]; }
+    }
   }
   for (int o = 32; o > 0; o >>= 1) {
     float ob = __shfl_xor(best, o, 64);
     int oi = __shfl_xor(idx, o, 64);
+    int om = __shfl_xor(mv, o, 64);
     bool take = (ob > best) || (ob == best && oi >= 0 && (idx < 0 || oi < idx));
-    if (take) { best = ob; idx = oi; }
+    if (take) { best = ob; idx = oi; mv = om; }
   }
+  if (move_out) *move_out = mv;
   return idx;  // -1: the reference panics "Cannot return nil" (node.go:232-234)
 }
 
@@ -399,10 +421,10 @@ __global__ __launch_bounds__(64) void k_select(Dev d, GameCfg c, MctsCfg mc, flo
       if (prep) { kind = LEAF_NONE; break; }  // root already has children: prepareRoot does nothing
       int n = d.kids_n[base + node];
       kids_seen += n;
-      int ci = select_child(d, base, off, n, st.to_move, mc.PUCT, lane, use_vl);
+      int mv;
+      int ci = select_child(d, base, off, n, st.to_move, mc.PUCT, lane, use_vl, &mv);
       if (ci < 0) { kind = LEAF_NULL; break; }
       int child = off + ci;
-      int mv = d.nmove[base + child];
       apply_move(c, d, s, st, mv, use_ring, lane);  // children were created from legal moves of this very state
       if (lane == 0) path[plen] = child;
       plen++;
@@ -464,10 +486,10 @@ __global__ __launch_bounds__(64) void k_select_paths(Dev d, GameCfg c, MctsCfg m
       if (prep) { kind = LEAF_NONE; break; }
       const int n = d.kids_n[base + node];
       kids_seen += n;
-      const int ci = select_child(d, base, off, n, to_move, mc.PUCT, lane, true);
+      int mv;
+      const int ci = select_child(d, base, off, n, to_move, mc.PUCT, lane, true, &mv);
       if (ci < 0) { kind = LEAF_NULL; break; }
       const int child = off + ci;
-      const int mv = d.nmove[base + child];
       // what Apply does to the scalars the descent reads (apply_move): mover, Passes(), move count
       if (c.go_like) { if (mv != AGZ_PASS) passes = 0; else passes++; }
       if (c.flip_in_tree) to_move = opp(to_move);
