@@ -792,16 +792,31 @@ __global__ __launch_bounds__(64) void k_expand(Dev d, GameCfg c, MctsCfg mc, Inf
       if (player == AGZ_WHITE) value = __fsub_rn(1.f, value);  // search.go:278-280
       // nodelist in move order, Pass last (search.go:285-296)
       int n = 0;
-      for (int b0 = 0; b0 < c.A; b0 += WAVE) {
-        int i = b0 + lane;
-        bool ok = i < c.A && legal[i];
-        unsigned long long m = __ballot(ok);
-        if (ok) {
-          int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-          s.fscore[pos] = policy_at(i);
-          s.fmove[pos] = i;
+      {
+        // legality bytes and network priors of all actions first, in one batch of loads (a prior read behind `if (legal)` is a
+        // dependent round trip per 64 actions), then the compaction
+        constexpr int PER = CELLS_PAD / WAVE;
+        uint8_t lg[PER]; float pr[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+          const int i = lane + k * WAVE;
+          const bool in = i < c.A;
+          lg[k] = in ? legal[i] : 0;
+          pr[k] = (ik == AGZ_INF_NET && in) ? pol[i] : 0.f;
         }
-        n += __popcll(m);
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+          const int i = lane + k * WAVE;
+          if (k * WAVE >= c.A) break;
+          bool ok = lg[k] != 0;
+          unsigned long long m = __ballot(ok);
+          if (ok) {
+            int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            s.fscore[pos] = ik == AGZ_INF_NET ? pr[k] : policy_at(i);
+            s.fmove[pos] = i;
+          }
+          n += __popcll(m);
+        }
       }
       if (legal[c.A]) {
         if (lane == 0) { s.fscore[n] = policy_at(plen_pol - 1); s.fmove[n] = AGZ_PASS; }  // passProb = policy[len-1]
@@ -846,9 +861,14 @@ __global__ __launch_bounds__(64) void k_expand(Dev d, GameCfg c, MctsCfg mc, Inf
               rank += (v4.w > si) || (v4.w == si && j + 3 < i);
             }
             for (; j < n; j++) { float sj = s.fscore[j]; rank += (sj > si) || (sj == si && j < i); }
-            size_t o = base + off + rank;
-            d.prior[o] = si; d.visits[o] = 1; d.bsum[o] = 0.f; d.kids_off[o] = -1; d.kids_n[o] = 0;  // tree.go:106-117
-            d.nmove[o] = (int16_t)s.fmove[i];
+            s.touch[rank] = __float_as_int(si);      // (scratch of the board analysis: the sorted list, so that the child block is
+            s.ghash[rank] = s.fmove[i];              //  written as whole rows instead of one scattered element per lane and array)
+          }
+          __syncthreads();
+          for (int r = lane; r < n; r += WAVE) {
+            size_t o = base + off + r;
+            d.prior[o] = __int_as_float(s.touch[r]); d.visits[o] = 1; d.bsum[o] = 0.f; d.kids_off[o] = -1; d.kids_n[o] = 0;  // tree.go:106-117
+            d.nmove[o] = (int16_t)s.ghash[r];
           }
           if (lane == 0) { d.kids_off[base + node] = off; d.kids_n[base + node] = (int16_t)n; d.n_nodes[t] = off + n; }
         }
