@@ -253,6 +253,221 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lat_x3_kernel(LatArgs a) {
   }
 }
 
+// ---- the same layer with fp16x2 products -----------------------------------------------------------------------------------
+// Half the matrix instructions (hi hi, hi lo, lo hi of v_mfma_f32_16x16x32_f16 instead of six bf16 products) and two thirds of the
+// weight bytes (4 B per weight instead of 6), which is what the layer is bound by (per-CU fill rate, profiles/r03/latency_tower.md).
+// Ranges as in conv_wino_h2.hpp: the weight image is equilibrated at commit — row ci divided by t_in[ci] = 2^floor(log2 max|w[.][ci][.]|),
+// column n multiplied by su[n] so that its maximum lands in [2^13, 2^14) — and the activations are multiplied by t_in[ci] and by the
+// BOARD's power of two sb = 2^(13 - E(max |x t_in|)) on their way into LDS (so a board's result does not depend on its batch
+// neighbours).  That maximum comes from the previous layer: every workgroup stores the maximum of (its outputs x next layer's t_in),
+// the consumer's waves reduce their board's words themselves (n_in_words each; layer 0: one word from board_amax_kernel).
+struct LatH2Args {
+  const float* x;            // [B][Hp][Wp][C] padded NHWC fp32
+  const _Float16* w2;        // [C/32][9][2][Ntot][32] fp16 hi / lo, equilibrated, columns in block-tile order (tile*128 + branch*64 + c%64)
+  const float* t_in;         // [C]
+  const float* col_unscale;  // [Ntot] 1 / su[n]
+  const float* t_next;       // [Cout_p] the next layer's t_in (nullptr: no range words written)
+  const float* wmax_in;      // [B][n_in_words] maxima of |x t_in| (>= 0)
+  float* wmax_out;           // [B][groups_per_board * Cout_p / 8]
+  const void* ep;            // float4 {sa,ta,sb,tb} [HW][Cout_p]
+  float* y;                  // [B][Hp][Wp][Cout_p]
+  int B, H, W, Hp, Wp, C, Cout_p, Ntot;
+  int groups_per_board, n_in_words;
+};
+typedef _Float16 lat_f16x8_t __attribute__((ext_vector_type(8)));
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_lat_h2_kernel(LatH2Args a) {
+  constexpr int PIECE = LAT_NPIX * 64;                 // bytes of one piece image of one wave (32 fp16 per pixel)
+  constexpr int WAVE_LDS = 2 * PIECE;                  // 12,800 B
+  constexpr int RED_BYTES = NW * LAT_ROWS * 16 * 4;    // the reduction buffer overlays the images
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(NW * WAVE_LDS > RED_BYTES ? NW * WAVE_LDS : RED_BYTES) + 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = blockIdx.x;
+  const int HW = a.H * a.W, HpWp = a.Hp * a.Wp;
+  const int r16 = lane & 15, q = lane >> 4;
+  unsigned char* my = lds + w * WAVE_LDS;
+  float* wgmax = reinterpret_cast<float*>(lds + (NW * WAVE_LDS > RED_BYTES ? NW * WAVE_LDS : RED_BYTES));   // [NW] (+ pad)
+  const int n_groups = a.B * a.groups_per_board;
+  const int sub = lane >> 3, c4 = (lane & 7) * 4;
+  constexpr int NIT = (LAT_NPIX + 7) / 8;
+  constexpr int NE = (LAT_ROWS * 8 + NW * 64 - 1) / (NW * 64);
+  constexpr int NWRD = 4;                              // range words per lane (n_in_words <= 256)
+  float4 v[NIT];
+  float4 E[NE];
+  float wr[NWRD];
+  const float4 t4 = *reinterpret_cast<const float4*>(a.t_in + 32 * w + c4);
+
+  auto issue_params = [&](int grp) {
+    const int b = grp / a.groups_per_board, gi = grp - b * a.groups_per_board;
+    const int p0 = gi * LAT_ROWS;
+#pragma unroll
+    for (int k = 0; k < NE; k++) {
+      const int o = tid + k * NW * 64;
+      int p = p0 + (o >> 3);
+      p = p < HW ? p : HW - 1;
+      E[k] = reinterpret_cast<const float4*>(a.ep)[(size_t)p * a.Cout_p + ct * 8 + (o & 7)];
+    }
+  };
+  auto issue_group = [&](int grp) {
+    const int b = grp / a.groups_per_board, gi = grp - b * a.groups_per_board;
+    const int p0 = gi * LAT_ROWS;
+    const int pix0 = p0 + 2 * (p0 / a.W);
+    // the board's range words first (they return first), then the activation slice
+    const float* wp = a.wmax_in + (size_t)b * a.n_in_words;
+#pragma unroll
+    for (int k = 0; k < NWRD; k++) { const int i = lane + k * 64; wr[k] = wp[i < a.n_in_words ? i : 0]; }
+    const float* xb = a.x + ((size_t)b * HpWp + pix0) * a.C + 32 * w;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, ((a.B - b) * HpWp - pix0) * a.C * 4 - 128 * w, 0x00020000);
+    const unsigned vo = (unsigned)(sub * a.C + c4) * 4u, step = (unsigned)a.C * 32u;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const u32x4_lat r = __builtin_amdgcn_raw_buffer_load_b128(rx, vo + it * step, 0, 0);
+      v[it] = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+    }
+  };
+  issue_params(blockIdx.y);
+  issue_group(blockIdx.y);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();                      // every wave's activation loads are queued before any wave's weight loads
+  __builtin_amdgcn_sched_barrier(0);
+
+  // the wave's weight slice: B fragment of (tap, piece) = 8 k of column j: chunk w, halves q*8 .. +7
+  lat_f16x8_t Bf[9][2];
+  {
+    const int j = r16, c = ct * 8 + (j & 7);
+    const int n = (c >> 6) * 128 + (j >> 3) * 64 + (c & 63);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w2), 0, (a.C / 32) * 18 * a.Ntot * 64, 0x00020000);
+    const unsigned vo = (unsigned)((w * 18 * a.Ntot + n) * 32 + q * 8) * 2u;
+    const unsigned pstride = (unsigned)a.Ntot * 64u;    // bytes between (tap, piece) planes
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const u32x4_lat r = __builtin_amdgcn_raw_buffer_load_b128(rw, vo, (t * 2 + p) * pstride, 0);
+        Bf[t][p] = __builtin_bit_cast(lat_f16x8_t, r);
+      }
+  }
+
+  auto process = [&](const int grp) __attribute__((always_inline)) {
+    const int b = grp / a.groups_per_board, gi = grp - b * a.groups_per_board;
+    const int p0 = gi * LAT_ROWS;
+    const int pix0 = p0 + 2 * (p0 / a.W);
+    // ---- the board's scale, then the split into hi / lo fp16 on the way into the wave's LDS image
+    float mx = fmaxf(fmaxf(wr[0], wr[1]), fmaxf(wr[2], wr[3]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sb, inv_sb;
+    h2_scales(__float_as_uint(mx), &sb, &inv_sb);
+    const float4 s4 = make_float4(sb * t4.x, sb * t4.y, sb * t4.z, sb * t4.w);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int px = it * 8 + sub;
+      const float x0 = v[it].x * s4.x, x1 = v[it].y * s4.y, x2 = v[it].z * s4.z, x3 = v[it].w * s4.w;
+      const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1, h2 = (_Float16)x2, h3 = (_Float16)x3;
+      const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1), l2 = (_Float16)(x2 - (float)h2), l3 = (_Float16)(x3 - (float)h3);
+      if (px < LAT_NPIX) {
+        unsigned char* dst = my + px * 64 + c4 * 2;
+        typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<f16x4_t*>(dst) = f16x4_t{h0, h1, h2, h3};
+        *reinterpret_cast<f16x4_t*>(dst + PIECE) = f16x4_t{l0, l1, l2, l3};
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes are visible to its own reads
+    __builtin_amdgcn_wave_barrier();
+
+    f32x4_lat acc[3];
+    unsigned loc[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      acc[i] = f32x4_lat{0.f, 0.f, 0.f, 0.f};
+      int p = p0 + i * 16 + r16;
+      if (p >= HW) p = HW - 1;
+      loc[i] = (unsigned)((p + 2 * (p / a.W) + a.Wp + 1 - pix0) * 64 + q * 16);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int toff = ((t / 3 - 1) * a.Wp + (t % 3 - 1)) * 64;
+      lat_f16x8_t A_[3][2];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const unsigned char* src = my + (int)loc[i] + toff;
+#pragma unroll
+        for (int p = 0; p < 2; p++) A_[i][p] = *reinterpret_cast<const lat_f16x8_t*>(src + p * PIECE);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++) {                    // lo*hi, hi*lo, hi*hi; the three row tiles interleaved
+        const int pa = k == 0 ? 1 : 0, pb = k == 1 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_[i][pa], Bf[t][pb], acc[i], 0, 0, 0);
+      }
+    }
+
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) red[((size_t)w * LAT_ROWS + i * 16 + 4 * q + r) * 16 + r16] = acc[i][r];
+    __syncthreads();
+    float omx = 0.f;
+#pragma unroll
+    for (int k = 0; k < NE; k++) {
+      const int o = tid + k * NW * 64;
+      const int row = o >> 3, ch = o & 7;
+      const int p = p0 + row;
+      if (o < LAT_ROWS * 8 && p < HW) {
+        float sa = 0.f, sbr = 0.f;
+#pragma unroll
+        for (int u = 0; u < NW; u++) {
+          sa += red[((size_t)u * LAT_ROWS + row) * 16 + ch];
+          sbr += red[((size_t)u * LAT_ROWS + row) * 16 + 8 + ch];
+        }
+        const int c = ct * 8 + ch;
+        const int na = (c >> 6) * 128 + (c & 63);       // column of branch a in the image (branch b: + 64)
+        const float4 e = E[k];
+        float va = (sa * (inv_sb * a.col_unscale[na])) * e.x + e.y, vb = (sbr * (inv_sb * a.col_unscale[na + 64])) * e.z + e.w;
+        va = va > 0.f ? va : 0.f;
+        vb = vb > 0.f ? vb : 0.f;
+        const float s_ = va + vb;
+        const float out = s_ > 0.f ? s_ : 0.f;
+        const int h = p / a.W, ww = p - h * a.W;
+        a.y[((size_t)b * HpWp + (size_t)(h + 1) * a.Wp + (ww + 1)) * a.Cout_p + c] = out;
+        if (a.t_next) omx = fmaxf(omx, out * a.t_next[c]);
+      }
+    }
+    if (a.wmax_out) {                                   // the workgroup's range word for the next layer
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) omx = fmaxf(omx, __shfl_xor(omx, o, 64));
+      if (lane == 0) wgmax[w] = omx;
+      __syncthreads();
+      if (tid == 0) {
+        float m = wgmax[0];
+#pragma unroll
+        for (int u = 1; u < NW; u++) m = fmaxf(m, wgmax[u]);
+        a.wmax_out[(size_t)b * (a.groups_per_board * (a.Cout_p / 8)) + gi * (a.Cout_p / 8) + ct] = m;
+      }
+    }
+  };
+  process((int)blockIdx.y);
+  for (int grp = blockIdx.y + LAT_SLOTS; grp < n_groups; grp += LAT_SLOTS) {
+    __syncthreads();
+    issue_params(grp);
+    issue_group(grp);
+    process(grp);
+  }
+}
+
+static void conv_lat_h2_launch(agz_ctx* ctx, const LatH2Args& a) {
+  const dim3 grid((unsigned)(a.Cout_p / 8), (unsigned)std::min(LAT_SLOTS, a.B * a.groups_per_board));
+  switch (a.C / 32) {
+    case 2: hipLaunchKernelGGL((conv3x3_lat_h2_kernel<2>), grid, dim3(128), 0, ctx->stream, a); break;
+    case 4: hipLaunchKernelGGL((conv3x3_lat_h2_kernel<4>), grid, dim3(256), 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL((conv3x3_lat_h2_kernel<8>), grid, dim3(512), 0, ctx->stream, a); break;
+  }
+}
+
 // shapes the kernel is instantiated for: C = Cout_p in {64, 128, 256} (NW = C / 32 waves; 512 would need 300 KB of LDS), boards whose
 // row groups fit the window
 static inline bool conv_lat_ok(int C, int Cout_p, int Wp) {

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(1024) void heads_fc_kernel(HeadArgs a) {
     {
       float fv[16], wv_[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) { const bool ok = i + u < i1; const int r = ok ? i + u : i0; fv[u] = ok ? f[r] : 0.f; wv_[u] = Wm[(size_t)r * ld + j]; }
+      for (int u = 0; u < 16; u++) { const bool ok = i + u < i1; const int r = ok ? i + u : 0; fv[u] = ok ? f[r] : 0.f; wv_[u] = Wm[(size_t)r * ld + j]; }   // (row 0: always inside the matrix)
 #pragma unroll
       for (int u = 0; u < 16; u++) if (i + u < i1) s += fv[u] * wv_[u];
     }
@@ -1115,25 +1115,32 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       hipLaunchKernelGGL((conv3x3_x3_kernel<true>), dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, a, d_w3_dual[l]);
       rc = AGZ_OK;
     }
-    else if (latency && cfg == 0 && (int)d_w3_dual.size() == conf.SharedLayers && d_w3_dual[l] && agz::conv_lat_ok(Kp, Kp, Wp)) {
-      // latency regime, one launch per layer: K split inside the workgroup, weights up front, no partial sums in memory (conv_lat.hpp)
-      // From the second layer on the activations arrive as the three bf16 pieces the previous layer's epilogue wrote (split once
-      // by the producer instead of by each of the 32 column tiles that read them; DMA'd straight into LDS).
-      const size_t need3 = (size_t)B * 3 * Hp * Wp * Kp * sizeof(unsigned short);
-      if (lat3_cap < need3) {
-        for (auto& p3 : d_lat3) { if (p3) hipFree(p3); p3 = nullptr; }
-        lat3_cap = 0;
-        for (auto& p3 : d_lat3) { AGZ_HIP_TRY(hipMalloc(&p3, need3)); AGZ_HIP_TRY(hipMemsetAsync(p3, 0, need3, ctx->stream)); }   // (borders stay zero)
-        lat3_cap = need3;
+    else if (latency && cfg == 0 && (int)d_lat_w2.size() == conf.SharedLayers && d_lat_w2[l] && agz::conv_lat_ok(Kp, Kp, Wp) &&
+             ceil_div(HW, agz::LAT_ROWS) * (Kp / 8) <= 256) {   // (range words per board: four per lane)
+      // latency regime, one launch per layer: K split inside the workgroup, weights up front, no partial sums in memory; fp16x2
+      // products on equilibrated operands (conv_lat.hpp).  Range words: layer 0 from a board reduction, then from layer to layer.
+      const int gpb = ceil_div(HW, agz::LAT_ROWS), words = gpb * (Kp / 8);
+      if (lat_wmax_cap < B) {
+        for (auto& p2 : d_lat_wmax) { if (p2) hipFree(p2); p2 = nullptr; }
+        lat_wmax_cap = 0;
+        for (auto& p2 : d_lat_wmax) AGZ_HIP_TRY(hipMalloc(&p2, (size_t)B * 256 * sizeof(float)));
+        lat_wmax_cap = B;
       }
-      agz::LatArgs la{};
-      la.x = cur; la.w3 = d_w3_dual[l]; la.ep = d_ep_dual[l]; la.y = nxt;
-      la.x3 = l > 0 ? d_lat3[(l - 1) & 1] : nullptr;
-      la.y3 = l + 1 < conf.SharedLayers ? d_lat3[l & 1] : nullptr;
+      agz::LatH2Args la{};
+      la.x = cur; la.w2 = d_lat_w2[l]; la.t_in = d_lat_tin[l]; la.col_unscale = d_lat_colun[l]; la.ep = d_ep_dual[l]; la.y = nxt;
       la.B = B; la.H = H; la.W = W; la.Hp = Hp; la.Wp = Wp; la.C = Kp; la.Cout_p = Kp; la.Ntot = 2 * Kp;
-      la.groups_per_board = ceil_div(HW, agz::LAT_ROWS);
+      la.groups_per_board = gpb;
+      if (l == 0) {
+        hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, ctx->stream, cur, reinterpret_cast<unsigned*>(d_lat_wmax[1]), HW, W, Wp, Hp * Wp, Kp, (const float*)d_lat_tin[0]);
+        la.wmax_in = d_lat_wmax[1]; la.n_in_words = 1;
+      } else {
+        la.wmax_in = d_lat_wmax[(l - 1) & 1]; la.n_in_words = words;
+      }
+      const bool more = l + 1 < conf.SharedLayers;
+      la.t_next = more ? d_lat_tin[l + 1] : nullptr;
+      la.wmax_out = more ? d_lat_wmax[l & 1] : nullptr;
       ProfScope ps(ctx, AGZ_PROF_CONV);
-      agz::conv_lat_launch(ctx, la);
+      agz::conv_lat_h2_launch(ctx, la);
       rc = AGZ_OK;
     }
     else if (cfg != 0) rc = launch_conv<4, 1, 1, true>(ctx, a, wsp, &ws_cap);
@@ -1444,6 +1451,37 @@ int agz_net_commit(agz_net* n) {
       AGZ_HIP_TRY(hipMalloc(&n->d_w3_dual[l], w3.size() * 2));
       AGZ_HIP_TRY(hipMemcpyAsync(n->d_w3_dual[l], w3.data(), w3.size() * 2, hipMemcpyHostToDevice, s));
       AGZ_HIP_TRY(hipStreamSynchronize(s));
+      // latency-regime fp16x2 image (conv_lat.hpp): rows equilibrated by t_in[ci], columns by su[n], hi / lo fp16, w2[cc32][tap][piece][n][32]
+      if (agz::conv_lat_ok(Kp, Kp, n->Wp)) {
+        if ((int)n->d_lat_w2.size() != c.SharedLayers) {
+          n->d_lat_w2.assign(c.SharedLayers, nullptr); n->d_lat_tin.assign(c.SharedLayers, nullptr); n->d_lat_colun.assign(c.SharedLayers, nullptr);
+        }
+        std::vector<float> tin(Kp, 1.0f), colun(Ntot, 1.0f), su(Ntot, 1.0f), rmax(Kp, 0.f), cmax(Ntot, 0.f);
+        for (int t = 0; t < 9; t++) for (int nn = 0; nn < Ntot; nn++) for (int ci = 0; ci < Kp; ci++)
+          rmax[ci] = std::max(rmax[ci], std::fabs(wt[((size_t)t * Ntot + nn) * Kp + ci]));
+        for (int ci = 0; ci < Kp; ci++)
+          if (rmax[ci] > 0.f && std::isfinite(rmax[ci])) { int ex = 0; std::frexp(rmax[ci], &ex); tin[ci] = std::ldexp(1.0f, std::max(-100, std::min(100, ex - 1))); }
+        for (int t = 0; t < 9; t++) for (int nn = 0; nn < Ntot; nn++) for (int ci = 0; ci < Kp; ci++)
+          cmax[nn] = std::max(cmax[nn], std::fabs(wt[((size_t)t * Ntot + nn) * Kp + ci] / tin[ci]));
+        for (int nn = 0; nn < Ntot; nn++)
+          if (cmax[nn] > 0.f && std::isfinite(cmax[nn])) { int ex = 0; std::frexp(cmax[nn], &ex); su[nn] = std::ldexp(1.0f, 14 - ex); colun[nn] = 1.0f / su[nn]; }
+        std::vector<_Float16> l2((size_t)9 * (Kp / 32) * 2 * Ntot * 32);
+        for (int t = 0; t < 9; t++) for (int nn = 0; nn < Ntot; nn++) for (int ci = 0; ci < Kp; ci++) {
+          const float xs = wt[((size_t)t * Ntot + nn) * Kp + ci] / tin[ci] * su[nn];   // exact: powers of two
+          const _Float16 hi = (_Float16)xs;
+          const _Float16 lo = (_Float16)(xs - (float)hi);
+          const size_t base = (((size_t)((ci / 32) * 9 + t) * 2) * Ntot + nn) * 32 + (ci % 32);
+          l2[base] = hi;
+          l2[base + (size_t)Ntot * 32] = lo;
+        }
+        if (n->d_lat_w2[l]) { hipFree(n->d_lat_w2[l]); n->d_lat_w2[l] = nullptr; }
+        AGZ_HIP_TRY(hipMalloc(&n->d_lat_w2[l], l2.size() * 2));
+        AGZ_HIP_TRY(hipMemcpyAsync(n->d_lat_w2[l], l2.data(), l2.size() * 2, hipMemcpyHostToDevice, s));
+        int r2;
+        if ((r2 = upload(&n->d_lat_tin[l], tin, s)) != AGZ_OK) return r2;
+        if ((r2 = upload(&n->d_lat_colun[l], colun, s)) != AGZ_OK) return r2;
+        AGZ_HIP_TRY(hipStreamSynchronize(s));
+      }
     }
     pi += 6; bi += 2;
   }

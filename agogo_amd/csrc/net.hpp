@@ -95,6 +95,11 @@ struct agz_net {
   float* d_ws = nullptr;      // split-K workspace (small batches)
   unsigned short* d_lat3[2] = {nullptr, nullptr};   // latency regime: the tower's activations as bf16x3 pieces, ping-pong (conv_lat.hpp)
   size_t lat3_cap = 0;        // bytes of each
+  // latency regime, fp16x2 form (conv_lat.hpp): per layer the equilibrated weight image, t_in[Kp], col_unscale[2Kp]; range words
+  std::vector<_Float16*> d_lat_w2;
+  std::vector<float*> d_lat_tin, d_lat_colun;
+  float* d_lat_wmax[2] = {nullptr, nullptr};   // [B][256] maxima per workgroup, ping-pong between layers
+  int lat_wmax_cap = 0;                        // boards
   size_t ws_cap = 0;
   float* d_hs = nullptr;      // latency-regime head scratch: [B][3][HW] features + [B][A+FC] columns
   size_t hs_cap = 0;
