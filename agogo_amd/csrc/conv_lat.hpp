@@ -459,6 +459,29 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lat_h2_kernel(LatH2Args a) {
   }
 }
 
+// range words of the FIRST layer's input: max |x t_in| over a slice of the board per workgroup, `parts` words per board (no atomics,
+// nothing to clear; one workgroup per board takes 37 us for a 19x19 x 256 board)
+__global__ __launch_bounds__(256) void lat_board_words_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ words,
+                                                              int HW, int W, int Wp, int HpWp, int C, int parts) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / parts, part = blockIdx.x - b * parts, tid = threadIdx.x;
+  const int c4 = C >> 2;
+  const int n = HW * c4, lo = (int)((long)n * part / parts), hi = (int)((long)n * (part + 1) / parts);
+  float m = 0.f;
+  for (int i = lo + tid; i < hi; i += 256) {
+    const int p = i / c4, c = (i - p * c4) << 2;
+    const int h = p / W, w = p - h * W;
+    const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * HpWp + (h + 1) * Wp + (w + 1)) * C + c);
+    const float4 tt = *reinterpret_cast<const float4*>(t + c);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x * tt.x), fabsf(v.y * tt.y)), fmaxf(fabsf(v.z * tt.z), fabsf(v.w * tt.w))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) words[(size_t)b * parts + part] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 static void conv_lat_h2_launch(agz_ctx* ctx, const LatH2Args& a) {
   const dim3 grid((unsigned)(a.Cout_p / 8), (unsigned)std::min(LAT_SLOTS, a.B * a.groups_per_board));
   switch (a.C / 32) {

@@ -1131,8 +1131,8 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       la.B = B; la.H = H; la.W = W; la.Hp = Hp; la.Wp = Wp; la.C = Kp; la.Cout_p = Kp; la.Ntot = 2 * Kp;
       la.groups_per_board = gpb;
       if (l == 0) {
-        hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, ctx->stream, cur, reinterpret_cast<unsigned*>(d_lat_wmax[1]), HW, W, Wp, Hp * Wp, Kp, (const float*)d_lat_tin[0]);
-        la.wmax_in = d_lat_wmax[1]; la.n_in_words = 1;
+        hipLaunchKernelGGL(agz::lat_board_words_kernel, dim3(B * 64), dim3(256), 0, ctx->stream, cur, (const float*)d_lat_tin[0], d_lat_wmax[1], HW, W, Wp, Hp * Wp, Kp, 64);
+        la.wmax_in = d_lat_wmax[1]; la.n_in_words = 64;
       } else {
         la.wmax_in = d_lat_wmax[(l - 1) & 1]; la.n_in_words = words;
       }

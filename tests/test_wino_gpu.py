@@ -335,7 +335,10 @@ def test_fp16x2_modes_with_heterogeneous_ranges_inside_a_layer_k256(ctx, wmode, 
              np.abs(val_g[idx] - val_o).max(), pol_o.max()))
     assert np.all(np.isfinite(pol_g)) and np.all(np.isfinite(val_g))
     assert pol_o.max() < 0.9, "the test network saturated: parity on a one-hot policy would be vacuous"
-    np.testing.assert_allclose(pol_f[idx], pol_o, atol=POL_ATOL, rtol=POL_RTOL)       # the exact-product path, for reference
+    # the default mode at this batch size is the latency regime: conv_lat.hpp's fp16x2 kernel with ITS per-channel / per-column
+    # equilibration and per-board ranges — held to the full tolerance at every E as well
+    np.testing.assert_allclose(pol_f[idx], pol_o, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(val_f[idx], val_o, atol=VAL_ATOL)
     if wmode == A.capi.COMPUTE_FP16X2 and E > 4:
         # the direct fp16x2 mode keeps one range per board and one per layer (include/agz.h: elements more than 2^17 below their
         # board's / layer's maximum lose relative precision — opt-in mode): beyond E = 4 only finiteness is promised
