@@ -1,21 +1,20 @@
 // Small-batch ("latency regime") dual block: tournament Agent.Search evaluates ONE board per simulation (agent.go:77-80,
-// dualnet/meta.go:168-190), so a 19x19 / K=256 layer is a 361 x 512 x 2304 GEMM over 7 MB of weights — bound by how fast the
-// weights stream and by launch / dependency latency, not by tiles.  Round 2 ran it as a 9-way split-K fp32-MFMA convolution plus a
-// reduction kernel (22.7 us per layer: two launches, 7 MB of partial sums written and read back, ~1.2 us per K iteration of load ->
-// LDS -> barrier -> MFMA chain).  This kernel is ONE launch per layer with no partial sums in memory:
+// dualnet/meta.go:168-190), so a 19x19 / K=256 layer is a 361 x 512 x 2304 GEMM over a few MB of weights that are touched for the first
+// time in every evaluation — bound by how fast weights and activations get INTO the CUs and by launch / dependency latency, not by
+// tiles.  Round 2 ran it as a 9-way split-K fp32-MFMA convolution plus a reduction kernel (22.7 us per layer).  Here: ONE launch per
+// layer with no partial sums in memory:
 //   * workgroup = (8 output channels x both branches = 16 GEMM columns) x (a slot of 48-pixel row groups); NW = C/32 waves, wave w
 //     owns input channels [32 w, 32 w + 32) — the K split is INSIDE the workgroup;
-//   * every wave issues the loads of its whole weight slice up front: 9 taps x 3 bf16 pieces x one 16-byte MFMA B fragment =
-//     27 registers-quads straight from the committed bf16x3 image (w3[cc16][tap][piece][n][16], conv_x3.hpp), kept for all row
-//     groups of the workgroup — every weight byte is read by exactly the workgroups of one column tile, which share an XCD's L2;
-//   * the wave's activation slice (the pixels of the row group plus its 3x3 halo, 32 channels) is split ONCE into the three
-//     exact bf16 pieces on its way into LDS ([piece][pixel][32] bf16, wave-private); the nine taps read their A fragments from
-//     there (no barrier: a wave reads only what it wrote);
-//   * 9 taps x 6 piece products (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi — conv_x3.hpp's fp32-grade product) of
-//     v_mfma_f32_16x16x32_bf16 per 16-row tile; the NW partial tiles are summed through LDS in wave order (deterministic, the same
-//     for every batch size of the regime) and the BN / ReLU / dual-add epilogue is applied by the same workgroup.
-// Per 19x19 K=256 layer: 256 workgroups (32 column tiles x 8 row groups) of 512 threads, 331,776 MFMAs = 2.5 us of matrix pipe at
-// the 16x16x32 rate, 7 MB from HBM.
+//   * every wave issues the loads of its whole weight slice up front (9 taps x pieces x one 16-byte MFMA B fragment, buffer loads with
+//     one lane offset and scalar offsets), kept in registers for all row groups of the workgroup; every weight byte is read by exactly
+//     the workgroups of one column tile, which share an XCD's L2;
+//   * the wave's activation slice (the pixels of the row group plus its 3x3 halo, 32 channels) is split once on its way into LDS
+//     ([piece][pixel][32], wave-private); the nine taps read their A fragments from there (no barrier: a wave reads what it wrote);
+//   * v_mfma_f32_16x16x32 over three interleaved 16-row tiles; the NW partial tiles are summed through LDS in wave order (deterministic,
+//     the same for every batch size of the regime) and the BN / ReLU / dual-add epilogue is applied by the same workgroup.
+// The library's kernel is the fp16x2 form (conv3x3_lat_h2_kernel below: 3 products per tap, 4.7 MB of weights per layer, 8.8 us per
+// layer); the bf16x3 form of round 3's first version (6 products, 7 MB, 10.2 us; its phases are in profiles/r03/latency_tower.md)
+// is compiled only into scripts/probes/lat_probe.hip.
 #pragma once
 // (included by net.hip INSIDE namespace agz, after conv_x3.hpp)
 
@@ -26,6 +25,7 @@ constexpr int LAT_ROWS = 48;         // pixels per row group (3 MFMA row tiles)
 constexpr int LAT_NPIX = 100;        // pixels of a row group incl. halo: 48 + up to 3 board-row seams * 2 + 2 * (Wp + 1) <= 98 at Wp = 21
 constexpr int LAT_SLOTS = 8;         // row-group slots (grid.y)
 
+#ifdef LAT_PROBE   // the bf16x3 form of round 3's first version: kept for scripts/probes/lat_probe.hip (phase stamps), not part of the library
 struct LatArgs {
   const float* x;            // [B][Hp][Wp][C] padded NHWC fp32 (PRE = false: split in the kernel)
   const unsigned short* x3;  // [B][3][Hp*Wp][C] the same activations as three bf16 pieces, written by the previous layer (PRE = true)
@@ -252,6 +252,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lat_x3_kernel(LatArgs a) {
     process(grp, std::integral_constant<bool, false>{});
   }
 }
+
+#endif  // LAT_PROBE
 
 // ---- the same layer with fp16x2 products -----------------------------------------------------------------------------------
 // Half the matrix instructions (hi hi, hi lo, lo hi of v_mfma_f32_16x16x32_f16 instead of six bf16 products) and two thirds of the
@@ -497,6 +499,7 @@ static inline bool conv_lat_ok(int C, int Cout_p, int Wp) {
   return C == Cout_p && (C == 64 || C == 128 || C == 256) && LAT_ROWS + 2 * ((LAT_ROWS - 1) / (Wp - 2) + 1) + 2 * (Wp + 1) <= LAT_NPIX;
 }
 
+#ifdef LAT_PROBE
 static void conv_lat_launch(agz_ctx* ctx, const LatArgs& a) {
   const dim3 grid((unsigned)(a.Cout_p / 8), (unsigned)std::min(LAT_SLOTS, a.B * a.groups_per_board));
   if (a.x3) {
@@ -513,3 +516,4 @@ static void conv_lat_launch(agz_ctx* ctx, const LatArgs& a) {
     }
   }
 }
+#endif

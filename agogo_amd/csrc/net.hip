@@ -610,8 +610,6 @@ void agz_net::free_device() {
   d_w_dual.clear(); d_ep_dual.clear(); d_w3_dual.clear(); d_w2_dual.clear(); d_u3_dual.clear();
   f(d_head_conv); f(d_head_bn); f(d_Wp); f(d_bp); f(d_W1); f(d_b1); f(d_W2); f(d_b2);
   f(d_act_in); f(d_actA); f(d_actB); f(d_planes); f(d_policy); f(d_value); f(d_ws); f(d_hs);
-  for (auto& p3 : d_lat3) { if (p3) hipFree(p3); p3 = nullptr; }
-  lat3_cap = 0;
   ws_cap = 0; hs_cap = 0;
   max_batch = 0;
 }

@@ -93,8 +93,6 @@ struct agz_net {
   float* d_policy = nullptr;  // [B][A]
   float* d_value = nullptr;   // [B]
   float* d_ws = nullptr;      // split-K workspace (small batches)
-  unsigned short* d_lat3[2] = {nullptr, nullptr};   // latency regime: the tower's activations as bf16x3 pieces, ping-pong (conv_lat.hpp)
-  size_t lat3_cap = 0;        // bytes of each
   // latency regime, fp16x2 form (conv_lat.hpp): per layer the equilibrated weight image, t_in[Kp], col_unscale[2Kp]; range words
   std::vector<_Float16*> d_lat_w2;
   std::vector<float*> d_lat_tin, d_lat_colun;

@@ -25,6 +25,13 @@ __device__ __forceinline__ void x3_split(float v, unsigned& h, unsigned& m, unsi
   h = hu; m = mu; l = __float_as_uint(r2);
 }
 __device__ __forceinline__ unsigned x3_pack(unsigned e0, unsigned e1) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
+__device__ __forceinline__ void h2_scales(unsigned amax_bits, float* s, float* inv) {   // (conv_h2.hpp)
+  int e = (int)((amax_bits >> 23) & 0xffu);
+  if (amax_bits == 0u) { *s = 1.f; *inv = 1.f; return; }
+  e = e < 30 ? 30 : (e > 230 ? 230 : e);
+  *s = __uint_as_float((unsigned)(267 - e) << 23);
+  *inv = __uint_as_float((unsigned)(e - 13) << 23);
+}
 #include "../../agogo_amd/csrc/conv_lat.hpp"
 }
 
