@@ -285,7 +285,7 @@ def latency_leg(ctx, lanes_list=(1, 16), moves=3, sims=1600):
                 lat.append(time.perf_counter() - t0)
         out["lanes_%d" % lanes] = {"p50_move_s": float(np.percentile(lat, 50)), "max_move_s": float(np.max(lat)),
                                    "ms_per_sim": float(np.median(lat)) / sims * 1e3,
-                                   "tower": "winograd fp16x2 (forced at every batch size)" if lanes > 1 else "fp32 MFMA split-K (latency regime)"}
+                                   "tower": "winograd fp16x2 (forced at every batch size)" if lanes > 1 else "fp16x2 one-launch-per-layer kernel (latency regime, conv_lat.hpp)"}
         arena.close()
     net.close()
     return out
