@@ -605,6 +605,9 @@ void agz_net::free_device() {
   d_u2_tin.clear();
   for (auto& p : d_u2_colun) if (p) hipFree(p);
   d_u2_colun.clear();
+  for (auto& p : d_ep_h2) if (p) hipFree(p);
+  d_ep_h2.clear();
+  if (d_ep_init_h2) { hipFree(d_ep_init_h2); d_ep_init_h2 = nullptr; }
   f(d_wV); f(d_wM);
   wino_chunk_cap = 0; wino_v_cap = 0;
   d_w_dual.clear(); d_ep_dual.clear(); d_w3_dual.clear(); d_w2_dual.clear(); d_u3_dual.clear();
@@ -882,6 +885,10 @@ int agz_net::build_wino_h2_weights() {
   d_u2_colun.assign(conf.SharedLayers, nullptr);
   u_unscale.assign(conf.SharedLayers, 1.0f);
   std::vector<float> tin, colun;
+  std::vector<std::vector<float>> tins(conf.SharedLayers), coluns(conf.SharedLayers);
+  for (auto& p : d_ep_h2) if (p) hipFree(p);
+  d_ep_h2.assign(conf.SharedLayers, nullptr);
+  if (d_ep_init_h2) { hipFree(d_ep_init_h2); d_ep_init_h2 = nullptr; }
   const int K = conf.K;
   size_t pi = 3;
   std::vector<_Float16> u2;
@@ -902,6 +909,37 @@ int agz_net::build_wino_h2_weights() {
     AGZ_HIP_TRY(hipMemcpyAsync(d_u2_tin[l], tin.data(), tin.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     AGZ_HIP_TRY(hipMemcpyAsync(d_u2_colun[l], colun.data(), colun.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     AGZ_HIP_TRY(hipMemcpyAsync(d_u2_dual[l], u2.data(), u2.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    tins[l] = tin; coluns[l] = colun;
+  }
+  // the tower's epilogue parameters with the scales folded in (net.hpp)
+  AGZ_REQUIRE((int)h_ep_dual.size() == conf.SharedLayers && !h_ep_init.empty(), AGZ_E_STATE, "agz_net: Winograd weights before commit");
+  const int hw = H * W;
+  std::vector<float> e2;
+  for (int l = 0; l < conf.SharedLayers; l++) {
+    const std::vector<float>& e = h_ep_dual[l];
+    const bool more = l + 1 < conf.SharedLayers;
+    e2.assign(e.size(), 0.f);
+    for (int p = 0; p < hw; p++)
+      for (int c = 0; c < Kp; c++) {
+        const float tn = more ? tins[l + 1][c] : 1.0f;
+        const size_t o = ((size_t)p * Kp + c) * 4;
+        e2[o + 0] = e[o + 0] * coluns[l][c] * tn; e2[o + 1] = e[o + 1] * tn;
+        e2[o + 2] = e[o + 2] * coluns[l][Kp + c] * tn; e2[o + 3] = e[o + 3] * tn;
+      }
+    AGZ_HIP_TRY(hipMalloc(&d_ep_h2[l], e2.size() * 4));
+    AGZ_HIP_TRY(hipMemcpyAsync(d_ep_h2[l], e2.data(), e2.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  if (conf.SharedLayers > 0) {
+    e2.assign(h_ep_init.size(), 0.f);
+    for (int p = 0; p < hw; p++)
+      for (int c = 0; c < Kp; c++) {
+        const size_t o = ((size_t)p * Kp + c) * 2;
+        e2[o] = h_ep_init[o] * tins[0][c]; e2[o + 1] = h_ep_init[o + 1] * tins[0][c];
+      }
+    AGZ_HIP_TRY(hipMalloc(&d_ep_init_h2, e2.size() * 4));
+    AGZ_HIP_TRY(hipMemcpyAsync(d_ep_init_h2, e2.data(), e2.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
   return AGZ_OK;
@@ -954,6 +992,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   const bool use_h2 = split_ok && compute_mode == AGZ_COMPUTE_FP16X2;
   const bool wino_ok = split_ok && compute_mode == AGZ_COMPUTE_WINO;
   const bool wino_h2_ok = split_ok && compute_mode == AGZ_COMPUTE_WINO_H2;
+  if (wino_h2_ok && d_ep_init_h2) a.ep = d_ep_init_h2;   // the tower takes its input pre-scaled by block 0's t_in (net.hpp)
   if (use_h2 && (size_t)B > amax_cap) {
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (d_amax) hipFree(d_amax);
@@ -1026,7 +1065,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       amax_cap = need_amax;
     }
     float* d_wave_max = reinterpret_cast<float*>(d_amax + (size_t)(conf.SharedLayers + 1) * B);
-    hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, ctx->stream, cur, d_amax, HW, W, Wp, Hp * Wp, Kp, (const float*)d_u2_tin[0]);
+    hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, ctx->stream, cur, d_amax, HW, W, Wp, Hp * Wp, Kp, (const float*)nullptr);   // (pre-scaled input)
     if (ns == 2) {
       if (!ctx->stream2) {
         AGZ_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -1044,10 +1083,10 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         WinoH2Args hh{};
         WinoArgs& wa = hh.w;
         wa.x = cur + (size_t)b0 * Hp * Wp * Kp; wa.y = nxt + (size_t)b0 * Hp * Wp * Kp;
-        wa.V = d_wV + (size_t)q * v_elems; wa.Mb = d_wM + (size_t)q * m_elems; wa.ep = d_ep_dual[l];
+        wa.V = d_wV + (size_t)q * v_elems; wa.Mb = d_wM + (size_t)q * m_elems; wa.ep = d_ep_h2[l];
         wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
         hh.U2 = d_u2_dual[l]; hh.w_unscale = 1.f; hh.tm = wino_tm;
-        hh.t_in = d_u2_tin[l]; hh.col_unscale = d_u2_colun[l]; hh.t_next = l + 1 < conf.SharedLayers ? d_u2_tin[l + 1] : nullptr;
+        hh.t_in = nullptr; hh.col_unscale = nullptr; hh.t_next = nullptr;   // all folded into d_ep_h2 / d_ep_init_h2: activations travel pre-scaled
         hh.amax_in = d_amax + (size_t)l * B + b0; hh.amax_out = d_amax + (size_t)(l + 1) * B + b0;
         hh.wave_max = d_wave_max + (size_t)b0 * wm_board;
         hh.fuse_prev = l > 0;   // block 0's input range comes from board_amax_kernel above
@@ -1345,6 +1384,7 @@ int agz_net_commit(agz_net* n) {
     int r;
     if ((r = upload(&n->d_w_init, wt, s)) != AGZ_OK) return r;
     if ((r = upload(&n->d_ep_init, ep, s)) != AGZ_OK) return r;
+    n->h_ep_init = ep;
     if (n->cfg == 0) {
       // bf16x3 image of the input filter for conv3x3_x3_kernel<false>: w3[cc16][tap][piece][n][16] (exact truncation split);
       // in the split modes the F -> K input convolution runs on the bf16 pipe too (0.33 -> 0.1x ms at B=512: it pads F=18 to 32
@@ -1406,6 +1446,8 @@ int agz_net_commit(agz_net* n) {
     int r;
     if ((r = upload(&n->d_w_dual[l], wt, s)) != AGZ_OK) return r;
     if ((r = upload(&n->d_ep_dual[l], ep, s)) != AGZ_OK) return r;
+    if ((int)n->h_ep_dual.size() != c.SharedLayers) n->h_ep_dual.assign(c.SharedLayers, std::vector<float>());
+    n->h_ep_dual[l] = ep;
     if (n->cfg == 0) {
       // bf16x3 image of the same (tile-interleaved) filter: w3[cc16][tap][piece][n][16], exact truncation split
       const int NC16 = Kp / 16, Ntot = 2 * Kp;
@@ -1517,6 +1559,9 @@ int agz_net_commit(agz_net* n) {
   n->d_u2_tin.clear();
   for (auto& p : n->d_u2_colun) if (p) hipFree(p);
   n->d_u2_colun.clear();
+  for (auto& p : n->d_ep_h2) if (p) hipFree(p);
+  n->d_ep_h2.clear();
+  if (n->d_ep_init_h2) { hipFree(n->d_ep_init_h2); n->d_ep_init_h2 = nullptr; }
   if (n->compute_mode == AGZ_COMPUTE_WINO && n->cfg == 0) return n->build_wino_weights();
   if ((n->compute_mode == AGZ_COMPUTE_WINO_H2 || n->compute_mode == AGZ_COMPUTE_AUTO) && n->cfg == 0) return n->build_wino_h2_weights();
   return AGZ_OK;

@@ -93,6 +93,14 @@ struct agz_net {
   float* d_policy = nullptr;  // [B][A]
   float* d_value = nullptr;   // [B]
   float* d_ws = nullptr;      // split-K workspace (small batches)
+  // AGZ_COMPUTE_WINO_H2 tower: epilogue parameters with the equilibration scales folded in — block l's {scale, shift} pairs multiplied
+  // by the NEXT block's t_in (so the activations travel pre-scaled: y' = y t_in, exact powers of two, ReLU commutes) and its scales
+  // also by the block's col_unscale; the input convolution's pairs by block 0's t_in.  The transform kernels then load no scale
+  // vectors at all.  Host copies of the plain parameters (from commit) are what these are built from.
+  std::vector<std::vector<float>> h_ep_dual;
+  std::vector<float> h_ep_init;
+  std::vector<float*> d_ep_h2;
+  float* d_ep_init_h2 = nullptr;
   // latency regime, fp16x2 form (conv_lat.hpp): per layer the equilibrated weight image, t_in[Kp], col_unscale[2Kp]; range words
   std::vector<_Float16*> d_lat_w2;
   std::vector<float*> d_lat_tin, d_lat_colun;
