@@ -636,7 +636,12 @@ def main():
                        "tower_queues": 2 if two_queues else 1},
             "roofline": ({"bound": "hbm", "achieved": wino_detail["wino_gemm"]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": wino_detail["wino_gemm"]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                          "algorithmic_bytes_per_launch": wino_detail["wino_gemm"]["algorithmic_bytes"]}
+                          "algorithmic_bytes_per_launch": wino_detail["wino_gemm"]["algorithmic_bytes"],
+                          # measured context for `frac` (scripts/probes/rw_probe.hip, profiles/r03/rw_probe.log): a bare streaming kernel
+                          # with this kernel's byte mix (1 part read : 2 parts written, nothing re-used) reaches 4.45-4.87 TB/s on
+                          # this part, pure reads 5.3 TB/s — not a claim about `peak`, which stays the 8 TB/s of the guide
+                          "stream_ceiling_same_mix_GBs": [4450.0, 4870.0],
+                          "frac_of_stream_ceiling": wino_detail["wino_gemm"]["achieved_GBs"] / 4660.0}
                          if (args.compute == "wino_h2" and wino_detail) else
                          {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic}) | {
