@@ -870,6 +870,127 @@ __global__ __launch_bounds__(256) void wino_out_seq_h2_kernel(WinoH2Args h) {
   }
 }
 
+// Quad form of the same transform (Cout_p a multiple of 256): every global access of a wave is ONE 1 KB run.  The memory pipeline's
+// throughput on this part goes with the bytes an instruction moves in one run (128-byte runs 0.31 ms, 256-byte runs 0.24 ms for the
+// same bytes, profiles/r02; a bare float4 stream with this kernel's read/write mix: 0.205 ms, profiles/r03/rw_probe.log), and one
+// thread per channel cannot do better than 256 bytes.  Here a lane owns FOUR consecutive channels and the 2-D transform is split
+// between waves through LDS: phase 1, wave nu = column nu of the position grid: AL float4 loads of M per branch (the column), the
+// column pass At . on each of the four channels, TM float4 per branch into LDS; phase 2, wave k = output row k: the row pass over
+// the AL columns from LDS, un-scale, the block epilogue on float4 parameters, TM float4 stores of y.  Same arithmetic in the same
+// order as the thread-per-channel kernel (bit-identical results, checked on a 300-board K=256 network).  Measured 0.251 -> 0.215 ms on
+// the headline block = 4.7 TB/s, 0.95 of the stream ceiling of its mix.  LDS: 72 KB per tile for F(5x5,3x3), two workgroups per CU.
+__device__ __forceinline__ float4 h2_ldf4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  const unsigned x = v[0], y = v[1], z = v[2], w = v[3];
+  return make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
+}
+template <int TM>
+__global__ __launch_bounds__((TM + 2) * 64) void wino_out_quad_h2_kernel(WinoH2Args h) {
+  using WT = WinoT<TM>;
+  constexpr int AL = WT::AL;
+  const WinoArgs& a = h.w;
+  __shared__ __attribute__((aligned(16))) float S[2][TM][AL][256];   // column-pass results [branch][row k][column nu][channel]
+  __shared__ float wmx[AL];
+  const int t = blockIdx.x;                                          // one tile per workgroup
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = blockIdx.y * 256 + 4 * lane;                        // this lane's four channels c0 .. c0 + 3
+  const int b = t / a.TPB, tt = t - b * a.TPB;
+  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
+  float s_, unscale0;
+  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &unscale0);
+  // ---- phase 1: column nu = wv of the AL x AL position grid, both branches
+  {
+    const int nu = wv;
+    const __amdgpu_buffer_rsrc_t mr = h2_rsrc(a.Mb + ((size_t)(t >> h.rsh) * h.rA + (size_t)(t & h.rmask)) * a.Ntot);
+    const unsigned pos_stride = h.rB * (unsigned)a.Ntot * 4u;        // bytes, uniform
+    float4 m[2][AL];
+#pragma unroll
+    for (int br = 0; br < 2; br++) {
+      const unsigned lane_off = (unsigned)(br * a.Cout_p + c0) * 4u;
+#pragma unroll
+      for (int xi = 0; xi < AL; xi++) m[br][xi] = h2_ldf4(mr, lane_off, (unsigned)(xi * AL + nu) * pos_stride);
+    }
+#pragma unroll
+    for (int br = 0; br < 2; br++) {
+      float mm[4][AL], oo[4][TM];
+#pragma unroll
+      for (int xi = 0; xi < AL; xi++) { mm[0][xi] = m[br][xi].x; mm[1][xi] = m[br][xi].y; mm[2][xi] = m[br][xi].z; mm[3][xi] = m[br][xi].w; }
+#pragma unroll
+      for (int e = 0; e < 4; e++) wino_atv<TM>(mm[e], oo[e]);
+#pragma unroll
+      for (int k = 0; k < TM; k++) *reinterpret_cast<float4*>(&S[br][k][nu][4 * lane]) = make_float4(oo[0][k], oo[1][k], oo[2][k], oo[3][k]);
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: output row k = wv (waves TM .. AL-1 have no row)
+  float mx = 0.f;
+  if (wv < TM) {
+    const int k = wv;
+    const int hh = TM * ty + k;                                      // uniform
+    float Y[2][4][TM];
+#pragma unroll
+    for (int br = 0; br < 2; br++) {
+      float rr[4][AL];
+#pragma unroll
+      for (int nu = 0; nu < AL; nu++) {
+        const float4 v = *reinterpret_cast<const float4*>(&S[br][k][nu][4 * lane]);
+        rr[0][nu] = v.x; rr[1][nu] = v.y; rr[2][nu] = v.z; rr[3][nu] = v.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) wino_atv<TM>(rr[e], Y[br][e]);
+    }
+    float ua[4], ub[4], tn[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      ua[e] = unscale0 * (h.col_unscale ? h.col_unscale[c0 + e] : h.w_unscale);
+      ub[e] = unscale0 * (h.col_unscale ? h.col_unscale[a.Cout_p + c0 + e] : h.w_unscale);
+      tn[e] = h.t_next ? h.t_next[c0 + e] : 1.f;
+    }
+    if (hh < a.H) {
+      const __amdgpu_buffer_rsrc_t er = h2_rsrc(a.ep);               // float4 {sa, ta, sb, tb} per (pixel, channel)
+      const __amdgpu_buffer_rsrc_t yr = h2_rsrc(a.y + (size_t)b * a.Hp * a.Wp * a.Cout_p);
+      const unsigned e_lane = (unsigned)c0 * 16u, e_pix = (unsigned)a.Cout_p * 16u;
+      const unsigned y_lane = (unsigned)c0 * 4u, y_pix = (unsigned)a.Cout_p * 4u;
+#pragma unroll
+      for (int l = 0; l < TM; l++) {
+        const int ww = TM * tx + l;
+        if (ww < a.W) {                                              // uniform
+          const unsigned pe = (unsigned)(hh * a.W + ww) * e_pix;
+          float4 E[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) E[e] = h2_ldf4(er, e_lane + 16u * e, pe);
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float va = (Y[0][e][l] * ua[e]) * E[e].x + E[e].y;
+            float vb = (Y[1][e][l] * ub[e]) * E[e].z + E[e].w;
+            va = va > 0.f ? va : 0.f;
+            vb = vb > 0.f ? vb : 0.f;
+            o[e] = va + vb;                                          // relu(a) + relu(b) >= 0 already
+            mx = fmaxf(mx, o[e] * tn[e]);
+          }
+          const unsigned ubits[4] = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+          typedef unsigned u32x4_o __attribute__((ext_vector_type(4)));
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_o{ubits[0], ubits[1], ubits[2], ubits[3]}, yr, y_lane, (unsigned)((hh + 1) * a.Wp + (ww + 1)) * y_pix, 0);
+        }
+      }
+    }
+  }
+  if (h.wave_max) {   // the tile's maximum, written to each of its 64-channel words (the consumer takes the board's maximum of all words)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) wmx[wv] = mx;
+    __syncthreads();
+    if (tid < 4) {
+      float m2 = wmx[0];
+#pragma unroll
+      for (int u = 1; u < AL; u++) m2 = fmaxf(m2, wmx[u]);
+      h.wave_max[(size_t)t * (a.Cout_p >> 6) + blockIdx.y * 4 + tid] = m2;
+    }
+  }
+}
+
 // Output transform without an epilogue (dual.Train's forward and data-gradient convolutions, train.hip): y = At M A * (1 / (s_b su)),
 // every one of the Ntot GEMM columns its own output channel.  One workgroup per tile, one thread per column, buffer addressing as above.
 template <int TM>
@@ -1125,6 +1246,10 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, hipStream_t s
       const dim3 gr((unsigned)a.T, (unsigned)a.Ntot / bd);
       if (tm == 5) hipLaunchKernelGGL(wino_out_raw_h2_kernel<5>, gr, dim3(bd), 0, st, h);
       else hipLaunchKernelGGL(wino_out_raw_h2_kernel<4>, gr, dim3(bd), 0, st, h);
+    } else if (form == 3 && a.Cout_p % 256 == 0) {   // 1 KB runs: 0.251 -> 0.215 ms on the headline block, bit-identical (A/B in profiles/r03/out_quad_ab.log)
+      const dim3 gq((unsigned)a.T, (unsigned)a.Cout_p / 256);
+      if (tm == 5) hipLaunchKernelGGL(wino_out_quad_h2_kernel<5>, gq, dim3(7 * 64), 0, st, h);
+      else hipLaunchKernelGGL(wino_out_quad_h2_kernel<4>, gq, dim3(6 * 64), 0, st, h);
     } else if (form == 3) {
       const unsigned bd = a.Cout_p % 256 == 0 ? 256u : (a.Cout_p % 128 == 0 ? 128u : 64u);
       const dim3 gs((unsigned)a.T, (unsigned)a.Cout_p / bd);
