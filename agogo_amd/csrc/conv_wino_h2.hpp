@@ -895,12 +895,13 @@ __global__ __launch_bounds__((TM + 2) * 64) void wino_out_quad_h2_kernel(WinoH2A
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c0 = blockIdx.y * 256 + 4 * lane;                        // this lane's four channels c0 .. c0 + 3
+  const bool act = c0 < a.Cout_p;                                    // (Cout_p = 128: half of every wave has no channels)
   const int b = t / a.TPB, tt = t - b * a.TPB;
   const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
   float s_, unscale0;
   wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &unscale0);
   // ---- phase 1: column nu = wv of the AL x AL position grid, both branches
-  {
+  if (act) {
     const int nu = wv;
     const __amdgpu_buffer_rsrc_t mr = h2_rsrc(a.Mb + ((size_t)(t >> h.rsh) * h.rA + (size_t)(t & h.rmask)) * a.Ntot);
     const unsigned pos_stride = h.rB * (unsigned)a.Ntot * 4u;        // bytes, uniform
@@ -925,7 +926,7 @@ __global__ __launch_bounds__((TM + 2) * 64) void wino_out_quad_h2_kernel(WinoH2A
   __syncthreads();
   // ---- phase 2: output row k = wv (waves TM .. AL-1 have no row)
   float mx = 0.f;
-  if (wv < TM) {
+  if (wv < TM && act) {
     const int k = wv;
     const int hh = TM * ty + k;                                      // uniform
     float Y[2][4][TM];
@@ -982,7 +983,8 @@ __global__ __launch_bounds__((TM + 2) * 64) void wino_out_quad_h2_kernel(WinoH2A
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) wmx[wv] = mx;
     __syncthreads();
-    if (tid < 4) {
+    const int n_words = min(4, (a.Cout_p - (int)blockIdx.y * 256) >> 6);
+    if (tid < n_words) {
       float m2 = wmx[0];
 #pragma unroll
       for (int u = 1; u < AL; u++) m2 = fmaxf(m2, wmx[u]);
@@ -1246,8 +1248,8 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, hipStream_t s
       const dim3 gr((unsigned)a.T, (unsigned)a.Ntot / bd);
       if (tm == 5) hipLaunchKernelGGL(wino_out_raw_h2_kernel<5>, gr, dim3(bd), 0, st, h);
       else hipLaunchKernelGGL(wino_out_raw_h2_kernel<4>, gr, dim3(bd), 0, st, h);
-    } else if (form == 3 && a.Cout_p % 256 == 0) {   // 1 KB runs: 0.251 -> 0.215 ms on the headline block, bit-identical (A/B in profiles/r03/out_quad_ab.log)
-      const dim3 gq((unsigned)a.T, (unsigned)a.Cout_p / 256);
+    } else if (form == 3 && (a.Cout_p % 256 == 0 || a.Cout_p == 128)) {   // 1 KB runs: 0.251 -> 0.215 ms on the headline block, bit-identical (A/B in profiles/r03/out_quad_ab.log)
+      const dim3 gq((unsigned)a.T, (unsigned)ceil_div(a.Cout_p, 256));
       if (tm == 5) hipLaunchKernelGGL(wino_out_quad_h2_kernel<5>, gq, dim3(7 * 64), 0, st, h);
       else hipLaunchKernelGGL(wino_out_quad_h2_kernel<4>, gq, dim3(6 * 64), 0, st, h);
     } else if (form == 3) {
