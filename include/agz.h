@@ -154,7 +154,7 @@ int agz_net_set_tower_queues(agz_net* net, int queues);
                             * the stated tolerance); opt-in, same shape conditions as the split modes */
 #define AGZ_COMPUTE_AUTO 4 /* the measured choice: WINO_H2 where its weight image exists (K a multiple of 64), else BF16X3 where the
                             * split kernels apply, else F32_MFMA   [tests/test_wino_gpu.py::test_compute_auto_takes_the_measured_mode] */
-#define AGZ_COMPUTE_WINO_H2 5 /* Winograd F(4x4,3x3) with FP16X2 products in the transform domain: the input transform writes the
+#define AGZ_COMPUTE_WINO_H2 5 /* Winograd F(5x5,3x3) / F(4x4,3x3) (whichever needs fewer rows for the board) with FP16X2 products in the transform domain: the input transform writes the
                             * operand already split into two fp16 pieces (scaled per board by a power of two from a proven bound,
                             * overflow impossible), three fp16 MFMAs per product — half the matrix instructions of AGZ_COMPUTE_WINO */
 #define AGZ_COMPUTE_FORCE 0x100 /* OR-ed in: take the split kernel even below the chip-filling threshold (tests) */
@@ -192,12 +192,14 @@ int agz_trainer_forward_backward_dev(agz_trainer* t, const float* planes_dev, co
 int agz_trainer_apply(agz_trainer* t, float lr, float grad_scale);
 int agz_trainer_grads_dev(agz_trainer* t, float** dev_ptr, size_t* n_floats);
 /* Arithmetic of training's three GEMMs (forward convolution, data gradient, weight gradient): AGZ_COMPUTE_F32_MFMA (default),
- * AGZ_COMPUTE_BF16X3 (all three on the bf16 pipe; weights re-split on the device every step) or AGZ_COMPUTE_WINO_H2 (the
- * data-gradient convolutions of the dual blocks through the Winograd fp16x2 path, weights transformed on the device every step;
- * forward convolutions and weight gradient as in BF16X3).  Every mode meets the same gradient tolerance against the reference
- * arithmetic — every gradient tensor within 2e-5 of its maximum, tested per mode at the headline width (K = 256, 19x19) —
- * which is why the forward convolutions do NOT take the Winograd path: its rounding (2e-6 of the output rms) puts a
- * pre-activation on the other side of a ReLU than the reference on every other batch at that width. */
+ * AGZ_COMPUTE_BF16X3 (all three on the bf16 pipe; weights re-split on the device every step) or AGZ_COMPUTE_WINO_H2 (fp16x2
+ * products throughout: forward = the DIRECT 3x3 convolution with fp16 hi/lo operands, weight image split on the device every step;
+ * data gradient = the Winograd fp16x2 path with device-transformed weights; weight gradient = fp16 hi/lo operands split once per
+ * layer; the first layer, 18 -> K, stays on BF16X3).  130 / 88 / 63 ms per step at 19x19, K = 256, 20 blocks, batch 256.  Every mode
+ * meets the same gradient tolerance against the reference arithmetic — every gradient tensor within 2e-5 of its maximum, tested per
+ * mode at the headline width (K = 256, 19x19) on several data draws — which is why the forward convolutions do NOT take the
+ * Winograd path: its rounding (2e-6 of the output rms against 3e-7 for the direct forms) puts a pre-activation on the other side of
+ * a ReLU than the reference on every other batch at that width. */
 int agz_trainer_set_compute_mode(agz_trainer* t, int mode);
 /* dual.Train(d, Xs, policies, values, batches, iterations) (dualnet/meta.go:16-54): lr 0.1 vanilla SGD, shuffleBatch
  * after every iteration (build RNG; Xs/policies/values are shuffled in place like the reference). */
