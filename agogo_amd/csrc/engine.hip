@@ -88,6 +88,53 @@ __device__ int select_child(const Dev& d, size_t base, int off, int n, int playe
   return idx;  // -1: the reference panics "Cannot return nil" (node.go:232-234)
 }
 
+// sort.Sort(byScore) as a STABLE descending sort of s.fscore[0..n): rank = #greater + #equal-before, for the (up
+// to CELLS_PAD / 64) entries lane + 64 k of this lane.  For non-negative, non-NaN scores (every prior that comes out of a softmax / the
+// renormalisation) the float order is the order of the bit patterns, so "(sj > si) || (sj == si && j < i)" is ONE unsigned 64-bit
+// comparison of the keys (bits << 32 | ~index); a lane counts for all its entries at once, independent chains per broadcast LDS read.
+// (One wave ranking ~300 moves with dependent float-compare chains took 36 of k_expand's 47 us at batch 1.)  Anything else — a NaN or
+// a negative score — takes the float comparisons as written.  Call with all 64 lanes; entries past n get rank 0 (unused).
+constexpr int RANK_PER = CELLS_PAD / WAVE;
+__device__ void stable_desc_ranks(const float* fscore, int n, int lane, int* rnk) {
+  bool odd = false;
+  for (int i2 = lane; i2 < n; i2 += WAVE) { const unsigned bts = __float_as_uint(fscore[i2]); odd |= (bts & 0x80000000u) != 0u || (bts & 0x7fffffffu) > 0x7f800000u; }
+  if (!__syncthreads_or(odd ? 1 : 0)) {
+    unsigned long long key[RANK_PER];
+#pragma unroll
+    for (int k = 0; k < RANK_PER; k++) {
+      const int i2 = lane + k * WAVE;
+      key[k] = i2 < n ? (((unsigned long long)__float_as_uint(fscore[i2]) << 32) | (unsigned)(0x7fffffff - i2)) : ~0ull;
+      rnk[k] = 0;
+    }
+    int jj = 0;
+    for (; jj + 4 <= n; jj += 4) {
+      const float4 v4 = *reinterpret_cast<const float4*>(&fscore[jj]);
+      const unsigned long long k0 = ((unsigned long long)__float_as_uint(v4.x) << 32) | (unsigned)(0x7fffffff - jj);
+      const unsigned long long k1 = ((unsigned long long)__float_as_uint(v4.y) << 32) | (unsigned)(0x7fffffff - jj - 1);
+      const unsigned long long k2 = ((unsigned long long)__float_as_uint(v4.z) << 32) | (unsigned)(0x7fffffff - jj - 2);
+      const unsigned long long k3 = ((unsigned long long)__float_as_uint(v4.w) << 32) | (unsigned)(0x7fffffff - jj - 3);
+#pragma unroll
+      for (int k = 0; k < RANK_PER; k++) rnk[k] += (int)(k0 > key[k]) + (int)(k1 > key[k]) + (int)(k2 > key[k]) + (int)(k3 > key[k]);
+    }
+    for (; jj < n; jj++) {
+      const unsigned long long kj = ((unsigned long long)__float_as_uint(fscore[jj]) << 32) | (unsigned)(0x7fffffff - jj);
+#pragma unroll
+      for (int k = 0; k < RANK_PER; k++) rnk[k] += (int)(kj > key[k]);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < RANK_PER; k++) {
+      const int i = lane + k * WAVE;
+      int rank = 0;
+      if (i < n) {
+        const float si = fscore[i];
+        for (int j = 0; j < n; j++) { const float sj = fscore[j]; rank += (sj > si) || (sj == si && j < i); }
+      }
+      rnk[k] = rank;
+    }
+  }
+}
+
 // ---- state in LDS -----------------------------------------------------------------------------------
 struct St {
   int to_move, ply, passes;
@@ -622,12 +669,14 @@ __global__ __launch_bounds__(64) void k_expand_prep(Dev d, GameCfg c, MctsCfg mc
     for (int i = lane; i < n; i += WAVE) s.fscore[i] = prob;
   }
   __syncthreads();
-  for (int i = lane; i < n; i += WAVE) {   // stable descending rank sort (as k_expand)
-    const float si = s.fscore[i];
-    int rank = 0;
-    for (int j = 0; j < n; j++) { const float sj = s.fscore[j]; rank += (sj > si) || (sj == si && j < i); }
-    d.exp_score[q * CELLS_PAD + rank] = si;
-    d.exp_move[q * CELLS_PAD + rank] = (int16_t)s.fmove[i];
+  {   // stable descending rank sort (as k_expand)
+    int rnk[RANK_PER];
+    stable_desc_ranks(s.fscore, n, lane, rnk);
+#pragma unroll
+    for (int k = 0; k < RANK_PER; k++) {
+      const int i = lane + k * WAVE;
+      if (i < n) { d.exp_score[q * CELLS_PAD + rnk[k]] = s.fscore[i]; d.exp_move[q * CELLS_PAD + rnk[k]] = (int16_t)s.fmove[i]; }
+    }
   }
   if (lane == 0) { d.exp_n[q] = n; d.exp_value[q] = value; }
 }
@@ -848,59 +897,14 @@ __global__ __launch_bounds__(64) void k_expand(Dev d, GameCfg c, MctsCfg mc, Inf
           if (lane == 0) { if (!d.overflow[t]) atomicAdd(&d.counters[CNT_FULL], 1ull); d.overflow[t] = 1; d.stalled[t] = 1; }
           have = false;
         } else {
-          // sort.Sort(byScore) as a STABLE descending sort: rank = #greater + #equal-before.
-          // For non-negative, non-NaN scores (every prior that comes out of a softmax / the renormalisation above) the float order is
-          // the order of the bit patterns, so "(sj > si) || (sj == si && j < i)" is ONE unsigned 64-bit comparison of the keys
-          // (bits << 32 | ~index); a lane counts for its (up to six) entries at once, six independent chains per broadcast LDS read.
-          // (One wave ranking ~300 moves with dependent float compare chains took 36 of k_expand's 47 us at batch 1.)  Anything else —
-          // a NaN or a negative score — takes the float comparisons as written.
-          constexpr int PER = CELLS_PAD / WAVE;
-          bool odd = false;
-          for (int i2 = lane; i2 < n; i2 += WAVE) { const unsigned bts = __float_as_uint(s.fscore[i2]); odd |= (bts & 0x80000000u) != 0u || (bts & 0x7fffffffu) > 0x7f800000u; }
-          if (!__syncthreads_or(odd ? 1 : 0)) {
-            unsigned long long key[PER];
-            int rnk[PER];
+          // stable descending sort by rank; the sorted list goes through LDS scratch of the board analysis so that the child block is
+          // written as whole rows instead of one scattered element per lane and array
+          int rnk[RANK_PER];
+          stable_desc_ranks(s.fscore, n, lane, rnk);
 #pragma unroll
-            for (int k = 0; k < PER; k++) {
-              const int i2 = lane + k * WAVE;
-              key[k] = i2 < n ? (((unsigned long long)__float_as_uint(s.fscore[i2]) << 32) | (unsigned)(0x7fffffff - i2)) : ~0ull;
-              rnk[k] = 0;
-            }
-            int jj = 0;
-            for (; jj + 4 <= n; jj += 4) {
-              const float4 v4 = *reinterpret_cast<const float4*>(&s.fscore[jj]);
-              const unsigned long long k0 = ((unsigned long long)__float_as_uint(v4.x) << 32) | (unsigned)(0x7fffffff - jj);
-              const unsigned long long k1 = ((unsigned long long)__float_as_uint(v4.y) << 32) | (unsigned)(0x7fffffff - jj - 1);
-              const unsigned long long k2 = ((unsigned long long)__float_as_uint(v4.z) << 32) | (unsigned)(0x7fffffff - jj - 2);
-              const unsigned long long k3 = ((unsigned long long)__float_as_uint(v4.w) << 32) | (unsigned)(0x7fffffff - jj - 3);
-#pragma unroll
-              for (int k = 0; k < PER; k++) rnk[k] += (int)(k0 > key[k]) + (int)(k1 > key[k]) + (int)(k2 > key[k]) + (int)(k3 > key[k]);
-            }
-            for (; jj < n; jj++) {
-              const unsigned long long kj = ((unsigned long long)__float_as_uint(s.fscore[jj]) << 32) | (unsigned)(0x7fffffff - jj);
-#pragma unroll
-              for (int k = 0; k < PER; k++) rnk[k] += (int)(kj > key[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < PER; k++) {
-              const int i2 = lane + k * WAVE;
-              if (i2 < n) { s.touch[rnk[k]] = __float_as_int(s.fscore[i2]); s.ghash[rnk[k]] = s.fmove[i2]; }
-            }
-          } else
-          for (int i = lane; i < n; i += WAVE) {
-            float si = s.fscore[i];
-            int rank = 0;
-            int j = 0;
-            for (; j + 4 <= n; j += 4) {   // (broadcast reads, four entries each)
-              const float4 v4 = *reinterpret_cast<const float4*>(&s.fscore[j]);
-              rank += (v4.x > si) || (v4.x == si && j < i);
-              rank += (v4.y > si) || (v4.y == si && j + 1 < i);
-              rank += (v4.z > si) || (v4.z == si && j + 2 < i);
-              rank += (v4.w > si) || (v4.w == si && j + 3 < i);
-            }
-            for (; j < n; j++) { float sj = s.fscore[j]; rank += (sj > si) || (sj == si && j < i); }
-            s.touch[rank] = __float_as_int(si);      // (scratch of the board analysis: the sorted list, so that the child block is
-            s.ghash[rank] = s.fmove[i];              //  written as whole rows instead of one scattered element per lane and array)
+          for (int k = 0; k < RANK_PER; k++) {
+            const int i2 = lane + k * WAVE;
+            if (i2 < n) { s.touch[rnk[k]] = __float_as_int(s.fscore[i2]); s.ghash[rnk[k]] = s.fmove[i2]; }
           }
           __syncthreads();
           for (int r = lane; r < n; r += WAVE) {
