@@ -135,3 +135,22 @@ def test_go_shim_only_references_declared_symbols():
     assert len(used) > 30
     missing = sorted(u for u in used if not re.search(r"\b%s\b" % re.escape(u), hdr))
     assert not missing, missing
+
+
+def test_environment_switches_are_few_documented_and_tested():
+    """at most eight environment switches in the library, every one of them documented in include/agz.h (with
+    the test that runs it) and actually set by some test; and DESIGN.md stays a design document (<= 300 lines)."""
+    import glob
+    srcs = glob.glob(os.path.join(ROOT, "agogo_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "agogo_amd", "csrc", "*.hpp"))
+    knobs = set()
+    for f in srcs:
+        knobs |= set(re.findall(r'getenv\("(AGZ_\w+)"\)', open(f).read()))
+    assert 0 < len(knobs) <= 8, sorted(knobs)
+    hdr = open(os.path.join(ROOT, "include", "agz.h")).read()
+    tests = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "tests", "*.py")) if not f.endswith("test_capi_cpu.py"))
+    for k in sorted(knobs):
+        assert re.search(r"\b%s\b" % k, hdr), "%s is not documented in include/agz.h" % k
+        assert re.search(r"\b%s\b" % k, tests), "%s is not exercised by any test" % k
+    documented = set(re.findall(r"^ \*   (AGZ_\w+)=", hdr, flags=re.M))
+    assert documented == knobs, (sorted(documented), sorted(knobs))
+    assert len(open(os.path.join(ROOT, "DESIGN.md")).read().splitlines()) <= 300
