@@ -176,6 +176,7 @@ def lib():
     sig("agz_ctx_prof_set_stride", i32, vp, i32, i32)
     sig("agz_wino_stages", i32, vp, pf, pf, i32, i32, i32, i32, i32, pf, pf)
     sig("agz_wino_h2_tile", i32, i32, i32)
+    sig("agz_net_set_wino_h2_form", i32, vp, i32)
     sig("agz_arena_random_moves", i32, vp, pi, u64)
     sig("agz_arena_set_state", i32, vp, i32, C.POINTER(State))
     sig("agz_arena_examples_labelled_dev", i32, vp, pvp)
@@ -358,6 +359,10 @@ class Net:
 
     def set_tower_queues(self, queues):
         _check(lib().agz_net_set_tower_queues(self.h, int(queues)), "agz_net_set_tower_queues")
+
+    def set_wino_h2_form(self, form):
+        """agz_debug.h A/B hook: -1 auto (chained block where the shape allows), 0 three-kernel block, 1 chained"""
+        _check(lib().agz_net_set_wino_h2_form(self.h, int(form)), "agz_net_set_wino_h2_form")
 
     def infer_dev(self, planes_ptr, B, policy_ptr, value_ptr):
         """device pointers (ints); asynchronous on the ctx stream"""

@@ -26,14 +26,14 @@ const Rccl* rccl() {
     void* h = nullptr;
     if (const char* path = getenv("AGZ_RCCL_LIB")) {
       h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
-      if (!h) { err = std::string("AGZ_RCCL_LIB=") + path + ": " + (dlerror() ? dlerror() : "?"); return; }
+      if (!h) { const char* de = dlerror(); err = std::string("AGZ_RCCL_LIB=") + path + ": " + (de ? de : "?"); return; }   // (dlerror() clears on read: once)
     }
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!h) { err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+    if (!h) { const char* de = dlerror(); err = std::string("librccl not found: ") + (de ? de : "?"); return; }
     bool all = true;
     auto get = [&](const char* name) { void* p = dlsym(h, name); if (!p) { all = false; err = std::string("librccl lacks ") + name; } return p; };
     table.GetUniqueId = (decltype(table.GetUniqueId))get("ncclGetUniqueId");
@@ -80,6 +80,10 @@ int agz_comm_init_rank(agz_ctx* ctx, int n_ranks, int rank, const void* id128, a
   c->ctx = ctx; c->rank = rank; c->size = n_ranks;
   ncclResult_t r = R->CommInitRank(&c->comm, n_ranks, id, rank);
   if (r != ncclSuccess) { set_error("agz_comm_init_rank: ncclCommInitRank -> %s", R->GetErrorString(r)); delete c; return AGZ_E_HIP; }
+  if (hipMalloc(&c->d_words, (size_t)(n_ranks + 3) * 8) != hipSuccess) {
+    set_error("agz_comm_init_rank: out of device memory for the exchange words");
+    R->CommDestroy(c->comm); delete c; return AGZ_E_NOMEM;
+  }
   *out = c;
   return AGZ_OK;
 }
@@ -96,18 +100,26 @@ int agz_comm_init_all(agz_ctx* const* ctxs, int n, agz_comm** comms) {
   }
   std::vector<ncclComm_t> cs(n, nullptr);
   AGZ_NCCL_TRY(R->CommInitAll(cs.data(), n, dev.data()));
+  for (int i = 0; i < n; i++) comms[i] = nullptr;
+  int rc = AGZ_OK;
   for (int i = 0; i < n; i++) {
     agz_comm* c = new agz_comm();
     c->ctx = ctxs[i]; c->comm = cs[i]; c->rank = i; c->size = n;
     comms[i] = c;
+    if (hipSetDevice(dev[i]) != hipSuccess || hipMalloc(&c->d_words, (size_t)(n + 3) * 8) != hipSuccess) rc = AGZ_E_NOMEM;
   }
-  return AGZ_OK;
+  if (rc != AGZ_OK) {
+    set_error("agz_comm_init_all: out of device memory for the exchange words");
+    for (int i = 0; i < n; i++) { agz_comm_destroy(comms[i]); comms[i] = nullptr; }
+  }
+  return rc;
 }
 
 void agz_comm_destroy(agz_comm* c) {
   if (!c) return;
   const Rccl* R = rccl();
   if (R && c->comm) { hipSetDevice(c->ctx->device); hipStreamSynchronize(c->ctx->stream); R->CommDestroy(c->comm); }
+  if (c->d_words) { hipSetDevice(c->ctx->device); hipFree(c->d_words); }
   delete c;
 }
 

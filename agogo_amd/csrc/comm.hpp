@@ -33,6 +33,9 @@ struct agz_comm {
   agz_ctx* ctx = nullptr;
   ncclComm_t comm = nullptr;
   int rank = 0, size = 1;
+  // size + 3 device words allocated with the communicator: the count exchange and the allocation agreement of
+  // agz_examples_allgather never allocate, so no rank can skip a collective its peers enter (a hang) for want of memory
+  unsigned long long* d_words = nullptr;
 };
 
 #define AGZ_NCCL_TRY(expr)                                                                                   \

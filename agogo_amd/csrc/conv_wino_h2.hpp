@@ -106,6 +106,15 @@ struct WinoH2Args {
   const float* t_in;
   const float* col_unscale;
   const float* t_next;
+  // ---- chained form (conv_wino_h2c.hpp): V2c[T/128][pos][C/32][128 rows][hi 64 B | lo 64 B], Mc[T/128][pos][C/32 slices][128 rows][64 cols]
+  // (column 2 j + branch of slice s = channel 32 s + j), U2c[pos][C/32][Ntot/256][256 cols][hi 64 B | lo 64 B].
+  int cform;                 // 1: wino_in_h2_kernel stores V2c
+  const _Float16* U2c;
+  const float* amax_true;    // [B] exact max |x| of this block's input (float bits) — block 0; nullptr: reduce wm_prev
+  const float* wm_prev;      // [B][TPB * C/32] per-(tile, slice) maxima of this block's input, left by the kernel that produced it
+  float* wm_out;             // the same for this block's output (the other half of the ping-pong pair)
+  unsigned* amax_next;       // [B] bits of the proven bound on max |y| of this block's output: the range word of V2(l+1)
+  float g1, g0;              // that bound = g1 * max|x| + g0 (agz_net::build_wino_h2_weights)
 };
 __device__ __forceinline__ size_t h2_row(const WinoH2Args& h, int pos, int t) {
   return (size_t)(t >> h.rsh) * h.rA + (size_t)pos * h.rB + (size_t)(t & h.rmask);
@@ -206,6 +215,16 @@ __global__ __launch_bounds__(256) void wino_in_h2_kernel(WinoH2Args h) {
     for (int j = 0; j < AL; j++) {
       unsigned lo;
       const unsigned hi = wino_h2_pack(ox[j] * sbx, oy[j] * sby, &lo);
+      if (h.cform) {   // (uniform; C % 128 == 0) chained layout: the wave's four K steps are four 16 KB chunks — two 128-byte row runs per store
+        const auto s16 = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);   // [hi k0, lo k0, hi k2, lo k2], [hi k1, lo k1, hi k3, lo k3]
+        const unsigned e0 = s16[0], e1 = s16[1];
+        const int NS = a.C >> 5;
+        const size_t chunk0 = ((size_t)(t >> 7) * h.npos + (size_t)(i * AL + j)) * NS + (size_t)((c2 >> 6) * 4 + 2 * (lane >> 5));   // K step of e0's half
+        unsigned* p0 = V2 + chunk0 * 4096 + (size_t)(t & 127) * 32 + (lane & 31);
+        p0[0] = e0;
+        p0[4096] = e1;                                                              // the next K step's chunk
+        continue;
+      }
       unsigned* rowp = V2 + h2_row(h, i * AL + j, t) * a.C;
       if (h.in_swap) {
         const auto s16 = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);   // [hi r0, lo r0, hi r2, lo r2], [hi r1, lo r1, hi r3, lo r3]

@@ -1,0 +1,584 @@
+// Chained form of the Winograd fp16x2 tower (AGZ_COMPUTE_WINO_H2, reference shape dualnet/ermahagerdmonards.go:60-73: `share` =
+// two convolutions of the same input, add, ReLU).
+//
+// conv_wino_h2.hpp runs a block as  x -> [in] -> V2 -> [GEMM] -> M -> [out] -> y  and the next block reads y again: of the
+// 2.87 GB a 512-board block moves, 0.38 GB is y written and read back.  Here the output transform of block l and the input
+// transform of block l+1 are ONE kernel (wino_oi_h2c_kernel): a workgroup owns 16 tile rows (a 19x19 board = 4x4 tiles of
+// F(5x5,3x3)) x one 32-channel slice, reads its slice of M(l), applies At . A, the block epilogue, keeps the 32-channel board in
+// LDS (46 KB), and writes Bt . B of it as the split fp16 operand V2(l+1).  y never reaches HBM between blocks: 2.49 GB per block.
+//
+// Range words.  V2(l+1) needs the board's power-of-two range BEFORE the board's maximum over all channel slices exists (the
+// slices are different workgroups), so the range comes from a bound proven at commit time:
+//     max |y_l * t_next|  <=  g1_l * max |x_l|  +  g0_l          (g1 = max_{p,c} t_next (|sa| L1(w_a,c) + |sb| L1(w_b,c)),  g0 = max (ta+ + tb+))
+// with max|x_l| the EXACT maximum of the block's input (per-(tile, slice) words left by the producing kernel, reduced by every
+// consumer itself — ping-pong arrays).  The bound is one layer deep (no compounding) and costs log2(bound / true max) bits of
+// the 2^-38 absolute piece error (conv_wino_h2.hpp header): ~5 bits on Glorot weights, invisible next to fp32's 2^-24.
+//
+// Layouts (all 16-byte runs of a wave are contiguous KBs):
+//   V2c[T/128][pos][C/32][128 rows][hi 32 fp16 | lo 32 fp16]      a GEMM K step of a 128-row tile = one 16 KB chunk
+//   U2c[pos][C/32][Ntot/256][256 cols][hi | lo]                    a K step of a 256-column tile = one 32 KB chunk
+//   Mc [T/128][pos][C/32 slices][128 rows][64 cols] fp32           column 2j + br of slice s = branch br of channel 32 s + j
+// LDS image of a staged chunk: row r, 16-byte slot q (0..3 hi, 4..7 lo) at r * 128 + ((q ^ ((r >> 1) & 7)) << 4): conflict-free
+// for the 128-byte row writes and for the MFMA fragment reads (ds_read_b128: even and odd rows are the two halves of the
+// 64-bank period, and the 8 even / 8 odd rows of a 16-lane group get 8 distinct slots).
+#pragma once
+// (included by net.hip INSIDE namespace agz, after conv_wino_h2.hpp)
+
+__device__ __forceinline__ unsigned h2c_img(int row, int slot) { return (unsigned)(row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)); }
+
+// ---- the transform-domain GEMMs on the chained layouts: 128 x 256 tile, A (HBM) fetched PFA K steps ahead into rotating register
+// sets, B (L2) one step ahead — wino_gemm_h2d_kernel's pipeline; every global access of a wave is one contiguous KB.
+template <int NK, int PFA>
+__global__ __launch_bounds__(256, 2) void wino_gemm_h2c_kernel(WinoH2Args h) {
+  const WinoArgs& a = h.w;
+  constexpr int SA = 128 * 128, SB = 256 * 128;   // 16 KB + 32 KB
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SA + SB];
+
+  const int n_nt = a.Ntot >> 8;
+  const int per_pos = a.n_mtiles * n_nt;
+  const int nblk = h.npos * per_pos;
+  const int id = blockIdx.x;
+  int q = nblk >> 3, rr = nblk & 7, xcd = id & 7, slot = id >> 3;
+  int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
+  const int pos = tile / per_pos;
+  const int rem = tile - pos * per_pos;
+  const int m_tile = rem / n_nt, n_tile = rem - m_tile * n_nt;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  // staging: thread t moves the 16-byte unit t + 256 j of a chunk (row t/8 + 32 j, slot t%8)
+  const unsigned st_lds = h2c_img(tid >> 3, tid & 7);          // + j * 4096: (row >> 1) & 7 does not depend on j
+  const char* abase = reinterpret_cast<const char*>(a.V) + ((size_t)m_tile * h.npos + pos) * (size_t)NK * SA + (size_t)tid * 16;
+  const char* bbase = reinterpret_cast<const char*>(h.U2c) + (((size_t)pos * NK) * n_nt + n_tile) * (size_t)SB + (size_t)tid * 16;
+  const size_t bstep = (size_t)n_nt * SB;
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int kh = lane >> 5, sw = (lane >> 1) & 7;
+  const unsigned fa = (unsigned)((wm * 64 + (lane & 31)) * 128);          // + i * 4096
+  const unsigned fb = (unsigned)(SA + (wn * 128 + (lane & 31)) * 128);    // + j * 4096
+
+  u32x4_t xa[PFA][4], xb[8];
+  auto load_a = [&](int set, int kk) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) xa[set][j] = *reinterpret_cast<const u32x4_t*>(abase + (size_t)kk * SA + j * 4096);
+  };
+  auto load_b = [&](int kk) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) xb[j] = *reinterpret_cast<const u32x4_t*>(bbase + (size_t)kk * bstep + j * 4096);
+  };
+  load_b(0);
+#pragma unroll
+  for (int p = 0; p < PFA; p++) load_a(p, p < NK ? p : NK - 1);
+#pragma unroll
+  for (int it = 0; it < NK; it++) {
+    const int set = it % PFA;
+#pragma unroll
+    for (int j = 0; j < 4; j++) *reinterpret_cast<u32x4_t*>(lds + st_lds + j * 4096) = xa[set][j];
+#pragma unroll
+    for (int j = 0; j < 8; j++) *reinterpret_cast<u32x4_t*>(lds + SA + st_lds + j * 4096) = xb[j];
+    __syncthreads();
+    if (it + 1 < NK) load_b(it + 1);            // B first (vmcnt retires in order: the wait before the stores is vmcnt(4))
+    if (it + PFA < NK) load_a(set, it + PFA);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      f16x8_t A_[2][2], B_[4][2];
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const unsigned so = (unsigned)(((p * 4 + 2 * ks + kh) ^ sw) << 4);
+#pragma unroll
+        for (int i = 0; i < 2; i++) A_[i][p] = *reinterpret_cast<const f16x8_t*>(lds + fa + i * 4096 + so);
+#pragma unroll
+        for (int j = 0; j < 4; j++) B_[j][p] = *reinterpret_cast<const f16x8_t*>(lds + fb + j * 4096 + so);
+      }
+#pragma unroll
+      for (int pp = 0; pp < 3; pp++) {            // small terms first: lo*hi, hi*lo, hi*hi
+        const int pa = pp == 0 ? 1 : 0, pb = pp == 1 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[i][pa], B_[j][pb], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // M: the tile's four 64-column slices are four contiguous 32 KB chunks.  A 32x32 accumulator holds row R in lanes 0..31 and row
+  // R + 4 in lanes 32..63; v_permlane32_swap of two neighbouring column tiles puts all 64 columns of one row into one register:
+  // every store is one 256-byte run.
+  float* mbase = a.Mb + ((((size_t)m_tile * h.npos + pos) * (size_t)(a.Ntot >> 6) + (size_t)n_tile * 4 + wn * 2) * 128 + (size_t)(wm * 64)) * 64 + lane;
+#pragma unroll
+  for (int qq = 0; qq < 2; qq++)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const unsigned x0 = __float_as_uint(acc[i][2 * qq][r]), x1 = __float_as_uint(acc[i][2 * qq + 1][r]);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);   // [x0 low half, x1 low half], [x0 high half, x1 high half]
+        const unsigned w0 = s32[0], w1 = s32[1];
+        float* d = mbase + (size_t)qq * 8192 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * 64;
+        d[0] = __uint_as_float(w0);
+        d[4 * 64] = __uint_as_float(w1);
+      }
+}
+
+// Y[l] += At[l][nu] * t for the output transform's row pass, one column nu at a time (nu is a constant after unrolling)
+template <int TM> __device__ __forceinline__ void wino_at_acc(int nu, float* Y, float t);
+template <> __device__ __forceinline__ void wino_at_acc<5>(int nu, float* Y, float t) {
+  switch (nu) {
+    case 0: Y[0] += t; break;
+    case 1: Y[0] += t; Y[1] += t; Y[2] += t; Y[3] += t; Y[4] += t; break;
+    case 2: Y[0] += t; Y[1] -= t; Y[2] += t; Y[3] -= t; Y[4] += t; break;
+    case 3: Y[0] += t; Y[1] += 0.5f * t; Y[2] += 0.25f * t; Y[3] += 0.125f * t; Y[4] += 0.0625f * t; break;
+    case 4: Y[0] += t; Y[1] -= 0.5f * t; Y[2] += 0.25f * t; Y[3] -= 0.125f * t; Y[4] += 0.0625f * t; break;
+    case 5: Y[0] += t; Y[1] += 2.f * t; Y[2] += 4.f * t; Y[3] += 8.f * t; Y[4] += 16.f * t; break;
+    default: Y[4] += t; break;
+  }
+}
+template <> __device__ __forceinline__ void wino_at_acc<4>(int nu, float* Y, float t) {
+  switch (nu) {
+    case 0: Y[0] += t; break;
+    case 1: Y[0] += t; Y[1] += t; Y[2] += t; Y[3] += t; break;
+    case 2: Y[0] += t; Y[1] -= t; Y[2] += t; Y[3] -= t; break;
+    case 3: Y[0] += t; Y[1] += 2.f * t; Y[2] += 4.f * t; Y[3] += 8.f * t; break;
+    case 4: Y[0] += t; Y[1] -= 2.f * t; Y[2] += 4.f * t; Y[3] -= 8.f * t; break;
+    default: Y[3] += t; break;
+  }
+}
+
+// Output transform of block l + block epilogue + (LAST ? y to HBM : input transform of block l+1).
+// grid (T / 16 rounded up, C / 32), 256 threads: thread = (tile row tl = tid / 16 of the group, channel pair pr = tid % 16 of the slice);
+// a 16-lane group is one tile, a wave four consecutive tile rows.  Requires 16 % TPB == 0 (a group holds whole boards).
+// Dynamic LDS (not LAST): [16 / TPB boards][H * W][32] fp32.
+// DBG (measurement only, results wrong): 1 = every M load reads position 0 (L1 hits), 2 = one epilogue parameter vector for all
+// pixels, 4 = no V2 stores
+template <int TM, bool LAST, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void wino_oi_h2c_kernel(WinoH2Args h) {
+  using WT = WinoT<TM>;
+  constexpr int AL = WT::AL;
+  const WinoArgs& a = h.w;
+  extern __shared__ __attribute__((aligned(16))) float ys[];
+  const int tid = threadIdx.x, tl = tid >> 4, pr = tid & 15, lane = tid & 63;
+  const int s = blockIdx.y, NS = a.C >> 5, HW = a.H * a.W;
+  const int t0 = blockIdx.x * 16;                      // uniform; t0 % 16 == 0, so t0 >> 7 is the 128-row tile of the whole group
+  const int t = t0 + tl;
+  const bool live = t < a.T;
+  const int tc = live ? t : a.T - 1;
+  const int b = tc / a.TPB, tt = tc - b * a.TPB;
+  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
+  const int bl = tl / a.TPB;                           // board of the group
+  float s_, un0;
+  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &un0);
+  // ---- output transform: stream the AL columns of the position grid (AL float4 {a c0, b c0, a c1, b c1} each), column pass, accumulate the row pass
+  const __amdgpu_buffer_rsrc_t mr = h2_rsrc(a.Mb + ((size_t)(t0 >> 7) * h.npos * NS + s) * 8192);
+  const unsigned m_lane = (unsigned)(((tc & 127) * 64 + pr * 4) * 4);
+  const unsigned m_pos = (unsigned)NS * 32768u;        // bytes between positions
+  float Y[TM][TM][4];
+#pragma unroll
+  for (int k = 0; k < TM; k++)
+#pragma unroll
+    for (int l = 0; l < TM; l++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) Y[k][l][e] = 0.f;
+  float4 m[2][AL];
+#pragma unroll
+  for (int xi = 0; xi < AL; xi++) m[0][xi] = h2_ldf4(mr, m_lane, (DBG & 1) ? 0u : (unsigned)(xi * AL) * m_pos);
+#pragma unroll
+  for (int nu = 0; nu < AL; nu++) {
+    if (nu + 1 < AL) {
+#pragma unroll
+      for (int xi = 0; xi < AL; xi++) m[(nu + 1) & 1][xi] = h2_ldf4(mr, m_lane, (DBG & 1) ? 0u : (unsigned)(xi * AL + nu + 1) * m_pos);
+    }
+    float mm[4][AL], oo[4][TM];
+#pragma unroll
+    for (int xi = 0; xi < AL; xi++) { const float4 v = m[nu & 1][xi]; mm[0][xi] = v.x; mm[1][xi] = v.y; mm[2][xi] = v.z; mm[3][xi] = v.w; }
+#pragma unroll
+    for (int e = 0; e < 4; e++) wino_atv<TM>(mm[e], oo[e]);
+#pragma unroll
+    for (int k = 0; k < TM; k++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float yl[TM];
+#pragma unroll
+        for (int l = 0; l < TM; l++) yl[l] = Y[k][l][e];
+        wino_at_acc<TM>(nu, yl, oo[e][k]);
+#pragma unroll
+        for (int l = 0; l < TM; l++) Y[k][l][e] = yl[l];
+      }
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch one column deep (the compiler would hoist all AL^2 loads and spill)
+  }
+  // ---- block epilogue (parameters float4 {sa, ta, sb, tb} per (pixel, channel), scales folded in: agz_net::build_wino_h2_weights)
+  const char* ep = reinterpret_cast<const char*>(a.ep);
+  const unsigned e_lane = (unsigned)(32 * s + 2 * pr) * 16u, e_pix = (unsigned)a.Cout_p * 16u;
+  float mx = 0.f;
+  float* yb = LAST ? a.y + (size_t)b * a.Hp * a.Wp * a.Cout_p + 32 * s + 2 * pr : nullptr;
+#pragma unroll
+  for (int k = 0; k < TM; k++) {
+    const int hh = TM * ty + k, hc = hh < a.H ? hh : a.H - 1;
+#pragma unroll
+    for (int l = 0; l < TM; l++) {
+      const int ww = TM * tx + l, wc = ww < a.W ? ww : a.W - 1;
+      const char* e = ep + ((DBG & 2) ? (size_t)0 : (size_t)(hc * a.W + wc) * e_pix) + e_lane;
+      const float4 E0 = *reinterpret_cast<const float4*>(e), E1 = *reinterpret_cast<const float4*>(e + 16);
+      float va = (Y[k][l][0] * un0) * E0.x + E0.y, vb = (Y[k][l][1] * un0) * E0.z + E0.w;
+      float vc = (Y[k][l][2] * un0) * E1.x + E1.y, vd = (Y[k][l][3] * un0) * E1.z + E1.w;
+      va = va > 0.f ? va : 0.f; vb = vb > 0.f ? vb : 0.f; vc = vc > 0.f ? vc : 0.f; vd = vd > 0.f ? vd : 0.f;
+      const float y0 = va + vb, y1 = vc + vd;          // relu(a) + relu(b) >= 0 already
+      if (live && hh < a.H && ww < a.W) {
+        if (LAST) *reinterpret_cast<float2*>(yb + ((size_t)(hh + 1) * a.Wp + (ww + 1)) * a.Cout_p) = make_float2(y0, y1);
+        else *reinterpret_cast<float2*>(&ys[((size_t)bl * HW + hh * a.W + ww) * 32 + 2 * pr]) = make_float2(y0, y1);
+        mx = fmaxf(mx, fmaxf(y0, y1));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // one row of parameter loads in flight (all TM^2 hoisted: spills)
+  }
+  if (LAST) return;
+  // the tile's maximum over this slice -> the next consumer's exact max|x|
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (pr == 0 && live) h.wm_out[(size_t)t * NS + s] = mx;
+  // ---- range of V2(l+1): the commit-time bound on max |y| from the exact maximum of this block's input
+  float ax;
+  if (h.amax_true) ax = __uint_as_float(reinterpret_cast<const unsigned*>(h.amax_true)[b]);
+  else {
+    const int wmpb = a.TPB * NS;
+    const float* wp = h.wm_prev + (size_t)b * wmpb;
+    ax = 0.f;
+    for (int i = pr; i < wmpb; i += 16) ax = fmaxf(ax, wp[i]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ax = fmaxf(ax, __shfl_xor(ax, o, 64));
+  }
+  const float bound = h.g1 * ax + h.g0;
+  const unsigned bbits = __float_as_uint(bound);
+  if (s == 0 && tt == 0 && pr == 0 && live) h.amax_next[b] = bbits;
+  float sb, inv_;
+  wino_h2_scales(bbits, WT::VSHIFT, &sb, &inv_);
+  __syncthreads();
+  // ---- input transform of block l+1 on the LDS board: tile t, channels 32 s + 2 pr, + 1 (conv_wino_h2.hpp's wino_in_h2_kernel)
+  const float* yl = ys + (size_t)bl * HW * 32 + 2 * pr;
+  float tmx[AL][AL], tmy[AL][AL];
+#pragma unroll
+  for (int j = 0; j < AL; j++) {
+    const int ww = TM * tx + j - 1;
+    const bool okx = ww >= 0 && ww < a.W;
+    const int wc = ww < 0 ? 0 : (ww < a.W ? ww : a.W - 1);
+    float dx[AL], dy[AL], ox[AL], oy[AL];
+#pragma unroll
+    for (int i = 0; i < AL; i++) {
+      const int hh = TM * ty + i - 1;
+      const bool ok = okx && hh >= 0 && hh < a.H;
+      const int hc = hh < 0 ? 0 : (hh < a.H ? hh : a.H - 1);
+      const float2 d = *reinterpret_cast<const float2*>(yl + (size_t)(hc * a.W + wc) * 32);
+      dx[i] = ok ? d.x : 0.f; dy[i] = ok ? d.y : 0.f;
+    }
+    wino_btv<TM>(dx, ox);
+    wino_btv<TM>(dy, oy);
+#pragma unroll
+    for (int i = 0; i < AL; i++) { tmx[i][j] = ox[i]; tmy[i][j] = oy[i]; }
+  }
+  const float sv = live ? sb : 0.f;                    // rows past the last tile: zeros
+  // V2c: the group's 16 rows of K step s are 2 KB; a wave's four rows 512 B = two 256-byte stores (hi | lo of two rows each)
+  const __amdgpu_buffer_rsrc_t vr = h2_rsrc(reinterpret_cast<const char*>(a.V) + ((size_t)(t0 >> 7) * h.npos * NS + s) * 16384);
+  const unsigned v_lane = (unsigned)(((t0 & 127) + (tid >> 6) * 4) * 128 + lane * 4);
+  const unsigned v_pos = (unsigned)NS * 16384u;
+#pragma unroll
+  for (int i = 0; i < AL; i++) {
+    float ox[AL], oy[AL];
+    wino_btv<TM>(tmx[i], ox);
+    wino_btv<TM>(tmy[i], oy);
+#pragma unroll
+    for (int j = 0; j < AL; j++) {
+      unsigned lo;
+      const unsigned hi = wino_h2_pack(ox[j] * sv, oy[j] * sv, &lo);
+      const auto s16 = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);   // [hi t0, lo t0, hi t2, lo t2], [hi t1, lo t1, hi t3, lo t3]
+      const unsigned e0 = s16[0], e1 = s16[1];
+      const auto s32 = __builtin_amdgcn_permlane32_swap(e0, e1, false, false);   // rows t0, t1 | rows t2, t3
+      const unsigned w0 = s32[0], w1 = s32[1];
+      if (!(DBG & 4) || sb == 12345.f) {
+        __builtin_amdgcn_raw_buffer_store_b32(w0, vr, v_lane, (unsigned)(i * AL + j) * v_pos, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(w1, vr, v_lane + 256u, (unsigned)(i * AL + j) * v_pos, 0);
+      }
+    }
+  }
+}
+
+// Row i of Bt . d (one output of the input transform's 1-D pass; i is a constant after unrolling) — the same expressions as wino_btv
+template <int TM> __device__ __forceinline__ float wino_bt_row(int i, const float* d);
+template <> __device__ __forceinline__ float wino_bt_row<5>(int i, const float* d) {
+  switch (i) {
+    case 0: return -0.5f * d[0] + 0.25f * d[1] + 2.5f * d[2] - 1.25f * d[3] - 2.f * d[4] + d[5];
+    case 1: return 0.5f * d[1] + 0.25f * d[2] - 2.25f * d[3] - d[4] + d[5];
+    case 2: return -0.5f * d[1] + 0.75f * d[2] + 1.75f * d[3] - 3.f * d[4] + d[5];
+    case 3: return d[1] + 1.5f * d[2] - 2.f * d[3] - 1.5f * d[4] + d[5];
+    case 4: return -d[1] + 2.5f * (d[2] - d[4]) + d[5];
+    case 5: return 0.25f * d[1] - 1.25f * d[3] + d[5];
+    default: return -0.5f * d[1] + 0.25f * d[2] + 2.5f * d[3] - 1.25f * d[4] - 2.f * d[5] + d[6];
+  }
+}
+template <> __device__ __forceinline__ float wino_bt_row<4>(int i, const float* d) {
+  switch (i) {
+    case 0: return 4.f * d[0] - 5.f * d[2] + d[4];
+    case 1: return -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
+    case 2: return 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
+    case 3: return -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+    case 4: return 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+    default: return 4.f * d[1] - 5.f * d[3] + d[5];
+  }
+}
+
+// rows [I0, I1) of the input transform of one (tile, channel pair) from the LDS board, scaled, split and stored as V2c (wave = four tile rows)
+template <int TM, int I0, int I1>
+__device__ __forceinline__ void wino_oi_in_rows(const float* yl, int H, int W, int ty, int tx, float sv, __amdgpu_buffer_rsrc_t vr, unsigned v_lane, unsigned v_pos) {
+  constexpr int AL = TM + 2, NR = I1 - I0;
+  float tmx[NR][AL], tmy[NR][AL];
+#pragma unroll
+  for (int j = 0; j < AL; j++) {
+    const int ww = TM * tx + j - 1;
+    const bool okx = ww >= 0 && ww < W;
+    const int wc = ww < 0 ? 0 : (ww < W ? ww : W - 1);
+    float dx[AL], dy[AL];
+#pragma unroll
+    for (int i = 0; i < AL; i++) {
+      const int hh = TM * ty + i - 1;
+      const bool ok = okx && hh >= 0 && hh < H;
+      const int hc = hh < 0 ? 0 : (hh < H ? hh : H - 1);
+      const float2 d = *reinterpret_cast<const float2*>(yl + (size_t)(hc * W + wc) * 32);
+      dx[i] = ok ? d.x : 0.f; dy[i] = ok ? d.y : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) { tmx[r][j] = wino_bt_row<TM>(I0 + r, dx); tmy[r][j] = wino_bt_row<TM>(I0 + r, dy); }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    float ox[AL], oy[AL];
+    wino_btv<TM>(tmx[r], ox);
+    wino_btv<TM>(tmy[r], oy);
+#pragma unroll
+    for (int j = 0; j < AL; j++) {
+      unsigned lo;
+      const unsigned hi = wino_h2_pack(ox[j] * sv, oy[j] * sv, &lo);
+      const auto s16 = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);   // [hi t0, lo t0, hi t2, lo t2], [hi t1, lo t1, hi t3, lo t3]
+      const unsigned e0 = s16[0], e1 = s16[1];
+      const auto s32 = __builtin_amdgcn_permlane32_swap(e0, e1, false, false);   // rows t0, t1 | rows t2, t3
+      const unsigned w0 = s32[0], w1 = s32[1];
+      __builtin_amdgcn_raw_buffer_store_b32(w0, vr, v_lane, (unsigned)((I0 + r) * AL + j) * v_pos, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(w1, vr, v_lane + 256u, (unsigned)((I0 + r) * AL + j) * v_pos, 0);
+    }
+  }
+}
+
+// The same kernel with twice the waves: 512 threads, thread = (tile row tid / 32, channel tid % 32) in the output transform — 8-byte
+// {a, b} loads, 25 x 2 accumulators, three position columns (21 loads = 10.5 KB per wave) in flight, 16 waves per CU — and
+// (half tid / 256, tile row, channel pair) in the input transform (each half the rows [I0, I1) of Bt . d).  The 256-thread form keeps
+// 7-14 KB per wave x 8 waves in flight and measured 3.35 TB/s (0.367 ms against 0.359 for the two separate kernels).
+template <int TM, bool LAST, int PF>
+__global__ __launch_bounds__(512, 4) void wino_oi2_h2c_kernel(WinoH2Args h) {
+  using WT = WinoT<TM>;
+  constexpr int AL = WT::AL;
+  const WinoArgs& a = h.w;
+  extern __shared__ __attribute__((aligned(16))) float ys[];
+  __shared__ float s_scale[16];
+  const int tid = threadIdx.x, tl = tid >> 5, ch = tid & 31, lane = tid & 63;
+  const int s = blockIdx.y, NS = a.C >> 5, HW = a.H * a.W;
+  const int t0 = blockIdx.x * 16;
+  const int t = t0 + tl;
+  const bool live = t < a.T;
+  const int tc = live ? t : a.T - 1;
+  const int b = tc / a.TPB, tt = tc - b * a.TPB;
+  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
+  const int bl = tl / a.TPB;
+  float s_, un0;
+  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &un0);
+  const __amdgpu_buffer_rsrc_t mr = h2_rsrc(a.Mb + ((size_t)(t0 >> 7) * h.npos * NS + s) * 8192);
+  const unsigned m_lane = (unsigned)(((tc & 127) * 64 + ch * 2) * 4);
+  const unsigned m_pos = (unsigned)NS * 32768u;
+  float Y[TM][TM][2];
+#pragma unroll
+  for (int k = 0; k < TM; k++)
+#pragma unroll
+    for (int l = 0; l < TM; l++) { Y[k][l][0] = 0.f; Y[k][l][1] = 0.f; }
+  float2 m[PF][AL];
+#pragma unroll
+  for (int p = 0; p < PF; p++)
+#pragma unroll
+    for (int xi = 0; xi < AL; xi++) m[p][xi] = h2_ldf2(mr, m_lane, (unsigned)(xi * AL + p) * m_pos);
+#pragma unroll
+  for (int nu = 0; nu < AL; nu++) {
+    float mm[2][AL], oo[2][TM];
+#pragma unroll
+    for (int xi = 0; xi < AL; xi++) { const float2 v = m[nu % PF][xi]; mm[0][xi] = v.x; mm[1][xi] = v.y; }
+    if (nu + PF < AL) {
+#pragma unroll
+      for (int xi = 0; xi < AL; xi++) m[nu % PF][xi] = h2_ldf2(mr, m_lane, (unsigned)(xi * AL + nu + PF) * m_pos);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++) wino_atv<TM>(mm[e], oo[e]);
+#pragma unroll
+    for (int k = 0; k < TM; k++)
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        float yl[TM];
+#pragma unroll
+        for (int l = 0; l < TM; l++) yl[l] = Y[k][l][e];
+        wino_at_acc<TM>(nu, yl, oo[e][k]);
+#pragma unroll
+        for (int l = 0; l < TM; l++) Y[k][l][e] = yl[l];
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const char* ep = reinterpret_cast<const char*>(a.ep);
+  const unsigned e_lane = (unsigned)(32 * s + ch) * 16u, e_pix = (unsigned)a.Cout_p * 16u;
+  float mx = 0.f;
+  float* yb = LAST ? a.y + (size_t)b * a.Hp * a.Wp * a.Cout_p + 32 * s + ch : nullptr;
+#pragma unroll
+  for (int k = 0; k < TM; k++) {
+    const int hh = TM * ty + k, hc = hh < a.H ? hh : a.H - 1;
+#pragma unroll
+    for (int l = 0; l < TM; l++) {
+      const int ww = TM * tx + l, wc = ww < a.W ? ww : a.W - 1;
+      const float4 E0 = *reinterpret_cast<const float4*>(ep + (size_t)(hc * a.W + wc) * e_pix + e_lane);
+      float va = (Y[k][l][0] * un0) * E0.x + E0.y, vb = (Y[k][l][1] * un0) * E0.z + E0.w;
+      va = va > 0.f ? va : 0.f; vb = vb > 0.f ? vb : 0.f;
+      const float y0 = va + vb;
+      if (live && hh < a.H && ww < a.W) {
+        if (LAST) yb[((size_t)(hh + 1) * a.Wp + (ww + 1)) * a.Cout_p] = y0;
+        else ys[((size_t)bl * HW + hh * a.W + ww) * 32 + ch] = y0;
+        mx = fmaxf(mx, y0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (LAST) return;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (ch == 0 && live) h.wm_out[(size_t)t * NS + s] = mx;
+  float ax;
+  if (h.amax_true) ax = __uint_as_float(reinterpret_cast<const unsigned*>(h.amax_true)[b]);
+  else {
+    const int wmpb = a.TPB * NS;
+    const float* wp = h.wm_prev + (size_t)b * wmpb;
+    ax = 0.f;
+    for (int i = ch; i < wmpb; i += 32) ax = fmaxf(ax, wp[i]);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) ax = fmaxf(ax, __shfl_xor(ax, o, 64));
+  }
+  const float bound = h.g1 * ax + h.g0;
+  const unsigned bbits = __float_as_uint(bound);
+  if (s == 0 && tt == 0 && ch == 0 && live) h.amax_next[b] = bbits;
+  float sb, inv_;
+  wino_h2_scales(bbits, WT::VSHIFT, &sb, &inv_);
+  if (ch == 0) s_scale[tl] = live ? sb : 0.f;              // rows past the last tile: zeros
+  __syncthreads();
+  // ---- input transform: (half, tile row, channel pair)
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int tl3 = (tid >> 4) & 15, pr = tid & 15;
+  const int t3 = t0 + tl3;
+  const int t3c = t3 < a.T ? t3 : a.T - 1;
+  const int b3 = t3c / a.TPB, tt3 = t3c - b3 * a.TPB;
+  const int ty3 = tt3 / a.ntx, tx3 = tt3 - ty3 * a.ntx;
+  const float sv = s_scale[tl3];
+  const float* yl = ys + (size_t)(tl3 / a.TPB) * HW * 32 + 2 * pr;
+  const __amdgpu_buffer_rsrc_t vr = h2_rsrc(reinterpret_cast<const char*>(a.V) + ((size_t)(t0 >> 7) * h.npos * NS + s) * 16384);
+  const unsigned v_lane = (unsigned)(((t0 & 127) + ((tid >> 6) & 3) * 4) * 128 + lane * 4);
+  const unsigned v_pos = (unsigned)NS * 16384u;
+  constexpr int IH = (AL + 1) / 2;
+  if (half == 0) wino_oi_in_rows<TM, 0, IH>(yl, a.H, a.W, ty3, tx3, sv, vr, v_lane, v_pos);
+  else wino_oi_in_rows<TM, IH, AL>(yl, a.H, a.W, ty3, tx3, sv, vr, v_lane, v_pos);
+}
+
+// U2 (conv_wino_h2.hpp: [pos][C/32][piece][Ntot][32]) -> U2c with the chained column order (host, at commit)
+static void wino_build_u2c(const std::vector<_Float16>& u2, std::vector<_Float16>& u2c, int npos, int Ntot, int C, int Cout_p) {
+  const int NC = C / 32, NT = Ntot / 256;
+  u2c.assign(u2.size(), (_Float16)0.f);
+  for (int pos = 0; pos < npos; pos++)
+    for (int kc = 0; kc < NC; kc++)
+      for (int nn = 0; nn < Ntot; nn++) {
+        const int s = nn >> 6, j2 = nn & 63, ch = 32 * s + (j2 >> 1), br = j2 & 1, n = br * Cout_p + ch;
+        for (int p = 0; p < 2; p++) {
+          const _Float16* src = &u2[((((size_t)pos * NC + kc) * 2 + p) * Ntot + n) * 32];
+          _Float16* dst = &u2c[((((size_t)pos * NC + kc) * NT + (nn >> 8)) * 256 + (nn & 255)) * 64 + p * 32];
+          for (int k = 0; k < 32; k++) dst[k] = src[k];
+        }
+      }
+}
+
+// shapes the chained form takes: whole boards per 16-row group, 256-column GEMM tiles, a wave of the block-0 input transform inside one tile
+static inline bool wino_h2c_ok(int H, int W, int tm, int Kp) {
+  const int tpb = ceil_div(H, tm) * ceil_div(W, tm);
+  const int nk = Kp / 32;
+  return Kp % 128 == 0 && 16 % tpb == 0 && (nk == 4 || nk == 8 || nk == 12 || nk == 16) && (size_t)(16 / tpb) * H * W * 128 <= 64 * 1024;
+}
+
+// one stage of the chained tower for a chunk of boards (geometry as wino_h2_launch sets it)
+static void wino_h2c_geometry(WinoH2Args& h) {
+  WinoArgs& a = h.w;
+  const int tm = h.tm == 5 ? 5 : 4;
+  h.tm = tm; h.npos = (tm + 2) * (tm + 2);
+  a.nty = ceil_div(a.H, tm); a.ntx = ceil_div(a.W, tm); a.TPB = a.nty * a.ntx; a.T = a.B * a.TPB;
+  h.rsh = 7; h.rmask = 127; h.rA = (unsigned)h.npos * 128u; h.rB = 128u;
+  a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
+  h.in_swap = 1; h.cform = 1; h.wm_per_board = 0;
+}
+static void wino_h2c_in(agz_ctx* ctx, WinoH2Args& h, hipStream_t st) {     // block 0: x -> V2c (exact range: h.amax_in, fuse_prev = 0)
+  wino_h2c_geometry(h);
+  h.fuse_prev = 0; h.amax_self = const_cast<unsigned*>(h.amax_in);
+  ProfScopeOn ps(ctx, AGZ_PROF_WINO_IN, st == ctx->stream);
+  const size_t n_in = (size_t)h.w.T * (h.w.C / 2);
+  if (h.tm == 5) hipLaunchKernelGGL(wino_in_h2_kernel<5>, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, h);
+  else hipLaunchKernelGGL(wino_in_h2_kernel<4>, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, h);
+}
+static void wino_h2c_gemm(agz_ctx* ctx, WinoH2Args& h, hipStream_t st) {
+  wino_h2c_geometry(h);
+  ProfScopeOn ps(ctx, AGZ_PROF_WINO_GEMM, st == ctx->stream);
+  const dim3 g(h.npos * h.w.n_mtiles * (h.w.Ntot >> 8));
+  switch (h.w.C >> 5) {
+    case 4: hipLaunchKernelGGL((wino_gemm_h2c_kernel<4, 2>), g, dim3(256), 0, st, h); break;
+    case 8: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2>), g, dim3(256), 0, st, h); break;
+    case 12: hipLaunchKernelGGL((wino_gemm_h2c_kernel<12, 2>), g, dim3(256), 0, st, h); break;
+    default: hipLaunchKernelGGL((wino_gemm_h2c_kernel<16, 2>), g, dim3(256), 0, st, h); break;
+  }
+}
+static void wino_h2c_oi(agz_ctx* ctx, WinoH2Args& h, bool last, hipStream_t st, int variant = 2) {
+  wino_h2c_geometry(h);
+  ProfScopeOn ps(ctx, AGZ_PROF_WINO_OUT, st == ctx->stream);
+  const WinoArgs& a = h.w;
+  const dim3 g((unsigned)ceil_div(a.T, 16), (unsigned)(a.C >> 5));
+  const size_t shm = last ? 0 : (size_t)(16 / a.TPB) * a.H * a.W * 32 * sizeof(float);
+  if (variant >= 2 && variant < 16) {
+#define AGZ_OI2(TM_, LAST_, PF_) hipLaunchKernelGGL((wino_oi2_h2c_kernel<TM_, LAST_, PF_>), g, dim3(512), shm, st, h)
+    if (variant == 2) {
+      if (h.tm == 5) { if (last) AGZ_OI2(5, true, 3); else AGZ_OI2(5, false, 3); }
+      else { if (last) AGZ_OI2(4, true, 3); else AGZ_OI2(4, false, 3); }
+    } else {
+      if (h.tm == 5) { if (last) AGZ_OI2(5, true, 2); else AGZ_OI2(5, false, 2); }
+      else { if (last) AGZ_OI2(4, true, 2); else AGZ_OI2(4, false, 2); }
+    }
+#undef AGZ_OI2
+    return;
+  }
+  if (variant >= 16 && h.tm == 5 && !last) {   // measurement variants of the 256-thread kernel
+    switch (variant - 16) {
+      case 1: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 1>), g, dim3(256), shm, st, h); return;
+      case 2: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 2>), g, dim3(256), shm, st, h); return;
+      case 4: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 4>), g, dim3(256), shm, st, h); return;
+      case 5: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 5>), g, dim3(256), shm, st, h); return;
+      case 3: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 3>), g, dim3(256), shm, st, h); return;
+      case 6: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 6>), g, dim3(256), shm, st, h); return;
+      case 7: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 7>), g, dim3(256), shm, st, h); return;
+      default: break;
+    }
+  }
+  if (h.tm == 5) {
+    if (last) hipLaunchKernelGGL((wino_oi_h2c_kernel<5, true>), g, dim3(256), shm, st, h);
+    else hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false>), g, dim3(256), shm, st, h);
+  } else {
+    if (last) hipLaunchKernelGGL((wino_oi_h2c_kernel<4, true>), g, dim3(256), shm, st, h);
+    else hipLaunchKernelGGL((wino_oi_h2c_kernel<4, false>), g, dim3(256), shm, st, h);
+  }
+}

@@ -222,15 +222,14 @@ int agz_examples_allgather(agz_comm* c, agz_examples* e) {
   AGZ_HIP_TRY(hipSetDevice(e->ctx->device));
   hipStream_t s = e->ctx->stream;
   const int n = c->size;
-  unsigned long long* d_cnt = nullptr;
-  AGZ_HIP_TRY(hipMalloc(&d_cnt, (size_t)(n + 1) * 8));
+  unsigned long long* d_cnt = c->d_words;            // [n] gathered counts + [1] mine (allocated with the communicator)
+  AGZ_REQUIRE(d_cnt, AGZ_E_STATE, "agz_examples_allgather: communicator without exchange words");
   std::vector<unsigned long long> cnt(n, 0);
   const unsigned long long mine = (unsigned long long)e->n;
   hipError_t he = hipMemcpyAsync(d_cnt + n, &mine, 8, hipMemcpyHostToDevice, s);
   ncclResult_t nr = he == hipSuccess ? R->AllGather(d_cnt + n, d_cnt, 1, ncclUint64, c->comm, s) : ncclSuccess;
   if (he == hipSuccess && nr == ncclSuccess) he = hipMemcpyAsync(cnt.data(), d_cnt, (size_t)n * 8, hipMemcpyDeviceToHost, s);
   if (he == hipSuccess && nr == ncclSuccess) he = hipStreamSynchronize(s);
-  hipFree(d_cnt);
   AGZ_REQUIRE(nr == ncclSuccess, AGZ_E_HIP, "agz_examples_allgather: count exchange -> %s", R->GetErrorString(nr));
   AGZ_HIP_TRY(he);
   size_t total = 0;
@@ -240,14 +239,15 @@ int agz_examples_allgather(agz_comm* c, agz_examples* e) {
   const bool got = hipMalloc(&p, total * e->xs * 4) == hipSuccess && hipMalloc(&q, total * e->A1 * 4) == hipSuccess && hipMalloc(&v, total * 4) == hipSuccess;
   // every rank must enter the broadcast group or none: the ranks agree on "everybody has its receive store" with a one-word sum
   {
-    unsigned long long* d_fail = nullptr;
+    // (the two words live in the communicator: nothing is allocated here, and the all-reduce is entered whatever the copy of this
+    //  rank's word returned — a rank that skipped it while its peers entered would hang them; a failed copy counts as a failure)
+    unsigned long long* d_fail = c->d_words + n + 1;
     unsigned long long fails = got ? 0 : 1, all_fails = 1;
-    he = hipMalloc(&d_fail, 16);
-    if (he == hipSuccess) he = hipMemcpyAsync(d_fail, &fails, 8, hipMemcpyHostToDevice, s);
-    nr = he == hipSuccess ? R->AllReduce(d_fail, d_fail + 1, 1, ncclUint64, ncclSum, c->comm, s) : ncclSuccess;
+    he = hipMemcpyAsync(d_fail, &fails, 8, hipMemcpyHostToDevice, s);
+    if (he != hipSuccess) { (void)hipMemsetAsync(d_fail, 0xff, 8, s); }
+    nr = R->AllReduce(d_fail, d_fail + 1, 1, ncclUint64, ncclSum, c->comm, s);
     if (he == hipSuccess && nr == ncclSuccess) he = hipMemcpyAsync(&all_fails, d_fail + 1, 8, hipMemcpyDeviceToHost, s);
     if (he == hipSuccess && nr == ncclSuccess) he = hipStreamSynchronize(s);
-    if (d_fail) hipFree(d_fail);
     if (nr != ncclSuccess || he != hipSuccess || all_fails != 0) {
       hipFree(p); hipFree(q); hipFree(v);
       AGZ_REQUIRE(nr == ncclSuccess, AGZ_E_HIP, "agz_examples_allgather: allocation agreement -> %s", R->GetErrorString(nr));

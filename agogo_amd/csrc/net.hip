@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 #include "conv_wino.hpp"
 #include "conv_h2.hpp"
 #include "conv_wino_h2.hpp"
+#include "conv_wino_h2c.hpp"
 #include "conv_lat.hpp"
 
 
@@ -605,6 +606,7 @@ void agz_net::free_device() {
   d_u2_tin.clear();
   for (auto& p : d_u2_colun) if (p) hipFree(p);
   d_u2_colun.clear();
+  free_u2c();
   for (auto& p : d_ep_h2) if (p) hipFree(p);
   d_ep_h2.clear();
   if (d_ep_init_h2) { hipFree(d_ep_init_h2); d_ep_init_h2 = nullptr; }
@@ -883,6 +885,11 @@ int agz_net::build_wino_h2_weights() {
   d_u2_dual.assign(conf.SharedLayers, nullptr);
   d_u2_tin.assign(conf.SharedLayers, nullptr);
   d_u2_colun.assign(conf.SharedLayers, nullptr);
+  free_u2c();
+  const bool chained = agz::wino_h2c_ok(H, W, wino_tm, Kp);
+  if (chained) { d_u2c_dual.assign(conf.SharedLayers, nullptr); wino_g1.assign(conf.SharedLayers, 0.f); wino_g0.assign(conf.SharedLayers, 0.f); }
+  std::vector<_Float16> u2c;
+  std::vector<std::vector<double>> l1s(conf.SharedLayers);   // per block [2 Kp]: sum_{ci,tap} |w[n][ci][tap]| / t_in[ci]
   u_unscale.assign(conf.SharedLayers, 1.0f);
   std::vector<float> tin, colun;
   std::vector<std::vector<float>> tins(conf.SharedLayers), coluns(conf.SharedLayers);
@@ -909,6 +916,15 @@ int agz_net::build_wino_h2_weights() {
     AGZ_HIP_TRY(hipMemcpyAsync(d_u2_tin[l], tin.data(), tin.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     AGZ_HIP_TRY(hipMemcpyAsync(d_u2_colun[l], colun.data(), colun.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     AGZ_HIP_TRY(hipMemcpyAsync(d_u2_dual[l], u2.data(), u2.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    if (chained) {
+      agz::wino_build_u2c(u2, u2c, (wino_tm + 2) * (wino_tm + 2), 2 * Kp, Kp, Kp);
+      AGZ_HIP_TRY(hipMalloc(&d_u2c_dual[l], u2c.size() * 2));
+      AGZ_HIP_TRY(hipMemcpyAsync(d_u2c_dual[l], u2c.data(), u2c.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+      l1s[l].assign(2 * Kp, 0.0);
+      for (int n = 0; n < 2 * Kp; n++)
+        for (int ci = 0; ci < Kp; ci++)
+          for (int tap = 0; tap < 9; tap++) l1s[l][n] += std::fabs(getw(n, ci, tap)) / (double)tin[ci];
+    }
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
     tins[l] = tin; coluns[l] = colun;
   }
@@ -927,6 +943,17 @@ int agz_net::build_wino_h2_weights() {
         e2[o + 0] = e[o + 0] * coluns[l][c] * tn; e2[o + 1] = e[o + 1] * tn;
         e2[o + 2] = e[o + 2] * coluns[l][Kp + c] * tn; e2[o + 3] = e[o + 3] * tn;
       }
+    if (chained) {   // max |y t_next| <= g1 max|x t_in| + g0 over every pixel and channel (relu(s v + t) <= |s| |v| + max(t, 0))
+      double g1 = 0.0, g0 = 0.0;
+      for (int p = 0; p < hw; p++)
+        for (int c = 0; c < Kp; c++) {
+          const double tn = more ? tins[l + 1][c] : 1.0;
+          const size_t o = ((size_t)p * Kp + c) * 4;
+          g1 = std::max(g1, tn * (std::fabs((double)e[o + 0]) * l1s[l][c] + std::fabs((double)e[o + 2]) * l1s[l][Kp + c]));
+          g0 = std::max(g0, tn * (std::max((double)e[o + 1], 0.0) + std::max((double)e[o + 3], 0.0)));
+        }
+      wino_g1[l] = (float)(g1 * (1.0 + 1e-6)); wino_g0[l] = (float)(g0 * (1.0 + 1e-6));
+    }
     AGZ_HIP_TRY(hipMalloc(&d_ep_h2[l], e2.size() * 4));
     AGZ_HIP_TRY(hipMemcpyAsync(d_ep_h2[l], e2.data(), e2.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1054,7 +1081,13 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     // per-board ranges [blocks+1][B], then the per-wave maxima of the output kernel [queues][chunk tiles][Kp/64] (as floats)
     // per-wave maxima of the output kernel: every chunk of boards keeps its own region from one block to the next (the next
     // block's input transform reduces them), one word per tile and 64 channels
-    const size_t wm_board = (size_t)tpb * (Kp >> 6);
+    // Chained form (conv_wino_h2c.hpp; AGZ_WINO_H2_FORM = 0 keeps the three-kernel block): output transform of block l and input
+    // transform of block l+1 in one kernel, y never leaves the chip between blocks
+    static const int form_env = [] { const char* e = getenv("AGZ_WINO_H2_FORM"); return e ? atoi(e) : -1; }();
+    const int form_want = wino_form >= 0 ? wino_form : form_env;
+    const bool chained = form_want != 0 && (int)d_u2c_dual.size() == conf.SharedLayers && agz::wino_h2c_ok(H, W, wino_tm, Kp) &&
+                         ceil_div(B, chunk) <= ns;   // (V2(l+1) of a chunk lives in its queue's scratch from one block to the next)
+    const size_t wm_board = chained ? (size_t)tpb * (Kp >> 5) * 2 : (size_t)tpb * (Kp >> 6);   // (chained: two arrays, ping-pong)
     const size_t need_amax = (size_t)(conf.SharedLayers + 1) * B + wm_board * B;
     if (need_amax > amax_cap) {
       AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1075,7 +1108,33 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       AGZ_HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
       AGZ_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     }
-    for (int l = 0; l < conf.SharedLayers; l++) {
+    for (int l = 0; chained && l < conf.SharedLayers; l++) {
+      ProfScope ps(ctx, AGZ_PROF_CONV);
+      int ci = 0;
+      const size_t wmb = (size_t)tpb * (Kp >> 5);
+      const bool last = l + 1 == conf.SharedLayers;
+      for (int b0 = 0; b0 < B; b0 += chunk, ci++) {
+        const int q = ci % ns;
+        hipStream_t st = q ? ctx->stream2 : ctx->stream;
+        WinoH2Args hh{};
+        WinoArgs& wa = hh.w;
+        wa.x = cur + (size_t)b0 * Hp * Wp * Kp; wa.y = nxt + (size_t)b0 * Hp * Wp * Kp;   // x: block 0 only; y: the last block only
+        wa.V = d_wV + (size_t)q * v_elems; wa.Mb = d_wM + (size_t)q * m_elems; wa.ep = d_ep_h2[l];
+        wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
+        hh.U2c = d_u2c_dual[l]; hh.w_unscale = 1.f; hh.tm = wino_tm;
+        hh.amax_in = d_amax + (size_t)l * B + b0;                                       // the range word V2(l) was written with
+        hh.amax_next = last ? nullptr : d_amax + (size_t)(l + 1) * B + b0;
+        hh.amax_true = l == 0 ? reinterpret_cast<const float*>(d_amax + b0) : nullptr;  // block 0: board_amax_kernel's exact word
+        hh.wm_prev = d_wave_max + ((size_t)((l + 1) & 1) * B + b0) * wmb;
+        hh.wm_out = d_wave_max + ((size_t)(l & 1) * B + b0) * wmb;
+        hh.g1 = wino_g1[l]; hh.g0 = wino_g0[l];
+        if (l == 0) agz::wino_h2c_in(ctx, hh, st);
+        agz::wino_h2c_gemm(ctx, hh, st);
+        agz::wino_h2c_oi(ctx, hh, last, st, form_want >= 1 ? form_want : 2);   // (A/B hook: form 1 = the 256-thread float4 kernel, 2 / 3 = 512 threads, 3 / 2 columns ahead)
+      }
+      if (last) std::swap(cur, nxt);
+    }
+    for (int l = 0; !chained && l < conf.SharedLayers; l++) {
       ProfScope ps(ctx, AGZ_PROF_CONV);
       int ci = 0;
       for (int b0 = 0; b0 < B; b0 += chunk, ci++) {
@@ -1152,7 +1211,9 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       hipLaunchKernelGGL((conv3x3_x3_kernel<true>), dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, a, d_w3_dual[l]);
       rc = AGZ_OK;
     }
-    else if (latency && cfg == 0 && (int)d_lat_w2.size() == conf.SharedLayers && d_lat_w2[l] && agz::conv_lat_ok(Kp, Kp, Wp) &&
+    // (fp16x2 products: only in the modes whose contract is split operands — AGZ_COMPUTE_F32_MFMA keeps exact fp32 products at
+    //  every batch size and takes the split-K fp32 kernels below)
+    else if (latency && cfg == 0 && this->compute_mode != AGZ_COMPUTE_F32_MFMA && (int)d_lat_w2.size() == conf.SharedLayers && d_lat_w2[l] && agz::conv_lat_ok(Kp, Kp, Wp) &&
              ceil_div(HW, agz::LAT_ROWS) * (Kp / 8) <= 256) {   // (range words per board: four per lane)
       // latency regime, one launch per layer: K split inside the workgroup, weights up front, no partial sums in memory; fp16x2
       // products on equilibrated operands (conv_lat.hpp).  Range words: layer 0 from a board reduction, then from layer to layer.
@@ -1559,6 +1620,7 @@ int agz_net_commit(agz_net* n) {
   n->d_u2_tin.clear();
   for (auto& p : n->d_u2_colun) if (p) hipFree(p);
   n->d_u2_colun.clear();
+  n->free_u2c();
   for (auto& p : n->d_ep_h2) if (p) hipFree(p);
   n->d_ep_h2.clear();
   if (n->d_ep_init_h2) { hipFree(n->d_ep_init_h2); n->d_ep_init_h2 = nullptr; }
@@ -1568,6 +1630,13 @@ int agz_net_commit(agz_net* n) {
 }
 
 int agz_wino_h2_tile(int H, int W) { return agz::wino_h2_pick_tm(H, W); }
+
+int agz_net_set_wino_h2_form(agz_net* n, int form) {
+  AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_wino_h2_form: null net");
+  AGZ_REQUIRE(form >= -1 && form <= 23, AGZ_E_INVALID, "agz_net_set_wino_h2_form: form %d (want -1, 0 or 1)", form);
+  n->wino_form = form;
+  return AGZ_OK;
+}
 
 int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, int W, int C, int N, float* V, float* M) {
   AGZ_REQUIRE(ctx && x && w && V && M, AGZ_E_INVALID, "agz_wino_stages: NULL argument");

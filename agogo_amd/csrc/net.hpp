@@ -63,6 +63,12 @@ struct agz_net {
   std::vector<float> u_unscale;            // (unused by the equilibrated image: kept 1)
   std::vector<float*> d_u2_tin;            // per layer [Kp] power-of-two input-channel factors of that image (conv_wino_h2.hpp)
   std::vector<float*> d_u2_colun;          // per layer [2*Kp] 1 / (power-of-two scale of GEMM column n)
+  // chained form of that tower (conv_wino_h2c.hpp): the same image in the chained column order / chunk layout, and per block the
+  // commit-time bound max|y t_next| <= g1 max|x t_in| + g0 that gives block l+1's operand range before its board maximum exists
+  std::vector<_Float16*> d_u2c_dual;
+  std::vector<float> wino_g1, wino_g0;
+  int wino_form = -1;                      // agz_net_set_wino_h2_form (agz_debug.h): -1 auto (chained where the shape allows), 0 three-kernel block, 1 chained
+  void free_u2c() { for (auto& p : d_u2c_dual) if (p) hipFree(p); d_u2c_dual.clear(); wino_g1.clear(); wino_g0.clear(); }
   int build_wino_h2_weights();
   int wino_tm = 4;                         // tile size of that path: 4 = F(4x4,3x3), 5 = F(5x5,3x3), chosen per board size
   size_t wino_v_cap = 0;                   // floats the V scratch holds (fp16x2 path)

@@ -114,7 +114,7 @@ def _oracle_selfplay_leg(O, T, kind, m, n, k, komi, enc, net, budget, moves_per_
             "sims": playouts, "moves": sum(moves), "games_finished": sum(done), "games_per_s": (sum(done) / dt) if complete else None}
 
 
-def cpu_baseline(size, K, L, budget_s=30.0, max_threads=64):
+def cpu_baseline(size, K, L, budget_s=30.0, max_threads=None):
     """The oracle (CPU restatement of the reference algorithm: per-leaf inference, sequential pipeline) timed on the box's host
     cores, SURVEY 8(d) / BASELINE.md section 3: one independent game per thread (the way the reference would use its cores), threads
     = min(host cores, 64).  Legs, ~30 s in total:
@@ -129,7 +129,7 @@ def cpu_baseline(size, K, L, budget_s=30.0, max_threads=64):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     cores = os.cpu_count() or 2
-    T = max(1, min(max_threads, cores))
+    T = max(1, min(max_threads, cores) if max_threads else cores)   # T = hardware_concurrency
     legs = {}
     # --- ttt: complete games
     net = _oracle_net(O, 3, 3, 6, 3, 3, 2, 10)
@@ -152,8 +152,10 @@ def cpu_baseline(size, K, L, budget_s=30.0, max_threads=64):
     t0 = time.perf_counter()
     net.infer(x)
     t_eval = time.perf_counter() - t0
-    # under T concurrent evaluations one evaluation takes ~2.5x its solo time on this class of host (memory bandwidth)
-    sims = int(max(2, min(64, 9.0 / max(2.5 * t_eval, 1e-3) - 1)))
+    # under T concurrent evaluations one evaluation takes ~2.5x its solo time at 64 threads on this class of host (memory
+    # bandwidth), more with every core busy: the sample is sized for ~9 s either way
+    slow = 2.5 * max(1.0, T / 64.0) ** 0.5
+    sims = int(max(2, min(64, 9.0 / max(slow * t_eval, 1e-3) - 1)))
     r = _oracle_selfplay_leg(O, T, O.WQ, size, size, 0, 7.5, O.ENC_WQ, net, sims, 1, opening=int(0.6 * size * size))
     legs["g19_fair"] = dict(r, workload="19x19 Go, K=%d, %d blocks, batch 1 per leaf: %d games from random mid-game openings x 1 move of %d sims"
                             % (K, L, T, sims), solo_eval_seconds=t_eval)
@@ -177,8 +179,8 @@ def cpu_baseline(size, K, L, budget_s=30.0, max_threads=64):
             "sample": "oracle (C++ restatement, per-leaf inference), %d threads on the box's %d host cores, one game per thread; legs ttt / c4 / go9 / "
                       "g19_fair / g19_faithful, %.1f s in total; value = g19_fair (19x19, K=%d, %d blocks: %d sims in %.1f s)"
                       % (T, cores, total, K, L, legs["g19_fair"]["sims"], legs["g19_fair"]["seconds"]),
-            "method": "round 3: threads = min(host cores, 64) (round 2: min(32, cores/2); round 1: min(32, cores)): aggregate values are not "
-                      "comparable across rounds, per_core_sims_per_s is the comparable figure",
+            "method": "round 4: threads = every host core (round 3: min(host cores, 64); round 2: min(32, cores/2); round 1: min(32, cores)): "
+                      "aggregate values are not comparable across rounds, per_core_sims_per_s is the comparable figure",
             "per_core_sims_per_s": legs["g19_fair"]["sims_per_s"] / T, "evals_per_s": legs["g19_fair"]["evals_per_s"],
             "host_cores": cores, **legs}
 
@@ -258,7 +260,7 @@ def config0_leg():
 def latency_leg(ctx, lanes_list=(1, 16), moves=3, sims=1600):
     """BASELINE config #5 (tournament Agent.Search): 19x19, K=256, 40 blocks, 1600 sims/move, ONE tree through the single-tree
     boundary's engine; p50 wall time of a move (begin_move + simulate(Budget) + end_move + sync) on a short sample: the
-    sequential search (lanes 1, the declared semantics; fp32 split-K tower) and lane rounds of 16 (deterministic, bit-exact vs
+    sequential search (lanes 1, the declared semantics; AGZ_COMPUTE_AUTO: the fp16x2 one-launch-per-layer tower) and lane rounds of 16 (deterministic, bit-exact vs
     the oracle's parallelRound) with the Winograd fp16x2 tower kept at every batch size (AGZ_COMPUTE_FORCE)."""
     S, K, L = 19, 256, 40
     net = A.Net(ctx, K, L, 2 * K, S, S, 18, S * S + 1, BatchSize=1, bn_mode=capi.BN_IDENTITY)
@@ -267,7 +269,7 @@ def latency_leg(ctx, lanes_list=(1, 16), moves=3, sims=1600):
     net.commit()
     out = {"workload": "config #5: 19x19 wq Agent.Search, K=256, 40 blocks, %d sims/move, one tree" % sims, "moves_timed": moves}
     for lanes in lanes_list:
-        net.set_compute_mode((capi.COMPUTE_WINO_H2 | capi.COMPUTE_FORCE) if lanes > 1 else capi.COMPUTE_F32_MFMA)
+        net.set_compute_mode((capi.COMPUTE_WINO_H2 | capi.COMPUTE_FORCE) if lanes > 1 else capi.COMPUTE_AUTO)   # AUTO at batch 1: the fp16x2 latency kernel (F32_MFMA keeps exact fp32 products)
         arena = A.Arena(ctx, capi.GAME_WQ, S, S, komi=7.5, encoder=capi.ENC_WQ, n_games=1, seed=7, Budget=sims)
         arena.set_inferencer(0, capi.INF_NET, net)
         arena.set_inferencer(1, capi.INF_NET, net)
@@ -289,6 +291,44 @@ def latency_leg(ctx, lanes_list=(1, 16), moves=3, sims=1600):
         arena.close()
     net.close()
     return out
+
+
+def launcher_command(argv, gpus, environ, port=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: the command that re-executes this script as N ranks,
+    one per GPU (the contract's own launch line: torch.distributed.run, 127.0.0.1 rendezvous).  None when there is nothing to
+    re-launch (N = 1, or RANK / WORLD_SIZE already set by a launcher)."""
+    if gpus <= 1 or ("RANK" in environ and "WORLD_SIZE" in environ):
+        return None
+    if port is None:
+        import socket
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def aggregate_over_ranks(dt, sims, evals, iters, rank, world, device=None):
+    """The bench line's aggregation: MAX over ranks of the timed region's wall time, SUM of the counters; every rank's own
+    non-null simulations travel along (per_rank_sims) so that the line is self-checking.  Runs on any process group (RCCL on the
+    GPUs, gloo in tests/test_dist_gloo.py)."""
+    per_rank = [0.0] * world
+    per_rank[rank] = float(sims)
+    t_max, sums = adist.reduce_step_timing(dt, [sims, evals, iters] + per_rank, device=device)
+    return {"t_max": t_max, "sims": sums[0], "evals": sums[1], "iters": sums[2], "per_rank_sims": sums[3:], "world_size": world}
+
+
+def headline_fields(agg, gpus, steps, warmup):
+    """metric / value / n_gpus / ms_per_step of the line from the aggregate; refuses to print a line whose n_gpus is not the
+    --gpus it was asked for, or whose per-rank counters do not add up to the aggregate."""
+    if agg["world_size"] != gpus:
+        raise SystemExit("bench.py: --gpus %d but %d rank(s) took part" % (gpus, agg["world_size"]))
+    if len(agg["per_rank_sims"]) != gpus or abs(sum(agg["per_rank_sims"]) - agg["sims"]) > 0.5 or min(agg["per_rank_sims"]) <= 0:
+        raise SystemExit("bench.py: per-rank simulations %r do not add up to %r on %d rank(s)" % (agg["per_rank_sims"], agg["sims"], gpus))
+    return {"metric": "mcts_sims_per_sec", "value": agg["sims"] / agg["t_max"], "unit": "sims/s", "n_gpus": gpus,
+            "steps": steps, "warmup": warmup, "ms_per_step": agg["t_max"] / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None}
 
 
 def main():
@@ -323,7 +363,17 @@ def main():
                          "durations of the roofline are taken on isolated one-queue steps right after the timed region")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="debug: all ranks use GPU 0 and gloo collectives (exercises the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--print-launch", action="store_true", help="print the re-launch command for --gpus N (JSON list) and exit")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` (N > 1) outside a launcher: become the N-rank job (one process per GPU over RCCL)
+    cmd = launcher_command([a_ for a_ in sys.argv[1:] if a_ != "--print-launch"], args.gpus, os.environ)
+    if args.print_launch:
+        print(json.dumps(cmd))
+        return
+    if cmd is not None:
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
 
     # the contract is ONE JSON line on stdout: libraries (gloo's "[Gloo] Rank ..." lines, RCCL's version banner) write to fd 1 too,
     # so fd 1 is pointed at stderr for the whole run and the line goes to the saved descriptor at the end
@@ -334,7 +384,7 @@ def main():
     rank, local, world = adist.init_from_env(backend="gloo" if args.shared_gpu else None)
     if args.shared_gpu:
         local = 0
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libagz has no CPU fallback)")
@@ -447,10 +497,8 @@ def main():
     sims_all = st1["sims_total"] - st0["sims_total"]
     evals = st1["nn_evals"] - st0["nn_evals"]
     # MAX of the wall time, SUM of the counters over ranks; the per-rank sims travel along so that the line is self-checking
-    per_rank = [0.0] * world
-    per_rank[rank] = float(sims)
-    t_max, sums = adist.reduce_step_timing(dt, [sims, evals, sims_all] + per_rank, device="cuda" if world > 1 else None)
-    sims_sum, evals_sum, iters_sum, per_rank_sims = sums[0], sums[1], sums[2], sums[3:]
+    agg = aggregate_over_ranks(dt, sims, evals, sims_all, rank, world, device="cuda" if world > 1 else None)
+    t_max, sims_sum, evals_sum, iters_sum, per_rank_sims = agg["t_max"], agg["sims"], agg["evals"], agg["iters"], agg["per_rank_sims"]
     prof = {}
     for name, k in (("conv_dual", capi.PROF_CONV), ("conv_init", capi.PROF_CONV_INIT), ("heads", capi.PROF_HEADS),
                     ("select", capi.PROF_SELECT), ("expand", capi.PROF_EXPAND), ("move", capi.PROF_MOVE),
@@ -621,17 +669,17 @@ def main():
                              "(transform-domain FLOPs against bf16 peak / 3) is extra.wino.wino_gemm.mfma_frac (DESIGN.md 4e)"
                              % ((flops_launch / 1e9, wino_detail["wino_gemm"]["algorithmic_bytes"] / 1e9,
                                  3 * flops_launch / wino_detail["wino_gemm"]["algorithmic_bytes"]) if wino_detail else (0, 0, 0)))}
-        out = {
-            "metric": "mcts_sims_per_sec", "value": sims_sum / t_max, "unit": "sims/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        out = headline_fields(agg, args.gpus, args.steps, args.warmup) | {
             "dtype": dtypes[args.compute],
             "data": "synthetic",
             "config": {"workload": "19x19 Go (wq) self-play: K=%d, %d dual-branch blocks, FC=%d, A=%d, WQEncoder F=18, "
                                    "%d concurrent games/GPU, %d sims/move, leaf batch=%d, one net for both agents=%s"
                                    % (K, L, 2 * K, Aspace, G, args.budget, G, str(not args.two_nets)),
                        "board": S, "K": K, "blocks": L, "games_per_gpu": G, "sims_per_move": args.budget,
-                       "weights": "random-init seed 1337 (GlorotU conv, GlorotN FC; BN gamma=1 beta=0, identity stats)",
+                       "weights": "random-init seed 1337: GlorotU conv, GlorotN FC as the reference (ermahagerdmonards.go:39,80); DEVIATION from the "
+                                  "reference initialiser: BatchNorm gamma=1, beta=0 with IDENTITY statistics instead of GlorotN gamma/beta under "
+                                  "the degenerate-eps reading (x316 per layer saturates softmax/tanh and every search tree degenerates); "
+                                  "FLOPs and bytes per evaluation are identical",
                        "parallelism": "games sharded %d/GPU, no data-path collective" % G,
                        "tower_queues": 2 if two_queues else 1},
             "roofline": ({"bound": "hbm", "achieved": wino_detail["wino_gemm"]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -655,6 +703,10 @@ def main():
                                     "where the half-batch chains overlap and a kernel's own duration is not defined; "
                                     "`bench.py --tower-queues 1` measures the same kernel inside the timed region" % n_launch) if two_queues else
                                    "HIP events on the launch stream, steps after the timed region (--prof-stride 0)"},
+            # N > 1 self-checks, top level: every rank's simulations, and what the RCCL exchange leg (extra.examples_allgather) saw
+            "per_rank_sims": per_rank_sims, "world_size": world,
+            "rccl_ranks": (gather or {}).get("rccl_ranks") if world > 1 else None,
+            "rows_gathered": (gather or {}).get("rows_gathered") if world > 1 else None,
             "extra": {"nn_evals_per_s": evals_sum / t_max, "iterations_per_s": iters_sum / t_max,
                       "per_rank_sims": per_rank_sims, "world_size": world,
                       "timed_region": {"moves_finished": st1["moves_played"] - st0["moves_played"],

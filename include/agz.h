@@ -25,6 +25,8 @@
  *   AGZ_WINO_H2_CHUNK=<n>     boards per chunk of the AGZ_COMPUTE_WINO_H2 tower (default: as many as 32-bit
  *                             offsets allow); results are bit-identical  [tests/test_wino_gpu.py knobs test]
  *   AGZ_WINO_H2_QUEUES=1|2    overrides agz_net_set_tower_queues         [tests/test_wino_gpu.py knobs test]
+ *   AGZ_WINO_H2_FORM=0        the three-kernel block (in / GEMM / out) instead of the chained one (out of block l + in of
+ *                             block l+1 in one kernel); same tolerance       [tests/test_wino_gpu.py knobs test]
  *   AGZ_WINO_CHUNK=<n>        boards per chunk of the AGZ_COMPUTE_WINO tower; bit-identical
  *                             [tests/test_wino_gpu.py::test_wino_board_chunks_in_a_subprocess]
  */
@@ -127,8 +129,11 @@ int agz_net_infer_dev(agz_net* net, const float* planes_dev, int B, float* polic
 /* Small-batch ("latency") regime for tournament-style single-tree Agent.Search (agent.go:76-81: one board per
  * Infer call): when a forward's tower would occupy <= 1/4 of the CUs, the convolutions run split-K and the heads are
  * spread over the chip.  On by default.  Within a regime results are bit-identical for every batch size; ACROSS the
- * two regimes the fp32 summation order differs (same tolerance vs the reference).  Turn it off for strict bitwise
- * batch-size independence at every batch size. */
+ * two regimes the fp32 summation order differs (same tolerance vs the reference).  In AGZ_COMPUTE_F32_MFMA (the default mode)
+ * the small-batch tower stays on exact fp32 products (split-K); in every other mode (AGZ_COMPUTE_AUTO included) K = 64 / 128 /
+ * 256 towers take the one-launch-per-layer kernel with fp16x2 products on equilibrated operands (hi/lo fp16 pieces, the lo*lo
+ * term of 2^-22 relative dropped; conv_lat.hpp) — same tolerance, 2.6x faster per layer at batch 1.  Turn the regime off for
+ * strict bitwise batch-size independence at every batch size. */
 int agz_net_set_latency_mode(agz_net* net, int on);
 /* Queues the Winograd fp16x2 tower (AGZ_COMPUTE_WINO_H2) runs on: 2 = the batch is split into two halves whose block chains
  * run on two HIP streams, so one half's HBM-bound transform kernels run under the other half's GEMM (boards are independent:

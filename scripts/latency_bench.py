@@ -25,7 +25,7 @@ ap.add_argument("--sims", type=int, default=1600)
 ap.add_argument("--moves", type=int, default=12)
 ap.add_argument("--games", type=int, default=1)
 ap.add_argument("--lanes", type=int, default=1, help="agz_arena_set_parallel: simulations per tree and round")
-ap.add_argument("--compute", choices=["f32", "bf16x3", "wino", "wino_h2"], default="f32",
+ap.add_argument("--compute", choices=["auto", "f32", "bf16x3", "wino", "wino_h2"], default="auto",
                 help="wino_h2: AGZ_COMPUTE_WINO_H2 | AGZ_COMPUTE_FORCE (the Winograd fp16x2 tower at every batch size: lane rounds); "
                      "wino: AGZ_COMPUTE_WINO")
 ap.add_argument("--open", type=int, default=0, help="random opening moves before the timed moves (mid-game trees)")
@@ -36,6 +36,8 @@ S = args.size
 net = A.Net(ctx, args.K, args.L, 2 * args.K, S, S, 18, S * S + 1, BatchSize=args.games, bn_mode=capi.BN_IDENTITY)
 net.init_random(1337)
 net.commit()
+if args.compute == "auto":     # the latency regime's fp16x2 one-launch-per-layer kernel (f32: exact fp32 products, split-K)
+    net.set_compute_mode(capi.COMPUTE_AUTO)
 if args.compute == "bf16x3":   # not forced: one board is the latency regime -> split-K on the bf16 pipe
     net.set_compute_mode(capi.COMPUTE_BF16X3)
 if args.compute == "wino":

@@ -71,5 +71,73 @@ def test_id_exchange_sharding_and_bench_aggregation_world2_gloo():
     assert s0 == s1 == [300.0, 14.0]          # SUM over ranks
 
 
+def _bench_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    adist.init_from_env(backend="gloo")
+    # rank r: 14.7 + r ms per step over 20 steps, 512 sims per step on rank 0 and 511 on rank 1 (one null simulation)
+    dt = (14.7 + rank) * 1e-3 * 20
+    agg = bench.aggregate_over_ranks(dt, 512 * 20 - rank * 20, 512 * 20, 512 * 20, rank, world)
+    line = bench.headline_fields(agg, world, 20, 4)
+    try:
+        bench.headline_fields(agg, world + 1, 20, 4)          # a line labelled with another N must not be printed
+        refused = False
+    except SystemExit:
+        refused = True
+    q.put((rank, agg, line, refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_aggregation_path_world2_gloo():
+    """bench.py's own aggregation + headline fields on a world-size-2 process group (gloo): value = all
+    ranks' simulations / the slowest rank's time, n_gpus = the ranks that took part, per-rank counters in the line."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, agg, line, refused in res:
+        assert refused
+        assert agg["per_rank_sims"] == [10240.0, 10220.0] and agg["world_size"] == 2
+        assert abs(agg["t_max"] - 15.7e-3 * 20) < 1e-12
+        assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 20
+        assert abs(line["value"] - 20460.0 / (15.7e-3 * 20)) < 1e-6
+        assert abs(line["ms_per_step"] - 15.7) < 1e-9
+
+
+def test_bench_relaunches_itself_for_n_gpus_without_a_launcher():
+    """`python bench.py --gpus N` outside torch.distributed.run must become the N-rank job (it silently measured one
+    GPU): the command is the contract's launch line; inside a launcher (RANK / WORLD_SIZE set) and at N = 1 nothing is re-launched."""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launcher_command(["--gpus", "4", "--steps", "5"], 4, {}, port=29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5"]
+    assert bench.launcher_command(["--gpus", "4"], 4, {"RANK": "0", "WORLD_SIZE": "4"}) is None
+    assert bench.launcher_command([], 1, {}) is None
+    # the script's own entry: --print-launch shows what it would exec
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--print-launch"],
+                         capture_output=True, text=True, env=env, timeout=120, check=True)
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got[cmd.index("--nproc-per-node") + 1] == "2" and got[-4:] == ["--gpus", "2", "--steps", "3"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--print-launch"], capture_output=True, text=True, env=env, timeout=120, check=True)
+    assert json.loads(out.stdout.strip().splitlines()[-1]) is None
+
+
 def test_single_process_passthrough():
     assert adist.reduce_step_timing(0.5, [3, 4]) == (0.5, [3.0, 4.0])

@@ -221,6 +221,7 @@ H2_KNOBS = [
     {"AGZ_WINO_H2_CHUNK": "16"},                                   # board chunks
     {"AGZ_WINO_H2_CHUNK": "16", "AGZ_WINO_H2_QUEUES": "2"},        # board chunks on two queues
     {"AGZ_WINO_H2_QUEUES": "1"},                                   # one queue whatever the batch
+    {"AGZ_WINO_H2_FORM": "0"},                                     # the three-kernel block instead of the chained one
 ]
 
 
@@ -264,7 +265,7 @@ np.save(sys.argv[1], np.concatenate(out))
         np.testing.assert_allclose(pg, pf, atol=POL_ATOL, rtol=POL_RTOL)
         np.testing.assert_allclose(vg, vf, atol=VAL_ATOL)
         n += 2 * B * A_ + 2 * B
-    if "AGZ_WINO_H2_TM" not in knobs:      # same arithmetic in the same order: only the data movement differs
+    if "AGZ_WINO_H2_TM" not in knobs and "AGZ_WINO_H2_FORM" not in knobs:      # same arithmetic in the same order: only the data movement differs
         np.testing.assert_array_equal(outs[0], outs[1])
 
 
@@ -325,7 +326,9 @@ def test_fp16x2_modes_with_heterogeneous_ranges_inside_a_layer_k256(ctx, wmode, 
     K, L, W, H, F, Aspace, B = 256, 2, 19, 19, 18, 362, 6
     onet, gnet = _heterogeneous_pair(ctx, K, L, W, H, F, Aspace, E)
     x = rand_planes(B, F, H, W, seed=E)
-    pol_f, val_f = gnet.infer(x)
+    pol_f, val_f = gnet.infer(x)                       # AGZ_COMPUTE_F32_MFMA, latency regime: exact fp32 products, split-K
+    gnet.set_compute_mode(A.capi.COMPUTE_AUTO)
+    pol_l, val_l = gnet.infer(x)                       # any other mode, latency regime: conv_lat.hpp's fp16x2 kernel
     gnet.set_compute_mode(wmode | A.capi.COMPUTE_FORCE)
     pol_g, val_g = gnet.infer(x)
     idx = [0, B - 1]
@@ -335,10 +338,14 @@ def test_fp16x2_modes_with_heterogeneous_ranges_inside_a_layer_k256(ctx, wmode, 
              np.abs(val_g[idx] - val_o).max(), pol_o.max()))
     assert np.all(np.isfinite(pol_g)) and np.all(np.isfinite(val_g))
     assert pol_o.max() < 0.9, "the test network saturated: parity on a one-hot policy would be vacuous"
-    # the default mode at this batch size is the latency regime: conv_lat.hpp's fp16x2 kernel with ITS per-channel / per-column
-    # equilibration and per-board ranges — held to the full tolerance at every E as well
+    # this batch size is the latency regime.  The default mode keeps exact fp32 products there (agz.h promises them for
+    # AGZ_COMPUTE_F32_MFMA at every batch size); every other mode takes conv_lat.hpp's fp16x2 kernel with ITS per-channel /
+    # per-column equilibration and per-board ranges — both held to the full tolerance at every E, and they are different arithmetic
     np.testing.assert_allclose(pol_f[idx], pol_o, atol=POL_ATOL, rtol=POL_RTOL)
     np.testing.assert_allclose(val_f[idx], val_o, atol=VAL_ATOL)
+    np.testing.assert_allclose(pol_l[idx], pol_o, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(val_l[idx], val_o, atol=VAL_ATOL)
+    assert not np.array_equal(pol_l, pol_f), "AGZ_COMPUTE_AUTO at batch 6 did not take the fp16x2 latency kernel"
     if wmode == A.capi.COMPUTE_FP16X2 and E > 4:
         # the direct fp16x2 mode keeps one range per board and one per layer (include/agz.h: elements more than 2^17 below their
         # board's / layer's maximum lose relative precision — opt-in mode): beyond E = 4 only finiteness is promised
