@@ -706,7 +706,7 @@ class Mcts:
         _check(lib().agz_mcts_nodes(self.h, C.byref(n)), "agz_mcts_nodes")
         return n.value
 
-    def to_dot(self, max_nodes=0):
+    def to_dot(self, max_nodes=200):
         """(*MCTS).ToDot (mcts/graph.go:34): Graphviz text of the live tree"""
         need = C.c_size_t(0)
         _check(lib().agz_mcts_to_dot(self.h, int(max_nodes), None, 0, C.byref(need)), "agz_mcts_to_dot")

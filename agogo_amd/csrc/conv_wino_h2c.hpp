@@ -173,6 +173,10 @@ __global__ __launch_bounds__(256, 2) void wino_oi_h2c_kernel(WinoH2Args h) {
   const int b = tc / a.TPB, tt = tc - b * a.TPB;
   const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
   const int bl = tl / a.TPB;                           // board of the group
+  if (DBG & 8) {   // the two workgroups a CU starts with run in lock step (load phase together, compute phase together): put one half a period behind
+    if (blockIdx.y * gridDim.x + blockIdx.x < 512u && (__builtin_amdgcn_s_getreg(6148) & 1u))   // HW_ID.WAVE_ID: the wave slot on its SIMD
+      for (int i = 0; i < h.stagger; i++) __builtin_amdgcn_s_sleep(127);
+  }
   float s_, un0;
   wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &un0);
   // ---- output transform: stream the AL columns of the position grid (AL float4 {a c0, b c0, a c1, b c1} each), column pass, accumulate the row pass
@@ -492,6 +496,279 @@ __global__ __launch_bounds__(512, 4) void wino_oi2_h2c_kernel(WinoH2Args h) {
   else wino_oi_in_rows<TM, IH, AL>(yl, a.H, a.W, ty3, tx3, sv, vr, v_lane, v_pos);
 }
 
+// ---- the pipelined form of the same kernel --------------------------------------------------------------------------------------
+// What the measurements of round 4 said about wino_oi_h2c_kernel (profiles/r04/oi_decomposition.log): 0.364 ms per headline block against
+// 0.359 for the two kernels it replaces, although it moves 0.38 GB less.  With the M loads served from L1 0.176, without the parameter
+// loads 0.31, without the V2 stores 0.335, with none of the three 0.111: the phases of a workgroup ADD (load M, 23 us; parameters,
+// 7 us; transform + store, 14 us), two workgroups per CU are all the registers allow (100 accumulators + 14 loads in flight), and
+// putting the CU's two workgroups half a period apart changes nothing — each workgroup's own chain of round trips is the time.
+// Here a workgroup is persistent and the next item's M columns are in flight while this item's input transform runs:
+//  * the input transform recomputes its column pass per output row from a ZERO-HALOED LDS board (every read a ds_read_b64 with an
+//    immediate offset, no bounds arithmetic): ~70 live registers instead of ~200, which leaves room for NPRE = AL - 2 columns
+//    (35 float4 at F(5x5,3x3)) of the next item's M to land during it; the last two columns are fetched under the first ones' arithmetic;
+//  * the epilogue's parameter rows are fetched one row ahead;
+//  * transform arithmetic on the packed-fp32 pipe (two channels / two branches per instruction).
+// Item = (16-tile-row group g, slice s), taken in the order item = g * NS + s, workgroup w takes items w, w + grid, ...
+typedef float f2c __attribute__((ext_vector_type(2)));
+template <int TM> __device__ __forceinline__ void wino_atv_p(const f2c* m, f2c* o);
+template <> __device__ __forceinline__ void wino_atv_p<4>(const f2c* m, f2c* o) {
+  const f2c s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = m[0] + s12 + s34;
+  o[1] = d12 + 2.f * d34;
+  o[2] = s12 + 4.f * s34;
+  o[3] = d12 + 8.f * d34 + m[5];
+}
+template <> __device__ __forceinline__ void wino_atv_p<5>(const f2c* m, f2c* o) {
+  const f2c s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = m[0] + s12 + s34 + m[5];
+  o[1] = d12 + 0.5f * d34 + 2.f * m[5];
+  o[2] = s12 + 0.25f * s34 + 4.f * m[5];
+  o[3] = d12 + 0.125f * d34 + 8.f * m[5];
+  o[4] = s12 + 0.0625f * s34 + 16.f * m[5] + m[6];
+}
+template <int TM> __device__ __forceinline__ void wino_at_acc_p(int nu, f2c* Y, f2c t);
+template <> __device__ __forceinline__ void wino_at_acc_p<5>(int nu, f2c* Y, f2c t) {
+  switch (nu) {
+    case 0: Y[0] += t; break;
+    case 1: Y[0] += t; Y[1] += t; Y[2] += t; Y[3] += t; Y[4] += t; break;
+    case 2: Y[0] += t; Y[1] -= t; Y[2] += t; Y[3] -= t; Y[4] += t; break;
+    case 3: Y[0] += t; Y[1] += 0.5f * t; Y[2] += 0.25f * t; Y[3] += 0.125f * t; Y[4] += 0.0625f * t; break;
+    case 4: Y[0] += t; Y[1] -= 0.5f * t; Y[2] += 0.25f * t; Y[3] -= 0.125f * t; Y[4] += 0.0625f * t; break;
+    case 5: Y[0] += t; Y[1] += 2.f * t; Y[2] += 4.f * t; Y[3] += 8.f * t; Y[4] += 16.f * t; break;
+    default: Y[4] += t; break;
+  }
+}
+template <> __device__ __forceinline__ void wino_at_acc_p<4>(int nu, f2c* Y, f2c t) {
+  switch (nu) {
+    case 0: Y[0] += t; break;
+    case 1: Y[0] += t; Y[1] += t; Y[2] += t; Y[3] += t; break;
+    case 2: Y[0] += t; Y[1] -= t; Y[2] += t; Y[3] -= t; break;
+    case 3: Y[0] += t; Y[1] += 2.f * t; Y[2] += 4.f * t; Y[3] += 8.f * t; break;
+    case 4: Y[0] += t; Y[1] -= 2.f * t; Y[2] += 4.f * t; Y[3] -= 8.f * t; break;
+    default: Y[3] += t; break;
+  }
+}
+template <int TM> __device__ __forceinline__ f2c wino_bt_row_p(int i, const f2c* d);
+template <> __device__ __forceinline__ f2c wino_bt_row_p<5>(int i, const f2c* d) {
+  switch (i) {
+    case 0: return -0.5f * d[0] + 0.25f * d[1] + 2.5f * d[2] - 1.25f * d[3] - 2.f * d[4] + d[5];
+    case 1: return 0.5f * d[1] + 0.25f * d[2] - 2.25f * d[3] - d[4] + d[5];
+    case 2: return -0.5f * d[1] + 0.75f * d[2] + 1.75f * d[3] - 3.f * d[4] + d[5];
+    case 3: return d[1] + 1.5f * d[2] - 2.f * d[3] - 1.5f * d[4] + d[5];
+    case 4: return -d[1] + 2.5f * (d[2] - d[4]) + d[5];
+    case 5: return 0.25f * d[1] - 1.25f * d[3] + d[5];
+    default: return -0.5f * d[1] + 0.25f * d[2] + 2.5f * d[3] - 1.25f * d[4] - 2.f * d[5] + d[6];
+  }
+}
+template <> __device__ __forceinline__ f2c wino_bt_row_p<4>(int i, const f2c* d) {
+  switch (i) {
+    case 0: return 4.f * d[0] - 5.f * d[2] + d[4];
+    case 1: return -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
+    case 2: return 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
+    case 3: return -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+    case 4: return 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+    default: return 4.f * d[1] - 5.f * d[3] + d[5];
+  }
+}
+template <int TM> __device__ __forceinline__ void wino_btv_p(const f2c* d, f2c* o) {
+#pragma unroll
+  for (int i = 0; i < TM + 2; i++) o[i] = wino_bt_row_p<TM>(i, d);
+}
+
+// grid: any number of workgroups <= items (2 per CU); 256 threads; dynamic LDS [16 / TPB boards][TM nty + 2][TM ntx + 2][32] fp32
+template <int TM>
+__global__ __launch_bounds__(256, 2) void wino_oip_h2c_kernel(WinoH2Args h) {
+  using WT = WinoT<TM>;
+  constexpr int AL = WT::AL, NPRE = AL - 3;
+  const WinoArgs& a = h.w;
+  extern __shared__ __attribute__((aligned(16))) float ys[];
+  const int tid = threadIdx.x, tl = tid >> 4, pr = tid & 15, lane = tid & 63;
+  const int NS = a.C >> 5;
+  const int PH = TM * a.nty + 2, PW = TM * a.ntx + 2;        // haloed board: pixel (hh, ww) at (hh + 1, ww + 1)
+  const int bpg = 16 / a.TPB;                                // boards per group
+  const int n_groups = (a.T + 15) >> 4, n_items = n_groups * NS;
+  const int tt = tl % a.TPB, bl = tl / a.TPB;
+  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
+  // zero the LDS boards once: the halo and the cells past H x W are never written afterwards
+  for (int i = tid; i < bpg * PH * PW * 32; i += 256) ys[i] = 0.f;
+  const __amdgpu_buffer_rsrc_t mr = h2_rsrc(a.Mb);
+  const __amdgpu_buffer_rsrc_t vr = h2_rsrc(a.V);
+  const unsigned m_lane = (unsigned)((tl * 64 + pr * 4) * 4);
+  const unsigned v_lane = (unsigned)((((tid >> 6) * 4) * 128) + lane * 4);
+  const unsigned e_pix = (unsigned)a.Cout_p * 16u;
+  // this thread's tile origin in the haloed LDS board (floats): output pixel (k, l) at yo + ((k + 1) * PW + l + 1) * 32, input patch (i, j) at yi + (i * PW + j) * 32
+  float* const ybase = ys + ((size_t)bl * PH * PW + (size_t)(TM * ty) * PW + TM * tx) * 32 + 2 * pr;
+  unsigned okmask = 0;                                       // bit k * TM + l: output pixel (k, l) of this thread's tile lies on the board
+#pragma unroll
+  for (int k = 0; k < TM; k++)
+#pragma unroll
+    for (int l = 0; l < TM; l++) okmask |= (TM * ty + k < a.H && TM * tx + l < a.W) ? 1u << (k * TM + l) : 0u;
+  const __amdgpu_buffer_rsrc_t er = h2_rsrc(a.ep);
+  float4 m[NPRE][AL];
+  auto m_soff = [&](int g, int s, int pos) -> unsigned { return (unsigned)((((g >> 3) * h.npos + pos) * NS + s)) * 32768u + (unsigned)(g & 7) * 4096u; };
+  int item = blockIdx.x;
+  {
+    const int g = __builtin_amdgcn_readfirstlane(item / NS), s = __builtin_amdgcn_readfirstlane(item - (item / NS) * NS);
+#pragma unroll
+    for (int nu = 0; nu < NPRE; nu++)
+#pragma unroll
+      for (int xi = 0; xi < AL; xi++) m[nu][xi] = h2_ldf4(mr, m_lane, m_soff(g, s, xi * AL + nu));
+  }
+  __syncthreads();
+  for (; item < n_items; item += gridDim.x) {
+    const int g = __builtin_amdgcn_readfirstlane(item / NS), s = __builtin_amdgcn_readfirstlane(item - (item / NS) * NS);
+    const int t = g * 16 + tl;
+    const bool live = t < a.T;
+    const int b = live ? g * bpg + bl : (a.T - 1) / a.TPB;
+    float s_, un0;
+    wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &un0);
+    // ---- output transform: columns 0 .. NPRE-1 are in registers (or landing); column nu + NPRE is fetched into column nu's registers
+    f2c Y[TM][TM][2];
+#pragma unroll
+    for (int k = 0; k < TM; k++)
+#pragma unroll
+      for (int l = 0; l < TM; l++) { Y[k][l][0] = f2c{0.f, 0.f}; Y[k][l][1] = f2c{0.f, 0.f}; }
+#pragma unroll
+    for (int nu = 0; nu < AL; nu++) {
+      f2c c0[AL], c1[AL], o0[TM], o1[TM];
+#pragma unroll
+      for (int xi = 0; xi < AL; xi++) {
+        const float4 v = m[nu % NPRE][xi];
+        c0[xi] = f2c{v.x, v.y}; c1[xi] = f2c{v.z, v.w};
+      }
+      if (nu + NPRE < AL) {
+#pragma unroll
+        for (int xi = 0; xi < AL; xi++) m[nu % NPRE][xi] = h2_ldf4(mr, m_lane, m_soff(g, s, xi * AL + nu + NPRE));
+      }
+      wino_atv_p<TM>(c0, o0);
+      wino_atv_p<TM>(c1, o1);
+#pragma unroll
+      for (int k = 0; k < TM; k++) {
+        f2c y0[TM], y1[TM];
+#pragma unroll
+        for (int l = 0; l < TM; l++) { y0[l] = Y[k][l][0]; y1[l] = Y[k][l][1]; }
+        wino_at_acc_p<TM>(nu, y0, o0[k]);
+        wino_at_acc_p<TM>(nu, y1, o1[k]);
+#pragma unroll
+        for (int l = 0; l < TM; l++) { Y[k][l][0] = y0[l]; Y[k][l][1] = y1[l]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- block epilogue, parameter rows one row ahead.  Addresses are built from one per-iteration base (made opaque to the
+    // compiler: hoisted out of the item loop the 2 TM^2 parameter addresses alone hold 50 registers across every phase); pixels past
+    // the board read the tile's first pixel and store a zero (the LDS cells past H x W stay the next transform's zero padding)
+    unsigned e_base = (unsigned)(32 * s + 2 * pr) * 16u + (unsigned)((TM * ty) * a.W + TM * tx) * e_pix;
+    asm volatile("" : "+v"(e_base));
+    float4 E[2][TM][2];
+    auto load_e = [&](int buf, int k) {
+#pragma unroll
+      for (int l = 0; l < TM; l++) {
+        const bool ok = (okmask >> (k * TM + l)) & 1u;
+        const unsigned off = e_base + (ok ? (unsigned)(k * a.W + l) * e_pix : 0u);
+        E[buf][l][0] = h2_ldf4(er, off, 0);
+        E[buf][l][1] = h2_ldf4(er, off + 16u, 0);
+      }
+    };
+    load_e(0, 0);
+    float mxv = 0.f;
+    float* yw = ybase;
+    asm volatile("" : "+v"(yw));
+#pragma unroll
+    for (int k = 0; k < TM; k++) {
+      if (k + 1 < TM) load_e((k + 1) & 1, k + 1);
+#pragma unroll
+      for (int l = 0; l < TM; l++) {
+        const bool ok = live && ((okmask >> (k * TM + l)) & 1u);
+        const float4 E0 = E[k & 1][l][0], E1 = E[k & 1][l][1];
+        const f2c u0 = Y[k][l][0] * un0, u1 = Y[k][l][1] * un0;
+        float va = u0.x * E0.x + E0.y, vb = u0.y * E0.z + E0.w;
+        float vc = u1.x * E1.x + E1.y, vd = u1.y * E1.z + E1.w;
+        va = va > 0.f ? va : 0.f; vb = vb > 0.f ? vb : 0.f; vc = vc > 0.f ? vc : 0.f; vd = vd > 0.f ? vd : 0.f;
+        const float y0 = ok ? va + vb : 0.f, y1 = ok ? vc + vd : 0.f;
+        *reinterpret_cast<float2*>(yw + ((k + 1) * PW + l + 1) * 32) = make_float2(y0, y1);
+        mxv = fmaxf(mxv, fmaxf(y0, y1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mxv = fmaxf(mxv, __shfl_xor(mxv, o, 64));
+    if (pr == 0 && live) h.wm_out[(size_t)t * NS + s] = mxv;
+    float ax;
+    if (h.amax_true) ax = __uint_as_float(reinterpret_cast<const unsigned*>(h.amax_true)[b]);
+    else {
+      const int wmpb = a.TPB * NS;
+      const float* wp = h.wm_prev + (size_t)b * wmpb;
+      ax = 0.f;
+      for (int i = pr; i < wmpb; i += 16) ax = fmaxf(ax, wp[i]);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ax = fmaxf(ax, __shfl_xor(ax, o, 64));
+    }
+    const float bound = h.g1 * ax + h.g0;
+    const unsigned bbits = __float_as_uint(bound);
+    if (s == 0 && tt == 0 && pr == 0 && live) h.amax_next[b] = bbits;
+    float sb, inv_;
+    wino_h2_scales(bbits, WT::VSHIFT, &sb, &inv_);
+    const float sv = live ? sb : 0.f;
+    __syncthreads();
+    // ---- the next item's first NPRE columns: in flight during the input transform below (always issued: no run-time branch around loads)
+    {
+      const int nx = item + (int)gridDim.x < n_items ? item + (int)gridDim.x : item;
+      const int g2 = __builtin_amdgcn_readfirstlane(nx / NS), s2 = __builtin_amdgcn_readfirstlane(nx - (nx / NS) * NS);
+#pragma unroll
+      for (int nu = 0; nu < NPRE; nu++)
+#pragma unroll
+        for (int xi = 0; xi < AL; xi++) m[nu][xi] = h2_ldf4(mr, m_lane, m_soff(g2, s2, xi * AL + nu));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- input transform of the next block, one output row at a time (column pass recomputed per row from LDS)
+    const unsigned v_base = (unsigned)((((g >> 3) * h.npos) * NS + s)) * 16384u + (unsigned)(g & 7) * 2048u;
+    const unsigned v_pos = (unsigned)NS * 16384u;
+    const float* yr = ybase;
+    asm volatile("" : "+v"(yr));
+    // rows in passes of <= 3: per pass every patch column is read once (AL ds_read_b64 with immediate offsets) and gives the pass's rows
+#pragma unroll
+    for (int i0 = 0; i0 < AL; i0 += 3) {
+      constexpr int NRMAX = 3;
+      const int nr = AL - i0 < NRMAX ? AL - i0 : NRMAX;   // (constant after unrolling)
+      f2c tmr[NRMAX][AL];
+#pragma unroll
+      for (int j = 0; j < AL; j++) {
+        f2c d[AL];
+#pragma unroll
+        for (int ii = 0; ii < AL; ii++) {
+          const float2 v = *reinterpret_cast<const float2*>(yr + (ii * PW + j) * 32);
+          d[ii] = f2c{v.x, v.y};
+        }
+#pragma unroll
+        for (int r = 0; r < NRMAX; r++)
+          if (r < nr) tmr[r][j] = wino_bt_row_p<TM>(i0 + r, d);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < NRMAX; r++) {
+        if (r >= nr) continue;
+        const int i = i0 + r;
+        f2c o[AL];
+        wino_btv_p<TM>(tmr[r], o);
+#pragma unroll
+        for (int j = 0; j < AL; j++) {
+          unsigned lo;
+          const unsigned hi = wino_h2_pack(o[j].x * sv, o[j].y * sv, &lo);
+          const auto s16 = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);
+          const unsigned e0 = s16[0], e1 = s16[1];
+          const auto s32 = __builtin_amdgcn_permlane32_swap(e0, e1, false, false);
+          const unsigned w0 = s32[0], w1 = s32[1];
+          __builtin_amdgcn_raw_buffer_store_b32(w0, vr, v_lane, v_base + (unsigned)(i * AL + j) * v_pos, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(w1, vr, v_lane + 256u, v_base + (unsigned)(i * AL + j) * v_pos, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // the LDS board is rewritten by the next item's epilogue
+  }
+}
+
 // U2 (conv_wino_h2.hpp: [pos][C/32][piece][Ntot][32]) -> U2c with the chained column order (host, at commit)
 static void wino_build_u2c(const std::vector<_Float16>& u2, std::vector<_Float16>& u2c, int npos, int Ntot, int C, int Cout_p) {
   const int NC = C / 32, NT = Ntot / 256;
@@ -512,7 +789,8 @@ static void wino_build_u2c(const std::vector<_Float16>& u2, std::vector<_Float16
 static inline bool wino_h2c_ok(int H, int W, int tm, int Kp) {
   const int tpb = ceil_div(H, tm) * ceil_div(W, tm);
   const int nk = Kp / 32;
-  return Kp % 128 == 0 && 16 % tpb == 0 && (nk == 4 || nk == 8 || nk == 12 || nk == 16) && (size_t)(16 / tpb) * H * W * 128 <= 64 * 1024;
+  return Kp % 128 == 0 && 16 % tpb == 0 && (nk == 4 || nk == 8 || nk == 12 || nk == 16) &&
+         (size_t)(16 / tpb) * (tm * ceil_div(H, tm) + 2) * (tm * ceil_div(W, tm) + 2) * 128 <= 80 * 1024;   // the haloed LDS boards of a group, two workgroups per CU
 }
 
 // one stage of the chained tower for a chunk of boards (geometry as wino_h2_launch sets it)
@@ -550,6 +828,23 @@ static void wino_h2c_oi(agz_ctx* ctx, WinoH2Args& h, bool last, hipStream_t st, 
   const WinoArgs& a = h.w;
   const dim3 g((unsigned)ceil_div(a.T, 16), (unsigned)(a.C >> 5));
   const size_t shm = last ? 0 : (size_t)(16 / a.TPB) * a.H * a.W * 32 * sizeof(float);
+  // (the pipelined kernel addresses M and V through one buffer descriptor each: 31-bit byte offsets)
+  const bool fits31 = wino_h2_rows(h.npos, (size_t)a.T) * a.Ntot * 4 < ((size_t)1 << 31);
+  if (variant == 4 && !last && fits31) {   // persistent, software-pipelined
+    const size_t shp = (size_t)(16 / a.TPB) * (h.tm * a.nty + 2) * (h.tm * a.ntx + 2) * 32 * sizeof(float);
+    const int items = ceil_div(a.T, 16) * (a.C >> 5);
+    const dim3 gp((unsigned)std::min(items, 2 * ctx->num_cus));
+    static bool attr_set = false;
+    if (!attr_set) {   // up to 80 KB of dynamic LDS (wino_h2c_ok)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_oip_h2c_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_oip_h2c_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      attr_set = true;
+    }
+    if (h.tm == 5) hipLaunchKernelGGL((wino_oip_h2c_kernel<5>), gp, dim3(256), shp, st, h);
+    else hipLaunchKernelGGL((wino_oip_h2c_kernel<4>), gp, dim3(256), shp, st, h);
+    return;
+  }
+  if (variant == 4) variant = 1;   // the last block: y to HBM
   if (variant >= 2 && variant < 16) {
 #define AGZ_OI2(TM_, LAST_, PF_) hipLaunchKernelGGL((wino_oi2_h2c_kernel<TM_, LAST_, PF_>), g, dim3(512), shm, st, h)
     if (variant == 2) {
@@ -571,6 +866,7 @@ static void wino_h2c_oi(agz_ctx* ctx, WinoH2Args& h, bool last, hipStream_t st, 
       case 3: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 3>), g, dim3(256), shm, st, h); return;
       case 6: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 6>), g, dim3(256), shm, st, h); return;
       case 7: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 7>), g, dim3(256), shm, st, h); return;
+      case 8: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 8>), g, dim3(256), shm, st, h); return;
       default: break;
     }
   }

@@ -1979,6 +1979,9 @@ int agz_arena_set_state(agz_arena* a, int g, const agz_state* st) {
 struct agz_mcts {
   agz_arena* arena = nullptr;
   bool have_game = false;
+  // agz_mcts_to_dot: the text of the size query kept for the fill call that follows it (key: what any change of the tree changes)
+  std::string dot_cache;
+  int64_t dot_key[5] = {-1, -1, -1, -1, -1};
 };
 
 namespace agz {
@@ -2155,6 +2158,20 @@ int agz_mcts_to_dot(agz_mcts* m, int max_nodes, char* buf, size_t cap, size_t* n
   }
   if (max_nodes > 0 && n_nodes > max_nodes) n_nodes = max_nodes;       // BFS block order: a prefix of the pool is a top of the tree
   const size_t base = (size_t)pool * a->d.cap;
+  {   // the size query builds the text; the fill call that follows reuses it (a 1600-simulation 19x19 tree is hundreds of MB of HTML)
+    uint32_t root_vis = 0;
+    if (n_nodes) AGZ_HIP_TRY(hipMemcpy(&root_vis, a->d.visits + base, 4, hipMemcpyDeviceToHost));
+    const int64_t key[5] = {max_nodes, hr, pool, n_nodes, (int64_t)root_vis};
+    if (cap && !m->dot_cache.empty() && std::equal(key, key + 5, m->dot_key)) {
+      *needed = m->dot_cache.size() + 1;
+      const size_t k = std::min(cap - 1, m->dot_cache.size());
+      memcpy(buf, m->dot_cache.data(), k);
+      buf[k] = 0;
+      m->dot_cache.clear(); m->dot_cache.shrink_to_fit();
+      return AGZ_OK;
+    }
+    std::copy(key, key + 5, m->dot_key);
+  }
   std::vector<int32_t> off(n_nodes);
   std::vector<int16_t> kn(n_nodes), mv(n_nodes);
   std::vector<uint32_t> vis(n_nodes);
@@ -2167,6 +2184,8 @@ int agz_mcts_to_dot(agz_mcts* m, int max_nodes, char* buf, size_t cap, size_t* n
     AGZ_HIP_TRY(hipMemcpy(pri.data(), a->d.prior + base, (size_t)n_nodes * 4, hipMemcpyDeviceToHost));
   }
   const int cells = a->gc.cells, stride = a->gc.m;
+  // (the root prints as Black whoever searched: the reference's statefulNode.Player starts as None and ToDot sets it to Black,
+  //  graph.go:62-64; the children alternate from there)
   std::vector<int> parent(n_nodes, -1), player(n_nodes, AGZ_BLACK);
   std::string out = "digraph G {\n";
   std::string edges, nodes;
@@ -2206,6 +2225,9 @@ int agz_mcts_to_dot(agz_mcts* m, int max_nodes, char* buf, size_t cap, size_t* n
     const size_t k = std::min(cap - 1, out.size());
     memcpy(buf, out.data(), k);
     buf[k] = 0;
+    m->dot_cache.clear();
+  } else {
+    m->dot_cache = std::move(out);
   }
   return AGZ_OK;
 }
