@@ -28,7 +28,8 @@ __device__ __forceinline__ unsigned h2c_img(int row, int slot) { return (unsigne
 
 // ---- the transform-domain GEMMs on the chained layouts: 128 x 256 tile, A (HBM) fetched PFA K steps ahead into rotating register
 // sets, B (L2) one step ahead — wino_gemm_h2d_kernel's pipeline; every global access of a wave is one contiguous KB.
-template <int NK, int PFA>
+// DBG (measurement only, results wrong): 1 = the A operand of every tile from chunk 0 (cache hits), 2 = no M stores, 4 = B from chunk 0
+template <int NK, int PFA, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void wino_gemm_h2c_kernel(WinoH2Args h) {
   const WinoArgs& a = h.w;
   constexpr int SA = 128 * 128, SB = 256 * 128;   // 16 KB + 32 KB
@@ -48,8 +49,8 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2c_kernel(WinoH2Args h) {
   const int wm = wid >> 1, wn = wid & 1;
   // staging: thread t moves the 16-byte unit t + 256 j of a chunk (row t/8 + 32 j, slot t%8)
   const unsigned st_lds = h2c_img(tid >> 3, tid & 7);          // + j * 4096: (row >> 1) & 7 does not depend on j
-  const char* abase = reinterpret_cast<const char*>(a.V) + ((size_t)m_tile * h.npos + pos) * (size_t)NK * SA + (size_t)tid * 16;
-  const char* bbase = reinterpret_cast<const char*>(h.U2c) + (((size_t)pos * NK) * n_nt + n_tile) * (size_t)SB + (size_t)tid * 16;
+  const char* abase = reinterpret_cast<const char*>(a.V) + ((DBG & 1) ? (size_t)0 : ((size_t)m_tile * h.npos + pos) * (size_t)NK * SA) + (size_t)tid * 16;
+  const char* bbase = reinterpret_cast<const char*>(h.U2c) + ((DBG & 4) ? (size_t)0 : (((size_t)pos * NK) * n_nt + n_tile) * (size_t)SB) + (size_t)tid * 16;
   const size_t bstep = (size_t)n_nt * SB;
 
   f32x16 acc[2][4];
@@ -121,6 +122,110 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2c_kernel(WinoH2Args h) {
       for (int r = 0; r < 16; r++) {
         const unsigned x0 = __float_as_uint(acc[i][2 * qq][r]), x1 = __float_as_uint(acc[i][2 * qq + 1][r]);
         const auto s32 = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);   // [x0 low half, x1 low half], [x0 high half, x1 high half]
+        const unsigned w0 = s32[0], w1 = s32[1];
+        float* d = mbase + (size_t)qq * 8192 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * 64;
+        if (!(DBG & 2) || h.g1 == 12345.f) {
+          d[0] = __uint_as_float(w0);
+          d[4 * 64] = __uint_as_float(w1);
+        }
+      }
+}
+
+// ---- the same GEMM with the operands DMA'd straight into LDS (buffer_load ... lds, 16 bytes per lane) ----------------------------
+// Round-4 decomposition of wino_gemm_h2c_kernel (profiles/r04/gemm_decomposition.log): 0.335 ms; A from cache 0.311; no M stores
+// 0.256; everything from cache and no stores 0.215 — the kernel is neither HBM- nor MFMA-bound (the three fp16 MFMAs per product
+// are 0.126 ms of matrix pipe): a workgroup's prologue, its eight barrier-separated K steps and its 128-stores-per-thread epilogue
+// ADD, and two workgroups per CU (224 registers: 128 accumulators + 64 staging + fragments) cannot cover one another.
+// Without staging registers (no VGPR destination, no ds_write pass — the LDS image is lane-linear, the swizzle goes on the SOURCE
+// address) and with the B fragments read just in time the kernel fits 168 registers: THREE workgroups per CU, single LDS stage
+// (48 KB each), plain __syncthreads() around every stage (no DMA is ever in flight across a barrier).
+typedef __attribute__((address_space(3))) void* h2c_lds_ptr_t;
+template <int NK>
+__global__ __launch_bounds__(256, 3) void wino_gemm_h2g_kernel(WinoH2Args h) {
+  const WinoArgs& a = h.w;
+  constexpr int SA = 128 * 128, SB = 256 * 128;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SA + SB];
+
+  const int n_nt = a.Ntot >> 8;
+  const int per_pos = a.n_mtiles * n_nt;
+  const int nblk = h.npos * per_pos;
+  const int id = blockIdx.x;
+  int q = nblk >> 3, rr = nblk & 7, xcd = id & 7, slot = id >> 3;
+  int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
+  const int pos = tile / per_pos;
+  const int rem = tile - pos * per_pos;
+  const int m_tile = rem / n_nt, n_tile = rem - m_tile * n_nt;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  // DMA: wave w fills rows 32 w .. 32 w + 31 of the A image (4 instructions of 8 rows) and rows 64 w .. + 63 of the B image (8);
+  // LDS unit (row r, slot q') receives global unit (r, q' ^ ((r >> 1) & 7)); (r >> 1) & 7 = (4 j + lane / 16) & 7 for instruction j
+  const __amdgpu_buffer_rsrc_t ar = h2_rsrc(a.V), br = h2_rsrc(h.U2c);
+  const unsigned sw0 = (unsigned)(lane >> 4) & 7u, sw1 = (4u + (unsigned)(lane >> 4)) & 7u;
+  const unsigned l8 = (unsigned)(lane >> 3) * 128u, q8 = (unsigned)(lane & 7);
+  const unsigned vo_e = l8 + ((q8 ^ sw0) << 4), vo_o = l8 + 1024u + ((q8 ^ sw1) << 4);   // instructions j even / odd: + (j / 2) * 2048
+  const unsigned a_w = (unsigned)wid * 4096u, b_w = (unsigned)wid * 8192u;               // the wave's part of a chunk (bytes)
+  unsigned a_so = (unsigned)(((size_t)m_tile * h.npos + pos) * (size_t)NK * SA) + a_w;
+  unsigned b_so = (unsigned)((((size_t)pos * NK) * n_nt + n_tile) * (size_t)SB) + b_w;
+  const unsigned b_step = (unsigned)n_nt * SB;
+  unsigned char* const la = lds + a_w;
+  unsigned char* const lb = lds + SA + b_w;
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int kh = lane >> 5, sw = (lane >> 1) & 7;
+  const unsigned fa = (unsigned)((wm * 64 + (lane & 31)) * 128);
+  const unsigned fb = (unsigned)(SA + (wn * 128 + (lane & 31)) * 128);
+
+  for (int it = 0; it < NK; it++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (h2c_lds_ptr_t)(la + j * 1024), 16, (j & 1) ? vo_o : vo_e, a_so + (unsigned)(j >> 1) * 2048u, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (h2c_lds_ptr_t)(lb + j * 1024), 16, (j & 1) ? vo_o : vo_e, b_so + (unsigned)(j >> 1) * 2048u, 0, 0);
+    a_so += SA; b_so += b_step;
+    __syncthreads();                                  // (its fence waits vmcnt(0): this wave's DMA has landed; then every wave's)
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      f16x8_t A_[2][2];
+      const unsigned so0 = (unsigned)(((2 * ks + kh) ^ sw) << 4), so1 = (unsigned)(((4 + 2 * ks + kh) ^ sw) << 4);
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        A_[i][0] = *reinterpret_cast<const f16x8_t*>(lds + fa + i * 4096 + so0);
+        A_[i][1] = *reinterpret_cast<const f16x8_t*>(lds + fa + i * 4096 + so1);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {                   // B fragments just in time: 8 registers live instead of 32
+        const f16x8_t b0 = *reinterpret_cast<const f16x8_t*>(lds + fb + j * 4096 + so0);
+        const f16x8_t b1 = *reinterpret_cast<const f16x8_t*>(lds + fb + j * 4096 + so1);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {                 // small terms first: lo*hi, hi*lo, hi*hi
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[i][1], b0, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[i][0], b1, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[i][0], b0, acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                                  // every wave has read the stage before the next DMA overwrites it
+  }
+
+  float* mbase = a.Mb + ((((size_t)m_tile * h.npos + pos) * (size_t)(a.Ntot >> 6) + (size_t)n_tile * 4 + wn * 2) * 128 + (size_t)(wm * 64)) * 64 + lane;
+#pragma unroll
+  for (int qq = 0; qq < 2; qq++)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const unsigned x0 = __float_as_uint(acc[i][2 * qq][r]), x1 = __float_as_uint(acc[i][2 * qq + 1][r]);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);
         const unsigned w0 = s32[0], w1 = s32[1];
         float* d = mbase + (size_t)qq * 8192 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * 64;
         d[0] = __uint_as_float(w0);
@@ -815,6 +920,28 @@ static void wino_h2c_gemm(agz_ctx* ctx, WinoH2Args& h, hipStream_t st) {
   wino_h2c_geometry(h);
   ProfScopeOn ps(ctx, AGZ_PROF_WINO_GEMM, st == ctx->stream);
   const dim3 g(h.npos * h.w.n_mtiles * (h.w.Ntot >> 8));
+  if (h.stagger >= 100 && (h.w.C >> 5) == 8) {   // measurement variants (agz_net_set_wino_h2_form: form >> 8 = 100 + DBG)
+    switch (h.stagger - 100) {
+      case 1: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 1>), g, dim3(256), 0, st, h); return;
+      case 2: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 2>), g, dim3(256), 0, st, h); return;
+      case 3: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 3>), g, dim3(256), 0, st, h); return;
+      case 4: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 4>), g, dim3(256), 0, st, h); return;
+      case 5: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 5>), g, dim3(256), 0, st, h); return;
+      case 6: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 6>), g, dim3(256), 0, st, h); return;
+      case 7: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 7>), g, dim3(256), 0, st, h); return;
+      default: break;
+    }
+  }
+  // (the DMA form addresses V and U2c through buffer descriptors: 31-bit byte offsets)
+  const bool dma_ok = wino_h2_rows(h.npos, (size_t)h.w.T) * h.w.C * 4 < ((size_t)1 << 31) && (size_t)h.npos * h.w.C * h.w.Ntot * 4 < ((size_t)1 << 31);
+  if (h.stagger != 99 && dma_ok) {   // (measurement hook: form >> 8 == 99 keeps the register-staged kernel)
+    switch (h.w.C >> 5) {
+      case 4: hipLaunchKernelGGL((wino_gemm_h2g_kernel<4>), g, dim3(256), 0, st, h); return;
+      case 8: hipLaunchKernelGGL((wino_gemm_h2g_kernel<8>), g, dim3(256), 0, st, h); return;
+      case 12: hipLaunchKernelGGL((wino_gemm_h2g_kernel<12>), g, dim3(256), 0, st, h); return;
+      default: hipLaunchKernelGGL((wino_gemm_h2g_kernel<16>), g, dim3(256), 0, st, h); return;
+    }
+  }
   switch (h.w.C >> 5) {
     case 4: hipLaunchKernelGGL((wino_gemm_h2c_kernel<4, 2>), g, dim3(256), 0, st, h); break;
     case 8: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2>), g, dim3(256), 0, st, h); break;

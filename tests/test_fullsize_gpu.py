@@ -247,16 +247,20 @@ def _drive_full_concurrency(ctx, kind, okind, S, komi, enc, F, K, L, G, budget, 
     net.close()
 
 
-def test_config2_connect4_256_concurrent_games_10_plies(ctx):
-    """BASELINE config #2 at its stated concurrency: Connect-4, K=64, 6 blocks, 256 concurrent games, 400 sims/move."""
-    _drive_full_concurrency(ctx, capi.GAME_C4, O.C4, (6, 7), 0.0, capi.ENC_TWOPLANE, 2, 64, 6, 256, 400, 10, capi.COMPUTE_F32_MFMA, k=4,
+@pytest.mark.parametrize("mode", [capi.COMPUTE_F32_MFMA, capi.COMPUTE_WINO_H2], ids=["f32", "wino_h2"])
+def test_config2_connect4_256_concurrent_games_10_plies(ctx, mode):
+    """BASELINE config #2 at its stated concurrency: Connect-4, K=64, 6 blocks, 256 concurrent games, 400 sims/move — in the
+    default arithmetic and under the mode bench.py's games_leg sets (AGZ_COMPUTE_WINO_H2; at this shape, 84 row tiles on 256 CUs,
+    the library keeps the fp32 half-tile kernels in that mode too: the leg's label names the MODE, this test pins what runs)."""
+    _drive_full_concurrency(ctx, capi.GAME_C4, O.C4, (6, 7), 0.0, capi.ENC_TWOPLANE, 2, 64, 6, 256, 400, 10, mode, k=4,
                             watch=(0, 1, 130))
 
 
-def test_config3_go9_512_concurrent_games_10_plies(ctx):
+@pytest.mark.parametrize("mode", [capi.COMPUTE_BF16X3, capi.COMPUTE_WINO_H2], ids=["bf16x3", "wino_h2"])
+def test_config3_go9_512_concurrent_games_10_plies(ctx, mode):
     """BASELINE config #3 at its stated concurrency: 9x9 Go, K=128, 10 blocks, 512 concurrent games, 400 sims/move, in the
-    arithmetic bench.py's 9x9 leg uses (bf16x3)."""
-    _drive_full_concurrency(ctx, capi.GAME_WQ, O.WQ, (9, 9), 7.5, capi.ENC_WQ, 18, 128, 10, 512, 400, 10, capi.COMPUTE_BF16X3,
+    arithmetic bench.py's 9x9 leg (go9_leg) measures — AGZ_COMPUTE_WINO_H2: F(5x5,3x3), the chained block — and in bf16x3."""
+    _drive_full_concurrency(ctx, capi.GAME_WQ, O.WQ, (9, 9), 7.5, capi.ENC_WQ, 18, 128, 10, 512, 400, 10, mode,
                             watch=(0, 3, 509))
 
 
