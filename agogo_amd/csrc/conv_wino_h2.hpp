@@ -115,7 +115,6 @@ struct WinoH2Args {
   float* wm_out;             // the same for this block's output (the other half of the ping-pong pair)
   unsigned* amax_next;       // [B] bits of the proven bound on max |y| of this block's output: the range word of V2(l+1)
   float g1, g0;              // that bound = g1 * max|x| + g0 (agz_net::build_wino_h2_weights)
-  int stagger;               // measurement: first-round workgroups in an odd wave slot sleep stagger x 8128 cycles (de-phases the two workgroups of a CU)
 };
 __device__ __forceinline__ size_t h2_row(const WinoH2Args& h, int pos, int t) {
   return (size_t)(t >> h.rsh) * h.rA + (size_t)pos * h.rB + (size_t)(t & h.rmask);

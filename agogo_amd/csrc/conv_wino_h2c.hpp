@@ -28,8 +28,7 @@ __device__ __forceinline__ unsigned h2c_img(int row, int slot) { return (unsigne
 
 // ---- the transform-domain GEMMs on the chained layouts: 128 x 256 tile, A (HBM) fetched PFA K steps ahead into rotating register
 // sets, B (L2) one step ahead — wino_gemm_h2d_kernel's pipeline; every global access of a wave is one contiguous KB.
-// DBG (measurement only, results wrong): 1 = the A operand of every tile from chunk 0 (cache hits), 2 = no M stores, 4 = B from chunk 0
-template <int NK, int PFA, int DBG = 0>
+template <int NK, int PFA>
 __global__ __launch_bounds__(256, 2) void wino_gemm_h2c_kernel(WinoH2Args h) {
   const WinoArgs& a = h.w;
   constexpr int SA = 128 * 128, SB = 256 * 128;   // 16 KB + 32 KB
@@ -49,8 +48,8 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2c_kernel(WinoH2Args h) {
   const int wm = wid >> 1, wn = wid & 1;
   // staging: thread t moves the 16-byte unit t + 256 j of a chunk (row t/8 + 32 j, slot t%8)
   const unsigned st_lds = h2c_img(tid >> 3, tid & 7);          // + j * 4096: (row >> 1) & 7 does not depend on j
-  const char* abase = reinterpret_cast<const char*>(a.V) + ((DBG & 1) ? (size_t)0 : ((size_t)m_tile * h.npos + pos) * (size_t)NK * SA) + (size_t)tid * 16;
-  const char* bbase = reinterpret_cast<const char*>(h.U2c) + ((DBG & 4) ? (size_t)0 : (((size_t)pos * NK) * n_nt + n_tile) * (size_t)SB) + (size_t)tid * 16;
+  const char* abase = reinterpret_cast<const char*>(a.V) + ((size_t)m_tile * h.npos + pos) * (size_t)NK * SA + (size_t)tid * 16;
+  const char* bbase = reinterpret_cast<const char*>(h.U2c) + (((size_t)pos * NK) * n_nt + n_tile) * (size_t)SB + (size_t)tid * 16;
   const size_t bstep = (size_t)n_nt * SB;
 
   f32x16 acc[2][4];
@@ -124,10 +123,8 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2c_kernel(WinoH2Args h) {
         const auto s32 = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);   // [x0 low half, x1 low half], [x0 high half, x1 high half]
         const unsigned w0 = s32[0], w1 = s32[1];
         float* d = mbase + (size_t)qq * 8192 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * 64;
-        if (!(DBG & 2) || h.g1 == 12345.f) {
-          d[0] = __uint_as_float(w0);
-          d[4 * 64] = __uint_as_float(w1);
-        }
+        d[0] = __uint_as_float(w0);
+        d[4 * 64] = __uint_as_float(w1);
       }
 }
 
@@ -261,9 +258,7 @@ template <> __device__ __forceinline__ void wino_at_acc<4>(int nu, float* Y, flo
 // grid (T / 16 rounded up, C / 32), 256 threads: thread = (tile row tl = tid / 16 of the group, channel pair pr = tid % 16 of the slice);
 // a 16-lane group is one tile, a wave four consecutive tile rows.  Requires 16 % TPB == 0 (a group holds whole boards).
 // Dynamic LDS (not LAST): [16 / TPB boards][H * W][32] fp32.
-// DBG (measurement only, results wrong): 1 = every M load reads position 0 (L1 hits), 2 = one epilogue parameter vector for all
-// pixels, 4 = no V2 stores
-template <int TM, bool LAST, int DBG = 0>
+template <int TM, bool LAST>
 __global__ __launch_bounds__(256, 2) void wino_oi_h2c_kernel(WinoH2Args h) {
   using WT = WinoT<TM>;
   constexpr int AL = WT::AL;
@@ -278,10 +273,6 @@ __global__ __launch_bounds__(256, 2) void wino_oi_h2c_kernel(WinoH2Args h) {
   const int b = tc / a.TPB, tt = tc - b * a.TPB;
   const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
   const int bl = tl / a.TPB;                           // board of the group
-  if (DBG & 8) {   // the two workgroups a CU starts with run in lock step (load phase together, compute phase together): put one half a period behind
-    if (blockIdx.y * gridDim.x + blockIdx.x < 512u && (__builtin_amdgcn_s_getreg(6148) & 1u))   // HW_ID.WAVE_ID: the wave slot on its SIMD
-      for (int i = 0; i < h.stagger; i++) __builtin_amdgcn_s_sleep(127);
-  }
   float s_, un0;
   wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &un0);
   // ---- output transform: stream the AL columns of the position grid (AL float4 {a c0, b c0, a c1, b c1} each), column pass, accumulate the row pass
@@ -297,12 +288,12 @@ __global__ __launch_bounds__(256, 2) void wino_oi_h2c_kernel(WinoH2Args h) {
       for (int e = 0; e < 4; e++) Y[k][l][e] = 0.f;
   float4 m[2][AL];
 #pragma unroll
-  for (int xi = 0; xi < AL; xi++) m[0][xi] = h2_ldf4(mr, m_lane, (DBG & 1) ? 0u : (unsigned)(xi * AL) * m_pos);
+  for (int xi = 0; xi < AL; xi++) m[0][xi] = h2_ldf4(mr, m_lane, (unsigned)(xi * AL) * m_pos);
 #pragma unroll
   for (int nu = 0; nu < AL; nu++) {
     if (nu + 1 < AL) {
 #pragma unroll
-      for (int xi = 0; xi < AL; xi++) m[(nu + 1) & 1][xi] = h2_ldf4(mr, m_lane, (DBG & 1) ? 0u : (unsigned)(xi * AL + nu + 1) * m_pos);
+      for (int xi = 0; xi < AL; xi++) m[(nu + 1) & 1][xi] = h2_ldf4(mr, m_lane, (unsigned)(xi * AL + nu + 1) * m_pos);
     }
     float mm[4][AL], oo[4][TM];
 #pragma unroll
@@ -333,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void wino_oi_h2c_kernel(WinoH2Args h) {
 #pragma unroll
     for (int l = 0; l < TM; l++) {
       const int ww = TM * tx + l, wc = ww < a.W ? ww : a.W - 1;
-      const char* e = ep + ((DBG & 2) ? (size_t)0 : (size_t)(hc * a.W + wc) * e_pix) + e_lane;
+      const char* e = ep + (size_t)(hc * a.W + wc) * e_pix + e_lane;
       const float4 E0 = *reinterpret_cast<const float4*>(e), E1 = *reinterpret_cast<const float4*>(e + 16);
       float va = (Y[k][l][0] * un0) * E0.x + E0.y, vb = (Y[k][l][1] * un0) * E0.z + E0.w;
       float vc = (Y[k][l][2] * un0) * E1.x + E1.y, vd = (Y[k][l][3] * un0) * E1.z + E1.w;
@@ -409,196 +400,10 @@ __global__ __launch_bounds__(256, 2) void wino_oi_h2c_kernel(WinoH2Args h) {
       const unsigned e0 = s16[0], e1 = s16[1];
       const auto s32 = __builtin_amdgcn_permlane32_swap(e0, e1, false, false);   // rows t0, t1 | rows t2, t3
       const unsigned w0 = s32[0], w1 = s32[1];
-      if (!(DBG & 4) || sb == 12345.f) {
-        __builtin_amdgcn_raw_buffer_store_b32(w0, vr, v_lane, (unsigned)(i * AL + j) * v_pos, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(w1, vr, v_lane + 256u, (unsigned)(i * AL + j) * v_pos, 0);
-      }
+      __builtin_amdgcn_raw_buffer_store_b32(w0, vr, v_lane, (unsigned)(i * AL + j) * v_pos, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(w1, vr, v_lane + 256u, (unsigned)(i * AL + j) * v_pos, 0);
     }
   }
-}
-
-// Row i of Bt . d (one output of the input transform's 1-D pass; i is a constant after unrolling) — the same expressions as wino_btv
-template <int TM> __device__ __forceinline__ float wino_bt_row(int i, const float* d);
-template <> __device__ __forceinline__ float wino_bt_row<5>(int i, const float* d) {
-  switch (i) {
-    case 0: return -0.5f * d[0] + 0.25f * d[1] + 2.5f * d[2] - 1.25f * d[3] - 2.f * d[4] + d[5];
-    case 1: return 0.5f * d[1] + 0.25f * d[2] - 2.25f * d[3] - d[4] + d[5];
-    case 2: return -0.5f * d[1] + 0.75f * d[2] + 1.75f * d[3] - 3.f * d[4] + d[5];
-    case 3: return d[1] + 1.5f * d[2] - 2.f * d[3] - 1.5f * d[4] + d[5];
-    case 4: return -d[1] + 2.5f * (d[2] - d[4]) + d[5];
-    case 5: return 0.25f * d[1] - 1.25f * d[3] + d[5];
-    default: return -0.5f * d[1] + 0.25f * d[2] + 2.5f * d[3] - 1.25f * d[4] - 2.f * d[5] + d[6];
-  }
-}
-template <> __device__ __forceinline__ float wino_bt_row<4>(int i, const float* d) {
-  switch (i) {
-    case 0: return 4.f * d[0] - 5.f * d[2] + d[4];
-    case 1: return -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
-    case 2: return 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
-    case 3: return -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
-    case 4: return 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-    default: return 4.f * d[1] - 5.f * d[3] + d[5];
-  }
-}
-
-// rows [I0, I1) of the input transform of one (tile, channel pair) from the LDS board, scaled, split and stored as V2c (wave = four tile rows)
-template <int TM, int I0, int I1>
-__device__ __forceinline__ void wino_oi_in_rows(const float* yl, int H, int W, int ty, int tx, float sv, __amdgpu_buffer_rsrc_t vr, unsigned v_lane, unsigned v_pos) {
-  constexpr int AL = TM + 2, NR = I1 - I0;
-  float tmx[NR][AL], tmy[NR][AL];
-#pragma unroll
-  for (int j = 0; j < AL; j++) {
-    const int ww = TM * tx + j - 1;
-    const bool okx = ww >= 0 && ww < W;
-    const int wc = ww < 0 ? 0 : (ww < W ? ww : W - 1);
-    float dx[AL], dy[AL];
-#pragma unroll
-    for (int i = 0; i < AL; i++) {
-      const int hh = TM * ty + i - 1;
-      const bool ok = okx && hh >= 0 && hh < H;
-      const int hc = hh < 0 ? 0 : (hh < H ? hh : H - 1);
-      const float2 d = *reinterpret_cast<const float2*>(yl + (size_t)(hc * W + wc) * 32);
-      dx[i] = ok ? d.x : 0.f; dy[i] = ok ? d.y : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < NR; r++) { tmx[r][j] = wino_bt_row<TM>(I0 + r, dx); tmy[r][j] = wino_bt_row<TM>(I0 + r, dy); }
-  }
-#pragma unroll
-  for (int r = 0; r < NR; r++) {
-    float ox[AL], oy[AL];
-    wino_btv<TM>(tmx[r], ox);
-    wino_btv<TM>(tmy[r], oy);
-#pragma unroll
-    for (int j = 0; j < AL; j++) {
-      unsigned lo;
-      const unsigned hi = wino_h2_pack(ox[j] * sv, oy[j] * sv, &lo);
-      const auto s16 = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);   // [hi t0, lo t0, hi t2, lo t2], [hi t1, lo t1, hi t3, lo t3]
-      const unsigned e0 = s16[0], e1 = s16[1];
-      const auto s32 = __builtin_amdgcn_permlane32_swap(e0, e1, false, false);   // rows t0, t1 | rows t2, t3
-      const unsigned w0 = s32[0], w1 = s32[1];
-      __builtin_amdgcn_raw_buffer_store_b32(w0, vr, v_lane, (unsigned)((I0 + r) * AL + j) * v_pos, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(w1, vr, v_lane + 256u, (unsigned)((I0 + r) * AL + j) * v_pos, 0);
-    }
-  }
-}
-
-// The same kernel with twice the waves: 512 threads, thread = (tile row tid / 32, channel tid % 32) in the output transform — 8-byte
-// {a, b} loads, 25 x 2 accumulators, three position columns (21 loads = 10.5 KB per wave) in flight, 16 waves per CU — and
-// (half tid / 256, tile row, channel pair) in the input transform (each half the rows [I0, I1) of Bt . d).  The 256-thread form keeps
-// 7-14 KB per wave x 8 waves in flight and measured 3.35 TB/s (0.367 ms against 0.359 for the two separate kernels).
-template <int TM, bool LAST, int PF>
-__global__ __launch_bounds__(512, 4) void wino_oi2_h2c_kernel(WinoH2Args h) {
-  using WT = WinoT<TM>;
-  constexpr int AL = WT::AL;
-  const WinoArgs& a = h.w;
-  extern __shared__ __attribute__((aligned(16))) float ys[];
-  __shared__ float s_scale[16];
-  const int tid = threadIdx.x, tl = tid >> 5, ch = tid & 31, lane = tid & 63;
-  const int s = blockIdx.y, NS = a.C >> 5, HW = a.H * a.W;
-  const int t0 = blockIdx.x * 16;
-  const int t = t0 + tl;
-  const bool live = t < a.T;
-  const int tc = live ? t : a.T - 1;
-  const int b = tc / a.TPB, tt = tc - b * a.TPB;
-  const int ty = tt / a.ntx, tx = tt - ty * a.ntx;
-  const int bl = tl / a.TPB;
-  float s_, un0;
-  wino_h2_scales(h.amax_in[b], WT::VSHIFT, &s_, &un0);
-  const __amdgpu_buffer_rsrc_t mr = h2_rsrc(a.Mb + ((size_t)(t0 >> 7) * h.npos * NS + s) * 8192);
-  const unsigned m_lane = (unsigned)(((tc & 127) * 64 + ch * 2) * 4);
-  const unsigned m_pos = (unsigned)NS * 32768u;
-  float Y[TM][TM][2];
-#pragma unroll
-  for (int k = 0; k < TM; k++)
-#pragma unroll
-    for (int l = 0; l < TM; l++) { Y[k][l][0] = 0.f; Y[k][l][1] = 0.f; }
-  float2 m[PF][AL];
-#pragma unroll
-  for (int p = 0; p < PF; p++)
-#pragma unroll
-    for (int xi = 0; xi < AL; xi++) m[p][xi] = h2_ldf2(mr, m_lane, (unsigned)(xi * AL + p) * m_pos);
-#pragma unroll
-  for (int nu = 0; nu < AL; nu++) {
-    float mm[2][AL], oo[2][TM];
-#pragma unroll
-    for (int xi = 0; xi < AL; xi++) { const float2 v = m[nu % PF][xi]; mm[0][xi] = v.x; mm[1][xi] = v.y; }
-    if (nu + PF < AL) {
-#pragma unroll
-      for (int xi = 0; xi < AL; xi++) m[nu % PF][xi] = h2_ldf2(mr, m_lane, (unsigned)(xi * AL + nu + PF) * m_pos);
-    }
-#pragma unroll
-    for (int e = 0; e < 2; e++) wino_atv<TM>(mm[e], oo[e]);
-#pragma unroll
-    for (int k = 0; k < TM; k++)
-#pragma unroll
-      for (int e = 0; e < 2; e++) {
-        float yl[TM];
-#pragma unroll
-        for (int l = 0; l < TM; l++) yl[l] = Y[k][l][e];
-        wino_at_acc<TM>(nu, yl, oo[e][k]);
-#pragma unroll
-        for (int l = 0; l < TM; l++) Y[k][l][e] = yl[l];
-      }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const char* ep = reinterpret_cast<const char*>(a.ep);
-  const unsigned e_lane = (unsigned)(32 * s + ch) * 16u, e_pix = (unsigned)a.Cout_p * 16u;
-  float mx = 0.f;
-  float* yb = LAST ? a.y + (size_t)b * a.Hp * a.Wp * a.Cout_p + 32 * s + ch : nullptr;
-#pragma unroll
-  for (int k = 0; k < TM; k++) {
-    const int hh = TM * ty + k, hc = hh < a.H ? hh : a.H - 1;
-#pragma unroll
-    for (int l = 0; l < TM; l++) {
-      const int ww = TM * tx + l, wc = ww < a.W ? ww : a.W - 1;
-      const float4 E0 = *reinterpret_cast<const float4*>(ep + (size_t)(hc * a.W + wc) * e_pix + e_lane);
-      float va = (Y[k][l][0] * un0) * E0.x + E0.y, vb = (Y[k][l][1] * un0) * E0.z + E0.w;
-      va = va > 0.f ? va : 0.f; vb = vb > 0.f ? vb : 0.f;
-      const float y0 = va + vb;
-      if (live && hh < a.H && ww < a.W) {
-        if (LAST) yb[((size_t)(hh + 1) * a.Wp + (ww + 1)) * a.Cout_p] = y0;
-        else ys[((size_t)bl * HW + hh * a.W + ww) * 32 + ch] = y0;
-        mx = fmaxf(mx, y0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (LAST) return;
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  if (ch == 0 && live) h.wm_out[(size_t)t * NS + s] = mx;
-  float ax;
-  if (h.amax_true) ax = __uint_as_float(reinterpret_cast<const unsigned*>(h.amax_true)[b]);
-  else {
-    const int wmpb = a.TPB * NS;
-    const float* wp = h.wm_prev + (size_t)b * wmpb;
-    ax = 0.f;
-    for (int i = ch; i < wmpb; i += 32) ax = fmaxf(ax, wp[i]);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) ax = fmaxf(ax, __shfl_xor(ax, o, 64));
-  }
-  const float bound = h.g1 * ax + h.g0;
-  const unsigned bbits = __float_as_uint(bound);
-  if (s == 0 && tt == 0 && ch == 0 && live) h.amax_next[b] = bbits;
-  float sb, inv_;
-  wino_h2_scales(bbits, WT::VSHIFT, &sb, &inv_);
-  if (ch == 0) s_scale[tl] = live ? sb : 0.f;              // rows past the last tile: zeros
-  __syncthreads();
-  // ---- input transform: (half, tile row, channel pair)
-  const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
-  const int tl3 = (tid >> 4) & 15, pr = tid & 15;
-  const int t3 = t0 + tl3;
-  const int t3c = t3 < a.T ? t3 : a.T - 1;
-  const int b3 = t3c / a.TPB, tt3 = t3c - b3 * a.TPB;
-  const int ty3 = tt3 / a.ntx, tx3 = tt3 - ty3 * a.ntx;
-  const float sv = s_scale[tl3];
-  const float* yl = ys + (size_t)(tl3 / a.TPB) * HW * 32 + 2 * pr;
-  const __amdgpu_buffer_rsrc_t vr = h2_rsrc(reinterpret_cast<const char*>(a.V) + ((size_t)(t0 >> 7) * h.npos * NS + s) * 16384);
-  const unsigned v_lane = (unsigned)(((t0 & 127) + ((tid >> 6) & 3) * 4) * 128 + lane * 4);
-  const unsigned v_pos = (unsigned)NS * 16384u;
-  constexpr int IH = (AL + 1) / 2;
-  if (half == 0) wino_oi_in_rows<TM, 0, IH>(yl, a.H, a.W, ty3, tx3, sv, vr, v_lane, v_pos);
-  else wino_oi_in_rows<TM, IH, AL>(yl, a.H, a.W, ty3, tx3, sv, vr, v_lane, v_pos);
 }
 
 // ---- the pipelined form of the same kernel --------------------------------------------------------------------------------------
@@ -920,21 +725,9 @@ static void wino_h2c_gemm(agz_ctx* ctx, WinoH2Args& h, hipStream_t st) {
   wino_h2c_geometry(h);
   ProfScopeOn ps(ctx, AGZ_PROF_WINO_GEMM, st == ctx->stream);
   const dim3 g(h.npos * h.w.n_mtiles * (h.w.Ntot >> 8));
-  if (h.stagger >= 100 && (h.w.C >> 5) == 8) {   // measurement variants (agz_net_set_wino_h2_form: form >> 8 = 100 + DBG)
-    switch (h.stagger - 100) {
-      case 1: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 1>), g, dim3(256), 0, st, h); return;
-      case 2: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 2>), g, dim3(256), 0, st, h); return;
-      case 3: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 3>), g, dim3(256), 0, st, h); return;
-      case 4: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 4>), g, dim3(256), 0, st, h); return;
-      case 5: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 5>), g, dim3(256), 0, st, h); return;
-      case 6: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 6>), g, dim3(256), 0, st, h); return;
-      case 7: hipLaunchKernelGGL((wino_gemm_h2c_kernel<8, 2, 7>), g, dim3(256), 0, st, h); return;
-      default: break;
-    }
-  }
   // (the DMA form addresses V and U2c through buffer descriptors: 31-bit byte offsets)
   const bool dma_ok = wino_h2_rows(h.npos, (size_t)h.w.T) * h.w.C * 4 < ((size_t)1 << 31) && (size_t)h.npos * h.w.C * h.w.Ntot * 4 < ((size_t)1 << 31);
-  if (h.stagger != 99 && dma_ok) {   // (measurement hook: form >> 8 == 99 keeps the register-staged kernel)
+  if (dma_ok) {
     switch (h.w.C >> 5) {
       case 4: hipLaunchKernelGGL((wino_gemm_h2g_kernel<4>), g, dim3(256), 0, st, h); return;
       case 8: hipLaunchKernelGGL((wino_gemm_h2g_kernel<8>), g, dim3(256), 0, st, h); return;
@@ -949,7 +742,8 @@ static void wino_h2c_gemm(agz_ctx* ctx, WinoH2Args& h, hipStream_t st) {
     default: hipLaunchKernelGGL((wino_gemm_h2c_kernel<16, 2>), g, dim3(256), 0, st, h); break;
   }
 }
-static void wino_h2c_oi(agz_ctx* ctx, WinoH2Args& h, bool last, hipStream_t st, int variant = 2) {
+// variant 4: the pipelined kernel (default); 1: the plain one (A/B hook; also the last block, whose y goes to HBM, and tensors past 2 GB)
+static void wino_h2c_oi(agz_ctx* ctx, WinoH2Args& h, bool last, hipStream_t st, int variant = 4) {
   wino_h2c_geometry(h);
   ProfScopeOn ps(ctx, AGZ_PROF_WINO_OUT, st == ctx->stream);
   const WinoArgs& a = h.w;
@@ -970,32 +764,6 @@ static void wino_h2c_oi(agz_ctx* ctx, WinoH2Args& h, bool last, hipStream_t st, 
     if (h.tm == 5) hipLaunchKernelGGL((wino_oip_h2c_kernel<5>), gp, dim3(256), shp, st, h);
     else hipLaunchKernelGGL((wino_oip_h2c_kernel<4>), gp, dim3(256), shp, st, h);
     return;
-  }
-  if (variant == 4) variant = 1;   // the last block: y to HBM
-  if (variant >= 2 && variant < 16) {
-#define AGZ_OI2(TM_, LAST_, PF_) hipLaunchKernelGGL((wino_oi2_h2c_kernel<TM_, LAST_, PF_>), g, dim3(512), shm, st, h)
-    if (variant == 2) {
-      if (h.tm == 5) { if (last) AGZ_OI2(5, true, 3); else AGZ_OI2(5, false, 3); }
-      else { if (last) AGZ_OI2(4, true, 3); else AGZ_OI2(4, false, 3); }
-    } else {
-      if (h.tm == 5) { if (last) AGZ_OI2(5, true, 2); else AGZ_OI2(5, false, 2); }
-      else { if (last) AGZ_OI2(4, true, 2); else AGZ_OI2(4, false, 2); }
-    }
-#undef AGZ_OI2
-    return;
-  }
-  if (variant >= 16 && h.tm == 5 && !last) {   // measurement variants of the 256-thread kernel
-    switch (variant - 16) {
-      case 1: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 1>), g, dim3(256), shm, st, h); return;
-      case 2: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 2>), g, dim3(256), shm, st, h); return;
-      case 4: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 4>), g, dim3(256), shm, st, h); return;
-      case 5: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 5>), g, dim3(256), shm, st, h); return;
-      case 3: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 3>), g, dim3(256), shm, st, h); return;
-      case 6: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 6>), g, dim3(256), shm, st, h); return;
-      case 7: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 7>), g, dim3(256), shm, st, h); return;
-      case 8: hipLaunchKernelGGL((wino_oi_h2c_kernel<5, false, 8>), g, dim3(256), shm, st, h); return;
-      default: break;
-    }
   }
   if (h.tm == 5) {
     if (last) hipLaunchKernelGGL((wino_oi_h2c_kernel<5, true>), g, dim3(256), shm, st, h);

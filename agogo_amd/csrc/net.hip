@@ -1128,11 +1128,9 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         hh.wm_prev = d_wave_max + ((size_t)((l + 1) & 1) * B + b0) * wmb;
         hh.wm_out = d_wave_max + ((size_t)(l & 1) * B + b0) * wmb;
         hh.g1 = wino_g1[l]; hh.g0 = wino_g0[l];
-        hh.stagger = form_want > 0 ? form_want >> 8 : 0;
         if (l == 0) agz::wino_h2c_in(ctx, hh, st);
         agz::wino_h2c_gemm(ctx, hh, st);
-        hh.stagger = form_want > 0 ? form_want >> 8 : 0;
-        agz::wino_h2c_oi(ctx, hh, last, st, form_want >= 1 ? (form_want & 0xff) : 4);   // (A/B hook: form 1 = the 256-thread float4 kernel, 2 / 3 = 512 threads, 3 / 2 columns ahead)
+        agz::wino_h2c_oi(ctx, hh, last, st, form_want == 1 ? 1 : 4);   // (A/B hook: form 1 = the plain out->in kernel)
       }
       if (last) std::swap(cur, nxt);
     }
@@ -1635,7 +1633,7 @@ int agz_wino_h2_tile(int H, int W) { return agz::wino_h2_pick_tm(H, W); }
 
 int agz_net_set_wino_h2_form(agz_net* n, int form) {
   AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_wino_h2_form: null net");
-  AGZ_REQUIRE(form >= -1 && form <= 0xffff, AGZ_E_INVALID, "agz_net_set_wino_h2_form: form %d (want -1, 0 or 1)", form);
+  AGZ_REQUIRE(form >= -1 && form <= 2, AGZ_E_INVALID, "agz_net_set_wino_h2_form: form %d (want -1, 0 or 1)", form);
   n->wino_form = form;
   return AGZ_OK;
 }

@@ -5,6 +5,7 @@
 // Errors: the reference returns `error` or panics; here agz::Error is thrown with agz_last_error().
 #pragma once
 #include <cstdint>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -144,6 +145,11 @@ struct Arena {
     agz::check(agz_arena_set_inferencer(h, 0, a ? AGZ_INF_NET : AGZ_INF_DUMMY, a ? a->h : nullptr), "Agent A");
     agz::check(agz_arena_set_inferencer(h, 1, b ? AGZ_INF_NET : AGZ_INF_DUMMY, b ? b->h : nullptr), "Agent B");
   }
+  // test hook: a synthetic inferencer kind per agent (AGZ_INF_NET keeps the network)
+  void SetAgentKinds(int ka, dual::Dual* a, int kb, dual::Dual* b) {
+    agz::check(agz_arena_set_inferencer(h, 0, ka, ka == AGZ_INF_NET ? a->h : nullptr), "Agent A");
+    agz::check(agz_arena_set_inferencer(h, 1, kb, kb == AGZ_INF_NET ? b->h : nullptr), "Agent B");
+  }
   // Tournament use (Agent.Search against an outside opponent, agent.go:76-81): Search() decides and plays one move for
   // every unfinished game; Opponent() applies the outside player's replies (State.Check'ed on the device).
   void Search(int budget) {
@@ -200,7 +206,25 @@ struct Config {
   int MaxExamples = 0;
   int Encoder = AGZ_ENC_TWOPLANE;
   bool AugmentRotate = false;  // Augmenter (datatypes.go:24): the RotateBoard-based rotation augmenter, or none
-  int ComputeMode = AGZ_COMPUTE_F32_MFMA;  // build extension: AGZ_COMPUTE_BF16X3 (inference + training convolutions) or AGZ_COMPUTE_WINO (inference; training then uses BF16X3)
+  // build extension: the arithmetic of the inference networks (agz_net_set_compute_mode) and, through it, of the trainer: AGZ_COMPUTE_F32_MFMA
+  // (default), AGZ_COMPUTE_BF16X3, AGZ_COMPUTE_WINO (training then uses BF16X3), AGZ_COMPUTE_WINO_H2 / AGZ_COMPUTE_AUTO (the measured mode;
+  // training takes the trainer's AGZ_COMPUTE_WINO_H2)
+  int ComputeMode = AGZ_COMPUTE_F32_MFMA;
+  // test hooks (not in the reference): inferencers of the self-play games once the dummy is no longer in use, and of the evaluation
+  // games — AGZ_INF_NET plays the networks as the reference does; the synthetic kinds make an epoch's games independent of fp32 rounding
+  // in a network evaluation (tests/test_learn_parity_gpu.py compares the epoch log with oracle/learn.hpp)
+  int SelfPlayInferencer[2] = {AGZ_INF_NET, AGZ_INF_NET};
+  int EvalInferencer[2] = {AGZ_INF_NET, AGZ_INF_NET};
+};
+// Statistics (statistics.go:10-38): per network — keyed by its identity, the reference formats the pointer — the A side's Wins / Loss /
+// Draw of every epoch in which it was A
+struct Statistics {
+  std::vector<int> Creation;
+  std::map<int, std::vector<float>> Wins, Losses, Draws;
+  void update(int a_id, float wins, float loss, float draw) {
+    if (!Wins.count(a_id)) Creation.push_back(a_id);
+    Wins[a_id].push_back(wins); Losses[a_id].push_back(loss); Draws[a_id].push_back(draw);
+  }
 };
 struct GameSpec { int kind, m, n, k; float komi; };
 
@@ -214,8 +238,10 @@ struct AZ {
   std::unique_ptr<dual::Dual> infA, infB;     // SwitchToInference products (agent.go:42-57)
   bool useDummy = true;
   uint64_t seed;
-  struct EpochStats { int epoch; size_t examples; int batches; float cost; long a_wins, b_wins, draws; bool killedA; };
+  struct EpochStats { int epoch; size_t examples; int batches; float cost; long a_wins, b_wins, draws; bool killedA; int a_id; };
   std::vector<EpochStats> log;
+  Statistics stats;
+  int a_id = 1, b_id = 2, next_id = 3;         // network identities (the reference's %p of Agent.NN)
 
   AZ(agz::Ctx& c, GameSpec g, const Config& cf, uint64_t seed_ = 1337) : ctx(c), game(g), conf(cf), seed(seed_) {  // agogo.go:41-72
     if (!cf.NNConf.IsValid()) throw agz::Error("NNConf is not valid. Unable to proceed");
@@ -232,10 +258,12 @@ struct AZ {
       agz::check(agz_net_set_compute_mode(infA->h, conf.ComputeMode), "compute mode");
       agz::check(agz_net_set_compute_mode(infB->h, conf.ComputeMode), "compute mode");
       if (conf.ComputeMode == AGZ_COMPUTE_BF16X3 || conf.ComputeMode == AGZ_COMPUTE_WINO) B->SetComputeMode(AGZ_COMPUTE_BF16X3);
+      else if (conf.ComputeMode == AGZ_COMPUTE_WINO_H2 || conf.ComputeMode == AGZ_COMPUTE_AUTO) B->SetComputeMode(AGZ_COMPUTE_WINO_H2);
       Examples ex(ctx, conf.NNConf.Features, conf.NNConf.Height, conf.NNConf.Width, conf.NNConf.ActionSpace);
       {
         Arena sp(ctx, game.kind, game.m, game.n, game.k, game.komi, conf.Encoder, conf.MCTSConf, episodes, seed + 1000 * epoch);
-        if (epoch == 0 && useDummy) sp.SetAgents(nullptr, nullptr); else sp.SetAgents(infA.get(), infB.get());
+        if (epoch == 0 && useDummy) sp.SetAgents(nullptr, nullptr);
+        else sp.SetAgentKinds(conf.SelfPlayInferencer[0], infA.get(), conf.SelfPlayInferencer[1], infB.get());
         sp.PlayOnDevice(true);                                             // episodes x SelfPlay(), agogo.go:110-114
         ex.Append(sp);                                                     // device to device, episode after episode
       }
@@ -251,7 +279,7 @@ struct AZ {
       B->SwitchToInference(*infB);                                         // agogo.go:137
       {
         Arena ev(ctx, game.kind, game.m, game.n, game.k, game.komi, conf.Encoder, conf.MCTSConf, arenaGames, seed + 1000 * epoch + 500);
-        ev.SetAgents(infA.get(), infB.get());
+        ev.SetAgentKinds(conf.EvalInferencer[0], infA.get(), conf.EvalInferencer[1], infB.get());
         ev.Play(false);                                                    // agogo.go:144-148
         int64_t aw = 0, bw = 0, dr = 0;
         agz::check(agz_arena_get_results(ev.h, &aw, &bw, &dr), "results");
@@ -259,9 +287,14 @@ struct AZ {
       }
       st.killedA = false;
       if (st.b_wins + st.a_wins > 0 && (float)st.b_wins / (float)(st.b_wins + st.a_wins) > (float)conf.UpdateThreshold) {  // agogo.go:155
-        A = std::move(B);                                                  // a.A.NN = a.B.NN
+        A = std::move(B); a_id = b_id;                                     // a.A.NN = a.B.NN
         st.killedA = true;
       }
+      // a.update(a.A) (agogo.go:166, statistics.go:27-38): the A agent's wins / losses / draws of the evaluation games, under the name of
+      // the network A holds NOW (B's, when A was killed)
+      stats.update(a_id, (float)st.a_wins, (float)st.b_wins, (float)st.draws);
+      st.a_id = a_id;
+      b_id = next_id++;
       B.reset(new dual::Trainable(ctx, conf.NNConf));                      // newB: a fresh random net (arena.go:205-224)
       B->Init(seed * 3 + 100 + epoch);
       useDummy = useDummy && false;                                        // the dummy is only used in epoch 0 (agogo.go:83-87)

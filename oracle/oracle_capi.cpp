@@ -8,6 +8,7 @@
 #include "arena.hpp"
 #include "train.hpp"
 #include "examples.hpp"
+#include "learn.hpp"
 
 using namespace oracle;
 
@@ -477,4 +478,28 @@ int orc_exset_prepare(void* h, int BatchSize, int maxExamples, uint64_t seed, fl
   return batches;
 }
 
+
+// ---- AZ.Learn restatement (oracle/learn.hpp).  out: per epoch 12 floats {epoch, examples, batches, cost, a_wins, a_loss, a_draw,
+// b_wins, b_loss, b_draw, killedA, a_id}; returns the epochs completed (fewer than iters: "batches is nil"), -1 on a bad config.
+int orc_learn_run(int kind, int m, int n, int k, double komi, int enc, int K, int L, int FC, int BatchSize, int F, int A,
+                  float PUCT, int Budget, int RandomCount, float threshold, int maxExamples, int augment,
+                  int sp_inf0, int sp_inf1, int ev_inf0, int ev_inf1, uint64_t seed,
+                  int iters, int episodes, int nniters, int arenaGames, float* out) {
+  LearnConfig c;
+  c.kind = kind; c.m = m; c.n = n; c.k = k; c.komi = komi; c.enc = enc;
+  c.nn = mkconf(K, L, FC, BatchSize, n, m, F, A, 1e-5f);
+  c.mc.PUCT = PUCT; c.mc.M = m; c.mc.N = n; c.mc.Budget = Budget; c.mc.RandomCount = RandomCount;
+  c.UpdateThreshold = threshold; c.MaxExamples = maxExamples; c.AugmentRotate = augment != 0;
+  c.sp_inf[0] = sp_inf0; c.sp_inf[1] = sp_inf1; c.eval_inf[0] = ev_inf0; c.eval_inf[1] = ev_inf1; c.seed = seed;
+  if (!c.nn.IsValid() || !c.mc.IsValid() || !learn_make_game(kind, m, n, k, komi)) return -1;
+  Learner lr(c);
+  lr.Learn(iters, episodes, nniters, arenaGames);
+  for (size_t e = 0; e < lr.log.size(); e++) {
+    const EpochLog& g = lr.log[e];
+    float* o = out + 12 * e;
+    o[0] = (float)g.epoch; o[1] = (float)g.examples; o[2] = (float)g.batches; o[3] = g.cost; o[4] = g.a_wins; o[5] = g.a_loss; o[6] = g.a_draw;
+    o[7] = g.b_wins; o[8] = g.b_loss; o[9] = g.b_draw; o[10] = g.killedA ? 1.f : 0.f; o[11] = (float)g.a_id;
+  }
+  return (int)lr.log.size();
+}
 }  // extern "C"

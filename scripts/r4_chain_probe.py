@@ -29,7 +29,7 @@ for (K, L, S, B) in ((128, 3, 9, 37), (256, 3, 19, 70), (256, 2, 19, 16), (128, 
     gnet.set_compute_mode(A.capi.COMPUTE_WINO_H2 | A.capi.COMPUTE_FORCE)
     gnet.set_wino_h2_form(0)
     p0, v0 = gnet.infer(x)
-    gnet.set_wino_h2_form(int(os.environ.get("PROBE_FORM", "4")))
+    gnet.set_wino_h2_form(int(os.environ.get("PROBE_FORM", "-1")))
     p1, v1 = gnet.infer(x)
     p1b, v1b = gnet.infer(x)
     nb = min(B, 6)
@@ -64,7 +64,7 @@ pol = torch.empty((B, S * S + 1), device="cuda")
 val = torch.empty((B,), device="cuda")
 torch.cuda.synchronize()
 res = {}
-for form in (0, 25348, 4):
+for form in (0, 1, -1):
     net.set_wino_h2_form(form)
     for queues in (1, 2):
         net.set_tower_queues(queues)

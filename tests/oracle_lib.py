@@ -95,6 +95,8 @@ def lib():
     sig("orc_exset_augment_rotate", i32, vp)
     sig("orc_exset_get", None, vp, pf, pf, pf)
     sig("orc_exset_prepare", i32, vp, i32, i32, u64, pf, pf, pf)
+    sig("orc_learn_run", i32, i32, i32, i32, i32, f64, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, f32, i32, i32, i32, i32, i32, i32, u64,
+        i32, i32, i32, i32, pf)
     sig("orc_train_new", vp, i32, i32, i32, i32, i32, i32, i32, i32, f32)
     sig("orc_train_free", None, vp)
     sig("orc_train_num_params", i32, vp)
@@ -562,3 +564,15 @@ class ExampleSet:
         v = np.zeros(max(rows, 1), np.float32)
         batches = lib().orc_exset_prepare(self.h, BatchSize, maxExamples, seed, _pf(x), _pf(p), _pf(v))
         return batches, x[:rows], p[:rows], v[:rows]
+
+
+def learn_run(kind, m, n, k, komi, enc, K, L, FC, BatchSize, F, A, PUCT, Budget, threshold, seed, iters, episodes, nniters, arenaGames,
+              sp_inf=(0, 0), eval_inf=(0, 0), RandomCount=0, maxExamples=0, augment=False):
+    """AZ.Learn restated (oracle/learn.hpp): list of per-epoch dicts; fewer than iters epochs = the reference's "batches is nil" error"""
+    out = np.zeros((iters, 12), np.float32)
+    r = lib().orc_learn_run(kind, m, n, k, float(komi), enc, K, L, FC, BatchSize, F, A, float(PUCT), Budget, RandomCount, float(threshold),
+                            maxExamples, int(augment), sp_inf[0], sp_inf[1], eval_inf[0], eval_inf[1], seed, iters, episodes, nniters,
+                            arenaGames, _pf(out))
+    assert r >= 0, "orc_learn_run: invalid configuration"
+    keys = ("epoch", "examples", "batches", "cost", "a_wins", "a_loss", "a_draw", "b_wins", "b_loss", "b_draw", "killedA", "a_id")
+    return [dict(zip(keys, (float(v) if k_ == "cost" else int(v) for k_, v in zip(keys, row)))) for row in out[:r]]
