@@ -177,6 +177,7 @@ def lib():
     sig("agz_wino_stages", i32, vp, pf, pf, i32, i32, i32, i32, i32, pf, pf)
     sig("agz_wino_h2_tile", i32, i32, i32)
     sig("agz_net_set_wino_h2_form", i32, vp, i32)
+    sig("agz_wino_h2_chained", i32, i32, i32, i32)
     sig("agz_arena_random_moves", i32, vp, pi, u64)
     sig("agz_arena_set_state", i32, vp, i32, C.POINTER(State))
     sig("agz_arena_examples_labelled_dev", i32, vp, pvp)
@@ -870,6 +871,11 @@ class Examples:
         v = np.zeros(rows, np.float32)
         _check(lib().agz_examples_get_tensors(self.h, _pf(x), _pf(p), _pf(v)), "agz_examples_get_tensors")
         return x, p, v
+
+
+def wino_h2_chained(H, W, K):
+    """agz_debug.h: 1 when AGZ_COMPUTE_WINO_H2 takes the chained block on this shape"""
+    return int(lib().agz_wino_h2_chained(H, W, K))
 
 
 def wino_h2_tile(H, W):

@@ -1631,6 +1631,12 @@ int agz_net_commit(agz_net* n) {
 
 int agz_wino_h2_tile(int H, int W) { return agz::wino_h2_pick_tm(H, W); }
 
+int agz_wino_h2_chained(int H, int W, int K) {
+  static const int form_env = [] { const char* e = getenv("AGZ_WINO_H2_FORM"); return e ? atoi(e) : -1; }();
+  const int Kp = agz::round_up(K, 32);
+  return form_env != 0 && agz::wino_h2c_ok(H, W, agz::wino_h2_pick_tm(H, W), Kp) ? 1 : 0;
+}
+
 int agz_net_set_wino_h2_form(agz_net* n, int form) {
   AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_wino_h2_form: null net");
   AGZ_REQUIRE(form >= -1 && form <= 2, AGZ_E_INVALID, "agz_net_set_wino_h2_form: form %d (want -1, 0 or 1)", form);

@@ -114,7 +114,7 @@ def _oracle_selfplay_leg(O, T, kind, m, n, k, komi, enc, net, budget, moves_per_
             "sims": playouts, "moves": sum(moves), "games_finished": sum(done), "games_per_s": (sum(done) / dt) if complete else None}
 
 
-def cpu_baseline(size, K, L, budget_s=30.0, max_threads=None):
+def cpu_baseline(size, K, L, budget_s=30.0, max_threads=64):
     """The oracle (CPU restatement of the reference algorithm: per-leaf inference, sequential pipeline) timed on the box's host
     cores, SURVEY 8(d) / BASELINE.md section 3: one independent game per thread (the way the reference would use its cores), threads
     = min(host cores, 64).  Legs, ~30 s in total:
@@ -129,7 +129,11 @@ def cpu_baseline(size, K, L, budget_s=30.0, max_threads=None):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     cores = os.cpu_count() or 2
-    T = max(1, min(max_threads, cores) if max_threads else cores)   # T = hardware_concurrency
+    # SURVEY 8(d) asks for T = hardware_concurrency.  Measured in round 4 on the GPU box (profiles/r04/cpu_baseline_all_cores.json): with all
+    # 256 host threads the memory-bound oracle is SLOWER in aggregate (g19_fair 2.8 sims/s against 5.4 at 64 threads, go9 138 against 245,
+    # c4 1.7 k against 3.2 k) and the legs take seven minutes — so the default stays min(cores, 64), the faster configuration, and
+    # --cpu-threads 0 runs every core
+    T = max(1, min(max_threads, cores) if max_threads else cores)
     legs = {}
     # --- ttt: complete games
     net = _oracle_net(O, 3, 3, 6, 3, 3, 2, 10)
@@ -179,8 +183,9 @@ def cpu_baseline(size, K, L, budget_s=30.0, max_threads=None):
             "sample": "oracle (C++ restatement, per-leaf inference), %d threads on the box's %d host cores, one game per thread; legs ttt / c4 / go9 / "
                       "g19_fair / g19_faithful, %.1f s in total; value = g19_fair (19x19, K=%d, %d blocks: %d sims in %.1f s)"
                       % (T, cores, total, K, L, legs["g19_fair"]["sims"], legs["g19_fair"]["seconds"]),
-            "method": "round 4: threads = every host core (round 3: min(host cores, 64); round 2: min(32, cores/2); round 1: min(32, cores)): "
-                      "aggregate values are not comparable across rounds, per_core_sims_per_s is the comparable figure",
+            "method": "threads = min(host cores, 64) as in round 3 (round 2: min(32, cores/2); round 1: min(32, cores)); every host core (256) was "
+                      "measured in round 4 and is slower in aggregate (g19_fair 2.8 sims/s, profiles/r04/cpu_baseline_all_cores.json); "
+                      "per_core_sims_per_s is the figure comparable across thread counts",
             "per_core_sims_per_s": legs["g19_fair"]["sims_per_s"] / T, "evals_per_s": legs["g19_fair"]["evals_per_s"],
             "host_cores": cores, **legs}
 
@@ -342,6 +347,7 @@ def main():
     ap.add_argument("--L", type=int, default=20)
     ap.add_argument("--budget", type=int, default=800, help="simulations per move")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=64, help="threads of the cpu_baseline legs (0 = every host core: slower in aggregate and ~7 minutes)")
     ap.add_argument("--no-games-leg", action="store_true", help="skip the measured games/s leg (config #2)")
     ap.add_argument("--two-nets", action="store_true", help="agents A and B hold different networks")
     ap.add_argument("--compute", choices=["wino_h2", "wino", "bf16x3", "f32", "fp16x2"], default="wino_h2",
@@ -610,12 +616,19 @@ def main():
             w_bytes = float(npos) * K * (2 * K) * (4 if args.compute == "wino_h2" else 6)   # the block's Winograd-domain weight image, read once
             gemm_bytes = 4.0 * (npos * tiles * K + npos * tiles * 2 * K) + w_bytes  # V read once + M written once + weights
             out_bytes = 4.0 * (npos * tiles * 2 * K + G * hw * K)       # M read + y written
+            # the chained block (conv_wino_h2c.hpp): the kernel counted under wino_out reads M(l) and writes V2(l+1) — y never leaves the
+            # chip between blocks; the input transform runs once per tower (block 0), the last block's output kernel writes y
+            chained = args.compute == "wino_h2" and capi.wino_h2_chained(S, S, K) == 1
+            if chained:
+                out_bytes = 4.0 * (npos * tiles * 2 * K + npos * tiles * K)
+            block_bytes = (gemm_bytes + out_bytes + (in_bytes + 4.0 * G * hw * K) / L) if chained else (in_bytes + gemm_bytes + out_bytes)
             def gbs(b, ms):
                 return (b / (ms * 1e-3) / 1e9) if ms else None
             wino_detail = {
                 "block_avg_ms": conv_ms, "block_direct_equivalent_tflops": conv_flops_launch / (conv_ms * 1e-3) / 1e12 if conv_ms else None,
                 "tile": wtm, "positions": npos, "tiles_per_launch": tiles,
-                "block_note": "one dual block = input transform + %d GEMMs + output transform/epilogue; direct-equivalent = the "
+                "block_note": "one dual block = %d GEMMs + (chained) the fused output-transform / epilogue / next block's input-transform kernel "
+                              "[three-kernel form: input transform + GEMMs + output transform]; direct-equivalent = the "
                               "FLOPs a direct 3x3 convolution would need for the same result (%.2fx the GEMM FLOPs here)"
                               % (npos, conv_flops_launch / flops_launch),
                 "wino_in": {"avg_ms": prof["wino_in"]["avg_ms"], "bound": "hbm", "algorithmic_bytes": in_bytes,
@@ -623,8 +636,9 @@ def main():
                 "wino_gemm": {"avg_ms": launch_ms, "bound": "hbm" if args.compute == "wino_h2" else "mfma", "flops": flops_launch,
                               "algorithmic_bytes": gemm_bytes, "achieved_GBs": gbs(gemm_bytes, launch_ms), "peak_GBs": HBM_PEAK_GBS,
                               "tflops": achieved, "mfma_frac": achieved / peak, "mfma_peak_tflops": peak},
-                "block_algorithmic_bytes": in_bytes + gemm_bytes + out_bytes,
-                "block_achieved_GBs": gbs(in_bytes + gemm_bytes + out_bytes, conv_ms),
+                "chained": chained,
+                "block_algorithmic_bytes": block_bytes,
+                "block_achieved_GBs": gbs(block_bytes, conv_ms),
                 "wino_out": {"avg_ms": prof["wino_out"]["avg_ms"], "bound": "hbm", "algorithmic_bytes": out_bytes,
                              "achieved_GBs": gbs(out_bytes, prof["wino_out"]["avg_ms"]), "peak_GBs": HBM_PEAK_GBS}}
         traffic = None
@@ -653,7 +667,7 @@ def main():
                    "bf16x3": "conv3x3_x3_kernel<DUAL> (fused dual-branch block, bf16x3)",
                    "fp16x2": "conv3x3_h2w_kernel (fused dual-branch block, fp16x2, 128x256 tile)",
                    "wino": "wino_gemm_kernel (36 transform-domain GEMMs of one dual block, bf16x3 products; 0.70 of the block's 1.09 ms)",
-                   "wino_h2": "wino_gemm_h2d_kernel<8,2,2> (the %d transform-domain GEMMs of one dual block, F(%dx%d,3x3), fp16x2 products, 128x256 tile, A operand fetched two steps ahead; the largest of the block's three kernels)" % (npos, wtm, wtm)}
+                   "wino_h2": "wino_gemm_h2g_kernel<8> (the %d transform-domain GEMMs of one dual block, F(%dx%d,3x3), fp16x2 products, 128x256 tile, operands DMA'd into LDS (buffer_load ... lds), three workgroups per CU; the larger of the chained block's two kernels)" % (npos, wtm, wtm)}
         notes = {"f32": "dense fp32 MFMA peak",
                  "bf16x3": ("algorithmic fp32-grade FLOPs against the dense bf16 MFMA peak / 6 (six bf16 MFMAs per product); the same "
                             "FLOPs are %.2fx the fp32-MFMA peak of 157.3; measured bare-MFMA ceiling under the power cap on random "
@@ -685,6 +699,11 @@ def main():
             "roofline": ({"bound": "hbm", "achieved": wino_detail["wino_gemm"]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": wino_detail["wino_gemm"]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                           "algorithmic_bytes_per_launch": wino_detail["wino_gemm"]["algorithmic_bytes"],
+                          # the whole dual block (all its kernels, one-queue HIP events around the block): VERDICT r3 item 2
+                          "block": {"algorithmic_bytes": wino_detail["block_algorithmic_bytes"], "avg_ms": wino_detail["block_avg_ms"],
+                                    "achieved": wino_detail["block_achieved_GBs"], "unit": "GB/s",
+                                    "frac": (wino_detail["block_achieved_GBs"] / HBM_PEAK_GBS) if wino_detail["block_achieved_GBs"] else None,
+                                    "kernels": "wino_gemm_h2g_kernel + wino_oip_h2c_kernel (chained)" if wino_detail.get("chained") else "in + GEMM + out"},
                           # measured context for `frac` (scripts/probes/rw_probe.hip, profiles/r03/rw_probe.log): a bare streaming kernel
                           # with this kernel's byte mix (1 part read : 2 parts written, nothing re-used) reaches 4.45-4.87 TB/s on
                           # this part, pure reads 5.3 TB/s — not a claim about `peak`, which stays the 8 TB/s of the guide
@@ -750,7 +769,7 @@ def main():
                 out["extra"]["config0_leg"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(S, K, L)
+                out["cpu_baseline"] = cpu_baseline(S, K, L, max_threads=args.cpu_threads or None)
             except Exception as e:  # the oracle is only the baseline leg; never the measured path
                 out["cpu_baseline"] = {"value": None, "unit": "sims/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
         sys.stdout.flush()

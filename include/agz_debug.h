@@ -40,6 +40,10 @@ int agz_wino_stages(agz_ctx* ctx, const float* x, const float* w, int B, int H, 
  * the fewest transform-domain rows, (m + 2)^2 * ceil(H/m) * ceil(W/m); bench.py prices the kernels' algorithmic bytes with it. */
 int agz_wino_h2_tile(int H, int W);
 
+/* Measurement: 1 when AGZ_COMPUTE_WINO_H2 runs the chained block (GEMM + fused out->in kernel, conv_wino_h2c.hpp) on an H x W board with K
+ * filters, 0 when it runs the three-kernel block — bench.py prices the kernels' algorithmic bytes accordingly. */
+int agz_wino_h2_chained(int H, int W, int K);
+
 /* A/B hook: which form of the AGZ_COMPUTE_WINO_H2 block a net runs.  -1 (default): the chained form (output transform of block l
  * and input transform of block l+1 in one kernel, conv_wino_h2c.hpp) wherever the shape allows, else the three-kernel block;
  * 0: the three-kernel block; 1: as -1.  The environment switch AGZ_WINO_H2_FORM=0 (agz.h) does the same for a whole process. */

@@ -39,18 +39,21 @@ static void run(const char* name, const float4* src, float4* dst, size_t unit_by
 }
 
 int main() {
-  const size_t cap = (size_t)2 << 30;
+  // round 4: streams of >= 2 GB per launch — the 0.4 GB / 0.08 ms launches of round 3 read 5.3 TB/s where
+  // stream_probe (round 2) and the guide read 6.3-6.5: at that size the launch ramp and the tail are a fifth of the kernel
+  const size_t cap = (size_t)8 << 30;
   float4 *src, *dst;
   CK(hipMalloc(&src, cap)); CK(hipMalloc(&dst, cap));
   CK(hipMemset(src, 0, cap)); CK(hipMemset(dst, 0, cap));
-  const size_t unit = (size_t)400 << 20;                  // bytes per "1" of the ratio
+  const size_t unit = (size_t)2 << 30;                    // bytes per "1" of the ratio
   for (int grid : {2048, 8192}) {
-    run<4, 0>("read only (4:0)", src, dst, unit / 4 * 1, grid);      // 0.4 GB... scaled below by RN
+    run<4, 0>("read only (4:0)", src, dst, unit / 4, grid);          // 4 x unit/4... = unit read per launch x4 (RN loads per iteration)
     run<0, 4>("write only (0:4)", src, dst, unit / 4, grid);
     run<2, 2>("copy (1:1)", src, dst, unit / 2, grid);
     run<1, 2>("GEMM mix (1 : 2)", src, dst, unit, grid);
     run<4, 1>("output transform mix (4 : 1)", src, dst, unit / 2, grid);
     run<1, 2>("input transform mix (1 : 2)", src, dst, unit / 2, grid);
+    run<2, 1>("out->in (chained) mix (2 : 1)", src, dst, unit, grid);
   }
   return 0;
 }

@@ -184,6 +184,63 @@ def test_headline_engine_512_games_on_their_own_positions_bit_exact(ctx, mode):
     net.close()
 
 
+def test_headline_engine_deep_tree_across_a_re_root_bit_exact(ctx):
+    """(ii-b) VERDICT r3 item 4: ONE watched game of the 512 under the measured arithmetic (AGZ_COMPUTE_WINO_H2, the chained block)
+    with a deep tree — Budget 220 simulations per move from a 90-move position, three searched plies, so the third ply searches a
+    tree RE-ROOTED from the agent's first search (mcts/search.go:424-500; prepareRoot / pipeline :209-257) — against an oracle arena
+    fed the same network outputs (the GPU network evaluated as a 512-row batch of the one board: same kernels, batch-independent
+    bit for bit).  Children, visit counts, blackScores and prior bits of the searching agent's root after every ply, and the moves played."""
+    L, G, budget, seed, g = 20, 512, 220, 77, 5
+    net = std_net(ctx, L)
+    net.set_compute_mode(MODES["wino_h2"])
+    dev = A.Arena(ctx, capi.GAME_WQ, S, S, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=seed, Budget=budget, max_nodes=120000)
+    dev.set_inferencer(0, capi.INF_NET, net)
+    dev.set_inferencer(1, capi.INF_NET, net)
+    ab = np.array([(i % 2) == 1 for i in range(G)], dtype=np.uint8)
+    dev.reset(ab)
+    rng = np.random.default_rng(seed)
+    n_moves = rng.integers(0, 217, size=G).astype(np.int32)
+    n_moves[g] = 90
+    dev.random_moves(n_moves, seed)
+
+    def cb(planes):
+        p, v = net.infer(np.repeat(planes.reshape(1, F, S, S), G, axis=0))
+        return p[0], float(v[0])
+
+    o = O.Arena(O.WQ, S, S, 0, 7.5, enc=O.ENC_WQ, Budget=budget, seed=seed + g)
+    o.set_callback(0, cb, ASPACE)
+    o.set_callback(1, cb, ASPACE)
+    o.begin(int(ab[g]))
+    for _ in range(int(n_moves[g])):
+        o.random_move(seed, g)
+    np.testing.assert_array_equal(dev.history(g), o.history())
+    nodes = []
+    for ply in range(3):
+        dev.begin_move()
+        dev.simulate(budget)
+        dev.end_move(True)
+        _, st0 = o.state()
+        agent = 0 if ((st0["to_move"] == O.BLACK) == bool(ab[g])) else 1
+        o.step(True)
+        omv, ovis, obs, opr = o.root_children(agent)
+        dmv, dvis, dbs, dpr = dev.root_children(g, agent)
+        np.testing.assert_array_equal(dmv, omv, err_msg="ply %d" % ply)
+        np.testing.assert_array_equal(dvis, ovis, err_msg="ply %d" % ply)
+        np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+        np.testing.assert_array_equal(dpr.view(np.uint32), opr.view(np.uint32))
+        if ply == 0:
+            first_root_visits = int(ovis.sum())
+        if ply == 2:   # the re-rooted search: its root carries the visits of the subtree kept from ply 0 on top of this search's
+            assert int(ovis.sum()) > first_root_visits, (int(ovis.sum()), first_root_visits)
+        assert dev.history(g)[-1] == o.history()[-1]
+        nodes.append(dev.tree_nodes(g, agent))
+    st = dev.stats()
+    assert st["tree_full"] == 0
+    assert min(nodes) > 10000, nodes          # 220 expansions x up to 362 children: deep pools, well past one block of children
+    dev.close()
+    net.close()
+
+
 def test_config4_l40_network_batch1_and_lane_batches_vs_oracle(ctx):
     """(iii-a) BASELINE configs[4] tower (40 blocks): batch 1 (the split-K latency regime), batches 8 and 16 (one lane round)
     against the oracle on three mid-game boards."""

@@ -260,9 +260,10 @@ def test_to_dot_renders_the_live_tree(ctx):
     dev.set_inferencer(capi.INF_HASH)
     dev.set_game(**host.state_kw())
     dev.search(O.BLACK)
-    dot = dev.to_dot()
+    dot = dev.to_dot(max_nodes=0)                      # 0: the whole tree, as the reference's ToDot
     assert dot.startswith("digraph G {") and dot.rstrip().endswith("}")
     n = dev.nodes()
+    assert n > 200 and dev.to_dot().count("[ fontname") == 200   # the wrapper's default is bounded (a 1600-simulation 19x19 tree is hundreds of MB of HTML)
     ids = [int(x) for x in re.findall(r"^\t(\d+) \[ fontname", dot, flags=re.M)]
     assert ids == list(range(n))
     edges = [(int(a), int(b)) for a, b in re.findall(r"^\t(\d+)->(\d+);", dot, flags=re.M)]
