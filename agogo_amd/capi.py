@@ -112,6 +112,8 @@ def lib():
     sig("agz_host_alloc", i32, vp, C.c_size_t, pvp)
     sig("agz_host_free", i32, vp, vp)
     sig("agz_mcts_to_dot", i32, vp, i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t))
+    sig("agz_mcts_set_timeout_ms", i32, vp, i32)
+    sig("agz_mcts_last_simulations", i32, vp, C.POINTER(C.c_int64))
     sig("agz_net_set_latency_mode", i32, vp, i32)
     sig("agz_net_set_tower_queues", i32, vp, i32)
     sig("agz_net_set_compute_mode", i32, vp, i32)
@@ -705,6 +707,15 @@ class Mcts:
     def nodes(self):
         n = C.c_int32(0)
         _check(lib().agz_mcts_nodes(self.h, C.byref(n)), "agz_mcts_nodes")
+        return n.value
+
+    def set_timeout_ms(self, ms):
+        """mcts.Config.Timeout (tree.go:18): > 0 = search by wall clock (not deterministic); 0 = exactly Budget simulations"""
+        _check(lib().agz_mcts_set_timeout_ms(self.h, int(ms)), "agz_mcts_set_timeout_ms")
+
+    def last_simulations(self):
+        n = C.c_int64(0)
+        _check(lib().agz_mcts_last_simulations(self.h, C.byref(n)), "agz_mcts_last_simulations")
         return n.value
 
     def to_dot(self, max_nodes=200):

@@ -137,6 +137,10 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_h2c_kernel(WinoH2Args h) {
 // address) and with the B fragments read just in time the kernel fits 168 registers: THREE workgroups per CU, single LDS stage
 // (48 KB each), plain __syncthreads() around every stage (no DMA is ever in flight across a barrier).
 typedef __attribute__((address_space(3))) void* h2c_lds_ptr_t;
+// (Measured and dropped, profiles/r04/gemm_l2_prefetch_ab.log: pulling the A chunk of step k + 1..3 into L2 while step k computes —
+// one 4-byte buffer_load ... lds per thread and 64 bytes — 0.298-0.315 ms against 0.300-0.304: the HBM round trip of A is not what a
+// K step waits for.  What the kernel runs into is the L2 -> CU operand stream: 2.4 GB per launch, 11 TB/s at the all-from-cache
+// floor of 0.215 ms — the rate round 3's l2_probe measured for a GEMM's mixed hit/miss stream.)
 template <int NK>
 __global__ __launch_bounds__(256, 3) void wino_gemm_h2g_kernel(WinoH2Args h) {
   const WinoArgs& a = h.w;
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_h2g_kernel(WinoH2Args h) {
   const unsigned fa = (unsigned)((wm * 64 + (lane & 31)) * 128);
   const unsigned fb = (unsigned)(SA + (wn * 128 + (lane & 31)) * 128);
 
+#pragma nounroll
   for (int it = 0; it < NK; it++) {
 #pragma unroll
     for (int j = 0; j < 4; j++)

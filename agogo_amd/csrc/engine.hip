@@ -19,6 +19,8 @@
 // Bound: these kernels are HBM/latency-bound integer + scalar-float work (select reads 12 B per child,
 // backup writes 8 B per path node); they are sized to stay off the critical path of the conv tower.
 #include <algorithm>
+#include <chrono>
+#include <climits>
 #include <cstring>
 #include <vector>
 
@@ -1982,6 +1984,8 @@ struct agz_mcts {
   // agz_mcts_to_dot: the text of the size query kept for the fill call that follows it (key: what any change of the tree changes)
   std::string dot_cache;
   int64_t dot_key[5] = {-1, -1, -1, -1, -1};
+  int timeout_ms = 0;              // agz_mcts_set_timeout_ms: > 0 = the reference's stopping rule (mcts.Config.Timeout), not deterministic
+  int64_t last_sims = 0;           // simulations the last Search ran
 };
 
 namespace agz {
@@ -2066,8 +2070,30 @@ int agz_mcts_search(agz_mcts* m, int player, int32_t* best) {
   a->a_is_black[0] = (uint8_t)ab;
   int r = agz_arena_begin_move(a);
   if (r != AGZ_OK) return r;
-  r = agz_arena_simulate(a, a->mc.Budget);
-  if (r != AGZ_OK) { a->in_move = false; return r; }
+  if (m->timeout_ms > 0) {
+    // mcts.Config.Timeout (tree.go:18,34; search.go:132-133,196-197): simulations until the wall clock says stop.  Rounds are enqueued
+    // in slices and the clock is read after each slice has finished on the device; the slice grows until it takes ~2 ms, so the
+    // overshoot stays small next to the reference's 100 ms default.  Budget > 0 still caps the search.
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto elapsed_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    int64_t done = 0;
+    int slice = std::max(1, a->d.V);
+    const int64_t cap = a->mc.Budget > 0 ? a->mc.Budget : INT64_MAX;
+    while (done < cap && elapsed_ms() < (double)m->timeout_ms) {
+      const int n = (int)std::min<int64_t>(slice, cap - done);
+      const double before = elapsed_ms();
+      r = agz_arena_simulate(a, n);
+      if (r == AGZ_OK && hipStreamSynchronize(s) != hipSuccess) { agz::set_error("agz_mcts_search: stream synchronisation failed"); r = AGZ_E_HIP; }
+      if (r != AGZ_OK) { a->in_move = false; return r; }
+      done += n;
+      if (elapsed_ms() - before < 2.0 && slice < 4096) slice *= 2;
+    }
+    m->last_sims = done;
+  } else {
+    r = agz_arena_simulate(a, a->mc.Budget);
+    if (r != AGZ_OK) { a->in_move = false; return r; }
+    m->last_sims = a->mc.Budget;
+  }
   {
     ProfScope ps(a->ctx, AGZ_PROF_MOVE);
     hipLaunchKernelGGL(k_end_move, dim3(1), dim3(64), 0, s, a->d, a->gc, a->mc, 0, 0, (const int32_t*)nullptr, 1);
@@ -2081,6 +2107,20 @@ int agz_mcts_search(agz_mcts* m, int player, int32_t* best) {
   AGZ_HIP_TRY(hipStreamSynchronize(s));
   *best = out[0];
   AGZ_REQUIRE(full == full0, AGZ_E_TREE_FULL, "agz_mcts_search: the node pool overflowed (max_nodes too small); the move is the best of the truncated search");
+  return AGZ_OK;
+}
+
+int agz_mcts_set_timeout_ms(agz_mcts* m, int timeout_ms) {
+  AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
+  AGZ_REQUIRE(timeout_ms >= 0, AGZ_E_INVALID, "agz_mcts_set_timeout_ms: %d", timeout_ms);
+  AGZ_REQUIRE(!m->arena->in_move, AGZ_E_STATE, "agz_mcts_set_timeout_ms: a search is in progress");
+  m->timeout_ms = timeout_ms;
+  return AGZ_OK;
+}
+
+int agz_mcts_last_simulations(agz_mcts* m, int64_t* sims) {
+  AGZ_REQUIRE(m && sims, AGZ_E_INVALID, "agz_mcts_last_simulations: NULL argument");
+  *sims = m->last_sims;
   return AGZ_OK;
 }
 

@@ -1068,25 +1068,26 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     const int ns = (queues_want == 2 && B >= 64) ? 2 : 1;
     if (ns == 2 && chunk >= B) chunk = (B + 1) / 2;
     const size_t v_elems = wino_h2_rows(npos, (size_t)chunk * tpb) * Kp, m_elems = 2 * v_elems;
-    if (v_elems * ns > wino_v_cap) {
+    // Chained form (conv_wino_h2c.hpp; AGZ_WINO_H2_FORM = 0 keeps the three-kernel block): output transform of block l and input
+    // transform of block l+1 in one kernel, y never leaves the chip between blocks.  V2(l+1) of a chunk lives in scratch from one
+    // block to the next, so every CHUNK keeps its own scratch there (the three-kernel block: every queue)
+    static const int form_env = [] { const char* e = getenv("AGZ_WINO_H2_FORM"); return e ? atoi(e) : -1; }();
+    const int form_want = wino_form >= 0 ? wino_form : form_env;
+    const bool chained = form_want != 0 && (int)d_u2c_dual.size() == conf.SharedLayers && agz::wino_h2c_ok(H, W, wino_tm, Kp);
+    const int n_scr = chained ? ceil_div(B, chunk) : ns;
+    if (v_elems * n_scr > wino_v_cap) {
       AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
       if (ctx->stream2) AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream2));
       if (d_wV) hipFree(d_wV);
       if (d_wM) hipFree(d_wM);
       d_wV = d_wM = nullptr; wino_chunk_cap = 0;
-      AGZ_HIP_TRY(hipMalloc(&d_wV, v_elems * ns * sizeof(float)));
-      AGZ_HIP_TRY(hipMalloc(&d_wM, m_elems * ns * sizeof(float)));
-      wino_v_cap = v_elems * ns; wino_chunk_cap = 0;   // (the fp32-V Winograd path sizes by boards: force its re-allocation)
+      AGZ_HIP_TRY(hipMalloc(&d_wV, v_elems * n_scr * sizeof(float)));
+      AGZ_HIP_TRY(hipMalloc(&d_wM, m_elems * n_scr * sizeof(float)));
+      wino_v_cap = v_elems * n_scr; wino_chunk_cap = 0;   // (the fp32-V Winograd path sizes by boards: force its re-allocation)
     }
     // per-board ranges [blocks+1][B], then the per-wave maxima of the output kernel [queues][chunk tiles][Kp/64] (as floats)
     // per-wave maxima of the output kernel: every chunk of boards keeps its own region from one block to the next (the next
     // block's input transform reduces them), one word per tile and 64 channels
-    // Chained form (conv_wino_h2c.hpp; AGZ_WINO_H2_FORM = 0 keeps the three-kernel block): output transform of block l and input
-    // transform of block l+1 in one kernel, y never leaves the chip between blocks
-    static const int form_env = [] { const char* e = getenv("AGZ_WINO_H2_FORM"); return e ? atoi(e) : -1; }();
-    const int form_want = wino_form >= 0 ? wino_form : form_env;
-    const bool chained = form_want != 0 && (int)d_u2c_dual.size() == conf.SharedLayers && agz::wino_h2c_ok(H, W, wino_tm, Kp) &&
-                         ceil_div(B, chunk) <= ns;   // (V2(l+1) of a chunk lives in its queue's scratch from one block to the next)
     const size_t wm_board = chained ? (size_t)tpb * (Kp >> 5) * 2 : (size_t)tpb * (Kp >> 6);   // (chained: two arrays, ping-pong)
     const size_t need_amax = (size_t)(conf.SharedLayers + 1) * B + wm_board * B;
     if (need_amax > amax_cap) {
@@ -1119,7 +1120,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         WinoH2Args hh{};
         WinoArgs& wa = hh.w;
         wa.x = cur + (size_t)b0 * Hp * Wp * Kp; wa.y = nxt + (size_t)b0 * Hp * Wp * Kp;   // x: block 0 only; y: the last block only
-        wa.V = d_wV + (size_t)q * v_elems; wa.Mb = d_wM + (size_t)q * m_elems; wa.ep = d_ep_h2[l];
+        wa.V = d_wV + (size_t)ci * v_elems; wa.Mb = d_wM + (size_t)ci * m_elems; wa.ep = d_ep_h2[l];   // (the chunk's own scratch)
         wa.B = std::min(chunk, B - b0); wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Kp; wa.Cout_p = Kp; wa.Ntot = 2 * Kp;
         hh.U2c = d_u2c_dual[l]; hh.w_unscale = 1.f; hh.tm = wino_tm;
         hh.amax_in = d_amax + (size_t)l * B + b0;                                       // the range word V2(l) was written with

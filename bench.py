@@ -298,6 +298,35 @@ def latency_leg(ctx, lanes_list=(1, 16), moves=3, sims=1600):
     return out
 
 
+def train_leg(ctx, steps=3):
+    """SURVEY 8(f)-1 under the driver's clock: one dual.Train batch (dualnet/meta.go:16-54) of the config #4 network —
+    19x19, K=256, 20 blocks, BatchSize 256 — forward (training-mode BatchNorm), loss, backward, vanilla SGD step, in the trainer's
+    AGZ_COMPUTE_WINO_H2 arithmetic (every gradient tensor within 2e-5 * max|g| of the oracle: tests/test_train_gpu.py); host batch in,
+    cost out, `steps` timed steps after one warm-up."""
+    S, K, L, B = 19, 256, 20, 256
+    t = A.Trainer(ctx, K, L, 2 * K, S, S, 18, S * S + 1, B)
+    t.init_random(1337)
+    t.set_compute_mode(capi.COMPUTE_WINO_H2)
+    rng = np.random.default_rng(0)
+    x = rng.choice(np.array([-1, 0, 1], np.float32), size=(B, 18, S, S)).astype(np.float32)
+    pi = np.zeros((B, S * S + 1), np.float32)
+    pi[np.arange(B), rng.integers(0, S * S + 1, B)] = 1
+    v = rng.choice(np.array([-1, 0, 1], np.float32), size=B).astype(np.float32)
+    c = t.batch(x, pi, v)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c = t.batch(x, pi, v)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    hw = S * S
+    flops = 3 * (2.0 * 18 * K * 9 * hw + L * 2 * 2.0 * K * K * 9 * hw) * B   # forward + data gradient + weight gradient, direct-equivalent
+    t.close()
+    return {"workload": "dual.Train batch: 19x19, K=256, 20 blocks, BatchSize 256 (config #4 network), trainer AGZ_COMPUTE_WINO_H2",
+            "steps_timed": steps, "step_ms": dt * 1e3, "examples_per_s": B / dt, "direct_equivalent_tflops": flops / dt / 1e12,
+            "cost": float(c), "note": "includes the host -> device copy of the batch (27 MB) and the cost read-back: the boundary's agz_trainer_batch"}
+
+
 def launcher_command(argv, gpus, environ, port=None):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: the command that re-executes this script as N ranks,
     one per GPU (the contract's own launch line: torch.distributed.run, 127.0.0.1 rendezvous).  None when there is nothing to
@@ -362,6 +391,7 @@ def main():
                     help="skip the untimed whole move and the tree pre-growth (the timed steps then run on the first simulations of a move)")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the configs[4] single-tree move-latency sample")
     ap.add_argument("--no-go9-leg", action="store_true", help="skip the measured 9x9 games/s leg (configs[2])")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the dual.Train step leg (SURVEY 8(f)-1)")
     ap.add_argument("--prof-stride", type=int, default=4,
                     help="inside the timed region every N-th launch of the dominant kernel is bracketed with HIP events (0: none)")
     ap.add_argument("--tower-queues", type=int, default=0, choices=[0, 1, 2],
@@ -762,6 +792,11 @@ def main():
                 out["extra"]["latency_leg"] = latency_leg(ctx)
             except Exception as e:
                 out["extra"]["latency_leg"] = {"error": repr(e)}
+        if world == 1 and not args.no_train_leg:
+            try:
+                out["extra"]["train_leg"] = train_leg(ctx)
+            except Exception as e:
+                out["extra"]["train_leg"] = {"error": repr(e)}
         if world == 1 and not args.no_games_leg:
             try:
                 out["extra"]["config0_leg"] = config0_leg()

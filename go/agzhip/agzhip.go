@@ -24,6 +24,7 @@ package agzhip
 import "C"
 
 import (
+	"time"
 	"errors"
 	"runtime"
 	"sync"
@@ -380,7 +381,25 @@ func NewMCTS(ctx *Ctx, kind GameKind, g game.State, k int, komi float32, encoder
 	if err := lastErr(C.agz_mcts_set_inferencer(t.h, kindInf, h)); err != nil {
 		return nil, err
 	}
+	// mcts.Config.Timeout is what a reference caller actually sets (Budget is inert there, search.go:183-185): a conf without a
+	// Budget keeps the reference's own stopping rule — search by wall clock, not deterministic; with a Budget the search runs
+	// exactly Budget simulations (the declared, bit-reproducible semantics)
+	if conf.Budget <= 0 && conf.Timeout > 0 {
+		ms := int(conf.Timeout / time.Millisecond)
+		if ms < 1 {
+			ms = 1
+		}
+		if err := lastErr(C.agz_mcts_set_timeout_ms(t.h, C.int(ms))); err != nil {
+			return nil, err
+		}
+	}
 	return t, nil
+}
+
+// SetTimeout: mcts.Config.Timeout on a live tree (0 restores "exactly Budget simulations").
+func (t *MCTS) SetTimeout(d time.Duration) error {
+	defer t.ctx.enter()()
+	return lastErr(C.agz_mcts_set_timeout_ms(t.h, C.int(d/time.Millisecond)))
 }
 
 // SetGame (tree.go:120-124).

@@ -412,6 +412,13 @@ int agz_mcts_children(agz_mcts* mcts, int node, int32_t* child_ids, int32_t* mov
  * the output to the first max_nodes nodes of the pool (a top of the tree); *needed = bytes incl. the terminating 0 — call with
  * cap = 0 to size the buffer. */
 int agz_mcts_to_dot(agz_mcts* mcts, int max_nodes, char* buf, size_t cap, size_t* needed);
+/* mcts.Config.Timeout (mcts/tree.go:18,34) — the reference's OWN stopping rule: its Search runs simulations until the wall clock
+ * says stop (search.go:132-133,196-197; Budget is inert there), 100 ms in mcts.DefaultConfig.  Opt-in: timeout_ms > 0
+ * makes agz_mcts_search run simulations for that long (the clock is read between slices of device work; a Budget > 0 still caps the
+ * search), timeout_ms = 0 (default) restores the deterministic "exactly Budget simulations".  NOT deterministic: the simulation count
+ * depends on the machine — parity tests use Budget.  agz_mcts_last_simulations: simulations the last agz_mcts_search ran. */
+int agz_mcts_set_timeout_ms(agz_mcts* mcts, int timeout_ms);
+int agz_mcts_last_simulations(agz_mcts* mcts, int64_t* sims);
 /* (*MCTS).Nodes() (tree.go:126): nodes of the live tree (the reference counts its arena slots, freed ones included) */
 int agz_mcts_nodes(agz_mcts* mcts, int* n_nodes);
 int agz_mcts_get_stats(agz_mcts* mcts, agz_arena_stats* out);

@@ -48,8 +48,8 @@ def test_az_learn_epoch_log_matches_the_oracle(threshold, ev, kills_want):
     iters, episodes, nniters, games, budget, seed, batch = 3, 48, 2, 24, 30, 4242, 32
     sp = (capi.INF_HASH, capi.INF_HASH)
     dev, stats = _device_log(iters, episodes, nniters, games, budget, threshold, seed, sp, ev, batch)
-    # the oracle's composition: mnk.TicTacToe(), dual.DefaultConf(3,3,10) with Features 2, K 3, 3 blocks (tests/cpp/az_learn_ttt.cpp)
-    orc = O.learn_run(O.MNK, 3, 3, 3, 0.0, O.ENC_TWOPLANE, 3, 3, 6, batch, 2, 10, 1.0, budget, threshold, seed, iters, episodes, nniters, games,
+    # the oracle's composition: mnk.TicTacToe(), dual.DefaultConf(3,3,10) (FC = 8) with Features 2, K 3, 3 blocks (tests/cpp/az_learn_ttt.cpp)
+    orc = O.learn_run(O.MNK, 3, 3, 3, 0.0, O.ENC_TWOPLANE, 3, 3, 8, batch, 2, 10, 1.0, budget, threshold, seed, iters, episodes, nniters, games,
                       sp_inf=sp, eval_inf=ev)
     assert len(dev) == len(orc) == iters
     kills = 0
