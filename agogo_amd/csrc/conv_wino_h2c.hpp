@@ -235,6 +235,11 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_h2g_kernel(WinoH2Args h) {
       }
 }
 
+// (Measured and dropped, profiles/r04/gemm_256x256_pipelined_ab.log: a 256 x 256 tile — 1.6 instead of 2.4 GB of operands from L2 — on 512
+// threads, one workgroup per CU, two 64 KB LDS stages with the DMA of step k + 1 in flight under step k's arithmetic (raw s_barrier +
+// counted vmcnt; the compiler's LDS-DMA tracking keeps the stages apart when they are separate __shared__ objects): correct, 0.359 ms
+// against 0.296 — one workgroup per CU cannot cover its own prologue and its 128-stores-per-thread epilogue, three can.)
+
 // Y[l] += At[l][nu] * t for the output transform's row pass, one column nu at a time (nu is a constant after unrolling)
 template <int TM> __device__ __forceinline__ void wino_at_acc(int nu, float* Y, float t);
 template <> __device__ __forceinline__ void wino_at_acc<5>(int nu, float* Y, float t) {

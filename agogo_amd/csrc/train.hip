@@ -113,11 +113,16 @@ __global__ void k_bn_apply(TGeo g, const float* __restrict__ z, const float* __r
 }
 
 // ---- tower BN backward, step 1: d(out) -> dgamma, dbeta, d(xhat) (stored in dz) and the two channel sums -------
-__global__ void k_bn_bwd1(TGeo g, const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
+// fuse_lr != 0 (single-process steps, agz_trainer_batch / agz_train_dev): the batch-shaped gamma / beta — 98 % of the learnables,
+// 7.7 GB at G19 — take their SGD step HERE (w -= lr * grad on the value just read) instead of writing the gradient and having
+// agz_trainer_apply sweep parameters and gradients again: 23 GB less traffic per step.  Same arithmetic (one fp32 multiply-subtract per
+// element, as k_axpy); the gradients of these tensors are then not materialised (agz_trainer_forward_backward keeps them: the
+// data-parallel path reduces them before its apply).
+__global__ void k_bn_bwd1(TGeo g, const float* __restrict__ z, float* gamma, float* beta,
                           const float* __restrict__ mean, const float* __restrict__ inv, const float* __restrict__ out,
                           const float* __restrict__ dout, float* __restrict__ dgamma, float* __restrict__ dbeta,
                           float* __restrict__ dz, double* __restrict__ s1, double* __restrict__ s2, int Kp, int nbr,
-                          int rows_per_block) {
+                          int rows_per_block, float fuse_lr) {
   int C = nbr * Kp;
   int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, g.M);
   for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
@@ -129,10 +134,16 @@ __global__ void k_bn_bwd1(TGeo g, const float* __restrict__ z, const float* __re
       if (nbr == 2 && !(out[po * Kp + c] > 0.f)) g0 = 0.f;
       float xh = (z[po * C + cc] - mean[cc]) * inv[cc];
       float gm = gamma[(size_t)r * C + cc];
-      float y = gm * xh + beta[(size_t)r * C + cc];
+      float bt = beta[(size_t)r * C + cc];
+      float y = gm * xh + bt;
       float gg = y > 0.f ? g0 : 0.f;
-      dgamma[(size_t)r * C + cc] = gg * xh;
-      dbeta[(size_t)r * C + cc] = gg;
+      if (fuse_lr != 0.f) {   // (uniform) p += alpha * g with alpha = -lr, exactly k_axpy's expression
+        gamma[(size_t)r * C + cc] = gm + (-fuse_lr) * (gg * xh);
+        beta[(size_t)r * C + cc] = bt + (-fuse_lr) * gg;
+      } else {
+        dgamma[(size_t)r * C + cc] = gg * xh;
+        dbeta[(size_t)r * C + cc] = gg;
+      }
       float dxh = gg * gm;
       dz[po * C + cc] = dxh;
       a1 += dxh; a2 += (double)dxh * xh;
@@ -792,6 +803,8 @@ struct agz_trainer {
     allocs.push_back(q); *p = (T*)q; return AGZ_OK;
   }
   int forward_backward_dev(const float* planes_dev, const float* pi_dev, const float* v_dev);
+  float fuse_lr = 0.f;      // != 0 during a fused step: k_bn_bwd1 updates gamma / beta in place, apply() skips them
+  bool fused_done = false;  // the backward that just ran took the fused path
 };
 
 static inline int nblk(size_t n, int bs = 256) { return (int)((n + bs - 1) / bs); }
@@ -860,7 +873,7 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     double* s1 = acc; double* s2 = acc + 1024;
     float* dz = l == 0 ? this->dz0 : this->dz;  // (different pixel strides: keep the [pix][2Kp] buffer's zero halo intact)
     hipLaunchKernelGGL(k_bn_bwd1, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean, ly.inv,
-                       ly.out, dcur, G + ly.o_gamma, G + ly.o_beta, dz, s1, s2, Kp, ly.nbr, RPB);
+                       ly.out, dcur, G + ly.o_gamma, G + ly.o_beta, dz, s1, s2, Kp, ly.nbr, RPB, fuse_lr);
     hipLaunchKernelGGL(k_bn_bwd2, dim3(nblk((size_t)g.M * C)), dim3(256), 0, s, g, ly.z, ly.mean, ly.inv, dz, s1, s2, C);
     AGZ_HIP_TRY(hipMemsetAsync(acc, 0, 2049 * sizeof(double), s));   // (also the weight gradient's range words)
     // weight gradient
@@ -1202,13 +1215,29 @@ int agz_trainer_forward_backward_dev(agz_trainer* t, const float* planes_dev, co
 int agz_trainer_apply(agz_trainer* t, float lr, float grad_scale) {  // solver.Step (meta.go:40): w -= lr * grad
   AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
   AGZ_HIP_TRY(hipSetDevice(t->ctx->device));
-  hipLaunchKernelGGL(k_axpy, dim3(nblk(t->n_flat)), dim3(256), 0, t->ctx->stream, t->P, t->G, -lr * grad_scale, t->n_flat);
+  if (t->fused_done) {
+    // the backward that just ran stepped the tower's gamma / beta itself (k_bn_bwd1): the filters of every layer and the head region remain
+    AGZ_REQUIRE(grad_scale == 1.0f, AGZ_E_STATE, "agz_trainer_apply: a fused step takes no gradient scale");
+    for (const auto& ly : t->layers) {
+      const size_t n = (size_t)9 * ly.Cout_p * ly.Cin_p;
+      hipLaunchKernelGGL(k_axpy, dim3(nblk(n)), dim3(256), 0, t->ctx->stream, t->P + ly.o_wf, t->G + ly.o_wf, -lr, n);
+    }
+    const size_t nh = t->n_flat - t->o_hc;
+    hipLaunchKernelGGL(k_axpy, dim3(nblk(nh)), dim3(256), 0, t->ctx->stream, t->P + t->o_hc, t->G + t->o_hc, -lr, nh);
+    t->fused_done = false;
+  } else {
+    hipLaunchKernelGGL(k_axpy, dim3(nblk(t->n_flat)), dim3(256), 0, t->ctx->stream, t->P, t->G, -lr * grad_scale, t->n_flat);
+  }
   AGZ_HIP_TRY(hipGetLastError());
   return AGZ_OK;
 }
 
 int agz_trainer_batch(agz_trainer* t, const float* planes, const float* pi, const float* v, float lr, float* cost) {
+  AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
+  t->fuse_lr = lr;                                   // lr = 0 (a dry step): the plain path, gradients materialised
   int r = agz_trainer_forward_backward(t, planes, pi, v, cost);
+  t->fused_done = r == AGZ_OK && t->fuse_lr != 0.f;
+  t->fuse_lr = 0.f;
   if (r != AGZ_OK) return r;
   r = agz_trainer_apply(t, lr, 1.0f);
   if (r != AGZ_OK) return r;
@@ -1298,7 +1327,10 @@ int agz_train_dev(agz_trainer* t, const float* Xs_dev, const float* policies_dev
       hipLaunchKernelGGL(k_gather_rows_t, dim3(nblk((size_t)t->B * xs)), dim3(256), 0, s, Xs_dev, ib, t->d_planes, (int)xs, (size_t)t->B * xs);
       hipLaunchKernelGGL(k_gather_rows_t, dim3(nblk((size_t)t->B * ps)), dim3(256), 0, s, policies_dev, ib, t->d_pi, (int)ps, (size_t)t->B * ps);
       hipLaunchKernelGGL(k_gather_rows_t, dim3(nblk((size_t)t->B)), dim3(256), 0, s, values_dev, ib, t->d_v, 1, (size_t)t->B);
+      t->fuse_lr = 0.1f;
       rc = t->forward_backward_dev(t->d_planes, t->d_pi, t->d_v);
+      t->fused_done = rc == AGZ_OK;
+      t->fuse_lr = 0.f;
       if (rc == AGZ_OK) rc = agz_trainer_apply(t, 0.1f, 1.0f);
     }
     for (size_t i = 0; i < n; i++) {  // shuffleBatch (meta.go:57-102) on the row index

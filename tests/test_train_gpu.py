@@ -110,6 +110,28 @@ def test_forward_backward_headline_width_19x19(ctx, mode):
     print("trainer %s at K=256 / 19x19 (strict tolerance 2e-5 of the tensor maximum): %s" % (mode, "; ".join(report)))
 
 
+def test_fused_gamma_beta_step_equals_the_two_pass_step(ctx):
+    """agz_trainer_batch lets the BatchNorm backward kernel take the SGD step of the batch-shaped gamma / beta in place (98 % of the
+    learnables: no gradient round trip); agz_trainer_forward_backward + agz_trainer_apply (the data-parallel path) materialises the
+    gradients and sweeps.  Same expression per element: the parameters after a step agree to the weight-gradient atomics' noise."""
+    K, L, FC, W, H, F, Aspace, B = 64, 2, 32, 7, 7, 2, 50, 6
+    _, t1 = make_pair(ctx, K, L, FC, W, H, F, Aspace, B, seed=21)
+    _, t2 = make_pair(ctx, K, L, FC, W, H, F, Aspace, B, seed=21)
+    for step in range(2):
+        x, pi, v = batch_data(B, F, H, W, Aspace, seed=300 + step)
+        c1 = t1.batch(x, pi, v, lr=0.1)                 # fused
+        c2 = t2.forward_backward(x, pi, v)              # two passes
+        t2.apply(0.1)
+        assert abs(c1 - c2) <= 1e-6 * max(1.0, abs(c2))
+    for i in range(t1.num_params()):
+        a, b = t1.get_param(i), t2.get_param(i)
+        name = t1.param_info(i)[0]
+        if name.endswith("_gamma") or name.endswith("_beta"):
+            np.testing.assert_allclose(a, b, rtol=0, atol=2e-6 * max(float(np.abs(b).max()), 1e-3), err_msg=name)
+        else:
+            assert float(np.abs(a - b).max()) <= 2e-6 * max(float(np.abs(b).max()), 1e-3), name
+
+
 def test_sgd_steps_and_export(ctx):
     """three dual.Train inner-loop steps (meta.go:33-40, lr 0.1), then dual.Infer's row-0 copy into an inference net."""
     K, L, FC, W, H, F, Aspace, B = 32, 2, 32, 5, 5, 2, 26, 4
