@@ -734,11 +734,11 @@ def main():
                                     "achieved": wino_detail["block_achieved_GBs"], "unit": "GB/s",
                                     "frac": (wino_detail["block_achieved_GBs"] / HBM_PEAK_GBS) if wino_detail["block_achieved_GBs"] else None,
                                     "kernels": "wino_gemm_h2g_kernel + wino_oip_h2c_kernel (chained)" if wino_detail.get("chained") else "in + GEMM + out"},
-                          # measured context for `frac` (scripts/probes/rw_probe.hip, profiles/r03/rw_probe.log): a bare streaming kernel
-                          # with this kernel's byte mix (1 part read : 2 parts written, nothing re-used) reaches 4.45-4.87 TB/s on
-                          # this part, pure reads 5.3 TB/s — not a claim about `peak`, which stays the 8 TB/s of the guide
-                          "stream_ceiling_same_mix_GBs": [4450.0, 4870.0],
-                          "frac_of_stream_ceiling": wino_detail["wino_gemm"]["achieved_GBs"] / 4660.0}
+                          # measured context for `frac` (scripts/probes/rw_probe.hip on 2 GB streams, profiles/r04/rw_probe.log): a bare
+                          # streaming kernel with this kernel's byte mix (1 part read : 2 parts written, nothing re-used) reaches 4.87-5.12 TB/s
+                          # on this part, pure reads 5.55-5.81, pure writes 4.30-4.44 — not a claim about `peak`, which stays the guide's 8 TB/s
+                          "stream_ceiling_same_mix_GBs": [4870.0, 5120.0],
+                          "frac_of_stream_ceiling": wino_detail["wino_gemm"]["achieved_GBs"] / 5000.0}
                          if (args.compute == "wino_h2" and wino_detail) else
                          {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic}) | {

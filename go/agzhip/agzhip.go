@@ -131,13 +131,20 @@ func NewInferencer(n *Net) (*Inferencer, error) {
 	defer n.ctx.enter()()
 	m := &Inferencer{Net: n}
 	nin := C.size_t(n.conf.Features * n.conf.Height * n.conf.Width * 4)
+	free := func() { // a later allocation failed: give back what was taken (agz_host_free accepts nil)
+		for _, p := range []unsafe.Pointer{m.in, m.pol, m.val} {
+			C.agz_host_free(n.ctx.h, p)
+		}
+	}
 	if err := lastErr(C.agz_host_alloc(n.ctx.h, nin, &m.in)); err != nil {
 		return nil, err
 	}
 	if err := lastErr(C.agz_host_alloc(n.ctx.h, C.size_t(n.conf.ActionSpace*4), &m.pol)); err != nil {
+		free()
 		return nil, err
 	}
 	if err := lastErr(C.agz_host_alloc(n.ctx.h, 4, &m.val)); err != nil {
+		free()
 		return nil, err
 	}
 	return m, nil
@@ -146,8 +153,14 @@ func NewInferencer(n *Net) (*Inferencer, error) {
 // Infer evaluates one encoded board (dualnet/meta.go:168-190).  The returned slice is freshly allocated —
 // the reference returns a slice aliasing the VM output (meta.go:186-189), a latent race not reproduced here.
 func (m *Inferencer) Infer(board []float32) (policy []float32, value float32, err error) {
-	defer m.ctx.enter()()
+	if m.Net == nil || m.in == nil || m.pol == nil || m.val == nil {
+		return nil, 0, errors.New("agzhip: Inferencer without staging buffers (use NewInferencer; a literal Inferencer{Net: n} has none)")
+	}
 	nin := m.conf.Features * m.conf.Height * m.conf.Width
+	if len(board) != nin {
+		return nil, 0, errors.New("agzhip: Infer wants Features*Height*Width floats")
+	}
+	defer m.ctx.enter()()
 	copy(unsafe.Slice((*float32)(m.in), nin), board)
 	err = lastErr(C.agz_net_infer(m.h, (*C.float)(m.in), 1, (*C.float)(m.pol), (*C.float)(m.val)))
 	policy = make([]float32, m.conf.ActionSpace)
@@ -155,7 +168,9 @@ func (m *Inferencer) Infer(board []float32) (policy []float32, value float32, er
 	return policy, *(*float32)(m.val), err // Agent.Infer panics on err (agent.go:66-71): behaviour preserved by the caller
 }
 
-// Close releases the staging buffers (agogo.Inferer.Close); the Net stays with its owner.
+// Close releases the staging buffers (agogo.Inferer.Close).  OWNERSHIP: the Net stays with its owner — this Close shadows the
+// embedded Net.Close on purpose (an Inferer handed to agogo must not tear down weights other agents still use); whoever made the
+// Net closes it with n.Close() (or m.Net.Close()).
 func (m *Inferencer) Close() error {
 	defer m.ctx.enter()()
 	for _, p := range []unsafe.Pointer{m.in, m.pol, m.val} {
