@@ -674,6 +674,8 @@ def main():
         traffic = None
         pmc_name = {"f32": "pmc_conv_dual.json", "bf16x3": "pmc_conv_x3.json", "fp16x2": "pmc_conv_h2.json",
                     "wino": "pmc_wino_gemm.json", "wino_h2": "pmc_wino_h2_gemm.json"}[args.compute]
+        if args.compute == "wino_h2" and capi.wino_h2_chained(S, S, K) == 1:
+            pmc_name = "pmc_wino_h2c.json"   # the chained block's GEMM (wino_gemm_h2g_kernel), round 4
         pmc_path = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc_path) and (S, K, L, G) == (19, 256, 20, 512):  # the PMC pass was taken on this exact shape
             try:

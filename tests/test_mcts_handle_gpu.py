@@ -251,6 +251,44 @@ def test_search_needs_a_game_and_judges_overflow_per_search(ctx):
         dev.search(O.BLACK)
 
 
+def test_wall_clock_stopping_rule_is_opt_in(ctx):
+    """mcts.Config.Timeout (tree.go:18,34; search.go:132-133) — the reference's own stopping rule — as the opt-in
+    agz_mcts_set_timeout_ms: the search runs simulations until the wall clock says stop (capped by Budget), reports how many it ran,
+    and setting the time-out back to 0 restores "exactly Budget simulations", bit for bit the oracle's search."""
+    import time
+    host = Host(O.WQ, 9, 9, 0, 7.5)
+    dev = A.Mcts(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, Budget=200000, max_nodes=400000)
+    dev.set_inferencer(capi.INF_HASH)
+    dev.set_game(**host.state_kw())
+    dev.set_timeout_ms(60)
+    t0 = time.perf_counter()
+    mv = dev.search(O.BLACK)
+    dt = time.perf_counter() - t0
+    n = dev.last_simulations()
+    assert 0.055 <= dt < 0.5, dt
+    assert 1 <= n < 200000 and -1 <= mv < 81
+    rmv, rvis, _, _ = dev.root_children()
+    assert int((rvis.astype(np.int64) - 1).sum()) >= n - 2          # the root's children carry the simulations that ran (q14: a null simulation adds none)
+    with pytest.raises(A.AgzError):
+        dev.set_timeout_ms(-1)
+    dev.close()
+    # deterministic again: Budget simulations, equal to the oracle's tree
+    dev = A.Mcts(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, Budget=64)
+    dev.set_inferencer(capi.INF_HASH)
+    dev.set_timeout_ms(5)
+    dev.set_timeout_ms(0)
+    dev.set_game(**host.state_kw())
+    orc = O.Mcts(host.g, enc=O.ENC_WQ, Budget=64, inf=O.INF_HASH)
+    orc.set_game(host.g)
+    assert dev.search(O.BLACK) == orc.search(O.BLACK)
+    assert dev.last_simulations() == 64
+    omv, ovis, obs, _ = orc.root_children()
+    dmv, dvis, dbs, _ = dev.root_children()
+    np.testing.assert_array_equal(dmv, omv)
+    np.testing.assert_array_equal(dvis, ovis)
+    np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+
+
 def test_to_dot_renders_the_live_tree(ctx):
     """(*MCTS).ToDot (mcts/graph.go:34-90) over the device tree: one node per tree node with the reference's rows, one edge per
     parent/child pair, children in move order, a node's board = the moves of its path (root: Black, then alternating)."""

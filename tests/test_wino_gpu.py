@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import agogo_amd as A
+from agogo_amd import capi
 from test_net_gpu import make_pair, rand_planes, POL_ATOL, POL_RTOL, VAL_ATOL
 
 pytestmark = pytest.mark.gpu
@@ -213,6 +214,46 @@ def test_wino_h2_two_queue_tower_is_bit_identical(ctx):
         np.testing.assert_array_equal(v1, v0)
     with pytest.raises(A.AgzError):
         gnet.set_tower_queues(3)
+
+
+@pytest.mark.parametrize("K,S,B", [(128, 9, 37), (384, 9, 5), (512, 9, 4), (256, 19, 33), (128, 7, 21)])
+def test_wino_h2_chained_block_forms_and_k_extents(ctx, K, S, B):
+    """The chained block (conv_wino_h2c.hpp: GEMM by LDS DMA + fused, pipelined out->in kernel; range words from the commit-time bound)
+    on every K extent it is instantiated for (C/32 = 4, 8, 12, 16), F(5x5,3x3) and F(4x4,3x3) boards, ragged 16-row groups: against
+    the oracle with the tolerance of every network test; its plain (non-pipelined) out->in kernel and the three-kernel block agree
+    with it to rounding; one queue, two queues and a repeated call give the same bits."""
+    L, F = 3, 18
+    onet, gnet = make_pair(ctx, K, L, 32, S, S, F, S * S + 1, 2, seed=K + S)
+    assert capi.wino_h2_chained(S, S, K) == 1
+    x = rand_planes(B, F, S, S, seed=B)
+    gnet.set_compute_mode(A.capi.COMPUTE_WINO_H2 | A.capi.COMPUTE_FORCE)
+    outs = {}
+    for form in (-1, 1, 0):                       # chained (default), chained with the plain out->in kernel, three-kernel block
+        gnet.set_wino_h2_form(form)
+        outs[form] = gnet.infer(x)
+    gnet.set_wino_h2_form(-1)
+    p2, v2 = gnet.infer(x)
+    np.testing.assert_array_equal(p2, outs[-1][0])
+    np.testing.assert_array_equal(v2, outs[-1][1])
+    if B >= 8:
+        gnet.set_tower_queues(1)
+        p1q, v1q = gnet.infer(np.concatenate([x] * 8)[:max(64, B)])      # >= 64 boards: two queues available
+        gnet.set_tower_queues(2)
+        p2q, v2q = gnet.infer(np.concatenate([x] * 8)[:max(64, B)])
+        gnet.set_tower_queues(0)
+        np.testing.assert_array_equal(p1q, p2q)
+        np.testing.assert_array_equal(v1q, v2q)
+        np.testing.assert_array_equal(p1q[:B], outs[-1][0])                # and a board's result does not depend on the batch around it
+    nb = min(B, 4)
+    po, vo = onet.infer(x[:nb])
+    for form, (p, v) in outs.items():
+        assert np.all(np.isfinite(p)) and np.all(np.isfinite(v))
+        np.testing.assert_allclose(p[:nb], po, atol=POL_ATOL, rtol=POL_RTOL, err_msg="form %d" % form)
+        np.testing.assert_allclose(v[:nb], vo, atol=VAL_ATOL, err_msg="form %d" % form)
+    assert not np.array_equal(outs[-1][0], outs[0][0])                     # the chained form really is another schedule of the arithmetic
+    np.testing.assert_allclose(outs[-1][0], outs[0][0], atol=POL_ATOL, rtol=POL_RTOL)
+    print("\n[chained block] K=%d %dx%d B=%d: max|dpol| vs oracle chained %.2e plain %.2e three-kernel %.2e"
+          % (K, S, S, B, np.abs(outs[-1][0][:nb] - po).max(), np.abs(outs[1][0][:nb] - po).max(), np.abs(outs[0][0][:nb] - po).max()))
 
 
 H2_KNOBS = [
