@@ -412,7 +412,17 @@ struct WgH2Args {
   float* dw;
   TGeo g; int N, Cin, rows_per_block, n_tiles, c_tiles, n_chunks;
 };
+// LDS image of this kernel: [k group of 8 rows (4)][column slot (128)][16 B = 8 k], slot = column with its low two bits XORed by
+// bits 4-5 (the staging writes of a half wave — columns 4 cg + c, 8 bytes each — then fall on 16 distinct 16-byte bank groups, and the
+// fragment reads of 32 consecutive columns stay a permutation of 32 consecutive slots)
+__device__ __forceinline__ unsigned wg2_lds_off(int col, int kg) { return (unsigned)(kg * 2048 + ((col ^ ((col >> 4) & 3)) << 4)); }
+typedef unsigned wg_u32x2_t __attribute__((ext_vector_type(2)));
+// Loads are 16 bytes (four channels of one row), 8 per thread and step, the next step's issued under this step's MFMAs.  Deeper
+// prefetch (2-4 steps in flight in registers) measured no faster, 4 workgroups per CU (this form: 123 registers) 0.67 ms per G19
+// layer against 0.76 for round 3's kernel (profiles/r04/wgrad_ab.log): the bound is the L2 -> CU operand stream (see k_wgrad_h2t3, which
+// replaces this kernel on boards >= 16 wide).
 __global__ __launch_bounds__(256, 2) void k_wgrad_h2(WgH2Args a) {
+  constexpr int D = 1;
   constexpr int PIECE = 128 * 64;                 // one piece image of one operand: 128 columns x 32 k x 2 B
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * PIECE];   // A (dz) hi, lo; B (x) hi, lo
   // XCD-aware order: the 9 taps x tiles of one row chunk re-read the same dz / x rows (6 MB per 2048 rows at K = 256); workgroup ids
@@ -427,15 +437,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h2(WgH2Args a) {
   const int tap = bid;
   const int n0 = nt * 128, c0 = ct * 128;
   const int ky = tap / 3, kx = tap - ky * 3;
-  const long tapoff = (long)(ky - 1) * a.g.Wp + (kx - 1);
+  const int tapoff = (ky - 1) * a.g.Wp + (kx - 1);
   const int r_begin = chunk * a.rows_per_block, r_end = min(r_begin + a.rows_per_block, a.g.M);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
-  const int kg = wid;                             // staging: this wave's k group = rows rb + 8 kg .. + 7
-  const bool na0 = n0 + lane < a.N, na1 = n0 + 64 + lane < a.N;
-  const bool cb0 = c0 + lane < a.Cin, cb1 = c0 + 64 + lane < a.Cin;
+  const int cg = lane & 31, half = lane >> 5;     // staging: columns 4 cg .. + 3, rows 8 wid + 4 half .. + 3 of the step
+  const bool na = n0 + 4 * cg < a.N, cb = c0 + 4 * cg < a.Cin;   // (N and Cin are multiples of 4)
   // buffer loads with a per-lane byte offset: masked lanes and rows past the chunk get an out-of-range offset and read zero — a
-  // conditional global_load costs a saveexec + two branches per load (32 loads per thread and K step: more cycles than the MFMAs)
+  // conditional global_load costs a saveexec + two branches per load
   const size_t n_pix = (size_t)a.g.B * a.g.Hp * a.g.Wp;
   const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.dz2), 0, (int)(n_pix * a.N * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.x2), 0, (int)(n_pix * a.Cin * 4), 0x00020000);
@@ -447,64 +456,82 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h2(WgH2Args a) {
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-  unsigned va0[8], va1[8], vb0[8], vb1[8];
-  auto fetch = [&](int rb) {
-    const int r0 = rb + kg * 8;                   // wave-uniform
+  wg_u32x4_t va[D][4], vb[D][4];
+  auto fetch = [&](wg_u32x4_t* pa, wg_u32x4_t* pb, int rb) {
+    const int r0 = rb + wid * 8;                  // wave-uniform
     int b = r0 / a.g.HW, p = r0 - b * a.g.HW;
     int h = p / a.g.W, w = p - h * a.g.W;
+    int r = r0 + 4 * half;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      // (rows past the last board lie past the end of both buffers and read zero; chunk ends are multiples of the 32-row K step)
+    for (int q = 0; q < 4; q++) {                 // the upper half wave starts four rows on (selects, not branches)
+      const bool adv = half != 0;
+      const bool we = adv && (w + 1 == a.g.W);
+      w = adv ? (we ? 0 : w + 1) : w; h += we ? 1 : 0;
+      const bool he = h == a.g.H;
+      h = he ? 0 : h; b += he ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      // (rows past the last board lie past the end of both buffers and read zero; rows of the padding steps past the chunk are masked)
       const int po = (b * a.g.Hp + h + 1) * a.g.Wp + w + 1;
-      const unsigned oa = (unsigned)(po * a.N + n0 + lane) * 4u;
-      const unsigned ob = (unsigned)((po + (int)tapoff) * a.Cin + c0 + lane) * 4u;
-      va0[q] = __builtin_amdgcn_raw_buffer_load_b32(rdz, na0 ? oa : OOB, 0, 0);
-      va1[q] = __builtin_amdgcn_raw_buffer_load_b32(rdz, na1 ? oa + 256u : OOB, 0, 0);
-      vb0[q] = __builtin_amdgcn_raw_buffer_load_b32(rx, cb0 ? ob : OOB, 0, 0);
-      vb1[q] = __builtin_amdgcn_raw_buffer_load_b32(rx, cb1 ? ob + 256u : OOB, 0, 0);
-      const bool we = ++w == a.g.W;                 // (selects, not branches)
+      const bool in = r + q < r_end;
+      const unsigned oa = (unsigned)(po * a.N + n0 + 4 * cg) * 4u;
+      const unsigned ob = (unsigned)((po + tapoff) * a.Cin + c0 + 4 * cg) * 4u;
+      pa[q] = __builtin_bit_cast(wg_u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rdz, (na && in) ? oa : OOB, 0, 0));
+      pb[q] = __builtin_bit_cast(wg_u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, (cb && in) ? ob : OOB, 0, 0));
+      const bool we = ++w == a.g.W;
       w = we ? 0 : w; h += we ? 1 : 0;
       const bool he = h == a.g.H;
       h = he ? 0 : h; b += he ? 1 : 0;
     }
   };
-  auto stage = [&](const unsigned* v, int piece0, int col) {   // eight k of one column: one 16-byte word of hi halves, one of lo halves
-    wg_u32x4_t ph, pl;
+  auto stage = [&](const wg_u32x4_t* v, int piece0) {   // four k of four columns: per column one 8-byte word of hi halves, one of lo halves
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      ph[q] = __builtin_amdgcn_perm(v[2 * q + 1], v[2 * q], 0x05040100u);
-      pl[q] = __builtin_amdgcn_perm(v[2 * q + 1], v[2 * q], 0x07060302u);
+    for (int c = 0; c < 4; c++) {
+      wg_u32x2_t ph, pl;
+      ph[0] = __builtin_amdgcn_perm(v[1][c], v[0][c], 0x05040100u);
+      ph[1] = __builtin_amdgcn_perm(v[3][c], v[2][c], 0x05040100u);
+      pl[0] = __builtin_amdgcn_perm(v[1][c], v[0][c], 0x07060302u);
+      pl[1] = __builtin_amdgcn_perm(v[3][c], v[2][c], 0x07060302u);
+      const unsigned off = wg2_lds_off(4 * cg + c, wid) + 8u * half;
+      *reinterpret_cast<wg_u32x2_t*>(lds + (piece0 + 0) * PIECE + off) = ph;
+      *reinterpret_cast<wg_u32x2_t*>(lds + (piece0 + 1) * PIECE + off) = pl;
     }
-    const unsigned off = wg_lds_off(col, kg);
-    *reinterpret_cast<wg_u32x4_t*>(lds + (piece0 + 0) * PIECE + off) = ph;
-    *reinterpret_cast<wg_u32x4_t*>(lds + (piece0 + 1) * PIECE + off) = pl;
   };
-  fetch(r_begin);
-  for (int rb = r_begin; rb < r_end; rb += 32) {
-    stage(va0, 0, lane); stage(va1, 0, 64 + lane);
-    stage(vb0, 2, lane); stage(vb1, 2, 64 + lane);
-    __syncthreads();
-    if (rb + 32 < r_end) fetch(rb + 32);          // in flight under the MFMAs below
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      const int kgr = ks * 2 + (lane >> 5);
-      wg_f16x8_t A_[2][2], B_[2][2];
+  for (int d = 0; d < D; d++) {
+    fetch(va[d], vb[d], r_begin + 32 * d);
+    __builtin_amdgcn_sched_barrier(0);            // issue order = consumption order: the loop's waits count loads, whichever edge it is entered by
+  }
+  // (the step count is rounded up to a multiple of D: the padding steps multiply zeros)
+  for (int rb = r_begin; rb < r_end; rb += 32 * D) {
 #pragma unroll
-      for (int pz = 0; pz < 2; pz++) {
+    for (int d = 0; d < D; d++) {
+      stage(va[d], 0); stage(vb[d], 2);
+      __syncthreads();
+      fetch(va[d], vb[d], rb + 32 * (d + D));     // in flight under the next D steps
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-          A_[i][pz] = *reinterpret_cast<const wg_f16x8_t*>(lds + pz * PIECE + wg_lds_off(wm * 64 + i * 32 + (lane & 31), kgr));
+      for (int ks = 0; ks < 2; ks++) {
+        const int kgr = ks * 2 + (lane >> 5);
+        wg_f16x8_t A_[2][2], B_[2][2];
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-          B_[j][pz] = *reinterpret_cast<const wg_f16x8_t*>(lds + (2 + pz) * PIECE + wg_lds_off(wn * 64 + j * 32 + (lane & 31), kgr));
-      }
+        for (int pz = 0; pz < 2; pz++) {
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+            A_[i][pz] = *reinterpret_cast<const wg_f16x8_t*>(lds + pz * PIECE + wg2_lds_off(wm * 64 + i * 32 + (lane & 31), kgr));
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+            B_[j][pz] = *reinterpret_cast<const wg_f16x8_t*>(lds + (2 + pz) * PIECE + wg2_lds_off(wn * 64 + j * 32 + (lane & 31), kgr));
+        }
 #define WG_MF(I, J, PA, PB) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[I][PA], B_[J][PB], acc[I][J], 0, 0, 0);
 #define WG_QUAD(PA, PB) WG_MF(0, 0, PA, PB) WG_MF(0, 1, PA, PB) WG_MF(1, 0, PA, PB) WG_MF(1, 1, PA, PB)
-      WG_QUAD(1, 0) WG_QUAD(0, 1) WG_QUAD(0, 0)   // smaller terms first
+        WG_QUAD(1, 0) WG_QUAD(0, 1) WG_QUAD(0, 0)   // smaller terms first
 #undef WG_QUAD
 #undef WG_MF
+      }
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);          // (the next step's regrouping hoisted into these MFMAs would wait on the NEWEST loads)
     }
-    __syncthreads();
   }
   const float un = 1.f / (wg_h2_scale(a.amax[0]) * wg_h2_scale(a.amax[1]));   // exact: a power of two
 #pragma unroll
@@ -517,6 +544,216 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h2(WgH2Args a) {
         int c = c0 + wn * 64 + j * 32 + (lane & 31);
         if (n < a.N && c < a.Cin) atomicAdd(&a.dw[((size_t)tap * a.N + n) * a.Cin + c], acc[i][j][r] * un);
       }
+}
+
+// ---- the weight gradient with the operands DMA'd into LDS and transposed by the LDS read (gfx950: ds_read_b64_tr_b16) ---------------
+// What bounds the register-staged kernel above is the L2 -> CU operand stream: 32 KB per workgroup and K step for 128 x 128 x 32
+// products is 6.9 GB per G19 layer, 10.3 TB/s at 0.67 ms — the rate round 3's l2_probe and round 4's all-from-cache GEMM floor gave
+// for that path (a single-tap DMA form of the same tile measured 0.88 ms: the same bytes through the narrower DMA path).  Fewer
+// bytes per product: the three taps of one kernel ROW read the same dz rows and x rows one pixel apart.  k_split_h2p writes the hi
+// and lo halves as two fp16 planes in the operand's own [pixel][channel] layout; a plane's rows arrive by buffer_load ... lds
+// (16 bytes per lane: one row, eight channels; each lane computes ITS row's padded pixel, so shifts and masks cost nothing) into
+// the image [row / 4][channel / 8 (16)][row % 4][16 B] — a DMA instruction fills 1 KB (four rows) — and are read k-major by the
+// transposing LDS read: within 16 lanes, lane i supplies the address of (row i / 4, channels 4 (i % 4) .. + 3) and receives channel
+// i's four rows (scripts/probes/tr16_probe.hip confirms the lane mapping); the 32 lanes such a read serves per cycle touch 256
+// contiguous bytes.  The x image is indexed by PADDED PIXEL (40 consecutive pixels cover a step's 32 rows, its <= 2 row ends and the
+// +-1 shifts): one landing serves all three taps, row of (k, kx) = delta(k) + kx, delta(k) = k + 2 (row ends between the step's first
+// row and row k).  36 KB per step for 3 x the products: 2.6 x less traffic per product.  K steps never straddle a board (12 steps of 32
+// rows per 19 x 19 board, the last one 9 rows + zeros: 6 % padding).  Boards >= 16 wide (two row ends per step at most); others keep
+// the register-staged kernel.  G19 layer: 0.55 ms (0.76 in round 3); without the DMA 0.41, DMA alone 0.34, neither 0.12 (the
+// epilogue's float atomics): landing and arithmetic of two workgroups per CU overlap only partly (profiles/r04/wgrad_ab.log).
+typedef short wg_s4_t __attribute__((vector_size(8)));
+typedef _Float16 wg_f16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
+typedef unsigned wg_rsrc_t __attribute__((ext_vector_type(4)));
+// One LDS-DMA instruction, written out: the compiler's own bookkeeping of buffer_load ... lds keeps at most eight such stores apart and
+// waits vmcnt(0) before LDS reads it can no longer tell from the NEXT stage's DMA (seen in the ISA: a drain in the middle of every K
+// step).  As inline assembly the DMA is invisible to that pass; the waits are the counted ones below.  (Compiler-known vector-memory
+// instructions stay safe: its counts can only be too strict, never too loose, with extra loads in flight.)
+__device__ __forceinline__ void wg_dma16(wg_rsrc_t rsrc, unsigned lds_addr, unsigned voff) {
+  unsigned keep;                                   // (M0 is put back: the compiler does not model assembly writes to it)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+typedef __attribute__((address_space(3))) wg_s4_t* wg_lds_s4_t;
+__global__ __launch_bounds__(256) void k_split_h2p(const float* __restrict__ x, _Float16* __restrict__ yh, _Float16* __restrict__ yl, size_t n4,
+                                                   const unsigned* __restrict__ amax_bits) {
+  const float s = wg_h2_scale(*amax_bits);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float in[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+    wg_f16x4_t h, l;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      h[k] = (_Float16)in[k];
+      l[k] = (_Float16)(in[k] - (float)h[k]);
+    }
+    reinterpret_cast<wg_f16x4_t*>(yh)[i] = h;
+    reinterpret_cast<wg_f16x4_t*>(yl)[i] = l;
+  }
+}
+struct WgH2t3Args {
+  const _Float16 *dzh, *dzl, *xh, *xl;
+  const unsigned* amax;
+  float* dw;
+  TGeo g; int N, Cin, steps_per_board, n_tiles, c_tiles, n_chunks;
+};
+__global__ __launch_bounds__(256, 2) void k_wgrad_h2t3(WgH2t3Args a) {
+  constexpr int PA = 32 * 128 * 2, PB = 40 * 128 * 2, STAGE = 2 * PA + 2 * PB;   // dz hi, lo (32 rows); x hi, lo (40 pixels)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds0[STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char lds1[STAGE];
+  const int per_chunk = a.n_tiles * a.c_tiles * 3;   // XCD-aware order, as above
+  const int local = (int)(blockIdx.x >> 3);
+  const int chunk = (local / per_chunk) * 8 + (int)(blockIdx.x & 7);
+  if (chunk >= a.n_chunks) return;
+  int bid = local % per_chunk;
+  const int ct = bid % a.c_tiles; bid /= a.c_tiles;
+  const int nt = bid % a.n_tiles; bid /= a.n_tiles;
+  const int ky = bid;
+  const int n0 = nt * 128, c0 = ct * 128;
+  const int b_begin = (int)((long)chunk * a.g.B / a.n_chunks), b_end = (int)((long)(chunk + 1) * a.g.B / a.n_chunks);   // 6 or 7 boards, say
+  const int n_steps = (b_end - b_begin) * a.steps_per_board;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
+  const int cs = lane >> 2, kk = lane & 3;        // DMA: this lane's eight channels and row of a four-row group
+  const bool na = n0 + 8 * cs < a.N, cb = c0 + 8 * cs < a.Cin;
+  const size_t n_pix = (size_t)a.g.B * a.g.Hp * a.g.Wp;
+  auto mk = [](const void* p, size_t bytes) -> wg_rsrc_t {
+    const unsigned long long u = (unsigned long long)p;
+    wg_rsrc_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)u); r[1] = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes); r[3] = 0x00020000u;
+    return r;
+  };
+  const wg_rsrc_t rah = mk(a.dzh, n_pix * a.N * 2), ral = mk(a.dzl, n_pix * a.N * 2);
+  const wg_rsrc_t rbh = mk(a.xh, n_pix * a.Cin * 2), rbl = mk(a.xl, n_pix * a.Cin * 2);
+  constexpr unsigned OOB = 0x80000000u;
+  f32x16 acc[3][2][2];
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][i][j][r] = 0.f;
+  // step s of the chunk: board b_begin + s / steps_per_board, rows 32 (s % steps_per_board) .. of that board
+  struct Step { int po0, w0, nv; };
+  auto step_of = [&](int s) -> Step {
+    const int bq = s / a.steps_per_board, sib = s - bq * a.steps_per_board;
+    const int r0 = sib * 32, h0 = r0 / a.g.W, w0 = r0 - h0 * a.g.W;
+    Step st;
+    st.po0 = ((b_begin + bq) * a.g.Hp + h0 + 1) * a.g.Wp + w0 + 1;
+    st.w0 = w0;
+    st.nv = s < n_steps ? min(32, a.g.HW - r0) : 0;   // (a padding step past the chunk lands zeros)
+    return st;
+  };
+  auto delta = [&](int k, int w0) -> int {         // padded-pixel distance of the step's row k from its first row (boards >= 16 wide)
+    const int c = w0 + k;
+    return k + (c >= a.g.W ? 2 : 0) + (c >= 2 * a.g.W ? 2 : 0);
+  };
+  // the landing of step s, in five pieces (two for dz: wave w lands rows 8 w .. 8 w + 7; three for x: ten four-row groups, waves 0, 1
+  // land three, waves 2, 3 two) so that they can be issued BETWEEN the MFMA groups of the step before: as one block ahead of the
+  // barrier their address arithmetic and issue slots (~0.4 us) delayed every step
+  auto issue_piece = [&](unsigned char* stage, const Step& st, int piece) {
+    const unsigned base = (unsigned)(size_t)(wg_lds_ptr_t)stage;
+    if (piece < 2) {
+      const int t = piece;
+      const int k = 8 * wid + 4 * t + kk;
+      const int po = st.po0 + delta(k, st.w0);
+      const unsigned oa = (na && k < st.nv) ? (unsigned)(po * a.N + n0 + 8 * cs) * 2u : OOB;
+      const unsigned d = base + (unsigned)(2 * wid + t) * 1024u;
+      wg_dma16(rah, d, oa);
+      wg_dma16(ral, d + PA, oa);
+    } else {
+      const int qb = st.po0 + (ky - 1) * a.g.Wp - 1;   // x: image row rho <-> padded pixel qb + rho (halo pixels hold zeros)
+      const int m = wid + 4 * (piece - 2);
+      if (m < 10) {
+        const int q = qb + 4 * m + kk;
+        const unsigned ob = (cb && st.nv > 0 && q >= 0) ? (unsigned)(q * a.Cin + c0 + 8 * cs) * 2u : OOB;
+        const unsigned d = base + 2 * PA + (unsigned)m * 1024u;
+        wg_dma16(rbh, d, ob);
+        wg_dma16(rbl, d + PB, ob);
+      }
+    }
+  };
+  const int i16 = lane & 15, kh = lane >> 5;
+  const unsigned cpart = (unsigned)(((((lane >> 4) & 1) * 2 + ((i16 & 3) >> 1)) * 4) * 16 + (i16 & 1) * 8);   // channel part of a read address
+  const unsigned foa = (unsigned)(kh * 2048 + (i16 >> 2) * 16) + cpart;                                   // dz: rows are the k themselves
+  auto tr2 = [&](const unsigned char* p0, const unsigned char* p1) -> wg_f16x8_t {
+    const wg_s4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s4_t)(p0));
+    const wg_s4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s4_t)(p1));
+    return __builtin_shufflevector(__builtin_bit_cast(wg_f16x4_t, v0), __builtin_bit_cast(wg_f16x4_t, v1), 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto compute = [&](const unsigned char* stage, int s, unsigned char* next_stage) {
+    const int w0 = step_of(s).w0;
+    const Step nx = step_of(s + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      wg_f16x8_t A_[2][2];
+#pragma unroll
+      for (int pz = 0; pz < 2; pz++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          const unsigned char* q = stage + pz * PA + foa + (wm * 64 + i * 32) * 8 + ks * 4096;
+          A_[i][pz] = tr2(q, q + 1024);
+        }
+      const int k0 = ks * 16 + kh * 8 + (i16 >> 2);  // this lane's rows of the step: k0 and k0 + 4
+      const int d0 = delta(k0, w0), d1 = delta(k0 + 4, w0);
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int r0 = d0 + kx, r1 = d1 + kx;
+        const unsigned o0 = (unsigned)((r0 >> 2) * 1024 + (r0 & 3) * 16) + cpart, o1 = (unsigned)((r1 >> 2) * 1024 + (r1 & 3) * 16) + cpart;
+        wg_f16x8_t B_[2][2];
+#pragma unroll
+        for (int pz = 0; pz < 2; pz++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            const unsigned char* q = stage + 2 * PA + pz * PB + (wn * 64 + j * 32) * 8;
+            B_[j][pz] = tr2(q + o0, q + o1);
+          }
+#define WG_MF(I, J, PA_, PB_) acc[kx][I][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[I][PA_], B_[J][PB_], acc[kx][I][J], 0, 0, 0);
+#define WG_QUAD(PA_, PB_) WG_MF(0, 0, PA_, PB_) WG_MF(0, 1, PA_, PB_) WG_MF(1, 0, PA_, PB_) WG_MF(1, 1, PA_, PB_)
+        WG_QUAD(1, 0) WG_QUAD(0, 1) WG_QUAD(0, 0)   // smaller terms first
+#undef WG_QUAD
+#undef WG_MF
+        const int piece = ks * 3 + kx;               // next step's landing, a piece after each of the first five MFMA groups
+        if (piece < 5) issue_piece(next_stage, nx, piece);
+      }
+    }
+  };
+  // raw s_barrier + explicit vmcnt: a __syncthreads() fence knows nothing of the assembly DMA
+  {
+    const Step st0 = step_of(0);
+#pragma unroll
+    for (int piece = 0; piece < 5; piece++) issue_piece(lds0, st0, piece);
+  }
+  for (int s = 0; s < n_steps; s += 2) {            // (an odd step count runs one step of zeros)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of step s has landed; after the barrier every wave's
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    compute(lds0, s, lds1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // (also: every wave is done reading lds0 before step s + 2 lands there)
+    __builtin_amdgcn_sched_barrier(0);
+    compute(lds1, s + 1, lds0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const float un = 1.f / (wg_h2_scale(a.amax[0]) * wg_h2_scale(a.amax[1]));   // exact: a power of two
+#pragma unroll
+  for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          int c = c0 + wn * 64 + j * 32 + (lane & 31);
+          if (n < a.N && c < a.Cin) atomicAdd(&a.dw[((size_t)(ky * 3 + kx) * a.N + n) * a.Cin + c], acc[kx][i][j][r] * un);
+        }
 }
 
 // wt[8-tap][c][n] = wf[tap][n][c]   (data-gradient weights: flipped taps, transposed)
@@ -893,12 +1130,29 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
       const unsigned gs = (unsigned)std::min<size_t>(nblk(n_dz / 4), (size_t)ctx->num_cus * 8);
       hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, s, dz, n_dz / 4, wg_amax);
       hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, s, xin, n_x / 4, wg_amax + 1);
-      hipLaunchKernelGGL(k_split_h2, dim3(gs), dim3(256), 0, s, dz, dz_h2, n_dz / 4, wg_amax);
-      hipLaunchKernelGGL(k_split_h2, dim3(gs), dim3(256), 0, s, xin, x_h2, n_x / 4, wg_amax + 1);
-      WgH2Args wh{};
-      wh.dz2 = dz_h2; wh.x2 = x_h2; wh.amax = wg_amax; wh.dw = wa.dw; wh.g = g; wh.N = wa.N; wh.Cin = wa.Cin;
-      wh.rows_per_block = wa.rows_per_block; wh.n_tiles = wa.n_tiles; wh.c_tiles = wa.c_tiles; wh.n_chunks = chunks;
-      hipLaunchKernelGGL(k_wgrad_h2, dim3(wg_grid), dim3(256), 0, s, wh);
+      if (g.W >= 16 && C % 8 == 0 && ly.Cin_p % 8 == 0) {
+        // three taps per workgroup from hi / lo fp16 planes (k_wgrad_h2t3)
+        _Float16* dzh = (_Float16*)dz_h2; _Float16* dzl = dzh + n_dz;
+        _Float16* xh = (_Float16*)x_h2; _Float16* xl = xh + n_x;
+        hipLaunchKernelGGL(k_split_h2p, dim3(gs), dim3(256), 0, s, dz, dzh, dzl, n_dz / 4, wg_amax);
+        hipLaunchKernelGGL(k_split_h2p, dim3(gs), dim3(256), 0, s, xin, xh, xl, n_x / 4, wg_amax + 1);
+        WgH2t3Args w3{};
+        w3.dzh = dzh; w3.dzl = dzl; w3.xh = xh; w3.xl = xl; w3.amax = wg_amax; w3.dw = wa.dw; w3.g = g; w3.N = wa.N; w3.Cin = wa.Cin;
+        w3.n_tiles = wa.n_tiles; w3.c_tiles = wa.c_tiles; w3.steps_per_board = ceil_div(g.HW, 32);
+        const int per_chunk3 = wa.n_tiles * wa.c_tiles * 3;
+        // chunks of boards: a chunk's workgroups share an XCD (its L2 holds the chunk's rows), an XCD runs 2 workgroups on each of its
+        // CUs; about two rounds of them (5 chunks x 24 workgroups on 64 slots at K = 256; 4 to 8 chunks per XCD measured within 5 %)
+        const int slots = ctx->num_cus / 8 * 2;
+        w3.n_chunks = std::min(B, 8 * std::max(1, 2 * slots / per_chunk3));
+        hipLaunchKernelGGL(k_wgrad_h2t3, dim3((unsigned)(per_chunk3 * round_up(w3.n_chunks, 8))), dim3(256), 0, s, w3);
+      } else {
+        hipLaunchKernelGGL(k_split_h2, dim3(gs), dim3(256), 0, s, dz, dz_h2, n_dz / 4, wg_amax);
+        hipLaunchKernelGGL(k_split_h2, dim3(gs), dim3(256), 0, s, xin, x_h2, n_x / 4, wg_amax + 1);
+        WgH2Args wh{};
+        wh.dz2 = dz_h2; wh.x2 = x_h2; wh.amax = wg_amax; wh.dw = wa.dw; wh.g = g; wh.N = wa.N; wh.Cin = wa.Cin;
+        wh.rows_per_block = wa.rows_per_block; wh.n_tiles = wa.n_tiles; wh.c_tiles = wa.c_tiles; wh.n_chunks = chunks;
+        hipLaunchKernelGGL(k_wgrad_h2, dim3(wg_grid), dim3(256), 0, s, wh);
+      }
     }
     // bf16x3 mode: the weight gradient runs on the bf16 pipe as well
     else if (x3 && off31 && chip_full)
