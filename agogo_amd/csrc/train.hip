@@ -112,6 +112,61 @@ __global__ void k_bn_apply(TGeo g, const float* __restrict__ z, const float* __r
   out[po * Kp + c] = (nbr == 2) ? (acc > 0.f ? acc : 0.f) : acc;
 }
 
+// block-wide maximum of |.| bit patterns -> one atomicMax per block (the range word of the fp16x2 weight gradient's split)
+__device__ __forceinline__ void block_amax_commit(unsigned m, unsigned* __restrict__ out_bits) {
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+  __shared__ unsigned sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned a = sm[0] > sm[1] ? sm[0] : sm[1], b = sm[2] > sm[3] ? sm[2] : sm[3];
+    atomicMax(out_bits, a > b ? a : b);
+  }
+}
+// The same apply, four channels per thread and a fixed channel quad per thread (Kp % 4 == 0, (Kp / 4) divides 256), with max|out| of
+// the whole tensor as a by-product: the NEXT layer's weight gradient splits this tensor into fp16 pieces and needs its range — a
+// separate sweep (k_absmax) re-read it.  Same expressions per element as k_bn_apply.
+__global__ __launch_bounds__(256) void k_bn_apply_v(TGeo g, const float* __restrict__ z, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const float* __restrict__ mean,
+                                                    const float* __restrict__ inv, float* __restrict__ out, int Kp, int nbr,
+                                                    int rows_per_block, unsigned* __restrict__ amax_bits) {
+  const int q = Kp >> 2, tpr = 256 / q, cq = threadIdx.x % q, rs = threadIdx.x / q;
+  const int C = nbr * Kp;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, g.M);
+  float4 mu[2], iv[2];
+  for (int br = 0; br < nbr; br++) {
+    mu[br] = reinterpret_cast<const float4*>(mean + br * Kp)[cq];
+    iv[br] = reinterpret_cast<const float4*>(inv + br * Kp)[cq];
+  }
+  unsigned mx = 0;
+  for (int r = r0 + rs; r < r1; r += tpr) {
+    const size_t po = pix_off(g, r);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int br = 0; br < nbr; br++) {
+      const float4 zz = reinterpret_cast<const float4*>(z + po * C + br * Kp)[cq];
+      const float4 gm = reinterpret_cast<const float4*>(gamma + (size_t)r * C + br * Kp)[cq];
+      const float4 bt = reinterpret_cast<const float4*>(beta + (size_t)r * C + br * Kp)[cq];
+      const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+      const float mv[4] = {mu[br].x, mu[br].y, mu[br].z, mu[br].w}, nv[4] = {iv[br].x, iv[br].y, iv[br].z, iv[br].w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float xh = (zv[k] - mv[k]) * nv[k];
+        const float y = gv[k] * xh + bv[k];
+        acc[k] += y > 0.f ? y : 0.f;
+      }
+    }
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      o[k] = (nbr == 2) ? (acc[k] > 0.f ? acc[k] : 0.f) : acc[k];
+      const unsigned b = __float_as_uint(o[k]) & 0x7fffffffu;
+      mx = b > mx ? b : mx;
+    }
+    reinterpret_cast<float4*>(out + po * Kp)[cq] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  block_amax_commit(mx, amax_bits);
+}
+
 // ---- tower BN backward, step 1: d(out) -> dgamma, dbeta, d(xhat) (stored in dz) and the two channel sums -------
 // fuse_lr != 0 (single-process steps, agz_trainer_batch / agz_train_dev): the batch-shaped gamma / beta — 98 % of the learnables,
 // 7.7 GB at G19 — take their SGD step HERE (w -= lr * grad on the value just read) instead of writing the gradient and having
@@ -162,6 +217,39 @@ __global__ void k_bn_bwd2(TGeo g, const float* __restrict__ z, const float* __re
   float xh = (z[po * C + cc] - mean[cc]) * inv[cc];
   float m = (float)g.M;
   dz[po * C + cc] = inv[cc] * (dz[po * C + cc] - (float)s1[cc] / m - xh * ((float)s2[cc] / m));
+}
+
+// step 2, four channels per thread, a fixed channel quad per thread (C % 4 == 0, (C / 4) divides 256: the per-channel terms are
+// loaded once), with max|dz| of the tensor as a by-product (the weight gradient's range word).  Same expression per element.
+__global__ __launch_bounds__(256) void k_bn_bwd2_v(TGeo g, const float* __restrict__ z, const float* __restrict__ mean,
+                                                   const float* __restrict__ inv, float* __restrict__ dz, const double* __restrict__ s1,
+                                                   const double* __restrict__ s2, int C, int rows_per_block, unsigned* __restrict__ amax_bits) {
+  const int q = C >> 2, tpr = 256 / q, cq = threadIdx.x % q, rs = threadIdx.x / q;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, g.M);
+  const float m = (float)g.M;
+  float mv[4], nv[4], a1[4], a2[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int cc = 4 * cq + k;
+    mv[k] = mean[cc]; nv[k] = inv[cc]; a1[k] = (float)s1[cc] / m; a2[k] = (float)s2[cc] / m;
+  }
+  unsigned mx = 0;
+  for (int r = r0 + rs; r < r1; r += tpr) {
+    const size_t po = pix_off(g, r);
+    const float4 zz = reinterpret_cast<const float4*>(z + po * C)[cq];
+    const float4 dd = reinterpret_cast<const float4*>(dz + po * C)[cq];
+    const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, dv[4] = {dd.x, dd.y, dd.z, dd.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float xh = (zv[k] - mv[k]) * nv[k];
+      o[k] = nv[k] * (dv[k] - a1[k] - xh * a2[k]);
+      const unsigned b = __float_as_uint(o[k]) & 0x7fffffffu;
+      mx = b > mx ? b : mx;
+    }
+    reinterpret_cast<float4*>(dz + po * C)[cq] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  block_amax_commit(mx, amax_bits);
 }
 
 // ---- weight gradient: dW[tap][n][c] += sum_r dz[pix(r)][n] * x[pix(r)+off(tap)][c]  (fp32 MFMA, split over rows) ----
@@ -1014,7 +1102,13 @@ struct agz_trainer {
   bool wino = false;
   WinoRawScratch wsc;
   // ... and the weight gradient with fp16x2 products: both operands split once per layer (k_wgrad_h2)
-  unsigned *dz_h2 = nullptr, *x_h2 = nullptr, *wg_amax = nullptr;
+  unsigned *dz_h2 = nullptr, *x_h2 = nullptr;
+  // per-layer scratch cleared ONCE per step (one memset each instead of one per layer): the backward BatchNorm channel sums
+  // [L + 1][2][1024] and the fp16x2 weight gradient's range words [L + 2][2] = {max|dz| of layer l, max|x| of its input}
+  double* acc_b = nullptr;
+  unsigned* amax_words = nullptr;
+  std::vector<char> x_amax_ready;      // layer l's input range was produced by the forward pass (k_bn_apply_v)
+  size_t* zero_tab = nullptr;          // [2][L + 1] offsets and counts of the filter-gradient regions (k_zero_regions)
   size_t dz_h2_cap = 0, x_h2_cap = 0;
   bool use_wino(int cin, int cout) const {
     return wino && cin % 32 == 0 && cin >= 64 && conv3x3_raw_wino_h2_fits(B, g.H, g.W, cin, cout) &&
@@ -1046,15 +1140,22 @@ struct agz_trainer {
 
 static inline int nblk(size_t n, int bs = 256) { return (int)((n + bs - 1) / bs); }
 
+// clears n regions of one buffer in a single launch (grid: x = blocks per region, y = region)
+__global__ __launch_bounds__(256) void k_zero_regions(float* __restrict__ base, const size_t* __restrict__ tab, int n) {
+  const size_t off = tab[blockIdx.y], cnt = tab[n + blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (size_t)gridDim.x * 256) base[off + i] = 0.f;
+}
+
 int agz_trainer::forward_backward_dev(const float* planes, const float* pi, const float* v) {
   hipStream_t s = ctx->stream;
   const int RPB = 64;
   hipLaunchKernelGGL(k_pack_planes_t, dim3(nblk((size_t)g.M * Fp)), dim3(256), 0, s, planes, x0, g, F, Fp);
   // zero the gradient regions that are ACCUMULATED into (filters: atomics; heads).  The batch-shaped gamma / beta gradients — 98 % of
   // the flat buffer — are plain stores of every element (k_bn_bwd1) and need no clearing (one 7.7 GB memset per G19 step saved)
-  for (int l = 0; l <= L; l++)
-    AGZ_HIP_TRY(hipMemsetAsync(G + layers[l].o_wf, 0, (size_t)9 * layers[l].Cout_p * layers[l].Cin_p * sizeof(float), s));
+  hipLaunchKernelGGL(k_zero_regions, dim3(64, L + 1), dim3(256), 0, s, G, zero_tab, L + 1);
   AGZ_HIP_TRY(hipMemsetAsync(G + o_hc, 0, (n_flat - o_hc) * sizeof(float), s));
+  AGZ_HIP_TRY(hipMemsetAsync(acc_b, 0, (size_t)(L + 1) * 2048 * sizeof(double), s));
+  AGZ_HIP_TRY(hipMemsetAsync(amax_words, 0, (size_t)(L + 2) * 2 * sizeof(unsigned), s));
   // ---- forward, training-mode BN
   const float* cur = x0;
   for (int l = 0; l <= L; l++) {
@@ -1079,8 +1180,15 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
       hipLaunchKernelGGL(k_bn_sum, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, C, (const float*)ly.mean, acc, RPB);
       hipLaunchKernelGGL(k_bn_fin, dim3(nblk(C)), dim3(256), 0, s, acc, C, (double)g.M, conf.bn_eps, ly.mean, ly.inv, 1);
     }
-    hipLaunchKernelGGL(k_bn_apply, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean,
-                       ly.inv, ly.out, Kp, ly.nbr);
+    x_amax_ready[l + 1] = 0;
+    if (wino && Kp % 4 == 0 && Kp / 4 <= 256 && 256 % (Kp / 4) == 0 && ly.nbr <= 2) {
+      const int tpr = 256 / (Kp / 4), rpb = round_up(std::max(tpr, ceil_div(g.M, 2048)), tpr);
+      hipLaunchKernelGGL(k_bn_apply_v, dim3(nblk(g.M, rpb)), dim3(256), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean, ly.inv, ly.out,
+                         Kp, ly.nbr, rpb, amax_words + 2 * (l + 1) + 1);
+      x_amax_ready[l + 1] = 1;
+    } else
+      hipLaunchKernelGGL(k_bn_apply, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean,
+                         ly.inv, ly.out, Kp, ly.nbr);
     cur = ly.out;
   }
   // ---- heads forward
@@ -1107,12 +1215,18 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     TLayer& ly = layers[l];
     int C = ly.Cout_p;
     const float* xin = l == 0 ? x0 : layers[l - 1].out;
-    double* s1 = acc; double* s2 = acc + 1024;
+    double* s1 = acc_b + (size_t)l * 2048; double* s2 = s1 + 1024;
+    unsigned* wg_amax = amax_words + 2 * l;
     float* dz = l == 0 ? this->dz0 : this->dz;  // (different pixel strides: keep the [pix][2Kp] buffer's zero halo intact)
     hipLaunchKernelGGL(k_bn_bwd1, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean, ly.inv,
                        ly.out, dcur, G + ly.o_gamma, G + ly.o_beta, dz, s1, s2, Kp, ly.nbr, RPB, fuse_lr);
-    hipLaunchKernelGGL(k_bn_bwd2, dim3(nblk((size_t)g.M * C)), dim3(256), 0, s, g, ly.z, ly.mean, ly.inv, dz, s1, s2, C);
-    AGZ_HIP_TRY(hipMemsetAsync(acc, 0, 2049 * sizeof(double), s));   // (also the weight gradient's range words)
+    bool dz_amax_ready = false;
+    if (wino && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0) {
+      const int tpr = 256 / (C / 4), rpb = round_up(std::max(tpr, ceil_div(g.M, 2048)), tpr);
+      hipLaunchKernelGGL(k_bn_bwd2_v, dim3(nblk(g.M, rpb)), dim3(256), 0, s, g, ly.z, ly.mean, ly.inv, dz, s1, s2, C, rpb, wg_amax);
+      dz_amax_ready = true;
+    } else
+      hipLaunchKernelGGL(k_bn_bwd2, dim3(nblk((size_t)g.M * C)), dim3(256), 0, s, g, ly.z, ly.mean, ly.inv, dz, s1, s2, C);
     // weight gradient
     WgArgs wa{};
     wa.dz = dz; wa.x = xin; wa.dw = G + ly.o_wf; wa.g = g; wa.N = C; wa.Cin = ly.Cin_p; wa.rows_per_block = 2048;   // rows of the reduction per workgroup
@@ -1128,8 +1242,8 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
       if (dz_h2_cap < n_dz) { if (dz_h2) hipFree(dz_h2); dz_h2 = nullptr; dz_h2_cap = 0; AGZ_HIP_TRY(hipMalloc(&dz_h2, n_dz * 4)); dz_h2_cap = n_dz; }
       if (x_h2_cap < n_x) { if (x_h2) hipFree(x_h2); x_h2 = nullptr; x_h2_cap = 0; AGZ_HIP_TRY(hipMalloc(&x_h2, n_x * 4)); x_h2_cap = n_x; }
       const unsigned gs = (unsigned)std::min<size_t>(nblk(n_dz / 4), (size_t)ctx->num_cus * 8);
-      hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, s, dz, n_dz / 4, wg_amax);
-      hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, s, xin, n_x / 4, wg_amax + 1);
+      if (!dz_amax_ready) hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, s, dz, n_dz / 4, wg_amax);
+      if (!x_amax_ready[l]) hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, s, xin, n_x / 4, wg_amax + 1);
       if (g.W >= 16 && C % 8 == 0 && ly.Cin_p % 8 == 0) {
         // three taps per workgroup from hi / lo fp16 planes (k_wgrad_h2t3)
         _Float16* dzh = (_Float16*)dz_h2; _Float16* dzl = dzh + n_dz;
@@ -1227,8 +1341,18 @@ int agz_trainer_create(agz_ctx* ctx, const agz_net_conf* c, agz_trainer** out) {
 #define TAL(p, n) if ((r = t->alloc(&t->p, (size_t)(n))) != AGZ_OK) { agz_trainer_destroy(t); return r; }
   TAL(P, t->n_flat) TAL(G, t->n_flat)
   size_t px = (size_t)B * g.Hp * g.Wp;
-  TAL(x0, px * t->Fp) TAL(dA, px * Kp) TAL(dB, px * Kp) TAL(dz, px * 2 * Kp) TAL(dz0, px * Kp) TAL(acc, 2049)   /* [2][1024] channel sums + the two range words of the fp16x2 weight gradient */
-  t->wg_amax = reinterpret_cast<unsigned*>(t->acc + 2048);
+  TAL(x0, px * t->Fp) TAL(dA, px * Kp) TAL(dB, px * Kp) TAL(dz, px * 2 * Kp) TAL(dz0, px * Kp) TAL(acc, 2048)   /* [2][1024] channel sums of the forward BatchNorm (self-clearing) */
+  TAL(acc_b, (size_t)(t->L + 1) * 2048) TAL(amax_words, (size_t)(t->L + 2) * 2) TAL(zero_tab, (size_t)(t->L + 1) * 2)
+  t->x_amax_ready.assign(t->L + 2, 0);
+  {
+    std::vector<size_t> tab((size_t)(t->L + 1) * 2);
+    for (int l = 0; l <= t->L; l++) {
+      tab[l] = t->layers[l].o_wf;
+      tab[t->L + 1 + l] = (size_t)9 * t->layers[l].Cout_p * t->layers[l].Cin_p;
+    }
+    AGZ_HIP_TRY(hipMemcpyAsync(t->zero_tab, tab.data(), tab.size() * sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));   // (after alloc()'s clear, same stream)
+    AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
   for (int l = 0; l <= t->L; l++) {
     TLayer& ly = t->layers[l];
     if ((r = t->alloc(&ly.z, px * ly.Cout_p)) != AGZ_OK || (r = t->alloc(&ly.out, px * Kp)) != AGZ_OK ||
