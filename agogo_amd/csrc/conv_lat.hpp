@@ -484,6 +484,92 @@ __global__ __launch_bounds__(256) void lat_board_words_kernel(const float* __res
   if (tid == 0) words[(size_t)b * parts + part] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// ---- latency regime, input layer in ONE launch: convolution of the (<= 32) input planes, epilogue (BatchNorm + ReLU) and the range
+// words of the first dual layer's input.  Round 3 ran a split-K MFMA convolution (9 splits), its reduction + epilogue and the range
+// reduction as three launches (5.9 + 4.8 + 4.4 us and two more ~2.8 us boundaries per simulation).  53 MFLOP at 19 x 19 / K = 256 need
+// no matrix pipe: a workgroup = 8 consecutive pixels x 64 output channels, thread = one channel x two pixels, the 8 x 9 x 32 input
+// window and the 288 x 64 weights (a [tap][plane][channel] image) in LDS; one fp32 FMA chain per output in (tap, plane) order, so a
+// board's result does not depend on what else is in the batch.  words[b][group][channel group] = max |y t| of the workgroup's outputs.
+struct LatInArgs {
+  const float* x; const float* w; const float2* ep; const float* t; float* y; float* words;
+  int B, H, W, Hp, Wp, Cout_p, groups_per_board;
+};
+constexpr int LAT_IN_PIX = 8;
+__global__ __launch_bounds__(256) void lat_input_kernel(LatInArgs a) {
+  // wt[tap][plane][channel]: the 288 x 64 weights of the workgroup's channels are DMA'd into LDS (16 bytes per lane: four rows of 256
+  // bytes per instruction, 18 instructions per wave) while the window is filled and the epilogue terms are read: everything is a
+  // first touch after the previous simulation's tower, so every DEPENDENT batch of loads costs a 2-3 us round trip — weights fetched tap
+  // by tap into registers: 13.7 us; in three batches: 12.8; all 288 into registers: spills; left to the compiler: two loads per
+  // s_waitcnt vmcnt(0), 47 us.
+  __shared__ __attribute__((aligned(16))) float wl[288][64];
+  __shared__ __attribute__((aligned(16))) float xs[LAT_IN_PIX][9][32];
+  __shared__ float red[4];
+  const int cg = blockIdx.x, b = blockIdx.y / a.groups_per_board, grp = blockIdx.y - b * a.groups_per_board;
+  const int tid = threadIdx.x, lane = tid & 63, c = cg * 64 + lane, psub = tid >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int HW = a.H * a.W, p0 = grp * LAT_IN_PIX;
+  {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 9 * 32 * a.Cout_p * 4, 0x00020000);
+    const unsigned vo = (unsigned)(((lane >> 4) * a.Cout_p + cg * 64 + (lane & 15) * 4) * 4);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#pragma unroll
+    for (int i = 0; i < 18; i++) {
+      const int row0 = wid * 72 + i * 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)&wl[row0][0], 16, vo, (unsigned)(row0 * a.Cout_p) * 4u, 0, 0);
+    }
+  }
+  const int pa = 2 * psub, pb = pa + 1;
+  const float tc = a.t[c];
+  float2 ep2[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) ep2[j] = a.ep[(size_t)min(p0 + pa + j, HW - 1) * a.Cout_p + c];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int e = tid + 256 * k;                    // 8 pixels x 9 taps x 8 float4
+    if (e < LAT_IN_PIX * 72) {
+      const int px = e / 72, r = e - px * 72, tap = r >> 3, c4 = (r & 7) << 2;
+      const int p = p0 + px;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < HW) {
+        const int h = p / a.W, w = p - h * a.W, ky = tap / 3, kx = tap - ky * 3;
+        v = *reinterpret_cast<const float4*>(a.x + (((size_t)b * a.Hp + h + ky) * a.Wp + w + kx) * 32 + c4);   // (padded input: pixel (h, w) sits at (h + 1, w + 1))
+      }
+      *reinterpret_cast<float4*>(&xs[px][tap][c4]) = v;
+    }
+  }
+  __syncthreads();                                  // (its fence waits vmcnt(0): this wave's DMA has landed; then every wave's)
+  float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 3
+  for (int tap = 0; tap < 9; tap++) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const float4 x0 = *reinterpret_cast<const float4*>(&xs[pa][tap][4 * q]);
+      const float4 x1 = *reinterpret_cast<const float4*>(&xs[pb][tap][4 * q]);
+      const float w0 = wl[tap * 32 + 4 * q][lane], w1 = wl[tap * 32 + 4 * q + 1][lane], w2 = wl[tap * 32 + 4 * q + 2][lane], w3 = wl[tap * 32 + 4 * q + 3][lane];
+      acc0 = fmaf(x0.x, w0, acc0); acc0 = fmaf(x0.y, w1, acc0); acc0 = fmaf(x0.z, w2, acc0); acc0 = fmaf(x0.w, w3, acc0);
+      acc1 = fmaf(x1.x, w0, acc1); acc1 = fmaf(x1.y, w1, acc1); acc1 = fmaf(x1.z, w2, acc1); acc1 = fmaf(x1.w, w3, acc1);
+    }
+  }
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int p = p0 + pa + j;
+    if (p < HW) {
+      const int h = p / a.W, w = p - h * a.W;
+      const float2 e = ep2[j];
+      float v = (j ? acc1 : acc0) * e.x + e.y;
+      v = v > 0.f ? v : 0.f;
+      a.y[(((size_t)b * a.Hp + h + 1) * a.Wp + w + 1) * a.Cout_p + c] = v;
+      m = fmaxf(m, fabsf(v * tc));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) a.words[((size_t)b * a.groups_per_board + grp) * gridDim.x + cg] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 static void conv_lat_h2_launch(agz_ctx* ctx, const LatH2Args& a) {
   const dim3 grid((unsigned)(a.Cout_p / 8), (unsigned)std::min(LAT_SLOTS, a.B * a.groups_per_board));
   switch (a.C / 32) {

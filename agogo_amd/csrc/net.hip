@@ -591,7 +591,7 @@ using namespace agz;
 // ------------------------------------------------------------------------------------------------
 void agz_net::free_device() {
   auto f = [](float*& p) { if (p) { hipFree(p); p = nullptr; } };
-  f(d_w_init); f(d_ep_init);
+  f(d_w_init); f(d_w_init_t); f(d_ep_init);
   if (d_w3_init) { hipFree(d_w3_init); d_w3_init = nullptr; }
   for (auto& p : d_w_dual) f(p);
   for (auto& p : d_ep_dual) f(p);
@@ -1027,8 +1027,30 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     AGZ_HIP_TRY(hipMalloc(&d_amax, (size_t)B * sizeof(unsigned)));
     amax_cap = (size_t)B;
   }
+  // latency regime with the one-launch-per-layer fp16x2 tower (conv_lat.hpp): the input layer, its epilogue and the first layer's range
+  // words in one launch as well (lat_input_kernel)
+  bool lat_h2 = latency && cfg == 0 && this->compute_mode != AGZ_COMPUTE_F32_MFMA && conf.SharedLayers > 0 &&
+                (int)d_lat_w2.size() == conf.SharedLayers && agz::conv_lat_ok(Kp, Kp, Wp) && ceil_div(HW, agz::LAT_ROWS) * (Kp / 8) <= 256;
+  for (int l = 0; lat_h2 && l < conf.SharedLayers; l++) lat_h2 = d_lat_w2[l] != nullptr;
+  const int in_groups = ceil_div(HW, agz::LAT_IN_PIX), in_words = in_groups * (Kp / 64);
+  const bool lat_in = lat_h2 && Fp == 32 && Kp % 64 == 0 && in_words <= 256 && d_w_init_t;
+  if (lat_h2 && lat_wmax_cap < B) {
+    AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto& p2 : d_lat_wmax) { if (p2) hipFree(p2); p2 = nullptr; }
+    lat_wmax_cap = 0;
+    for (auto& p2 : d_lat_wmax) AGZ_HIP_TRY(hipMalloc(&p2, (size_t)B * 256 * sizeof(float)));
+    lat_wmax_cap = B;
+  }
   int rc;
-  if (split_ok && compute_mode != AGZ_COMPUTE_F32_MFMA && d_w3_init && Kp % 128 == 0 &&
+  if (lat_in) {
+    agz::LatInArgs li{};
+    li.x = d_act_in; li.w = d_w_init_t; li.ep = reinterpret_cast<const float2*>(d_ep_init); li.t = d_lat_tin[0]; li.y = d_actA; li.words = d_lat_wmax[1];
+    li.B = B; li.H = H; li.W = W; li.Hp = Hp; li.Wp = Wp; li.Cout_p = Kp; li.groups_per_board = in_groups;
+    ProfScope ps(ctx, AGZ_PROF_CONV_INIT);
+    hipLaunchKernelGGL(agz::lat_input_kernel, dim3(Kp / 64, B * in_groups), dim3(256), 0, ctx->stream, li);
+    rc = AGZ_OK;
+  }
+  else if (split_ok && compute_mode != AGZ_COMPUTE_F32_MFMA && d_w3_init && Kp % 128 == 0 &&
       (size_t)B * Hp * Wp * Fp * sizeof(float) < ((size_t)1 << 32)) {
     // the split modes: input convolution with bf16x3 products too (same fp32-grade arithmetic as AGZ_COMPUTE_BF16X3)
     a.n_ntiles = ceil_div(a.Ntot, 128); a.n_mtiles = ceil_div(a.M, 128);
@@ -1214,24 +1236,17 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     }
     // (fp16x2 products: only in the modes whose contract is split operands — AGZ_COMPUTE_F32_MFMA keeps exact fp32 products at
     //  every batch size and takes the split-K fp32 kernels below)
-    else if (latency && cfg == 0 && this->compute_mode != AGZ_COMPUTE_F32_MFMA && (int)d_lat_w2.size() == conf.SharedLayers && d_lat_w2[l] && agz::conv_lat_ok(Kp, Kp, Wp) &&
-             ceil_div(HW, agz::LAT_ROWS) * (Kp / 8) <= 256) {   // (range words per board: four per lane)
+    else if (lat_h2) {   // (range words per board: four per lane)
       // latency regime, one launch per layer: K split inside the workgroup, weights up front, no partial sums in memory; fp16x2
       // products on equilibrated operands (conv_lat.hpp).  Range words: layer 0 from a board reduction, then from layer to layer.
       const int gpb = ceil_div(HW, agz::LAT_ROWS), words = gpb * (Kp / 8);
-      if (lat_wmax_cap < B) {
-        for (auto& p2 : d_lat_wmax) { if (p2) hipFree(p2); p2 = nullptr; }
-        lat_wmax_cap = 0;
-        for (auto& p2 : d_lat_wmax) AGZ_HIP_TRY(hipMalloc(&p2, (size_t)B * 256 * sizeof(float)));
-        lat_wmax_cap = B;
-      }
       agz::LatH2Args la{};
       la.x = cur; la.w2 = d_lat_w2[l]; la.t_in = d_lat_tin[l]; la.col_unscale = d_lat_colun[l]; la.ep = d_ep_dual[l]; la.y = nxt;
       la.B = B; la.H = H; la.W = W; la.Hp = Hp; la.Wp = Wp; la.C = Kp; la.Cout_p = Kp; la.Ntot = 2 * Kp;
       la.groups_per_board = gpb;
       if (l == 0) {
-        hipLaunchKernelGGL(agz::lat_board_words_kernel, dim3(B * 64), dim3(256), 0, ctx->stream, cur, (const float*)d_lat_tin[0], d_lat_wmax[1], HW, W, Wp, Hp * Wp, Kp, 64);
-        la.wmax_in = d_lat_wmax[1]; la.n_in_words = 64;
+        if (!lat_in) hipLaunchKernelGGL(agz::lat_board_words_kernel, dim3(B * 64), dim3(256), 0, ctx->stream, cur, (const float*)d_lat_tin[0], d_lat_wmax[1], HW, W, Wp, Hp * Wp, Kp, 64);
+        la.wmax_in = d_lat_wmax[1]; la.n_in_words = lat_in ? in_words : 64;
       } else {
         la.wmax_in = d_lat_wmax[(l - 1) & 1]; la.n_in_words = words;
       }
@@ -1445,6 +1460,12 @@ int agz_net_commit(agz_net* n) {
       fold(bi, o, n->params[pi + 1], n->params[pi + 2], p, &ep[((size_t)p * Kp + o) * 2], &ep[((size_t)p * Kp + o) * 2 + 1]);
     int r;
     if ((r = upload(&n->d_w_init, wt, s)) != AGZ_OK) return r;
+    {
+      std::vector<float> wtt((size_t)9 * Fp * Kp, 0.f);
+      for (int t = 0; t < 9; t++) for (int o = 0; o < Kp; o++) for (int ci = 0; ci < Fp; ci++)
+        wtt[((size_t)t * Fp + ci) * Kp + o] = wt[((size_t)t * Kp + o) * Fp + ci];
+      if ((r = upload(&n->d_w_init_t, wtt, s)) != AGZ_OK) return r;
+    }
     if ((r = upload(&n->d_ep_init, ep, s)) != AGZ_OK) return r;
     n->h_ep_init = ep;
     if (n->cfg == 0) {

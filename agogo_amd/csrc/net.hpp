@@ -51,6 +51,7 @@ struct agz_net {
 
   // device parameters (repacked)
   float* d_w_init = nullptr;    // [9][Ntot_init][Fp]
+  float* d_w_init_t = nullptr;  // [9][Fp][Ntot_init]: the same filter, channel-contiguous (lat_input_kernel)
   float* d_ep_init = nullptr;   // float2 {scale,shift} [HW][Kp]
   unsigned short* d_w3_init = nullptr;   // bf16x3 image of the input filter [Fp/16][9][3][Kp][16] (cfg 0), conv_x3.hpp
   std::vector<float*> d_w_dual;   // per layer [9][2*Kp][Kp] in block-tile order
