@@ -1123,6 +1123,12 @@ struct agz_trainer {
   unsigned* amax_words = nullptr;
   std::vector<char> x_amax_ready;      // layer l's input range was produced by the forward pass (k_bn_apply_v)
   size_t* zero_tab = nullptr;          // [2][L + 1] offsets and counts of the filter-gradient regions (k_zero_regions)
+  // the weight gradient of a layer (matrix pipe / L2 bound, ~0.35 GB of HBM traffic) runs on its own stream beside the same layer's data
+  // gradient and the next layer's BatchNorm backward (HBM bound): both only need dz.  Measured 50.6-50.9 -> 49.1-50.0 ms per G19 step —
+  // the weight gradient's two workgroups per CU hold 496 of a SIMD's 512 registers, so little else becomes resident beside them (forcing
+  // ONE workgroup per CU to make room: 49.4-50.4, no better)
+  hipStream_t wg_stream = nullptr;
+  hipEvent_t ev_dz = nullptr, ev_split = nullptr, ev_join = nullptr;
   size_t dz_h2_cap = 0, x_h2_cap = 0;
   bool use_wino(int cin, int cout) const {
     return wino && cin % 32 == 0 && cin >= 64 && conv3x3_raw_wino_h2_fits(B, g.H, g.W, cin, cout) &&
@@ -1225,6 +1231,13 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   float* dnext = dB;
   hipLaunchKernelGGL(k_head_conv_bwd_x, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, dzh, P + o_hc, dcur, Kp);
   // ---- tower backward
+  if (!wg_stream) {
+    AGZ_HIP_TRY(hipStreamCreateWithFlags(&wg_stream, hipStreamNonBlocking));
+    AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_dz, hipEventDisableTiming));
+    AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_split, hipEventDisableTiming));
+    AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
+  hipStream_t sw = wg_stream;
   for (int l = L; l >= 0; l--) {
     TLayer& ly = layers[l];
     int C = ly.Cout_p;
@@ -1232,6 +1245,7 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     double* s1 = acc_b + (size_t)l * 2048; double* s2 = s1 + 1024;
     unsigned* wg_amax = amax_words + 2 * l;
     float* dz = l == 0 ? this->dz0 : this->dz;  // (different pixel strides: keep the [pix][2Kp] buffer's zero halo intact)
+    if (sw != s && l < L) AGZ_HIP_TRY(hipStreamWaitEvent(s, ev_split, 0));   // the previous layer's weight gradient has taken its copy of dz
     hipLaunchKernelGGL(k_bn_bwd1, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean, ly.inv,
                        ly.out, dcur, G + ly.o_gamma, G + ly.o_beta, dz, s1, s2, Kp, ly.nbr, RPB, fuse_lr);
     bool dz_amax_ready = false;
@@ -1241,7 +1255,9 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
       dz_amax_ready = true;
     } else
       hipLaunchKernelGGL(k_bn_bwd2, dim3(nblk((size_t)g.M * C)), dim3(256), 0, s, g, ly.z, ly.mean, ly.inv, dz, s1, s2, C);
-    // weight gradient
+    // weight gradient (on its own stream from here)
+    if (sw != s) { AGZ_HIP_TRY(hipEventRecord(ev_dz, s)); AGZ_HIP_TRY(hipStreamWaitEvent(sw, ev_dz, 0)); }
+    bool split_recorded = false;
     WgArgs wa{};
     wa.dz = dz; wa.x = xin; wa.dw = G + ly.o_wf; wa.g = g; wa.N = C; wa.Cin = ly.Cin_p; wa.rows_per_block = 2048;   // rows of the reduction per workgroup
     wa.n_tiles = ceil_div(C, 128); wa.c_tiles = ceil_div(ly.Cin_p, 128);
@@ -1256,14 +1272,15 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
       if (dz_h2_cap < n_dz) { if (dz_h2) hipFree(dz_h2); dz_h2 = nullptr; dz_h2_cap = 0; AGZ_HIP_TRY(hipMalloc(&dz_h2, n_dz * 4)); dz_h2_cap = n_dz; }
       if (x_h2_cap < n_x) { if (x_h2) hipFree(x_h2); x_h2 = nullptr; x_h2_cap = 0; AGZ_HIP_TRY(hipMalloc(&x_h2, n_x * 4)); x_h2_cap = n_x; }
       const unsigned gs = (unsigned)std::min<size_t>(nblk(n_dz / 4), (size_t)ctx->num_cus * 8);
-      if (!dz_amax_ready) hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, s, dz, n_dz / 4, wg_amax);
-      if (!x_amax_ready[l]) hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, s, xin, n_x / 4, wg_amax + 1);
+      if (!dz_amax_ready) hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, sw, dz, n_dz / 4, wg_amax);
+      if (!x_amax_ready[l]) hipLaunchKernelGGL(k_absmax, dim3(gs), dim3(256), 0, sw, xin, n_x / 4, wg_amax + 1);
       if (g.W >= 16 && C % 8 == 0 && ly.Cin_p % 8 == 0) {
         // three taps per workgroup from hi / lo fp16 planes (k_wgrad_h2t3)
         _Float16* dzh = (_Float16*)dz_h2; _Float16* dzl = dzh + n_dz;
         _Float16* xh = (_Float16*)x_h2; _Float16* xl = xh + n_x;
-        hipLaunchKernelGGL(k_split_h2p, dim3(gs), dim3(256), 0, s, dz, dzh, dzl, n_dz / 4, wg_amax);
-        hipLaunchKernelGGL(k_split_h2p, dim3(gs), dim3(256), 0, s, xin, xh, xl, n_x / 4, wg_amax + 1);
+        hipLaunchKernelGGL(k_split_h2p, dim3(gs), dim3(256), 0, sw, dz, dzh, dzl, n_dz / 4, wg_amax);
+        if (sw != s) { AGZ_HIP_TRY(hipEventRecord(ev_split, sw)); split_recorded = true; }
+        hipLaunchKernelGGL(k_split_h2p, dim3(gs), dim3(256), 0, sw, xin, xh, xl, n_x / 4, wg_amax + 1);
         WgH2t3Args w3{};
         w3.dzh = dzh; w3.dzl = dzl; w3.xh = xh; w3.xl = xl; w3.amax = wg_amax; w3.dw = wa.dw; w3.g = g; w3.N = wa.N; w3.Cin = wa.Cin;
         w3.n_tiles = wa.n_tiles; w3.c_tiles = wa.c_tiles; w3.steps_per_board = ceil_div(g.HW, 32);
@@ -1272,21 +1289,23 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
         // CUs; about two rounds of them (5 chunks x 24 workgroups on 64 slots at K = 256; 4 to 8 chunks per XCD measured within 5 %)
         const int slots = ctx->num_cus / 8 * 2;
         w3.n_chunks = std::min(B, 8 * std::max(1, 2 * slots / per_chunk3));
-        hipLaunchKernelGGL(k_wgrad_h2t3, dim3((unsigned)(per_chunk3 * round_up(w3.n_chunks, 8))), dim3(256), 0, s, w3);
+        hipLaunchKernelGGL(k_wgrad_h2t3, dim3((unsigned)(per_chunk3 * round_up(w3.n_chunks, 8))), dim3(256), 0, sw, w3);
       } else {
-        hipLaunchKernelGGL(k_split_h2, dim3(gs), dim3(256), 0, s, dz, dz_h2, n_dz / 4, wg_amax);
-        hipLaunchKernelGGL(k_split_h2, dim3(gs), dim3(256), 0, s, xin, x_h2, n_x / 4, wg_amax + 1);
+        hipLaunchKernelGGL(k_split_h2, dim3(gs), dim3(256), 0, sw, dz, dz_h2, n_dz / 4, wg_amax);
+        if (sw != s) { AGZ_HIP_TRY(hipEventRecord(ev_split, sw)); split_recorded = true; }
+        hipLaunchKernelGGL(k_split_h2, dim3(gs), dim3(256), 0, sw, xin, x_h2, n_x / 4, wg_amax + 1);
         WgH2Args wh{};
         wh.dz2 = dz_h2; wh.x2 = x_h2; wh.amax = wg_amax; wh.dw = wa.dw; wh.g = g; wh.N = wa.N; wh.Cin = wa.Cin;
         wh.rows_per_block = wa.rows_per_block; wh.n_tiles = wa.n_tiles; wh.c_tiles = wa.c_tiles; wh.n_chunks = chunks;
-        hipLaunchKernelGGL(k_wgrad_h2, dim3(wg_grid), dim3(256), 0, s, wh);
+        hipLaunchKernelGGL(k_wgrad_h2, dim3(wg_grid), dim3(256), 0, sw, wh);
       }
     }
     // bf16x3 mode: the weight gradient runs on the bf16 pipe as well
     else if (x3 && off31 && chip_full)
-      hipLaunchKernelGGL(k_wgrad_x3, dim3(wg_grid), dim3(256), 0, s, wa);
+      hipLaunchKernelGGL(k_wgrad_x3, dim3(wg_grid), dim3(256), 0, sw, wa);
     else
-      hipLaunchKernelGGL(k_wgrad, dim3(wa.n_tiles * wa.c_tiles * 9 * chunks), dim3(256), 0, s, wa);
+      hipLaunchKernelGGL(k_wgrad, dim3(wa.n_tiles * wa.c_tiles * 9 * chunks), dim3(256), 0, sw, wa);
+    if (sw != s && !split_recorded) AGZ_HIP_TRY(hipEventRecord(ev_split, sw));   // (kernels that read dz itself: after the weight gradient)
     if (l > 0) {  // data gradient: the forward GEMM with flipped/transposed weights over the [a|b] channels of dz
       hipLaunchKernelGGL(k_make_wt, dim3(nblk((size_t)9 * C * ly.Cin_p)), dim3(256), 0, s, P + ly.o_wf, ly.wt, C, ly.Cin_p);
       int r;
@@ -1302,6 +1321,7 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
       std::swap(dcur, dnext);
     }
   }
+  if (sw != s) { AGZ_HIP_TRY(hipEventRecord(ev_join, sw)); AGZ_HIP_TRY(hipStreamWaitEvent(s, ev_join, 0)); }   // the step's stream carries everything again
   AGZ_HIP_TRY(hipGetLastError());
   return AGZ_OK;
 }
@@ -1386,6 +1406,10 @@ void agz_trainer_destroy(agz_trainer* t) {
   if (!t) return;
   hipSetDevice(t->ctx->device);
   hipStreamSynchronize(t->ctx->stream);
+  if (t->wg_stream) { hipStreamSynchronize(t->wg_stream); hipStreamDestroy(t->wg_stream); }
+  if (t->ev_dz) hipEventDestroy(t->ev_dz);
+  if (t->ev_split) hipEventDestroy(t->ev_split);
+  if (t->ev_join) hipEventDestroy(t->ev_join);
   for (void* p : t->allocs) hipFree(p);
   wino_raw_scratch_free(&t->wsc);
   if (t->dz_h2) hipFree(t->dz_h2);
