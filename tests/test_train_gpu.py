@@ -55,6 +55,8 @@ CASES = [
     (3, 3, 8, 3, 3, 2, 10, 5),        # the README tic-tac-toe net (DefaultConf(3,3,10), K=3 SharedLayers=3): K padded 3 -> 32
     (20, 1, 8, 4, 4, 2, 17, 1),       # BatchSize 1 (batch statistics over 16 pixels only), K=20 padded
     (40, 2, 24, 5, 4, 3, 21, 7),      # nothing a multiple of anything
+    (64, 1, 16, 16, 17, 3, 273, 2),   # a board >= 16 wide that is not 19x19 (non-square, 272 = 8.5 K steps of 32 rows per board): the
+                                      # three-tap DMA weight gradient with a 64-channel operand in a 128-column tile (masked lanes)
 ]
 
 
