@@ -44,8 +44,16 @@ __device__ __forceinline__ unsigned x3_pack(unsigned e0, unsigned e1) { return _
 // ds_write_b128 (rows t/2, halves t%2) and the fragment ds_read_b128 (32 rows x fixed half) conflict-free
 __device__ __forceinline__ unsigned x3_lds_off(int row, int half) { return (unsigned)(row * 32 + ((half ^ ((row >> 3) & 1)) << 4)); }
 
+// the 32 lanes of a half wave hold one row's columns: their maximum goes to the row's board with one atomic (outputs are >= 0 after
+// the ReLU, so the float's bits order like the value: the word board_amax_kernel computes)
+__device__ __forceinline__ void x3_amax_flush(unsigned* amax, int b, float m, int lane) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((lane & 31) == 0) atomicMax(&amax[b], __float_as_uint(m));
+}
 // shared epilogue (same as conv_tile): BN(scale,shift) + ReLU (+ dual add + ReLU), interior of padded NHWC
 #define X3_EPILOGUE \
+  int amx_b = -1; float amx_m = 0.f;   /* running maximum of this thread's outputs of board amx_b (rows ascend: so do boards) */ \
   _Pragma("unroll") \
   for (int i = 0; i < 2; i++) { \
   _Pragma("unroll") \
@@ -69,6 +77,10 @@ __device__ __forceinline__ unsigned x3_lds_off(int row, int half) { return (unsi
           a.y[obase + c] = s > 0.f ? s : 0.f; \
         } \
       } else { \
+        if (a.amax_out && mvalid && b != amx_b) {   /* (uniform over the 32 lanes that share this row) */ \
+          if (amx_b >= 0) x3_amax_flush(a.amax_out, amx_b, amx_m, lane); \
+          amx_b = b; amx_m = 0.f; \
+        } \
   _Pragma("unroll") \
         for (int j = 0; j < 2; j++) { \
           int c = n0 + (wn * 2 + j) * 32 + (lane & 31); \
@@ -78,13 +90,16 @@ __device__ __forceinline__ unsigned x3_lds_off(int row, int half) { return (unsi
             } else { \
               float2 e = reinterpret_cast<const float2*>(a.ep)[(size_t)p * a.Cout_p + c]; \
               float v = acc[i][j][r] * e.x + e.y; \
-              a.y[obase + c] = v > 0.f ? v : 0.f; \
+              v = v > 0.f ? v : 0.f; \
+              a.y[obase + c] = v; \
+              amx_m = fmaxf(amx_m, v); \
             } \
           } \
         } \
       } \
     } \
-  }
+  } \
+  if (!DUAL && a.amax_out && amx_b >= 0) x3_amax_flush(a.amax_out, amx_b, amx_m, lane);
 
 template <bool DUAL>
 __global__ __launch_bounds__(256, 3) void conv3x3_x3_kernel(ConvArgs a, const unsigned short* __restrict__ w3) {

@@ -48,6 +48,8 @@ struct ConvArgs {
   const unsigned* amax_in;
   float w_unscale;
   const unsigned* w_amax_dev;   // raw fp16x2 form (conv3x3_raw_h2): bits of max|w|, the scale of the device-built weight image
+  unsigned* amax_out;           // conv3x3_x3_kernel<false>, != nullptr: atomicMax of the output's bits per board (zeroed by the caller): the
+                                // range words board_amax_kernel would compute from the stored tensor
 };
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -530,14 +532,14 @@ __global__ __launch_bounds__(1024) void heads_fc_kernel(HeadArgs a) {
 #pragma unroll
       for (int u = 0; u < 16; u++) { fv[u] = f[i + u]; wv_[u] = Wm[(size_t)(i + u) * ld + j]; }
 #pragma unroll
-      for (int u = 0; u < 16; u++) s += fv[u] * wv_[u];
+      for (int u = 0; u < 16; u++) s = fmaf(fv[u], wv_[u], s);   // (explicit: both forms of this kernel must round alike)
     }
     {
       float fv[16], wv_[16];
 #pragma unroll
       for (int u = 0; u < 16; u++) { const bool ok = i + u < i1; const int r = ok ? i + u : 0; fv[u] = ok ? f[r] : 0.f; wv_[u] = Wm[(size_t)r * ld + j]; }   // (row 0: always inside the matrix)
 #pragma unroll
-      for (int u = 0; u < 16; u++) if (i + u < i1) s += fv[u] * wv_[u];
+      for (int u = 0; u < 16; u++) if (i + u < i1) s = fmaf(fv[u], wv_[u], s);
     }
   }
   part[wv][lane] = s;
@@ -549,6 +551,68 @@ __global__ __launch_bounds__(1024) void heads_fc_kernel(HeadArgs a) {
     t += is_pol ? a.bp[j] : a.b1[j];
     if (!is_pol) t = t > 0.f ? t : 0.f;
     a.cols[(size_t)b * (a.A + a.FC) + col] = t;
+  }
+}
+// (2b) the same columns for NB boards per workgroup (many boards: every weight is read once per NB boards instead of once per board —
+//      5120 workgroups x 185 KB of weights were 0.95 GB through L2 per 512-board pass, 87 us).  Per (board, column) the additions run in
+//      exactly heads_fc_kernel's order (sixteen-row groups, masked tail, partials in wave order): bit-identical outputs.
+template <int NB>
+__global__ __launch_bounds__(1024) void heads_fc_nb_kernel(HeadArgs a, int B) {
+  __shared__ float part[NB][16][64];
+  const int b0 = blockIdx.y * NB, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = blockIdx.x * 64 + lane;
+  const bool is_pol = col < a.A;
+  const int j = is_pol ? col : col - a.A;
+  const bool live = col < a.A + a.FC;
+  const int rows = is_pol ? 2 * a.HW : a.HW, ld = is_pol ? a.A : a.FC;
+  const float* Wm = is_pol ? a.Wp : a.W1;
+  const float* f[NB];
+#pragma unroll
+  for (int n = 0; n < NB; n++) f[n] = a.feat + (size_t)min(b0 + n, B - 1) * 3 * a.HW + (is_pol ? 0 : 2 * a.HW);
+  const int chunk = (rows + 15) >> 4;
+  int i0 = wv * chunk, i1 = i0 + chunk < rows ? i0 + chunk : rows;
+  float s[NB];
+#pragma unroll
+  for (int n = 0; n < NB; n++) s[n] = 0.f;
+  if (live) {
+    int i = i0;
+    for (; i + 16 <= i1; i += 16) {
+      float wv_[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) wv_[u] = Wm[(size_t)(i + u) * ld + j];
+#pragma unroll
+      for (int n = 0; n < NB; n++) {
+        float fv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) fv[u] = f[n][i + u];
+#pragma unroll
+        for (int u = 0; u < 16; u++) s[n] = fmaf(fv[u], wv_[u], s[n]);
+      }
+    }
+    {
+      float wv_[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) { const int r = i + u < i1 ? i + u : 0; wv_[u] = Wm[(size_t)r * ld + j]; }   // (row 0: always inside the matrix)
+#pragma unroll
+      for (int n = 0; n < NB; n++) {
+        float fv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const bool ok = i + u < i1; fv[u] = ok ? f[n][ok ? i + u : 0] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 16; u++) if (i + u < i1) s[n] = fmaf(fv[u], wv_[u], s[n]);
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NB; n++) part[n][wv][lane] = s[n];
+  __syncthreads();
+  if (live && wv < NB && b0 + wv < B) {             // wave n finishes board n
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) t += part[wv][q][lane];
+    t += is_pol ? a.bp[j] : a.b1[j];
+    if (!is_pol) t = t > 0.f ? t : 0.f;
+    a.cols[(size_t)(b0 + wv) * (a.A + a.FC) + col] = t;
   }
 }
 // (3) softmax over the logits; value = tanh(hidden . W2 + b2)
@@ -1042,6 +1106,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     lat_wmax_cap = B;
   }
   int rc;
+  bool amax0_done = false;   // the input layer's epilogue produced the tower's per-board input ranges (d_amax[0 .. B))
   if (lat_in) {
     agz::LatInArgs li{};
     li.x = d_act_in; li.w = d_w_init_t; li.ep = reinterpret_cast<const float2*>(d_ep_init); li.t = d_lat_tin[0]; li.y = d_actA; li.words = d_lat_wmax[1];
@@ -1056,7 +1121,14 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     a.n_ntiles = ceil_div(a.Ntot, 128); a.n_mtiles = ceil_div(a.M, 128);
     a.splits = 1; a.per = 0; a.ws = nullptr; a.raw = 0;
     ProfScope ps(ctx, AGZ_PROF_CONV_INIT);
+    // Winograd fp16x2 tower: the per-board range of its input comes out of this epilogue (one atomic per half wave and board) instead
+    // of a sweep over the stored tensor (board_amax_kernel: 56 us per 512-board pass); the words must exist already (any later forward)
+    if (wino_h2_ok && d_amax && amax_cap >= (size_t)B) {
+      AGZ_HIP_TRY(hipMemsetAsync(d_amax, 0, (size_t)B * sizeof(unsigned), ctx->stream));
+      a.amax_out = d_amax; amax0_done = true;
+    }
     hipLaunchKernelGGL((conv3x3_x3_kernel<false>), dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, ctx->stream, a, d_w3_init);
+    a.amax_out = nullptr;
     rc = AGZ_OK;
   }
   else if (cfg != 0) rc = launch_conv<4, 1, 1, false>(ctx, a, wsp, &ws_cap);
@@ -1119,9 +1191,11 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       d_amax = nullptr; amax_cap = 0;
       AGZ_HIP_TRY(hipMalloc(&d_amax, need_amax * sizeof(unsigned)));
       amax_cap = need_amax;
+      amax0_done = false;   // (the words just written went with the old buffer)
     }
     float* d_wave_max = reinterpret_cast<float*>(d_amax + (size_t)(conf.SharedLayers + 1) * B);
-    hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, ctx->stream, cur, d_amax, HW, W, Wp, Hp * Wp, Kp, (const float*)nullptr);   // (pre-scaled input)
+    if (!amax0_done)
+      hipLaunchKernelGGL(board_amax_kernel, dim3(B), dim3(256), 0, ctx->stream, cur, d_amax, HW, W, Wp, Hp * Wp, Kp, (const float*)nullptr);   // (pre-scaled input)
     if (ns == 2) {
       if (!ctx->stream2) {
         AGZ_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -1284,7 +1358,10 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       }
       h.feat = d_hs; h.cols = d_hs + (size_t)B * 3 * HW;
       hipLaunchKernelGGL(heads_feat_kernel, dim3(ceil_div(HW, 4), B), dim3(256), 0, ctx->stream, h);
-      hipLaunchKernelGGL(heads_fc_kernel, dim3(ceil_div(conf.ActionSpace + conf.FC, 64), B), dim3(1024), 0, ctx->stream, h);
+      if (B >= 32)
+        hipLaunchKernelGGL(heads_fc_nb_kernel<4>, dim3(ceil_div(conf.ActionSpace + conf.FC, 64), ceil_div(B, 4)), dim3(1024), 0, ctx->stream, h, B);
+      else
+        hipLaunchKernelGGL(heads_fc_kernel, dim3(ceil_div(conf.ActionSpace + conf.FC, 64), B), dim3(1024), 0, ctx->stream, h);
       hipLaunchKernelGGL(heads_out_kernel, dim3(B), dim3(256), 0, ctx->stream, h);
     } else {
       hipLaunchKernelGGL(heads_kernel, dim3(B), dim3(256), smem, ctx->stream, h);
