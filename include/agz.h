@@ -200,7 +200,7 @@ int agz_trainer_grads_dev(agz_trainer* t, float** dev_ptr, size_t* n_floats);
  * AGZ_COMPUTE_BF16X3 (all three on the bf16 pipe; weights re-split on the device every step) or AGZ_COMPUTE_WINO_H2 (fp16x2
  * products throughout: forward = the DIRECT 3x3 convolution with fp16 hi/lo operands, weight image split on the device every step;
  * data gradient = the Winograd fp16x2 path with device-transformed weights; weight gradient = fp16 hi/lo operands split once per
- * layer; the first layer, 18 -> K, stays on BF16X3).  130 / 88 / 63 ms per step at 19x19, K = 256, 20 blocks, batch 256.  Every mode
+ * layer; the first layer, 18 -> K, stays on BF16X3).  130 / 88 / 50 ms per step at 19x19, K = 256, 20 blocks, batch 256.  Every mode
  * meets the same gradient tolerance against the reference arithmetic — every gradient tensor within 2e-5 of its maximum, tested per
  * mode at the headline width (K = 256, 19x19) on several data draws — which is why the forward convolutions do NOT take the
  * Winograd path: its rounding (2e-6 of the output rms against 3e-7 for the direct forms) puts a pre-activation on the other side of
