@@ -522,7 +522,7 @@ typedef unsigned wg_u32x2_t __attribute__((ext_vector_type(2)));
 // layer against 0.76 for round 3's kernel (profiles/r04/wgrad_ab.log): the bound is the L2 -> CU operand stream (see k_wgrad_h2t3, which
 // replaces this kernel on boards >= 16 wide).
 __global__ __launch_bounds__(256, 2) void k_wgrad_h2(WgH2Args a) {
-  constexpr int D = 1;
+  constexpr int D = 1;                             // K steps in flight in registers (2, 3, 4 measured no faster: the comment above)
   constexpr int PIECE = 128 * 64;                 // one piece image of one operand: 128 columns x 32 k x 2 B
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * PIECE];   // A (dz) hi, lo; B (x) hi, lo
   // XCD-aware order: the 9 taps x tiles of one row chunk re-read the same dz / x rows (6 MB per 2048 rows at K = 256); workgroup ids
