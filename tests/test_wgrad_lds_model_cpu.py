@@ -85,3 +85,36 @@ def test_x_fragment_addresses(w0):
                     for e in range(8):
                         k = 16 * ks + 8 * (lane >> 5) + e
                         assert v[lane, e] == 1000 * (delta(k, w0, W) + kx) + col0 + (lane & 31)
+
+
+def _worst_way(addr):
+    from collections import Counter
+    return max(max(Counter((addr[l] % 256) // 8 for l in range(32 * h, 32 * h + 32)).values()) for h in (0, 1))
+
+
+def test_transposing_reads_and_lds_banks():
+    """a transposing read serves 32 lanes per LDS cycle (8 bytes each: one 256-byte bank row when every lane hits its own 8-byte slot).
+    dz image: always 32 distinct slots.  x image: the rows of a 16-lane group are delta(k) + kx for four consecutive k — consecutive
+    rows except across a row end (+2), where two lanes can meet on a slot: at most two-way, on about a sixth of the reads."""
+    for ks in range(2):
+        for e in range(2):
+            addr = []
+            for lane in range(64):
+                i16, kh, cpart = lane_parts(lane)
+                addr.append(kh * 2048 + (i16 >> 2) * 16 + cpart + ks * 4096 + e * 1024)
+            assert _worst_way(addr) == 1
+    W, total, conflicting = 19, 0, 0
+    for w0 in range(W):
+        for ks in range(2):
+            for kx in range(3):
+                for e in range(2):
+                    addr = []
+                    for lane in range(64):
+                        i16, kh, cpart = lane_parts(lane)
+                        r = delta(ks * 16 + kh * 8 + (i16 >> 2) + 4 * e, w0, W) + kx
+                        addr.append((r >> 2) * 1024 + (r & 3) * 16 + cpart)
+                    way = _worst_way(addr)
+                    assert way <= 2
+                    total += 1
+                    conflicting += way > 1
+    assert conflicting * 5 < total
