@@ -816,7 +816,8 @@ __global__ __launch_bounds__(256) void split_w2_kernel(const float* __restrict__
 bool agz::conv3x3_raw_h2_fits(int B, int H, int W, int Cin_p, int Cout_p) {
   return Cin_p % 32 == 0 && Cout_p % 256 == 0 && (size_t)B * (H + 2) * (W + 2) * (size_t)std::max(Cin_p, Cout_p) * sizeof(float) < ((size_t)1 << 32);
 }
-int agz::conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc) {
+int agz::conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc,
+                        const unsigned* ranges) {
   AGZ_REQUIRE(conv3x3_raw_h2_fits(B, H, W, Cin_p, Cout_p), AGZ_E_UNSUPPORTED, "conv3x3_raw_h2: shape %d x %dx%d, %d -> %d not supported", B, H, W, Cin_p, Cout_p);
   hipStream_t s = ctx->stream;
   const size_t w_elems = (size_t)9 * Cout_p * Cin_p;
@@ -838,12 +839,12 @@ int agz::conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, 
   sc->h2_flip ^= 1;
   hipLaunchKernelGGL(w_absmax_kernel, dim3((unsigned)std::min<size_t>((w_elems + 255) / 256, 256)), dim3(256), 0, s, w, w_elems, wmax);
   hipLaunchKernelGGL(split_w2_kernel, dim3((unsigned)((w_elems + 255) / 256)), dim3(256), 0, s, w, (_Float16*)sc->w2, Cout_p, Cin_p, wmax, sc->h2_words, B, wmax_next);
-  hipLaunchKernelGGL(board_amax_parts_kernel, dim3(B * 8), dim3(256), 0, s, x, sc->h2_words, H * W, W, W + 2, (H + 2) * (W + 2), Cin_p, 8);
+  if (!ranges) hipLaunchKernelGGL(board_amax_parts_kernel, dim3(B * 8), dim3(256), 0, s, x, sc->h2_words, H * W, W, W + 2, (H + 2) * (W + 2), Cin_p, 8);
   ConvArgs a{};
   a.M = B * H * W; a.HW = H * W; a.W = W; a.Wp = W + 2; a.HpWp = (H + 2) * (W + 2);
   a.x = x; a.w = nullptr; a.ep = nullptr; a.y = y; a.Cin_p = Cin_p; a.Cout_p = Cout_p; a.Ntot = Cout_p; a.raw = 1;
   a.n_ntiles = Cout_p / 256; a.n_mtiles = ceil_div(a.M, 128); a.splits = 1;
-  a.amax_in = sc->h2_words; a.w_unscale = 1.f; a.w_amax_dev = wmax;
+  a.amax_in = ranges ? ranges : sc->h2_words; a.w_unscale = 1.f; a.w_amax_dev = wmax;
   ProfScope ps(ctx, AGZ_PROF_CONV_INIT);
   hipLaunchKernelGGL(conv3x3_h2w_kernel, dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, s, a, (const _Float16*)sc->w2);
   AGZ_HIP_TRY(hipGetLastError());
@@ -869,7 +870,8 @@ void agz::wino_raw_scratch_free(WinoRawScratch* sc) {
   *sc = WinoRawScratch{};
 }
 
-int agz::conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc) {
+int agz::conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc,
+                             const unsigned* ranges) {
   AGZ_REQUIRE(conv3x3_raw_wino_h2_fits(B, H, W, Cin_p, Cout_p), AGZ_E_UNSUPPORTED, "conv3x3_raw_wino_h2: shape %d x %dx%d, %d -> %d not supported", B, H, W, Cin_p, Cout_p);
   hipStream_t s = ctx->stream;
   const int tm = wino_h2_pick_tm(H, W), npos = (tm + 2) * (tm + 2);
@@ -897,14 +899,16 @@ int agz::conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float
     hipLaunchKernelGGL(wino_u_build_kernel<4>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax, (_Float16*)sc->U2, unscale);
   }
   // per-board range of the input (training activations are signed: the kernel takes |x|)
-  AGZ_HIP_TRY(hipMemsetAsync(sc->words, 0, (size_t)B * sizeof(unsigned), s));
-  hipLaunchKernelGGL(board_amax_parts_kernel, dim3(B * 8), dim3(256), 0, s, x, sc->words, H * W, W, Wp, Hp * Wp, Cin_p, 8);
+  if (!ranges) {
+    AGZ_HIP_TRY(hipMemsetAsync(sc->words, 0, (size_t)B * sizeof(unsigned), s));
+    hipLaunchKernelGGL(board_amax_parts_kernel, dim3(B * 8), dim3(256), 0, s, x, sc->words, H * W, W, Wp, Hp * Wp, Cin_p, 8);
+  }
   WinoH2Args hh{};
   WinoArgs& wa = hh.w;
   wa.x = x; wa.y = y; wa.V = sc->V; wa.Mb = sc->M; wa.ep = nullptr;
   wa.B = B; wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Cin_p; wa.Cout_p = Cout_p; wa.Ntot = Cout_p;
   hh.U2 = (const _Float16*)sc->U2; hh.w_unscale = 1.f; hh.w_unscale_dev = unscale; hh.raw = 1; hh.tm = tm;
-  hh.amax_in = sc->words; hh.amax_out = nullptr; hh.wave_max = nullptr; hh.fuse_prev = 0;
+  hh.amax_in = ranges ? ranges : sc->words; hh.amax_out = nullptr; hh.wave_max = nullptr; hh.fuse_prev = 0;
   wino_h2_launch(ctx, hh, Cout_p % 256 == 0, s);
   AGZ_HIP_TRY(hipGetLastError());
   return AGZ_OK;

@@ -29,9 +29,12 @@ struct WinoRawScratch {
   size_t w2_cap = 0; int h2_b_cap = 0, h2_flip = 0;
 };
 // raw 3x3 convolution with fp16x2 products (direct form; weights split on the device every call)
-int conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc);
+// ranges != nullptr: [B] bits of max |x| per board, already on the device (the trainer's BatchNorm passes produce them): no range sweep of x here
+int conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc,
+                   const unsigned* ranges = nullptr);
 bool conv3x3_raw_h2_fits(int B, int H, int W, int Cin_p, int Cout_p);
-int conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc);
+int conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc,
+                        const unsigned* ranges = nullptr);
 bool conv3x3_raw_wino_h2_fits(int B, int H, int W, int Cin_p, int Cout_p);
 void wino_raw_scratch_free(WinoRawScratch* sc);
 }  // namespace agz

@@ -135,13 +135,29 @@ __device__ __forceinline__ void block_amax_commit(unsigned m, unsigned* __restri
     atomicMax(out_bits, a > b ? a : b);
   }
 }
+// per-board maxima of a workgroup's rows (rows_per_block <= HW: at most two boards, bf and bf + 1) -> one atomicMax per board and block:
+// the per-board range words the fp16x2 convolutions scale their input rows by (board_amax_parts_kernel swept the stored tensor for them)
+__device__ __forceinline__ void board_amax_commit(unsigned m0, unsigned m1, int bf, int B, unsigned* __restrict__ board_bits) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t0 = (unsigned)__shfl_xor((int)m0, o, 64), t1 = (unsigned)__shfl_xor((int)m1, o, 64);
+    m0 = t0 > m0 ? t0 : m0; m1 = t1 > m1 ? t1 : m1;
+  }
+  __shared__ unsigned sb[2][4];
+  if ((threadIdx.x & 63) == 0) { sb[0][threadIdx.x >> 6] = m0; sb[1][threadIdx.x >> 6] = m1; }
+  __syncthreads();
+  if (threadIdx.x < 2 && bf + (int)threadIdx.x < B) {
+    const unsigned* q = sb[threadIdx.x];
+    const unsigned a = q[0] > q[1] ? q[0] : q[1], b = q[2] > q[3] ? q[2] : q[3];
+    atomicMax(&board_bits[bf + threadIdx.x], a > b ? a : b);
+  }
+}
 // The same apply, four channels per thread and a fixed channel quad per thread (Kp % 4 == 0, (Kp / 4) divides 256), with max|out| of
 // the whole tensor as a by-product: the NEXT layer's weight gradient splits this tensor into fp16 pieces and needs its range — a
 // separate sweep (k_absmax) re-read it.  Same expressions per element as k_bn_apply.
 __global__ __launch_bounds__(256) void k_bn_apply_v(TGeo g, const float* __restrict__ z, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, const float* __restrict__ mean,
                                                     const float* __restrict__ inv, float* __restrict__ out, int Kp, int nbr,
-                                                    int rows_per_block, unsigned* __restrict__ amax_bits) {
+                                                    int rows_per_block, unsigned* __restrict__ amax_bits, unsigned* __restrict__ board_bits) {
   const int q = Kp >> 2, tpr = 256 / q, cq = threadIdx.x % q, rs = threadIdx.x / q;
   const int C = nbr * Kp;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, g.M);
@@ -150,7 +166,8 @@ __global__ __launch_bounds__(256) void k_bn_apply_v(TGeo g, const float* __restr
     mu[br] = reinterpret_cast<const float4*>(mean + br * Kp)[cq];
     iv[br] = reinterpret_cast<const float4*>(inv + br * Kp)[cq];
   }
-  unsigned mx = 0;
+  unsigned mx = 0, mb[2] = {0, 0};
+  const int bf = r0 / g.HW, r_next = (bf + 1) * g.HW;   // (board_bits: rows_per_block <= HW, so rows >= r_next belong to board bf + 1)
   for (int r = r0 + rs; r < r1; r += tpr) {
     const size_t po = pix_off(g, r);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -168,15 +185,19 @@ __global__ __launch_bounds__(256) void k_bn_apply_v(TGeo g, const float* __restr
       }
     }
     float o[4];
+    unsigned rowm = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       o[k] = (nbr == 2) ? (acc[k] > 0.f ? acc[k] : 0.f) : acc[k];
       const unsigned b = __float_as_uint(o[k]) & 0x7fffffffu;
-      mx = b > mx ? b : mx;
+      rowm = b > rowm ? b : rowm;
     }
+    mx = rowm > mx ? rowm : mx;
+    if (r >= r_next) mb[1] = rowm > mb[1] ? rowm : mb[1]; else mb[0] = rowm > mb[0] ? rowm : mb[0];
     reinterpret_cast<float4*>(out + po * Kp)[cq] = make_float4(o[0], o[1], o[2], o[3]);
   }
   block_amax_commit(mx, amax_bits);
+  if (board_bits) board_amax_commit(mb[0], mb[1], bf, g.B, board_bits);
 }
 
 // ---- tower BN backward, step 1: d(out) -> dgamma, dbeta, d(xhat) (stored in dz) and the two channel sums -------
@@ -235,7 +256,8 @@ __global__ void k_bn_bwd2(TGeo g, const float* __restrict__ z, const float* __re
 // loaded once), with max|dz| of the tensor as a by-product (the weight gradient's range word).  Same expression per element.
 __global__ __launch_bounds__(256) void k_bn_bwd2_v(TGeo g, const float* __restrict__ z, const float* __restrict__ mean,
                                                    const float* __restrict__ inv, float* __restrict__ dz, const double* __restrict__ s1,
-                                                   const double* __restrict__ s2, int C, int rows_per_block, unsigned* __restrict__ amax_bits) {
+                                                   const double* __restrict__ s2, int C, int rows_per_block, unsigned* __restrict__ amax_bits,
+                                                   unsigned* __restrict__ board_bits) {
   const int q = C >> 2, tpr = 256 / q, cq = threadIdx.x % q, rs = threadIdx.x / q;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, g.M);
   const float m = (float)g.M;
@@ -245,23 +267,28 @@ __global__ __launch_bounds__(256) void k_bn_bwd2_v(TGeo g, const float* __restri
     const int cc = 4 * cq + k;
     mv[k] = mean[cc]; nv[k] = inv[cc]; a1[k] = (float)s1[cc] / m; a2[k] = (float)s2[cc] / m;
   }
-  unsigned mx = 0;
+  unsigned mx = 0, mb[2] = {0, 0};
+  const int bf = r0 / g.HW, r_next = (bf + 1) * g.HW;
   for (int r = r0 + rs; r < r1; r += tpr) {
     const size_t po = pix_off(g, r);
     const float4 zz = reinterpret_cast<const float4*>(z + po * C)[cq];
     const float4 dd = reinterpret_cast<const float4*>(dz + po * C)[cq];
     const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, dv[4] = {dd.x, dd.y, dd.z, dd.w};
     float o[4];
+    unsigned rowm = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const float xh = (zv[k] - mv[k]) * nv[k];
       o[k] = nv[k] * (dv[k] - a1[k] - xh * a2[k]);
       const unsigned b = __float_as_uint(o[k]) & 0x7fffffffu;
-      mx = b > mx ? b : mx;
+      rowm = b > rowm ? b : rowm;
     }
+    mx = rowm > mx ? rowm : mx;
+    if (r >= r_next) mb[1] = rowm > mb[1] ? rowm : mb[1]; else mb[0] = rowm > mb[0] ? rowm : mb[0];
     reinterpret_cast<float4*>(dz + po * C)[cq] = make_float4(o[0], o[1], o[2], o[3]);
   }
   block_amax_commit(mx, amax_bits);
+  if (board_bits) board_amax_commit(mb[0], mb[1], bf, g.B, board_bits);
 }
 
 // ---- weight gradient: dW[tap][n][c] += sum_r dz[pix(r)][n] * x[pix(r)+off(tap)][c]  (fp32 MFMA, split over rows) ----
@@ -1121,7 +1148,9 @@ struct agz_trainer {
   // [L + 1][2][1024] and the fp16x2 weight gradient's range words [L + 2][2] = {max|dz| of layer l, max|x| of its input}
   double* acc_b = nullptr;
   unsigned* amax_words = nullptr;
+  unsigned* board_words = nullptr;     // [2][L + 2][B] per-board ranges: [0] layer inputs (from k_bn_apply_v), [1] dz (from k_bn_bwd2_v)
   std::vector<char> x_amax_ready;      // layer l's input range was produced by the forward pass (k_bn_apply_v)
+  std::vector<char> xb_ready;          // ... and its per-board ranges (board_words)
   size_t* zero_tab = nullptr;          // [2][L + 1] offsets and counts of the filter-gradient regions (k_zero_regions)
   // the weight gradient of a layer (matrix pipe / L2 bound, ~0.35 GB of HBM traffic) runs on its own stream beside the same layer's data
   // gradient and the next layer's BatchNorm backward (HBM bound): both only need dz.  Measured 50.6-50.9 -> 49.1-50.0 ms per G19 step —
@@ -1176,13 +1205,14 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   AGZ_HIP_TRY(hipMemsetAsync(G + o_hc, 0, (n_flat - o_hc) * sizeof(float), s));
   AGZ_HIP_TRY(hipMemsetAsync(acc_b, 0, (size_t)(L + 1) * 2048 * sizeof(double), s));
   AGZ_HIP_TRY(hipMemsetAsync(amax_words, 0, (size_t)(L + 2) * 2 * sizeof(unsigned), s));
+  AGZ_HIP_TRY(hipMemsetAsync(board_words, 0, (size_t)2 * (L + 2) * B * sizeof(unsigned), s));
   // ---- forward, training-mode BN
   const float* cur = x0;
   for (int l = 0; l <= L; l++) {
     TLayer& ly = layers[l];
     int r;
     if (use_h2_fwd(ly.Cin_p, ly.Cout_p)) {
-      r = conv3x3_raw_h2(ctx, cur, P + ly.o_wf, ly.z, B, g.H, g.W, ly.Cin_p, ly.Cout_p, &wsc);
+      r = conv3x3_raw_h2(ctx, cur, P + ly.o_wf, ly.z, B, g.H, g.W, ly.Cin_p, ly.Cout_p, &wsc, xb_ready[l] ? board_words + (size_t)l * B : nullptr);
     } else if (use_x3(ly, ly.Cin_p, ly.Cout_p)) {
       if ((r = split_w3(ctx, P + ly.o_wf, ly.w3f, ly.Cout_p, ly.Cin_p)) != AGZ_OK) return r;
       r = conv3x3_raw_x3(ctx, cur, ly.w3f, ly.z, B, g.H, g.W, ly.Cin_p, ly.Cout_p);
@@ -1200,12 +1230,14 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
       hipLaunchKernelGGL(k_bn_sum, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, C, (const float*)ly.mean, acc, RPB);
       hipLaunchKernelGGL(k_bn_fin, dim3(nblk(C)), dim3(256), 0, s, acc, C, (double)g.M, conf.bn_eps, ly.mean, ly.inv, 1);
     }
-    x_amax_ready[l + 1] = 0;
+    x_amax_ready[l + 1] = 0; xb_ready[l + 1] = 0;
     if (wino && Kp % 4 == 0 && Kp / 4 <= 256 && 256 % (Kp / 4) == 0 && ly.nbr <= 2) {
       const int tpr = 256 / (Kp / 4), rpb = round_up(std::max(tpr, ceil_div(g.M, 2048)), tpr);
+      const bool per_board = rpb <= g.HW;   // (a block's rows then lie in at most two boards)
       hipLaunchKernelGGL(k_bn_apply_v, dim3(nblk(g.M, rpb)), dim3(256), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean, ly.inv, ly.out,
-                         Kp, ly.nbr, rpb, amax_words + 2 * (l + 1) + 1);
+                         Kp, ly.nbr, rpb, amax_words + 2 * (l + 1) + 1, per_board ? board_words + (size_t)(l + 1) * B : nullptr);
       x_amax_ready[l + 1] = 1;
+      xb_ready[l + 1] = per_board;
     } else
       hipLaunchKernelGGL(k_bn_apply, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean,
                          ly.inv, ly.out, Kp, ly.nbr);
@@ -1248,10 +1280,12 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     if (sw != s && l < L) AGZ_HIP_TRY(hipStreamWaitEvent(s, ev_split, 0));   // the previous layer's weight gradient has taken its copy of dz
     hipLaunchKernelGGL(k_bn_bwd1, dim3(nblk(g.M, RPB)), dim3(std::min(C, 512)), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean, ly.inv,
                        ly.out, dcur, G + ly.o_gamma, G + ly.o_beta, dz, s1, s2, Kp, ly.nbr, RPB, fuse_lr);
-    bool dz_amax_ready = false;
+    bool dz_amax_ready = false, dzb_ready = false;
     if (wino && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0) {
       const int tpr = 256 / (C / 4), rpb = round_up(std::max(tpr, ceil_div(g.M, 2048)), tpr);
-      hipLaunchKernelGGL(k_bn_bwd2_v, dim3(nblk(g.M, rpb)), dim3(256), 0, s, g, ly.z, ly.mean, ly.inv, dz, s1, s2, C, rpb, wg_amax);
+      dzb_ready = rpb <= g.HW;
+      hipLaunchKernelGGL(k_bn_bwd2_v, dim3(nblk(g.M, rpb)), dim3(256), 0, s, g, ly.z, ly.mean, ly.inv, dz, s1, s2, C, rpb, wg_amax,
+                         dzb_ready ? board_words + (size_t)(L + 2 + l) * B : nullptr);
       dz_amax_ready = true;
     } else
       hipLaunchKernelGGL(k_bn_bwd2, dim3(nblk((size_t)g.M * C)), dim3(256), 0, s, g, ly.z, ly.mean, ly.inv, dz, s1, s2, C);
@@ -1310,7 +1344,7 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
       hipLaunchKernelGGL(k_make_wt, dim3(nblk((size_t)9 * C * ly.Cin_p)), dim3(256), 0, s, P + ly.o_wf, ly.wt, C, ly.Cin_p);
       int r;
       if (use_wino(C, ly.Cin_p)) {
-        r = conv3x3_raw_wino_h2(ctx, dz, ly.wt, dnext, B, g.H, g.W, C, ly.Cin_p, &wsc);
+        r = conv3x3_raw_wino_h2(ctx, dz, ly.wt, dnext, B, g.H, g.W, C, ly.Cin_p, &wsc, dzb_ready ? board_words + (size_t)(L + 2 + l) * B : nullptr);
       } else if (use_x3(ly, C, ly.Cin_p)) {
         if ((r = split_w3(ctx, ly.wt, ly.w3t, ly.Cin_p, C)) != AGZ_OK) return r;
         r = conv3x3_raw_x3(ctx, dz, ly.w3t, dnext, B, g.H, g.W, C, ly.Cin_p);
@@ -1377,7 +1411,8 @@ int agz_trainer_create(agz_ctx* ctx, const agz_net_conf* c, agz_trainer** out) {
   size_t px = (size_t)B * g.Hp * g.Wp;
   TAL(x0, px * t->Fp) TAL(dA, px * Kp) TAL(dB, px * Kp) TAL(dz, px * 2 * Kp) TAL(dz0, px * Kp) TAL(acc, 2048)   /* [2][1024] channel sums of the forward BatchNorm (self-clearing) */
   TAL(acc_b, (size_t)(t->L + 1) * 2048) TAL(amax_words, (size_t)(t->L + 2) * 2) TAL(zero_tab, (size_t)(t->L + 1) * 2)
-  t->x_amax_ready.assign(t->L + 2, 0);
+  TAL(board_words, (size_t)2 * (t->L + 2) * B)
+  t->x_amax_ready.assign(t->L + 2, 0); t->xb_ready.assign(t->L + 2, 0);
   {
     std::vector<size_t> tab((size_t)(t->L + 1) * 2);
     for (int l = 0; l <= t->L; l++) {
