@@ -61,3 +61,35 @@ def test_fragment_reads_fetch_the_mfma_operands_without_bank_conflicts():
                     for g in B128_GROUPS:
                         slots = {(addr[l] // 16) % 16 for l in g}
                         assert len(slots) == 16, (wm, i, ks, half, sorted(slots))
+
+
+def test_m_store_covers_the_mc_tile_in_256_byte_runs():
+    """the GEMM's epilogue (permlane32_swap + two stores per accumulator register pair): every (row, column) of the workgroup's
+    128 x 256 tile is written exactly once, at Mc[tile][pos][slice = column / 64][row][column % 64], and a wave's store instruction
+    writes 64 consecutive floats of one row (a 256-byte run)."""
+    n_tile, ntot = 1, 512
+    base_tile = 0                                           # ((m_tile * npos + pos) * (Ntot / 64)) * 128 * 64, taken as 0
+    seen = {}
+    for wid in range(4):
+        wm, wn = wid >> 1, wid & 1
+        for qq in range(2):
+            for i in range(2):
+                for r in range(16):
+                    row_lo = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2)
+                    for which, drow in ((0, 0), (1, 4)):    # w0 -> d[0], w1 -> d[4 * 64]
+                        addrs = []
+                        for lane in range(64):
+                            # permlane32_swap(x0 = acc[i][2 qq][r], x1 = acc[i][2 qq + 1][r]): w0 = (x0 lanes 0-31 | x1 lanes 0-31), w1 = (x0 lanes 32-63 | x1 lanes 32-63)
+                            src_blk = 2 * qq + (lane >> 5)
+                            src_lane = (lane & 31) + 32 * which
+                            row = row_lo + 4 * (src_lane >> 5)                       # accumulator layout: row += 4 for lanes 32..63
+                            col = n_tile * 256 + wn * 128 + src_blk * 32 + (src_lane & 31)
+                            mbase = (((n_tile * 4 + wn * 2) * 128) + wm * 64) * 64 + lane
+                            addr = base_tile + mbase + qq * 8192 + (i * 32 + (r & 3) + 8 * (r >> 2)) * 64 + drow * 64
+                            want = ((col // 64) * 128 + row) * 64 + col % 64
+                            assert addr == want
+                            assert (row, col) not in seen
+                            seen[(row, col)] = addr
+                            addrs.append(addr)
+                        assert addrs == list(range(addrs[0], addrs[0] + 64))   # one 256-byte run
+    assert len(seen) == 128 * 256
