@@ -179,6 +179,9 @@ def lib():
     sig("agz_wino_stages", i32, vp, pf, pf, i32, i32, i32, i32, i32, pf, pf)
     sig("agz_wino_h2_tile", i32, i32, i32)
     sig("agz_net_set_wino_h2_form", i32, vp, i32)
+    sig("agz_net_set_wino_h2_gemm", i32, vp, i32)
+    sig("agz_arena_set_prep_compact", i32, vp, i32)
+    sig("agz_arena_last_prep_batch", i32, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
     sig("agz_wino_h2_chained", i32, i32, i32, i32)
     sig("agz_arena_random_moves", i32, vp, pi, u64)
     sig("agz_arena_set_state", i32, vp, i32, C.POINTER(State))
@@ -366,6 +369,10 @@ class Net:
     def set_wino_h2_form(self, form):
         """agz_debug.h A/B hook: -1 auto (chained block where the shape allows), 0 three-kernel block, 1 chained"""
         _check(lib().agz_net_set_wino_h2_form(self.h, int(form)), "agz_net_set_wino_h2_form")
+
+    def set_wino_h2_gemm(self, variant):
+        """agz_debug.h A/B hook: 0 default, 1 wino_gemm_h2g_kernel, 2 wino_gemm_h2p_kernel (persistent; K = 256)"""
+        _check(lib().agz_net_set_wino_h2_gemm(self.h, int(variant)), "agz_net_set_wino_h2_gemm")
 
     def infer_dev(self, planes_ptr, B, policy_ptr, value_ptr):
         """device pointers (ints); asynchronous on the ctx stream"""
@@ -598,6 +605,16 @@ class Arena:
                                              _pf(bs), _pf(pr), cap, C.byref(n)), "agz_arena_root_children")
         k = n.value
         return mv[:k].copy(), vis[:k].copy(), bs[:k].copy(), pr[:k].copy()
+
+    def set_prep_compact(self, on=True):
+        """agz_debug.h: prepareRoot's forward on the packed batch of the roots that need it (default) or on the whole arena batch"""
+        _check(lib().agz_arena_set_prep_compact(self.h, int(on)), "agz_arena_set_prep_compact")
+
+    def last_prep_batch(self):
+        """agz_debug.h: (boards the last begin_move's forward ran on, roots it had to evaluate)"""
+        b, r = C.c_int(0), C.c_int(0)
+        _check(lib().agz_arena_last_prep_batch(self.h, C.byref(b), C.byref(r)), "agz_arena_last_prep_batch")
+        return b.value, r.value
 
     def tree_nodes(self, g, agent):
         n = C.c_int32(0)

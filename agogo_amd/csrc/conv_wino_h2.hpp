@@ -115,6 +115,7 @@ struct WinoH2Args {
   float* wm_out;             // the same for this block's output (the other half of the ping-pong pair)
   unsigned* amax_next;       // [B] bits of the proven bound on max |y| of this block's output: the range word of V2(l+1)
   float g1, g0;              // that bound = g1 * max|x| + g0 (agz_net::build_wino_h2_weights)
+  int gemm_variant;          // 0: default, 1: wino_gemm_h2g_kernel, 2: wino_gemm_h2p_kernel (agz_net_set_wino_h2_gemm, agz_debug.h)
 };
 __device__ __forceinline__ size_t h2_row(const WinoH2Args& h, int pos, int t) {
   return (size_t)(t >> h.rsh) * h.rA + (size_t)pos * h.rB + (size_t)(t & h.rmask);

@@ -240,6 +240,202 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_h2g_kernel(WinoH2Args h) {
 // counted vmcnt; the compiler's LDS-DMA tracking keeps the stages apart when they are separate __shared__ objects): correct, 0.359 ms
 // against 0.296 — one workgroup per CU cannot cover its own prologue and its 128-stores-per-thread epilogue, three can.)
 
+// ---- persistent form, B stationary in REGISTERS (round 5) ------------------------------------------------------------------------
+// wino_gemm_h2g_kernel streams both operands per 128 x 256 tile: 2.4 GB per launch through the L2 -> CU path, 1.6 GB of it the
+// 25.7 MB weight image re-read 62 times, and its 128-stores-per-thread epilogue is serial with the K loop.  Here a workgroup keeps
+// ONE weight slab for many tiles: 128 GEMM columns x K = 256 x (hi | lo) fp16 = 128 KB — not in LDS (that would leave 32 KB for the A
+// ring: ~16 KB in flight per CU, a latency-bound stream) but in the MFMA B-fragment REGISTERS of its four waves (64 columns x 256 k x
+// 2 pieces = 256 registers per lane; a one-workgroup-per-CU kernel owns all 512).  LDS is then one 16-stage ring of 8 KB A stages
+// (64 rows x one 32-channel K step) filled by assembly LDS-DMA D = 10 stages ahead (~72 KB in flight per CU) — the counted
+// s_waitcnt vmcnt(N) below rely on gfx9's in-order retirement of a wave's vector-memory operations, stores included.
+//   team   = the four workgroups (column slabs 0..3) of one XCD slot group; they walk the SAME (position, 64-row half tile) units
+//            in the same order, so three of the four A reads are L2 hits: L2 -> CU 1.64 GB (A) + 0.1 GB (B), HBM as before
+//   tile   = 64 rows x 128 columns per workgroup, 32 x 64 per wave (two 32x32 accumulators); two accumulator sets: the M stores of
+//            tile t (the same permlane32_swap 256-byte runs) are issued four per K step between the MFMAs of tile t + 1
+//   units  = npos x 2 n_mtiles half tiles, split evenly over the teams (19x19, B = 512: 6272 units / 64 teams = 98 each, no tail)
+// Per accumulator the MFMA sequence (K steps ascending; lo*hi, hi*lo, hi*hi) is wino_gemm_h2g_kernel's: M is bit-identical.
+typedef unsigned h2p_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void h2p_dma16(h2p_rsrc_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  unsigned keep;                                   // (M0 is put back: the compiler does not model assembly writes to it)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+#define H2P_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+constexpr int H2P_D = 10;                          // DMA lookahead in stages (ring: 16)
+// unit u of a team's list -> byte offset of its K step 0 in V2c (half tile hm of position pos: rows 64 (hm & 1) .. of m-tile hm >> 1)
+__host__ __device__ constexpr unsigned h2p_v_base(int pos, int hm, int npos) {
+  return (unsigned)(((hm >> 1) * npos + pos) * (8 * 16384) + (hm & 1) * 8192);
+}
+// MODE (decomposition runs only, agz_net_set_wino_h2_gemm(net, 2 + 16 * MODE)): bit 0 = no M stores, bit 1 = no DMA (the ring holds whatever LDS held)
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
+  const WinoArgs& a = h.w;
+  constexpr int NK = 8, R = 16, SA = 64 * 128, D = H2P_D;
+  static_assert(D == 10, "the ring slot / K step arithmetic below is written for D = 10");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[R * SA];   // 128 KB
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
+  const int n_slabs = a.Ntot >> 7, n_nt = a.Ntot >> 8;
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int tpx = (int)(gridDim.x >> 3) / n_slabs;           // teams per XCD
+  if (slot >= tpx * n_slabs) return;
+  const int team = xcd * tpx + slot / n_slabs, slab = slot % n_slabs, nteams = 8 * tpx;
+  // units are dealt in PAIRS (n_half is even): a team's range starts at an even unit and holds an even number, so the two tiles
+  // of a pair (ring halves / accumulator sets 0 and 1) always share a position
+  const int n_half = a.n_mtiles * 2, U2 = h.npos * a.n_mtiles;
+  const int u0 = 2 * (int)((long)team * U2 / nteams), nT = 2 * (int)((long)(team + 1) * U2 / nteams) - u0;
+  if (nT <= 0) return;
+
+  h2p_rsrc_t ar;
+  {
+    const unsigned long long u = (unsigned long long)a.V;
+    ar[0] = __builtin_amdgcn_readfirstlane((unsigned)u); ar[1] = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32) & 0xffffu);
+    ar[2] = 0x7fffffffu; ar[3] = 0x00020000u;
+  }
+  // DMA of an 8 KB stage: wave w fills rows 16 w .. 16 w + 15 (2 instructions of 8 rows); LDS unit (row r, slot q') receives global
+  // unit (r, q' ^ ((r >> 1) & 7)) — h2c_img's swizzle on the SOURCE address, (r >> 1) & 7 = (4 j + lane / 16) & 7 for instruction j
+  const unsigned sw0 = (unsigned)(lane >> 4) & 7u, sw1 = (4u + (unsigned)(lane >> 4)) & 7u;
+  const unsigned l8 = (unsigned)(lane >> 3) * 128u, q8 = (unsigned)(lane & 7);
+  const unsigned vo_e = l8 + ((q8 ^ sw0) << 4), vo_o = l8 + 1024u + ((q8 ^ sw1) << 4);
+  const unsigned a_w = (unsigned)wid * 2048u;
+  const unsigned dma_l = (unsigned)(size_t)(h2c_lds_ptr_t)lds + a_w;
+  auto issue = [&](unsigned vb, int kk, int rslot) {
+    if (MODE & 2) return;
+    const unsigned so = vb + (unsigned)kk * 16384u + a_w;
+    h2p_dma16(ar, dma_l + (unsigned)rslot * SA, vo_e, so);
+    h2p_dma16(ar, dma_l + (unsigned)rslot * SA + 1024u, vo_o, so);
+  };
+  const int kh = lane >> 5, sw = (lane >> 1) & 7;
+  const unsigned fa = (unsigned)((wm * 32 + (lane & 31)) * 128);
+  auto frag = [&](int rslot, int ks, int p) -> f16x8_t {
+    return *reinterpret_cast<const f16x8_t*>(lds + rslot * SA + fa + (unsigned)(((p * 4 + 2 * ks + kh) ^ sw) << 4));
+  };
+
+  // B fragments of this wave's 64 columns, every K step: Bf[kk][ks][j][piece]
+  f16x8_t Bf[NK][2][2][2];
+  auto load_b = [&](int pos) {
+    const char* bb = reinterpret_cast<const char*>(h.U2c) + ((size_t)pos * NK * n_nt + (slab >> 1)) * 32768 +
+                     (size_t)(((slab & 1) * 128 + wn * 64 + (lane & 31)) * 128 + kh * 16);
+#pragma unroll
+    for (int kk = 0; kk < NK; kk++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int p = 0; p < 2; p++)
+            Bf[kk][ks][j][p] = *reinterpret_cast<const f16x8_t*>(bb + (size_t)kk * n_nt * 32768 + j * 4096 + (p * 4 + 2 * ks) * 16);
+    // the slab lives in the 256 accumulation registers (MFMA reads B operands from there), everything else in the 256 vector
+    // registers: left to itself the allocator mixes the two files and shuffles ~20 registers per K step between them
+#pragma unroll
+    for (int kk = 0; kk < NK; kk++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int p = 0; p < 2; p++) asm volatile("" : "+a"(Bf[kk][ks][j][p]));
+  };
+  auto m_base = [&](int pos, int hm) -> float* {
+    return a.Mb + ((((size_t)(hm >> 1) * h.npos + pos) * (size_t)(a.Ntot >> 6) + (size_t)(slab * 2 + wn)) * 128 + (size_t)((hm & 1) * 64 + wm * 32)) * 64 + lane;
+  };
+  auto store_rows = [&](const f32x16 (&ac)[2], float* mb, int r) {     // accumulator register r of both column tiles: rows R and R + 4
+    const unsigned x0 = __float_as_uint(ac[0][r]), x1 = __float_as_uint(ac[1][r]);
+    const auto s32 = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);
+    const unsigned w0 = s32[0], w1 = s32[1];
+    float* d = mb + (size_t)((r & 3) + 8 * (r >> 2)) * 64;
+    if (MODE & 1) { asm volatile("" ::"v"(w0), "v"(w1)); return; }
+    d[0] = __uint_as_float(w0);
+    d[4 * 64] = __uint_as_float(w1);
+  };
+
+  int pos = u0 / n_half;
+  // byte offset in V2c of tile tt's K step 0, tt within two tiles of the current position's run (tt clamped: past the end the ring
+  // re-fetches the last unit — the counted waits need the same number of operations in every step)
+  auto unit_base = [&](int tt) -> unsigned {
+    int m = u0 + (tt < nT ? tt : nT - 1) - pos * n_half, p = pos;
+    if (m >= n_half) { m -= n_half; p++; }
+    return h2p_v_base(p, m, h.npos);
+  };
+  {                                                          // prologue: stages 0 .. D - 1 (units 0 and 1)
+    const unsigned vb0 = unit_base(0), vb1 = unit_base(1);
+#pragma unroll
+    for (int g = 0; g < D; g++) issue(g < NK ? vb0 : vb1, g & 7, g);
+  }
+  f32x16 accA[2], accB[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) accB[j][r] = 0.f;
+  f16x8_t Fc[2][2];                                          // A fragments of the step about to run: [ks][piece]
+  H2P_WAIT((D - 1) * 2);                                     // stage 0 has landed (this wave's part; after the barrier every wave's)
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+    for (int p = 0; p < 2; p++) Fc[ks][p] = frag(0, ks, p);
+  // tile 0 has no predecessor: its store slots write the zeros of accB to its OWN rows (overwritten by its results during tile 1:
+  // a wave's stores to one address stay in order) — every step of the kernel then issues the same 2 DMAs + 4 stores
+  float* mprev = m_base(pos, u0 - pos * n_half);
+
+  // one tile: PAR = t & 1 selects the ring half of its own stages (compile-time LDS offsets) and the accumulator set
+  auto tile = [&](auto par_c, int t, f32x16 (&accC)[2], f32x16 (&accP)[2]) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value;
+    const int hm = u0 + t - pos * n_half;
+    const unsigned vb1 = unit_base(t + 1), vb2 = unit_base(t + 2);
+    float* const mcur = m_base(pos, hm);
+    const unsigned early = (unsigned)__builtin_amdgcn_readfirstlane((t < 2 || (MODE & 1)) ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) accC[j][r] = 0.f;
+      asm volatile("" : "+v"(accC[j]));
+    }
+#pragma unroll
+    for (int kk = 0; kk < NK; kk++) {
+      // stage g + 1 has landed: younger operations than its two DMAs = 4 stores of the issuing step + 8 steps x (2 DMA + 4 stores)
+      // = 52; in the first pair the younger operations are prologue DMAs: >= (D - 2) x 2 (a count that is too small only waits longer)
+      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lh2p_steady_%=\n\ts_waitcnt vmcnt(16)\n\ts_branch .Lh2p_done_%=\n"
+                   ".Lh2p_steady_%=:\n\ts_waitcnt vmcnt(52)\n.Lh2p_done_%=:" ::"s"(early) : "memory", "scc");
+      __builtin_amdgcn_s_barrier();
+      issue((kk + D) / NK == 1 ? vb1 : vb2, (kk + D) % NK, (PAR * NK + kk + D) % R);
+      f16x8_t Fn[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int p = 0; p < 2; p++) Fn[ks][p] = frag((PAR * NK + kk + 1) % R, ks, p);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {                       // small terms first: lo*hi, hi*lo, hi*hi (per accumulator as h2g)
+        accC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][1], Bf[kk][ks][0][0], accC[0], 0, 0, 0);
+        accC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][1], Bf[kk][ks][1][0], accC[1], 0, 0, 0);
+        accC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][0], Bf[kk][ks][0][1], accC[0], 0, 0, 0);
+        accC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][0], Bf[kk][ks][1][1], accC[1], 0, 0, 0);
+        store_rows(accP, mprev, 2 * kk + ks);                // the previous tile's M, two row groups per K step
+        accC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][0], Bf[kk][ks][0][0], accC[0], 0, 0, 0);
+        accC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][0], Bf[kk][ks][1][0], accC[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int p = 0; p < 2; p++) Fc[ks][p] = Fn[ks][p];
+    }
+    mprev = mcur;
+  };
+  for (int t = 0; t < nT;) {                                 // a run of tiles at one position: its weight slab into the B registers
+    const int seg_end = min(nT, (pos + 1) * n_half - u0);
+    load_b(pos);
+    for (; t < seg_end; t += 2) {
+      tile(std::integral_constant<int, 0>{}, t, accA, accB);
+      tile(std::integral_constant<int, 1>{}, t + 1, accB, accA);
+    }
+    pos++;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) store_rows(accB, mprev, r);   // the last tile (odd)
+  H2P_WAIT(0);                                               // no DMA may still be landing when the LDS goes back to the CU
+}
+
 // Y[l] += At[l][nu] * t for the output transform's row pass, one column nu at a time (nu is a constant after unrolling)
 template <int TM> __device__ __forceinline__ void wino_at_acc(int nu, float* Y, float t);
 template <> __device__ __forceinline__ void wino_at_acc<5>(int nu, float* Y, float t) {
@@ -731,12 +927,28 @@ static void wino_h2c_in(agz_ctx* ctx, WinoH2Args& h, hipStream_t st) {     // bl
   if (h.tm == 5) hipLaunchKernelGGL(wino_in_h2_kernel<5>, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, h);
   else hipLaunchKernelGGL(wino_in_h2_kernel<4>, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, h);
 }
+constexpr int WINO_H2_GEMM_DEFAULT = 1;   // 1: wino_gemm_h2g_kernel (three workgroups per CU), 2: wino_gemm_h2p_kernel (persistent)
 static void wino_h2c_gemm(agz_ctx* ctx, WinoH2Args& h, hipStream_t st) {
   wino_h2c_geometry(h);
   ProfScopeOn ps(ctx, AGZ_PROF_WINO_GEMM, st == ctx->stream);
   const dim3 g(h.npos * h.w.n_mtiles * (h.w.Ntot >> 8));
   // (the DMA form addresses V and U2c through buffer descriptors: 31-bit byte offsets)
   const bool dma_ok = wino_h2_rows(h.npos, (size_t)h.w.T) * h.w.C * 4 < ((size_t)1 << 31) && (size_t)h.npos * h.w.C * h.w.Ntot * 4 < ((size_t)1 << 31);
+  // persistent form (wino_gemm_h2p_kernel; gemm_variant 2, AGZ_WINO_H2_GEMM=2): K = 256, whole 128-column slabs, one workgroup per CU
+  static const int gemm_env = [] { const char* e = getenv("AGZ_WINO_H2_GEMM"); return e ? atoi(e) : 0; }();
+  const int variant_all = h.gemm_variant > 0 ? h.gemm_variant : (gemm_env > 0 ? gemm_env : WINO_H2_GEMM_DEFAULT);
+  const int variant = variant_all & 15, mode = variant_all >> 4;   // (mode: agz_debug.h decomposition runs — results are then NOT valid)
+  const int n_slabs = h.w.Ntot >> 7;
+  if (variant == 2 && dma_ok && (h.w.C >> 5) == 8 && h.w.Ntot % 256 == 0 && ctx->num_cus / 8 >= n_slabs) {
+    const dim3 gp((unsigned)(8 * ((ctx->num_cus / 8) / n_slabs) * n_slabs));
+    switch (mode) {
+      case 1: hipLaunchKernelGGL(wino_gemm_h2p_kernel<1>, gp, dim3(256), 0, st, h); break;
+      case 2: hipLaunchKernelGGL(wino_gemm_h2p_kernel<2>, gp, dim3(256), 0, st, h); break;
+      case 3: hipLaunchKernelGGL(wino_gemm_h2p_kernel<3>, gp, dim3(256), 0, st, h); break;
+      default: hipLaunchKernelGGL(wino_gemm_h2p_kernel<0>, gp, dim3(256), 0, st, h); break;
+    }
+    return;
+  }
   if (dma_ok) {
     switch (h.w.C >> 5) {
       case 4: hipLaunchKernelGGL((wino_gemm_h2g_kernel<4>), g, dim3(256), 0, st, h); return;

@@ -1301,6 +1301,8 @@ struct agz_arena {
   std::vector<int32_t> slot_host;
   int32_t* d_remaining = nullptr;   // agz_arena_random_moves staging
   unsigned long long prep_expand_seen = 0;   // CNT_PREP_EXPAND at the last prepareRoot step
+  bool prep_compact = true;                  // agz_arena_set_prep_compact (agz_debug.h)
+  int last_prep_batch = 0, last_prep_roots = 0;   // boards in / roots evaluated by the last prepareRoot forward (0: skipped)
   int nA_slots = 0, nB_slots = 0;
   bool in_move = false;
   bool restart = false;  // continuous self-play: finished games restart immediately
@@ -1319,6 +1321,25 @@ struct agz_arena {
   int update_slots();
   int nn_step(int prep, int nl = 1);   // nl lanes per tree in this round (<= d.V)
 };
+
+// prepareRoot evaluates only roots without children (search.go:392-408): with tree reuse a minority of an arena's games (19x19, 512
+// games: 80-130 per move boundary — the opponent's reply was never expanded in this agent's tree).  Their input planes, written by
+// k_select at the games' own slots, are packed to the front of the batch IN PLACE: game g's planes move to slot rank(g) = the number
+// of earlier games that need the network.  Thread i moves float4 i of every board, in game order: slot rank(g) <= slot g, and a
+// slot is overwritten only after the same thread has moved its element out — no barrier, one pass, deterministic.
+__global__ __launch_bounds__(256) void k_prep_compact(Dev d, float* act, int slot_f4) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float4* a4 = reinterpret_cast<float4*>(act);
+  int rank = 0;
+  for (int g = 0; g < d.G; g++) {
+    const bool need = d.leaf_kind[(size_t)g * d.V] == LEAF_EXPAND && !d.ended[g];
+    if (i == 0) d.prep_slot[g] = need ? rank : 0;
+    if (!need) continue;
+    const int src = d.slot_of_game[g];
+    if (src != rank && i < slot_f4) a4[(size_t)rank * slot_f4 + i] = a4[(size_t)src * slot_f4 + i];
+    rank++;
+  }
+}
 
 // NN batch slots.  One shared net (or synthetic inferencers): slot = game.  Two different nets: games whose
 // current agent is A take slots [0, nA), B's take [nA, G) so that each net runs one dense sub-batch.
@@ -1365,13 +1386,28 @@ int agz_arena::nn_step(int prep, int nl) {
   // prepareRoot evaluates the network only for a root without children (search.go:392-408).  With tree reuse that is the rare
   // case: if NO game of this arena needs it, the batched forward is skipped (one 8-byte read-back per move)
   bool need_forward = true;
+  int prep_batch = 0;              // > 0: prepareRoot's network batch, packed to the front (k_prep_compact)
   if (prep) {
     unsigned long long cnt = 0;
     AGZ_HIP_TRY(hipMemcpyAsync(&cnt, d.counters + CNT_PREP_EXPAND, 8, hipMemcpyDeviceToHost, ctx->stream));
     AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
     need_forward = cnt != prep_expand_seen;
+    const unsigned long long n_need = cnt - prep_expand_seen;
     prep_expand_seen = cnt;
+    // one shared network, identity slots: evaluate the n_need roots as a batch of their own when a smaller batch runs the same
+    // kernels (agz_net::min_same_batch: per board the results are those of the whole-arena batch, bit for bit)
+    last_prep_roots = (int)n_need; last_prep_batch = need_forward ? G : 0;
+    if (need_forward && prep_compact && !split_nets() && nl == 1 && inf_kind[0] == AGZ_INF_NET && inf_kind[1] == AGZ_INF_NET && n_need < (unsigned long long)G) {
+      const int nb = net[0]->min_same_batch((int)n_need, G);
+      if (nb < G) {
+        const int slot_f4 = (int)(slot_elems / 4);
+        hipLaunchKernelGGL(k_prep_compact, dim3(ceil_div(slot_f4, 256)), dim3(256), 0, ctx->stream, d, act0, slot_f4);
+        prep_batch = nb; last_prep_batch = nb;
+      }
+    }
   }
+  Dev dx = d;                      // what k_expand reads its network rows through
+  if (prep_batch > 0) dx.slot_of_game = d.prep_slot;
   InfDesc inf{};
   for (int a = 0; a < 2; a++) {
     inf.kind[a] = inf_kind[a];
@@ -1391,7 +1427,7 @@ int agz_arena::nn_step(int prep, int nl) {
     agz_net* n = inf_kind[0] == AGZ_INF_NET ? net[0] : (inf_kind[1] == AGZ_INF_NET ? net[1] : nullptr);
     if (n) {
       int a = inf_kind[0] == AGZ_INF_NET ? 0 : 1;
-      int r = n->forward_packed(G * nl, d_policy[a], d_value[a]);   // lane-major slots: one dense batch
+      int r = n->forward_packed(prep_batch > 0 ? prep_batch : G * nl, d_policy[a], d_value[a]);   // lane-major slots: one dense batch
       if (r != AGZ_OK) return r;
       if (inf_kind[0] == AGZ_INF_NET && inf_kind[1] == AGZ_INF_NET) { inf.policy[1] = d_policy[0]; inf.value[1] = d_value[0]; }
     }
@@ -1410,10 +1446,10 @@ int agz_arena::nn_step(int prep, int nl) {
   {
     ProfScope ps(ctx, AGZ_PROF_EXPAND);
     if (split_lanes) {
-      hipLaunchKernelGGL(k_expand_prep, dim3(G * nl), dim3(64), 0, ctx->stream, d, gc, mc, inf, nl);
-      hipLaunchKernelGGL(k_expand_commit, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, prep, nl);
+      hipLaunchKernelGGL(k_expand_prep, dim3(G * nl), dim3(64), 0, ctx->stream, dx, gc, mc, inf, nl);
+      hipLaunchKernelGGL(k_expand_commit, dim3(G), dim3(64), 0, ctx->stream, dx, gc, mc, prep, nl);
     } else {
-      hipLaunchKernelGGL(k_expand, dim3(G), dim3(64), 0, ctx->stream, d, gc, mc, inf, prep, nl);
+      hipLaunchKernelGGL(k_expand, dim3(G), dim3(64), 0, ctx->stream, dx, gc, mc, inf, prep, nl);
     }
   }
   AGZ_HIP_TRY(hipGetLastError());
@@ -1462,7 +1498,10 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
   Dev& d = a->d;
   const int G = n_games, T = 2 * G;
   d.G = G; d.T = T;
-  long long cap = max_nodes > 0 ? max_nodes : (long long)(2 * (mcts->Budget + 2)) * (c.A + 1) + 16;
+  // (a single tree with Budget <= 0 = a search that stops on the wall clock, agz_mcts_set_timeout_ms: no simulation count to size by —
+  // room for 65536 expansions, at most the 8 M-node ceiling; a full pool ends such a search, agz_mcts_search)
+  const long long size_by = mcts->Budget > 0 || n_games > 1 ? mcts->Budget : 65536;
+  long long cap = max_nodes > 0 ? max_nodes : (long long)(2 * (size_by + 2)) * (c.A + 1) + 16;
   if (cap > 8000000) cap = 8000000;
   d.cap = (int)cap;
   d.moves_stride = c.max_moves + 4;
@@ -1477,7 +1516,7 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
   AL(stalled, T) AL(overflow, T) AL(pc_hash, (size_t)T * d.moves_stride) AL(pc_move, (size_t)T * d.moves_stride) AL(pc_n, T) AL(rng, T) AL(rng_game, G)
   d.V = 1;
   AL(vl, pool)
-  AL(slot_of_game, G) AL(leaf_kind, G) AL(leaf_player, G) AL(leaf_ply, G) AL(leaf_result, G) AL(leaf_board, (size_t)G * CELLS_PAD)
+  AL(slot_of_game, G) AL(prep_slot, G) AL(leaf_kind, G) AL(leaf_player, G) AL(leaf_ply, G) AL(leaf_result, G) AL(leaf_board, (size_t)G * CELLS_PAD)
   AL(leaf_legal, (size_t)G * CELLS_PAD) AL(path, (size_t)G * MAXPATH) AL(path_len, G) AL(counters, CNT_N)
   {
     size_t per_ex = (size_t)c.F * c.cells + (c.A + 1) + 3;
@@ -1606,6 +1645,18 @@ int agz_arena_begin_move(agz_arena* a) {
   }
   a->in_move = true;
   return a->nn_step(1);  // prepareRoot
+}
+
+int agz_arena_set_prep_compact(agz_arena* a, int on) {
+  AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
+  a->prep_compact = on != 0;
+  return AGZ_OK;
+}
+
+int agz_arena_last_prep_batch(agz_arena* a, int* boards, int* roots) {
+  AGZ_REQUIRE(a && boards && roots, AGZ_E_INVALID, "agz_arena_last_prep_batch: NULL argument");
+  *boards = a->last_prep_batch; *roots = a->last_prep_roots;
+  return AGZ_OK;
 }
 
 int agz_arena_simulate(agz_arena* a, int k) {
@@ -2070,6 +2121,7 @@ int agz_mcts_search(agz_mcts* m, int player, int32_t* best) {
   a->a_is_black[0] = (uint8_t)ab;
   int r = agz_arena_begin_move(a);
   if (r != AGZ_OK) return r;
+  bool pool_full_stop = false;   // wall-clock search without a Budget, ended by a full node pool: a stopping condition, not an error
   if (m->timeout_ms > 0) {
     // mcts.Config.Timeout (tree.go:18,34; search.go:132-133,196-197): simulations until the wall clock says stop.  Rounds are enqueued
     // in slices and the clock is read after each slice has finished on the device; the slice grows until it takes ~2 ms, so the
@@ -2083,9 +2135,15 @@ int agz_mcts_search(agz_mcts* m, int player, int32_t* best) {
       const int n = (int)std::min<int64_t>(slice, cap - done);
       const double before = elapsed_ms();
       r = agz_arena_simulate(a, n);
-      if (r == AGZ_OK && hipStreamSynchronize(s) != hipSuccess) { agz::set_error("agz_mcts_search: stream synchronisation failed"); r = AGZ_E_HIP; }
+      // the overflow counter rides on the same synchronisation: a full pool ENDS a wall-clock search (the tree is as large as this
+      // handle can hold; the reference's arena is unbounded, its clock is what stops it) instead of spinning on a stalled tree
+      unsigned long long full_now = full0;
+      if (r == AGZ_OK && (hipMemcpyAsync(&full_now, a->d.counters + CNT_FULL, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) {
+        agz::set_error("agz_mcts_search: stream synchronisation failed"); r = AGZ_E_HIP;
+      }
       if (r != AGZ_OK) { a->in_move = false; return r; }
       done += n;
+      if (full_now != full0) { pool_full_stop = a->mc.Budget <= 0; break; }
       if (elapsed_ms() - before < 2.0 && slice < 4096) slice *= 2;
     }
     m->last_sims = done;
@@ -2106,7 +2164,7 @@ int agz_mcts_search(agz_mcts* m, int player, int32_t* best) {
   AGZ_HIP_TRY(hipMemcpyAsync(&full, a->d.counters + CNT_FULL, 8, hipMemcpyDeviceToHost, s));
   AGZ_HIP_TRY(hipStreamSynchronize(s));
   *best = out[0];
-  AGZ_REQUIRE(full == full0, AGZ_E_TREE_FULL, "agz_mcts_search: the node pool overflowed (max_nodes too small); the move is the best of the truncated search");
+  AGZ_REQUIRE(full == full0 || pool_full_stop, AGZ_E_TREE_FULL, "agz_mcts_search: the node pool overflowed (max_nodes too small); the move is the best of the truncated search");
   return AGZ_OK;
 }
 

@@ -96,6 +96,7 @@ struct Dev {
   uint64_t* rng_game;     // [G] SplitMix64 state of Arena.r (colour draws on restart)
   // ---- per-simulation scratch
   int32_t* slot_of_game;  // [G] NN batch slot
+  int32_t* prep_slot;     // [G] prepareRoot's compact batch: rank of game g among the roots the network has to evaluate (k_prep_compact)
   int32_t* leaf_kind;     // [G*V]
   int32_t* leaf_player;   // [G*V]
   int32_t* leaf_ply;      // [G*V]

@@ -1040,6 +1040,62 @@ int agz_net::build_wino_h2_weights() {
   return AGZ_OK;
 }
 
+agz_net::FwdPlan agz_net::fwd_plan(int B) const {
+  const int M = B * HW;
+  FwdPlan p{};
+  // tile height: 128-row tiles are the most efficient; when a layer has fewer of them than half the CU slots
+  // (Connect-4: 84 tiles on 512 slots) 64-row tiles spread the work over twice as many CUs (measured +5%)
+  auto n_tiles128 = [&](int ntot) { return ceil_div(M, 128) * ceil_div(ntot, 128); };
+  p.half_init = cfg == 0 && n_tiles128(Kp) < ctx->num_cus;
+  p.half_dual = cfg == 0 && n_tiles128(2 * Kp) < ctx->num_cus;
+  // latency regime (one decision per forward, so every layer and the heads agree): the dual layers would occupy
+  // at most a quarter of the CUs.  Tournament Agent.Search (one tree, batch 1) lands here.
+  const int tiles_dual = cfg != 0 ? ceil_div(M, 128) * ceil_div(2 * Kp, 64) : ceil_div(M, 64) * ceil_div(2 * Kp, 128);
+  // ... or, for wide towers (K >= 256: 72 K-iterations per tile), would not even give every CU one tile: a round of 8-16
+  // lanes of a single tree (agz_arena_set_parallel) — measured 1.135 -> 1.05 s per move at 8 lanes.  Narrow towers must
+  // not take this branch (Connect-4, K=64, 168 tiles: 183 -> 139 games/s).
+  p.small = latency_mode && Kp >= 64 &&
+            (tiles_dual * 4 <= ctx->num_cus || (Kp >= 256 && tiles_dual <= ctx->num_cus));  // 32-wide towers are launch-bound
+  // A split mode with AGZ_COMPUTE_FORCE keeps ITS tower at every batch size (so a lane round of 16 boards and the batch-1
+  // prepareRoot of the same search run the same arithmetic, bit for bit per board): measured on G19T (40 blocks), per block:
+  // 16 boards 0.086 ms Winograd fp16x2 vs 0.150 ms split-K fp32; 8 boards 0.068 vs 0.086; 1 board 0.053 vs 0.023 — the
+  // batch-1 evaluation happens once per move, the rounds 100 times (profiles/r02/latency_modes.log).  The heads keep the
+  // spread small-batch form either way.
+  p.forced_split = compute_force && cfg == 0 && conf.SharedLayers > 0 &&
+                   (this->compute_mode == AGZ_COMPUTE_WINO_H2 || this->compute_mode == AGZ_COMPUTE_WINO ||
+                    this->compute_mode == AGZ_COMPUTE_BF16X3 || this->compute_mode == AGZ_COMPUTE_FP16X2);
+  p.latency = p.small && !p.forced_split;          // split-K convolutions
+  const int spread_max = 64;
+  // (wide towers: the spread form also wins at 512 boards — 0.17 vs 0.35 ms at 19x19 / K=256, profiles/r02/init_heads_ab.log)
+  p.heads_spread = p.small || (latency_mode && (B <= spread_max || Kp >= 256));
+  p.heads_nb = B >= 32;   // heads_fc_nb_kernel<4> (four boards per workgroup) from 32 boards
+  // the split kernels only pay once the 128-row tiles fill the chip (Connect-4, K=64, 256 games: 84 tiles -> the fp32
+  // half-tile kernel is faster: 187 vs 162 / 158 games/s measured)
+  // (the split kernels use 32-bit BYTE offsets: activation tensor below 4 GiB)
+  p.split_ok = cfg == 0 && !p.latency && (!p.half_dual || compute_force) && conf.SharedLayers > 0 &&
+               (size_t)B * Hp * Wp * Kp * sizeof(float) < ((size_t)1 << 32);
+  // the three-kernel Winograd fp16x2 block picks its GEMM tile by how many workgroups the batch gives (forward_packed)
+  {
+    const int npos = (wino_tm + 2) * (wino_tm + 2), tpb = ceil_div(H, wino_tm) * ceil_div(W, wino_tm);
+    p.wino_wide = (2 * Kp) % 256 == 0 && (size_t)npos * ceil_div(B * tpb, 128) * ((2 * Kp) / 256) >= (size_t)ctx->num_cus;
+  }
+  return p;
+}
+
+int agz_net::min_same_batch(int n, int G) const {
+  if (n >= G) return G;
+  const FwdPlan want = fwd_plan(G);
+  auto same = [&](int B) {
+    const FwdPlan q = fwd_plan(B);
+    return q.half_init == want.half_init && q.half_dual == want.half_dual && q.small == want.small && q.forced_split == want.forced_split &&
+           q.latency == want.latency && q.heads_spread == want.heads_spread && q.split_ok == want.split_ok && q.heads_nb == want.heads_nb && q.wino_wide == want.wino_wide;
+  };
+  if (same(n)) return n;
+  for (int B = 16; B < G; B *= 2)
+    if (B > n && same(B)) return B;
+  return G;
+}
+
 int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   AGZ_REQUIRE(committed, AGZ_E_STATE, "agz_net: infer before agz_net_commit");
   AGZ_REQUIRE(B >= 1 && B <= max_batch, AGZ_E_INVALID, "agz_net: batch %d exceeds allocated %d", B, max_batch);
@@ -1048,37 +1104,9 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
   // K1: init conv  F -> K  (+BN+ReLU)
   a.x = d_act_in; a.w = d_w_init; a.ep = d_ep_init; a.y = d_actA;
   a.Cin_p = Fp; a.Cout_p = Kp; a.Ntot = Kp;
-  // tile height: 128-row tiles are the most efficient; when a layer has fewer of them than half the CU slots
-  // (Connect-4: 84 tiles on 512 slots) 64-row tiles spread the work over twice as many CUs (measured +5%)
-  auto n_tiles128 = [&](int ntot) { return ceil_div(a.M, 128) * ceil_div(ntot, 128); };
-  const bool half_init = cfg == 0 && n_tiles128(Kp) < ctx->num_cus;
-  const bool half_dual = cfg == 0 && n_tiles128(2 * Kp) < ctx->num_cus;
-  // latency regime (one decision per forward, so every layer and the heads agree): the dual layers would occupy
-  // at most a quarter of the CUs.  Tournament Agent.Search (one tree, batch 1) lands here.
-  const int tiles_dual = cfg != 0 ? ceil_div(a.M, 128) * ceil_div(2 * Kp, 64) : ceil_div(a.M, 64) * ceil_div(2 * Kp, 128);
-  // ... or, for wide towers (K >= 256: 72 K-iterations per tile), would not even give every CU one tile: a round of 8-16
-  // lanes of a single tree (agz_arena_set_parallel) — measured 1.135 -> 1.05 s per move at 8 lanes.  Narrow towers must
-  // not take this branch (Connect-4, K=64, 168 tiles: 183 -> 139 games/s).
-  const bool small = latency_mode && Kp >= 64 &&
-                     (tiles_dual * 4 <= ctx->num_cus || (Kp >= 256 && tiles_dual <= ctx->num_cus));  // 32-wide towers are launch-bound
-  // A split mode with AGZ_COMPUTE_FORCE keeps ITS tower at every batch size (so a lane round of 16 boards and the batch-1
-  // prepareRoot of the same search run the same arithmetic, bit for bit per board): measured on G19T (40 blocks), per block:
-  // 16 boards 0.086 ms Winograd fp16x2 vs 0.150 ms split-K fp32; 8 boards 0.068 vs 0.086; 1 board 0.053 vs 0.023 — the
-  // batch-1 evaluation happens once per move, the rounds 100 times (profiles/r02/latency_modes.log).  The heads keep the
-  // spread small-batch form either way.
-  const bool forced_split = compute_force && cfg == 0 && conf.SharedLayers > 0 &&
-                            (this->compute_mode == AGZ_COMPUTE_WINO_H2 || this->compute_mode == AGZ_COMPUTE_WINO ||
-                             this->compute_mode == AGZ_COMPUTE_BF16X3 || this->compute_mode == AGZ_COMPUTE_FP16X2);
-  const bool latency = small && !forced_split;          // split-K convolutions
-  const int spread_max = 64;
-  // (wide towers: the spread form also wins at 512 boards — 0.17 vs 0.35 ms at 19x19 / K=256, profiles/r02/init_heads_ab.log)
-  const bool heads_spread = small || (latency_mode && (B <= spread_max || Kp >= 256));
+  const FwdPlan plan = fwd_plan(B);
+  const bool half_init = plan.half_init, half_dual = plan.half_dual, latency = plan.latency, heads_spread = plan.heads_spread, split_ok = plan.split_ok;
   float** wsp = latency ? &d_ws : nullptr;
-  // the split kernels only pay once the 128-row tiles fill the chip (Connect-4, K=64, 256 games: 84 tiles -> the fp32
-  // half-tile kernel is faster: 187 vs 162 / 158 games/s measured)
-  // (the split kernels use 32-bit BYTE offsets: activation tensor below 4 GiB)
-  const bool split_ok = cfg == 0 && !latency && (!half_dual || compute_force) && conf.SharedLayers > 0 &&
-                        (size_t)B * Hp * Wp * Kp * sizeof(float) < ((size_t)1 << 32);
   // AGZ_COMPUTE_AUTO: the measured choice — the Winograd fp16x2 tower wherever its weights exist (K a multiple of 64; 19x19 K=256:
   // 0.72 vs 2.03 ms per block for bf16x3, 9x9 K=128: 21.4 vs 13.5 games/s), else bf16x3; shapes below the chip-filling threshold
   // keep the fp32 kernels either way
@@ -1152,7 +1180,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
     const int tpb = ceil_div(H, wino_tm) * ceil_div(W, wino_tm);
     // ... and the 128-column tile when the 256-column grid would leave CUs without a workgroup (a lane round of 16 boards: 196
     // against 392 workgroups, 0.0747 -> 0.0726 ms per block, p50 move 0.250 -> 0.241 s)
-    const bool wide = (2 * Kp) % 256 == 0 && (size_t)npos * ceil_div(B * tpb, 128) * ((2 * Kp) / 256) >= (size_t)ctx->num_cus;
+    const bool wide = plan.wino_wide;
     // Board chunks and queues (agz_net_set_tower_queues; AGZ_WINO_H2_CHUNK = boards per chunk, AGZ_WINO_H2_QUEUES = 1 | 2 override):
     // chunk i runs its block chain on queue i % queues with that queue's scratch — chains of different boards are independent
     // (per-board ranges, bit-identical results), so one half-batch's HBM-bound transform kernels run under the other's GEMM and
@@ -1228,7 +1256,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         hh.amax_true = l == 0 ? reinterpret_cast<const float*>(d_amax + b0) : nullptr;  // block 0: board_amax_kernel's exact word
         hh.wm_prev = d_wave_max + ((size_t)((l + 1) & 1) * B + b0) * wmb;
         hh.wm_out = d_wave_max + ((size_t)(l & 1) * B + b0) * wmb;
-        hh.g1 = wino_g1[l]; hh.g0 = wino_g0[l];
+        hh.g1 = wino_g1[l]; hh.g0 = wino_g0[l]; hh.gemm_variant = wino_gemm;
         if (l == 0) agz::wino_h2c_in(ctx, hh, st);
         agz::wino_h2c_gemm(ctx, hh, st);
         agz::wino_h2c_oi(ctx, hh, last, st, form_want == 1 ? 1 : 4);   // (A/B hook: form 1 = the plain out->in kernel)
@@ -1362,7 +1390,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
       }
       h.feat = d_hs; h.cols = d_hs + (size_t)B * 3 * HW;
       hipLaunchKernelGGL(heads_feat_kernel, dim3(ceil_div(HW, 4), B), dim3(256), 0, ctx->stream, h);
-      if (B >= 32)
+      if (plan.heads_nb)
         hipLaunchKernelGGL(heads_fc_nb_kernel<4>, dim3(ceil_div(conf.ActionSpace + conf.FC, 64), ceil_div(B, 4)), dim3(1024), 0, ctx->stream, h, B);
       else
         hipLaunchKernelGGL(heads_fc_kernel, dim3(ceil_div(conf.ActionSpace + conf.FC, 64), B), dim3(1024), 0, ctx->stream, h);
@@ -1744,6 +1772,13 @@ int agz_net_set_wino_h2_form(agz_net* n, int form) {
   AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_wino_h2_form: null net");
   AGZ_REQUIRE(form >= -1 && form <= 2, AGZ_E_INVALID, "agz_net_set_wino_h2_form: form %d (want -1, 0 or 1)", form);
   n->wino_form = form;
+  return AGZ_OK;
+}
+
+int agz_net_set_wino_h2_gemm(agz_net* n, int variant) {
+  AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_wino_h2_gemm: null net");
+  AGZ_REQUIRE((variant >= 0 && variant <= 2) || ((variant & 15) == 2 && (variant >> 4) <= 3), AGZ_E_INVALID, "agz_net_set_wino_h2_gemm: variant %d (want 0, 1, 2 or 2 + 16 * mode)", variant);
+  n->wino_gemm = variant;
   return AGZ_OK;
 }
 

@@ -71,6 +71,7 @@ struct agz_net {
   // commit-time bound max|y t_next| <= g1 max|x t_in| + g0 that gives block l+1's operand range before its board maximum exists
   std::vector<_Float16*> d_u2c_dual;
   std::vector<float> wino_g1, wino_g0;
+  int wino_gemm = 0;                       // agz_net_set_wino_h2_gemm (agz_debug.h): 0 default, 1 wino_gemm_h2g_kernel, 2 wino_gemm_h2p_kernel
   int wino_form = -1;                      // agz_net_set_wino_h2_form (agz_debug.h): -1 auto (chained where the shape allows), 0 three-kernel block, 1 chained
   void free_u2c() { for (auto& p : d_u2c_dual) if (p) hipFree(p); d_u2c_dual.clear(); wino_g1.clear(); wino_g0.clear(); }
   int build_wino_h2_weights();
@@ -128,4 +129,10 @@ struct agz_net {
   int forward_dev(const float* planes_dev, int B, float* policy_dev, float* value_dev);
   // same but the input already sits in d_act_in (padded NHWC, written by the MCTS encoder)
   int forward_packed(int B, float* policy_dev, float* value_dev);
+  // Which kernels a forward of B boards runs (one decision per forward; forward_packed takes exactly these).  Two batch sizes with
+  // equal plans run the same kernels, and those are batch-independent bit for bit per board — what lets the engine evaluate a
+  // handful of prepareRoot positions as a small batch instead of the arena's whole one (min_same_batch).
+  struct FwdPlan { bool half_init, half_dual, small, forced_split, latency, heads_spread, split_ok, heads_nb, wino_wide; };
+  FwdPlan fwd_plan(int B) const;
+  int min_same_batch(int n, int G) const;   // smallest batch >= n (from n, 16, 32, ... ) with the plan of G; G if there is none
 };

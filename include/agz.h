@@ -27,6 +27,9 @@
  *   AGZ_WINO_H2_QUEUES=1|2    overrides agz_net_set_tower_queues         [tests/test_wino_gpu.py knobs test]
  *   AGZ_WINO_H2_FORM=0        the three-kernel block (in / GEMM / out) instead of the chained one (out of block l + in of
  *                             block l+1 in one kernel); same tolerance       [tests/test_wino_gpu.py knobs test]
+ *   AGZ_WINO_H2_GEMM=1|2      the GEMM kernel of the chained AGZ_COMPUTE_WINO_H2 block: 1 = 128 x 256 tiles, both operands streamed,
+ *                             three workgroups per CU (default); 2 = persistent, the weight slab stationary in registers (K = 256);
+ *                             bit-identical                              [tests/test_wino_gpu.py knobs test]
  *   AGZ_WINO_CHUNK=<n>        boards per chunk of the AGZ_COMPUTE_WINO tower; bit-identical
  *                             [tests/test_wino_gpu.py::test_wino_board_chunks_in_a_subprocess]
  */
@@ -416,7 +419,10 @@ int agz_mcts_to_dot(agz_mcts* mcts, int max_nodes, char* buf, size_t cap, size_t
  * says stop (search.go:132-133,196-197; Budget is inert there), 100 ms in mcts.DefaultConfig.  Opt-in: timeout_ms > 0
  * makes agz_mcts_search run simulations for that long (the clock is read between slices of device work; a Budget > 0 still caps the
  * search), timeout_ms = 0 (default) restores the deterministic "exactly Budget simulations".  NOT deterministic: the simulation count
- * depends on the machine — parity tests use Budget.  agz_mcts_last_simulations: simulations the last agz_mcts_search ran. */
+ * depends on the machine — parity tests use Budget.  With Budget <= 0 (what the Go shim passes for a reference conf that only sets
+ * Timeout) agz_mcts_create sizes the node pool for 65536 expansions when max_nodes is 0, and a pool that fills up ENDS the search
+ * (AGZ_OK, the best move of the tree as it stands) instead of failing with AGZ_E_TREE_FULL: the reference's arena is unbounded and only
+ * its clock stops it.  agz_mcts_last_simulations: simulations the last agz_mcts_search ran. */
 int agz_mcts_set_timeout_ms(agz_mcts* mcts, int timeout_ms);
 int agz_mcts_last_simulations(agz_mcts* mcts, int64_t* sims);
 /* (*MCTS).Nodes() (tree.go:126): nodes of the live tree (the reference counts its arena slots, freed ones included) */

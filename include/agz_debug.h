@@ -49,6 +49,20 @@ int agz_wino_h2_chained(int H, int W, int K);
  * 0: the three-kernel block; 1: as -1.  The environment switch AGZ_WINO_H2_FORM=0 (agz.h) does the same for a whole process. */
 int agz_net_set_wino_h2_form(agz_net* net, int form);
 
+/* A/B hook: which GEMM kernel the chained AGZ_COMPUTE_WINO_H2 block runs.  0 (default): the build's default; 1: wino_gemm_h2g_kernel
+ * (128 x 256 tile, both operands streamed, three workgroups per CU); 2: wino_gemm_h2p_kernel (persistent, the weight slab stationary in
+ * registers, M stores under the next tile's arithmetic; K = 256 only, other shapes keep kernel 1).  Results are bit-identical.  The
+ * environment switch AGZ_WINO_H2_GEMM=1|2 (agz.h) does the same for a whole process.  Decomposition runs (timing only, the results are
+ * NOT valid): 2 + 16 * mode with mode bit 0 = kernel 2 without its M stores, bit 1 = without its operand DMA (profiles/r05). */
+int agz_net_set_wino_h2_gemm(agz_net* net, int variant);
+
+/* prepareRoot (mcts/search.go:392-408) evaluates the network only for roots without children.  agz_arena_begin_move packs those roots to
+ * the front of the batch and runs the forward on the smallest batch that takes the same kernels as the arena's whole batch (per board the
+ * results are bit-identical); on = 0 restores the whole-batch forward (A/B and parity hook).  agz_arena_last_prep_batch: boards the last
+ * begin_move's forward ran on (0: skipped, no root needed it) and roots it had to evaluate. */
+int agz_arena_set_prep_compact(agz_arena* arena, int on);
+int agz_arena_last_prep_batch(agz_arena* arena, int* boards, int* roots);
+
 #ifdef __cplusplus
 }
 #endif

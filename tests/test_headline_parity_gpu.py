@@ -241,6 +241,60 @@ def test_headline_engine_deep_tree_across_a_re_root_bit_exact(ctx):
     net.close()
 
 
+@pytest.mark.parametrize("mode", ["wino_h2", "f32"])
+def test_prepare_root_packed_batch_equals_the_whole_batch(ctx, mode):
+    """Round 5: prepareRoot (mcts/search.go:392-408) evaluates only the roots without children — with tree reuse a minority of the 512
+    games per move boundary — as a PACKED batch of the smallest size that takes the kernels of the whole-arena batch
+    (agz_net::min_same_batch), instead of all 512 boards (12 ms of a move boundary at L = 20).  Two arenas on the same seeds, one with the
+    packed forward, one with the whole-batch forward (agz_arena_set_prep_compact, agz_debug.h): every watched root's children, visit
+    counts, blackScores bits and prior bits after each of four searched plies, every game's history, and the statistics must be
+    identical; the packed batch must really be smaller, and cover the roots that needed the network."""
+    L, G, budget, seed = 3, 512, 12, 31
+    net = std_net(ctx, L)
+    net.set_compute_mode(MODES[mode])
+    arenas = []
+    for packed in (True, False):
+        dev = A.Arena(ctx, capi.GAME_WQ, S, S, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=seed, Budget=budget, max_nodes=20000)
+        dev.set_inferencer(0, capi.INF_NET, net)
+        dev.set_inferencer(1, capi.INF_NET, net)
+        dev.reset(np.array([(i % 2) == 1 for i in range(G)], dtype=np.uint8))
+        rng = np.random.default_rng(seed)
+        dev.random_moves(rng.integers(0, 200, size=G).astype(np.int32), seed)
+        dev.set_prep_compact(packed)
+        arenas.append(dev)
+    packed_batches = []
+    for ply in range(4):
+        for dev in arenas:
+            dev.begin_move()
+        b1, r1 = arenas[0].last_prep_batch()
+        b0, r0 = arenas[1].last_prep_batch()
+        assert r1 == r0                                   # the same roots need the network
+        assert b0 in (0, G) and (b0 == 0) == (r0 == 0)    # the whole-batch arena: all boards, or no forward at all
+        assert (b1 == 0) == (r1 == 0) and r1 <= b1 <= G
+        packed_batches.append((b1, r1))
+        for dev in arenas:
+            dev.simulate(budget)
+            dev.end_move(True)
+        for g in list(range(0, G, 37)) + [G - 1]:
+            for agent in (0, 1):
+                a, b = arenas[0].root_children(g, agent), arenas[1].root_children(g, agent)
+                np.testing.assert_array_equal(a[0], b[0], err_msg="game %d agent %d ply %d" % (g, agent, ply))
+                np.testing.assert_array_equal(a[1], b[1])
+                np.testing.assert_array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+                np.testing.assert_array_equal(a[3].view(np.uint32), b[3].view(np.uint32))
+            np.testing.assert_array_equal(arenas[0].history(g), arenas[1].history(g))
+    s1, s0 = arenas[0].stats(), arenas[1].stats()
+    for k in ("sims_total", "sims_nonnull", "nn_evals", "moves_played", "examples", "tree_full"):
+        assert s1[k] == s0[k], k
+    # ply 0: no tree yet, every root needs the network (whole batch); from ply 2 on (both agents have searched once) trees are re-used
+    assert packed_batches[0] == (G, G), packed_batches
+    assert any(0 < r < G and b < G for b, r in packed_batches[2:]), packed_batches
+    print("prepareRoot batches (boards, roots):", packed_batches)
+    for dev in arenas:
+        dev.close()
+    net.close()
+
+
 def test_config4_l40_network_batch1_and_lane_batches_vs_oracle(ctx):
     """(iii-a) BASELINE configs[4] tower (40 blocks): batch 1 (the split-K latency regime), batches 8 and 16 (one lane round)
     against the oracle on three mid-game boards."""

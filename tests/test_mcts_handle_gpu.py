@@ -289,6 +289,45 @@ def test_wall_clock_stopping_rule_is_opt_in(ctx):
     np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
 
 
+def test_wall_clock_search_without_a_budget(ctx):
+    """ADVICE r4 (engine.hip): the path the Go shim takes for a reference conf that only sets Timeout — Budget = 0, max_nodes = 0.  The pool
+    is sized for a wall-clock search (not from the absent Budget), the search runs until the clock stops it and returns AGZ_OK; with a
+    deliberately tiny pool the search ENDS when the pool is full (no error, no spinning until the deadline) and still names a legal move."""
+    import time
+    host = Host(O.WQ, 9, 9, 0, 7.5)
+    dev = A.Mcts(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, Budget=0, max_nodes=0)
+    dev.set_inferencer(capi.INF_HASH)
+    dev.set_game(**host.state_kw())
+    dev.set_timeout_ms(50)
+    t0 = time.perf_counter()
+    mv = dev.search(O.BLACK)
+    dt = time.perf_counter() - t0
+    n = dev.last_simulations()
+    assert 0.045 <= dt < 0.5, dt
+    assert n >= 16 and -1 <= mv < 81, (n, mv)                      # (the default pool holds far more than the ~4 expansions of round 4's sizing)
+    _, rvis, _, _ = dev.root_children()
+    assert int((rvis.astype(np.int64) - 1).sum()) >= n - 2
+    dev.close()
+    # a pool of 400 nodes (~4 expansions of an 82-move position): full long before a 2 s deadline
+    dev = A.Mcts(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, Budget=0, max_nodes=400)
+    dev.set_inferencer(capi.INF_HASH)
+    dev.set_game(**host.state_kw())
+    dev.set_timeout_ms(2000)
+    t0 = time.perf_counter()
+    mv = dev.search(O.BLACK)                                       # AGZ_OK: no AgzError
+    dt = time.perf_counter() - t0
+    assert dt < 1.0, dt
+    assert -1 <= mv < 81 and dev.last_simulations() >= 1
+    # the same full pool under the deterministic rule stays an error (Budget semantics unchanged)
+    dev.close()
+    dev = A.Mcts(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, Budget=64, max_nodes=400)
+    dev.set_inferencer(capi.INF_HASH)
+    dev.set_game(**host.state_kw())
+    with pytest.raises(A.AgzError):
+        dev.search(O.BLACK)
+    dev.close()
+
+
 def test_to_dot_renders_the_live_tree(ctx):
     """(*MCTS).ToDot (mcts/graph.go:34-90) over the device tree: one node per tree node with the reference's rows, one edge per
     parent/child pair, children in move order, a node's board = the moves of its path (root: Black, then alternating)."""

@@ -263,6 +263,8 @@ H2_KNOBS = [
     {"AGZ_WINO_H2_CHUNK": "16", "AGZ_WINO_H2_QUEUES": "2"},        # board chunks on two queues
     {"AGZ_WINO_H2_QUEUES": "1"},                                   # one queue whatever the batch
     {"AGZ_WINO_H2_FORM": "0"},                                     # the three-kernel block instead of the chained one
+    {"AGZ_WINO_H2_GEMM": "2"},                                     # the persistent GEMM (weight slab stationary in registers; K = 256)
+    {"AGZ_WINO_H2_GEMM": "2", "AGZ_WINO_H2_CHUNK": "16", "AGZ_WINO_H2_QUEUES": "2"},   # ... on short per-team unit lists, two queues
 ]
 
 
@@ -308,6 +310,32 @@ np.save(sys.argv[1], np.concatenate(out))
         n += 2 * B * A_ + 2 * B
     if "AGZ_WINO_H2_TM" not in knobs and "AGZ_WINO_H2_FORM" not in knobs:      # same arithmetic in the same order: only the data movement differs
         np.testing.assert_array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,L,B", [(19, 3, 70), (19, 2, 1), (19, 2, 3), (19, 2, 16), (19, 3, 300), (9, 3, 37), (9, 2, 512)])
+def test_persistent_gemm_is_bit_identical(ctx, S, L, B):
+    """wino_gemm_h2p_kernel (conv_wino_h2c.hpp; agz_net_set_wino_h2_gemm(net, 2)): per accumulator the same MFMA sequence as
+    wino_gemm_h2g_kernel, so policy and value must be BIT-IDENTICAL — on short team lists (B = 1, 3, 16: some teams get no units), ragged
+    last m-tiles (B = 70, 300), 9x9 boards (four boards per 16-tile group), and run twice (the ring / counted waits are deterministic)."""
+    onet, gnet = make_pair(ctx, 256, L, 32, S, S, 18, S * S + 1, 2)
+    x = rand_planes(B, 18, S, S, seed=11)
+    gnet.set_compute_mode(A.capi.COMPUTE_WINO_H2 | A.capi.COMPUTE_FORCE)
+    gnet.set_wino_h2_gemm(1)
+    p1, v1 = gnet.infer(x)
+    gnet.set_wino_h2_gemm(2)
+    p2, v2 = gnet.infer(x)
+    p3, v3 = gnet.infer(x)
+    np.testing.assert_array_equal(p2, p1)
+    np.testing.assert_array_equal(v2, v1)
+    np.testing.assert_array_equal(p3, p2)
+    nb = min(B, 4)
+    po, vo = onet.infer(x[:nb])
+    np.testing.assert_allclose(p2[:nb], po, atol=POL_ATOL, rtol=POL_RTOL)
+    np.testing.assert_allclose(v2[:nb], vo, atol=VAL_ATOL)
+    with pytest.raises(A.AgzError):
+        gnet.set_wino_h2_gemm(3)
+    gnet.close()
 
 
 def _heterogeneous_pair(ctx, K, L, W, H, F, Aspace, E, seed=5):
