@@ -206,6 +206,8 @@ def lib():
     sig("agz_comm_size", i32, vp)
     sig("agz_examples_allgather", i32, vp, vp)
     sig("agz_trainer_allreduce", i32, vp, vp)
+    sig("agz_trainer_forward_backward_allreduce", i32, vp, vp, pf, pf, pf, pf)
+    sig("agz_trainer_forward_backward_allreduce_dev", i32, vp, vp, vp, vp, vp, pf)
     _LIB = L
     return L
 
@@ -816,6 +818,23 @@ class Comm:
 
     def allreduce_trainer(self, trainer):
         _check(lib().agz_trainer_allreduce(self.h, trainer.h), "agz_trainer_allreduce")
+
+    def forward_backward_allreduce(self, trainer, planes, pi, v):
+        """the data-parallel step's gradients: forward / backward on this rank's batch with every slice of the flat gradient buffer
+        summed over the ranks while the rest of the backward runs (agz_trainer_forward_backward_allreduce)"""
+        x = np.ascontiguousarray(planes, np.float32)
+        p = np.ascontiguousarray(pi, np.float32)
+        vv = np.ascontiguousarray(v, np.float32)
+        c = C.c_float(0)
+        _check(lib().agz_trainer_forward_backward_allreduce(self.h, trainer.h, _pf(x), _pf(p), _pf(vv), C.byref(c)),
+               "agz_trainer_forward_backward_allreduce")
+        return c.value
+
+    def forward_backward_allreduce_dev(self, trainer, planes_ptr, pi_ptr, v_ptr, want_cost=True):
+        c = C.c_float(0)
+        _check(lib().agz_trainer_forward_backward_allreduce_dev(self.h, trainer.h, C.c_void_p(planes_ptr), C.c_void_p(pi_ptr), C.c_void_p(v_ptr),
+                                                                C.byref(c) if want_cost else None), "agz_trainer_forward_backward_allreduce_dev")
+        return c.value if want_cost else None
 
 
 class Examples:

@@ -120,6 +120,7 @@ void agz_comm_destroy(agz_comm* c) {
   const Rccl* R = rccl();
   if (R && c->comm) { hipSetDevice(c->ctx->device); hipStreamSynchronize(c->ctx->stream); R->CommDestroy(c->comm); }
   if (c->d_words) { hipSetDevice(c->ctx->device); hipFree(c->d_words); }
+  if (c->ar_stream) { hipSetDevice(c->ctx->device); hipStreamSynchronize(c->ar_stream); hipStreamDestroy(c->ar_stream); hipEventDestroy(c->ev_ready); hipEventDestroy(c->ev_done); }
   delete c;
 }
 
@@ -140,6 +141,62 @@ int agz_trainer_allreduce(agz_comm* c, agz_trainer* t) {
   // ONE collective per step: all learnables' gradients live in one flat buffer (train.hip); in place, on the ctx stream
   AGZ_NCCL_TRY(R->AllReduce(g, g, n, ncclFloat32, ncclSum, c->comm, c->ctx->stream));
   return AGZ_OK;
+}
+
+// The data-parallel step with the reduction UNDER the backward pass.  The flat gradient buffer of the G19 trainer is 7.7 GB (98 % the
+// reference's batch-shaped gamma / beta, dual.go:105-132): as one call after the backward (agz_trainer_allreduce) that is ~40 ms of
+// xGMI time on eight GPUs next to a 49 ms compute step.  Here every slice — the heads, then layer L .. 0 as the backward pass
+// finishes them — is handed to RCCL on the communicator's own queue the moment its last writer is enqueued: the first slices move
+// while the rest of the backward runs; only layer 0's 0.19 GB is left exposed.  Slices tile the buffer exactly and a sum over ranks
+// does not depend on how the buffer is cut: the result is that of agz_trainer_allreduce (bit for bit wherever RCCL's own result is).
+static int dp_begin(agz_comm* c, agz_trainer* t, const Rccl* R) {
+  if (!c->ar_stream) {
+    AGZ_HIP_TRY(hipStreamCreateWithFlags(&c->ar_stream, hipStreamNonBlocking));
+    AGZ_HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    AGZ_HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  }
+  float* g = nullptr;
+  size_t n_all = 0;
+  int r = agz_trainer_grads_dev(t, &g, &n_all);
+  if (r != AGZ_OK) return r;
+  agz_trainer_set_slice_hook(t, [c, g, n_all, R](size_t off, size_t n, hipStream_t ready) -> int {
+    AGZ_REQUIRE(off + n <= n_all, AGZ_E_STATE, "data-parallel step: slice [%zu, %zu) outside the gradient buffer", off, off + n);
+    AGZ_HIP_TRY(hipEventRecord(c->ev_ready, ready));
+    AGZ_HIP_TRY(hipStreamWaitEvent(c->ar_stream, c->ev_ready, 0));
+    AGZ_NCCL_TRY(R->AllReduce(g + off, g + off, n, ncclFloat32, ncclSum, c->comm, c->ar_stream));
+    return AGZ_OK;
+  });
+  return AGZ_OK;
+}
+static int dp_end(agz_comm* c, agz_trainer* t, int r) {
+  agz_trainer_set_slice_hook(t, nullptr);
+  // the step's stream carries everything again: whatever comes next (agz_trainer_apply) sees the summed gradients
+  if (hipEventRecord(c->ev_done, c->ar_stream) != hipSuccess || hipStreamWaitEvent(c->ctx->stream, c->ev_done, 0) != hipSuccess) {
+    if (r == AGZ_OK) { set_error("data-parallel step: joining the reduction queue failed"); r = AGZ_E_HIP; }
+  }
+  return r;
+}
+
+int agz_trainer_forward_backward_allreduce(agz_comm* c, agz_trainer* t, const float* planes, const float* pi, const float* v, float* cost) {
+  AGZ_REQUIRE(c && t && planes && pi && v, AGZ_E_INVALID, "agz_trainer_forward_backward_allreduce: NULL argument");
+  AGZ_REQUIRE(agz_trainer_ctx(t) == c->ctx, AGZ_E_INVALID, "agz_trainer_forward_backward_allreduce: the communicator and the trainer belong to different contexts");
+  const Rccl* R = rccl();
+  if (!R) return AGZ_E_UNSUPPORTED;
+  AGZ_HIP_TRY(hipSetDevice(c->ctx->device));
+  int r = dp_begin(c, t, R);
+  if (r != AGZ_OK) return r;
+  return dp_end(c, t, agz_trainer_forward_backward(t, planes, pi, v, cost));
+}
+
+int agz_trainer_forward_backward_allreduce_dev(agz_comm* c, agz_trainer* t, const float* planes_dev, const float* pi_dev, const float* v_dev, float* cost) {
+  AGZ_REQUIRE(c && t && planes_dev && pi_dev && v_dev, AGZ_E_INVALID, "agz_trainer_forward_backward_allreduce_dev: NULL argument");
+  AGZ_REQUIRE(agz_trainer_ctx(t) == c->ctx, AGZ_E_INVALID, "agz_trainer_forward_backward_allreduce_dev: the communicator and the trainer belong to different contexts");
+  const Rccl* R = rccl();
+  if (!R) return AGZ_E_UNSUPPORTED;
+  AGZ_HIP_TRY(hipSetDevice(c->ctx->device));
+  int r = dp_begin(c, t, R);
+  if (r != AGZ_OK) return r;
+  return dp_end(c, t, agz_trainer_forward_backward_dev(t, planes_dev, pi_dev, v_dev, cost));
 }
 
 }  // extern "C"

@@ -7,6 +7,8 @@
 #pragma once
 #include <rccl/rccl.h>
 
+#include <functional>
+
 #include "common.hpp"
 
 namespace agz {
@@ -26,8 +28,9 @@ struct Rccl {
 const Rccl* rccl();
 }  // namespace agz
 
-// (train.hip) the context a trainer was created on
+// (train.hip) the context a trainer was created on; the per-slice hook of a data-parallel step (agz_trainer::on_slice)
 agz_ctx* agz_trainer_ctx(const agz_trainer* t);
+void agz_trainer_set_slice_hook(agz_trainer* t, std::function<int(size_t off, size_t n, hipStream_t ready)> f);
 
 struct agz_comm {
   agz_ctx* ctx = nullptr;
@@ -36,6 +39,9 @@ struct agz_comm {
   // size + 3 device words allocated with the communicator: the count exchange and the allocation agreement of
   // agz_examples_allgather never allocate, so no rank can skip a collective its peers enter (a hang) for want of memory
   unsigned long long* d_words = nullptr;
+  // the gradient slices of a data-parallel step are reduced on their own queue while the backward pass goes on (comm.hip)
+  hipStream_t ar_stream = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
 };
 
 #define AGZ_NCCL_TRY(expr)                                                                                   \

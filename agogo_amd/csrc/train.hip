@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstring>
 #include <thread>
+#include <functional>
 #include <vector>
 
 #include "net.hpp"
@@ -1183,6 +1184,10 @@ struct agz_trainer {
     allocs.push_back(q); *p = (T*)q; return AGZ_OK;
   }
   int forward_backward_dev(const float* planes_dev, const float* pi_dev, const float* v_dev);
+  // data-parallel step (comm.hip, agz_trainer_forward_backward_allreduce): called once per slice of the flat gradient buffer as soon
+  // as the kernels that write it have been ENQUEUED — heads first, then layer L .. 0 (the order of the backward pass, the same on
+  // every rank) — with the stream whose completion means "slice written"; the slices tile [0, n_flat) exactly
+  std::function<int(size_t off, size_t n, hipStream_t ready)> on_slice;
   float fuse_lr = 0.f;      // != 0 during a fused step: k_bn_bwd1 updates gamma / beta in place, apply() skips them
   bool fused_done = false;  // the backward that just ran took the fused path
 };
@@ -1262,6 +1267,7 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   float* dcur = dA;
   float* dnext = dB;
   hipLaunchKernelGGL(k_head_conv_bwd_x, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, dzh, P + o_hc, dcur, Kp);
+  if (on_slice) { int r = on_slice(o_hc, n_flat - o_hc, s); if (r != AGZ_OK) return r; }   // the heads' gradients are final
   // ---- tower backward
   if (!wg_stream) {
     AGZ_HIP_TRY(hipStreamCreateWithFlags(&wg_stream, hipStreamNonBlocking));
@@ -1340,6 +1346,8 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     else
       hipLaunchKernelGGL(k_wgrad, dim3(wa.n_tiles * wa.c_tiles * 9 * chunks), dim3(256), 0, sw, wa);
     if (sw != s && !split_recorded) AGZ_HIP_TRY(hipEventRecord(ev_split, sw));   // (kernels that read dz itself: after the weight gradient)
+    // layer l's slice [filter | gamma | beta] is final once its weight gradient has run (sw: it started after this layer's BatchNorm backward)
+    if (on_slice) { int r = on_slice(ly.o_wf, (l < L ? layers[l + 1].o_wf : o_hc) - ly.o_wf, sw); if (r != AGZ_OK) return r; }
     if (l > 0) {  // data gradient: the forward GEMM with flipped/transposed weights over the [a|b] channels of dz
       hipLaunchKernelGGL(k_make_wt, dim3(nblk((size_t)9 * C * ly.Cin_p)), dim3(256), 0, s, P + ly.o_wf, ly.wt, C, ly.Cin_p);
       int r;
@@ -1362,6 +1370,7 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
 
 // (comm.hip) the context a trainer was created on
 agz_ctx* agz_trainer_ctx(const agz_trainer* t) { return t ? t->ctx : nullptr; }
+void agz_trainer_set_slice_hook(agz_trainer* t, std::function<int(size_t, size_t, hipStream_t)> f) { t->on_slice = std::move(f); }
 
 extern "C" {
 

@@ -615,6 +615,20 @@ def main():
             gather, gather_hung = {"error": "the example all-gather leg did not return within 120 s"}, True
         else:
             gather = box.get("gather")
+    # every rank's own row count, over the process group (not RCCL-in-libagz: an independent path), so that the line can check
+    # rows_gathered = the sum; same two-minute rule (a rank stuck in the leg above never joins this reduction)
+    rows_per_rank = None
+    if world > 1 and not gather_hung:
+        per = [0.0] * world
+        per[rank] = float((gather or {}).get("rows_this_rank", -1))
+        box2 = {}
+        th2 = threading.Thread(target=lambda: box2.__setitem__("rows", adist.reduce_step_timing(0.0, per, device="cuda")[1]), daemon=True)
+        th2.start()
+        th2.join(120.0)
+        if th2.is_alive():
+            gather_hung = True
+        else:
+            rows_per_rank = [int(x) for x in box2.get("rows", [])]
     gather_ms = gather
 
     if rank == 0:
@@ -758,6 +772,9 @@ def main():
             "per_rank_sims": per_rank_sims, "world_size": world,
             "rccl_ranks": (gather or {}).get("rccl_ranks") if world > 1 else None,
             "rows_gathered": (gather or {}).get("rows_gathered") if world > 1 else None,
+            "rows_per_rank": rows_per_rank,
+            "rows_check": (None if world == 1 else "ok" if rows_per_rank and min(rows_per_rank) >= 0 and sum(rows_per_rank) == (gather or {}).get("rows_gathered")
+                           else "MISMATCH: rows_gathered is not the sum of rows_per_rank"),
             "extra": {"nn_evals_per_s": evals_sum / t_max, "iterations_per_s": iters_sum / t_max,
                       "per_rank_sims": per_rank_sims, "world_size": world,
                       "timed_region": {"moves_finished": st1["moves_played"] - st0["moves_played"],

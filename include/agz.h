@@ -488,6 +488,15 @@ int agz_examples_allgather(agz_comm* comm, agz_examples* ex);
 /* sum the flat gradient buffer of the trainer over all ranks (one collective per step, in place, asynchronous on the ctx
  * stream); follow with agz_trainer_apply(t, lr, 1.0f / agz_comm_size(comm)) */
 int agz_trainer_allreduce(agz_comm* comm, agz_trainer* t);
+/* The data-parallel step with the reduction UNDER the backward pass: agz_trainer_forward_backward (host buffers) /
+ * agz_trainer_forward_backward_dev (device buffers) on this rank's batch, every slice of the flat gradient buffer — the heads, then
+ * layer L .. 0 as the backward pass finishes them — summed over the ranks on the communicator's own queue while the rest of the
+ * backward runs (the G19 trainer's buffer is 7.7 GB: as one call after the backward it would cost about as much xGMI time as the
+ * whole compute step).  On return (asynchronous on the ctx stream, like agz_trainer_allreduce) the gradients are the sums; the result
+ * equals forward_backward + agz_trainer_allreduce.  Follow with agz_trainer_apply(t, lr, 1.0f / agz_comm_size(comm)).  Every rank
+ * must call it for the same step (the slices are collectives, issued in the same order everywhere).  dualnet/meta.go:16-54. */
+int agz_trainer_forward_backward_allreduce(agz_comm* comm, agz_trainer* t, const float* planes, const float* pi, const float* v, float* cost);
+int agz_trainer_forward_backward_allreduce_dev(agz_comm* comm, agz_trainer* t, const float* planes_dev, const float* pi_dev, const float* v_dev, float* cost);
 
 #ifdef __cplusplus
 }

@@ -82,10 +82,10 @@ for it in range(args.nniters):
         b = s * world + rank
         row0 = b * args.batch
         last = it == args.nniters - 1 and s == n_local - 1
-        c = trainB.forward_backward_dev(xd + row0 * xs, pd + row0 * ps, vd + row0 * 4, want_cost=last)
+        # agz_trainer_forward_backward_allreduce_dev: the gradient slices are summed over the ranks under the backward pass
+        c = comm.forward_backward_allreduce_dev(trainB, xd + row0 * xs, pd + row0 * ps, vd + row0 * 4, want_cost=last)
         if last:
             cost = c
-        comm.allreduce_trainer(trainB)   # agz_trainer_allreduce: one RCCL all-reduce per step
         trainB.apply(0.1, 1.0 / comm.size())
         steps += 1
 ctx.sync()

@@ -3,7 +3,8 @@ all episodes' examples) executed on a ONE-GPU box.  Ranks are processes sharing 
 tests/fake_rccl/librccl_fake.so (AGZ_RCCL_LIB: the dlopen path libagz honours for any RCCL build), a shared-memory stand-in with
 NCCL's semantics for the ten entry points comm.hip binds.  What runs is the PRODUCT code: agz_comm_unique_id / agz_comm_init_rank,
 agz_examples_allgather (count exchange, allocation agreement, one grouped set of n broadcasts with rank r the root of its own rows,
-received in place, store swap) with uneven counts including a zero-count rank, and agz_trainer_allreduce + agz_trainer_apply(1/n).
+received in place, store swap) with uneven counts including a zero-count rank, agz_trainer_allreduce + agz_trainer_apply(1/n), and
+agz_trainer_forward_backward_allreduce (the per-slice reduction under the backward pass: bit-identical sums).
 """
 import os
 import subprocess
@@ -66,11 +67,17 @@ before = [tr.get_param(i).copy() for i in range(tr.num_params())]
 comm.allreduce_trainer(tr)
 ctx.sync()
 summed = [tr.get_grad(i).copy() for i in range(tr.num_params())]
+# the same step with the reduction under the backward pass (one collective per slice: heads, then layer L .. 0)
+tr2 = A.Trainer(ctx, 32, 1, 16, 3, 3, 2, 10, 4)
+tr2.init_random(3)
+comm.forward_backward_allreduce(tr2, x, pi, val)
+ctx.sync()
+summed2 = [tr2.get_grad(i).copy() for i in range(tr2.num_params())]
 tr.apply(0.1, 1.0 / n)
 ctx.sync()
 after = [tr.get_param(i).copy() for i in range(tr.num_params())]
 np.savez(out + ".r%d.npz" % rank, gp=gp, gq=gq, gv=gv, gp2=gp2, gv2=gv2, own_p=p, own_q=q, own_v=v,
-         **{"local%d" % i: g for i, g in enumerate(local)}, **{"sum%d" % i: g for i, g in enumerate(summed)},
+         **{"local%d" % i: g for i, g in enumerate(local)}, **{"sum%d" % i: g for i, g in enumerate(summed)}, **{"osum%d" % i: g for i, g in enumerate(summed2)},
          **{"before%d" % i: g for i, g in enumerate(before)}, **{"after%d" % i: g for i, g in enumerate(after)}, nparams=tr.num_params())
 comm.close()
 """
@@ -116,6 +123,8 @@ def test_allgather_and_allreduce_over_n_ranks_on_one_gpu(counts, tmp_path):
         assert any(np.abs(R[r]["local%d" % i]).max() > 0 for r in range(n)) or s.size == 0
         for r in range(n):
             np.testing.assert_array_equal(R[r]["sum%d" % i], s)
+            # agz_trainer_forward_backward_allreduce (one collective per slice, under the backward pass): the same bits
+            np.testing.assert_array_equal(R[r]["osum%d" % i], s)
             np.testing.assert_array_equal(R[r]["before%d" % i], R[0]["before%d" % i])
             np.testing.assert_array_equal(R[r]["after%d" % i], R[0]["after%d" % i])
         np.testing.assert_allclose(R[0]["after%d" % i], R[0]["before%d" % i] - np.float32(0.1 / n) * s, rtol=2e-6, atol=1e-7)
@@ -129,3 +138,59 @@ def test_fake_rccl_is_test_infrastructure_only():
         for f in fs:
             if f.endswith((".hip", ".hpp", ".py", ".h")):
                 assert "fake_rccl" not in open(os.path.join(d, f), errors="replace").read().replace("tests/fake_rccl's", ""), f
+
+
+def test_bench_two_ranks_end_to_end_through_the_self_relaunch(tmp_path):
+    """`python bench.py --gpus 2` OUTSIDE a launcher — the path the first multi-GPU run takes if the driver calls the
+    script plainly: it re-executes itself under torch.distributed.run (two ranks, 127.0.0.1 rendezvous), both ranks run the timed
+    region on GPU 0 (--shared-gpu: gloo for the process group), the example exchange runs inside libagz over the in-tree RCCL double
+    (AGZ_RCCL_LIB), and rank 0 prints ONE line whose self-checks hold: n_gpus = 2, both ranks simulated, rccl_ranks = 2 and
+    rows_gathered = the sum of the ranks' own rows.  The line is kept under gpurun_out/ (profiles/r05/bench_n2_two_ranks_one_gpu.json)."""
+    import json
+    env = dict(os.environ, AGZ_RCCL_LIB=FAKE, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu", "--games", "32", "--budget", "16", "--steps", "2",
+           "--warmup", "1", "--L", "4", "--no-cpu-baseline", "--no-games-leg", "--no-go9-leg", "--no-latency-leg", "--no-train-leg", "--no-f32-leg"]
+    pr = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in pr.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["scaling"] == "weak"
+    assert len(d["per_rank_sims"]) == 2 and min(d["per_rank_sims"]) > 0
+    assert abs(sum(d["per_rank_sims"]) - d["value"] * d["ms_per_step"] * d["steps"] * 1e-3) < 1.0
+    assert d["rccl_ranks"] == 2
+    assert d["rows_check"] == "ok" and len(d["rows_per_rank"]) == 2 and sum(d["rows_per_rank"]) == d["rows_gathered"] > 0
+    assert min(d["rows_per_rank"]) > 0                         # both ranks' arenas recorded examples (a move boundary inside the run)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_n2_two_ranks_one_gpu.json"), "w") as f:
+        json.dump(d, f, indent=1)
+
+
+def test_comm_init_all_argument_paths_for_more_than_one_rank(ctx):
+    """agz_comm_init_all's n > 1 argument handling without a second GPU — a NULL entry in the ctx list, the same device
+    twice (one rank per GPU), n out of range, NULL output: every one a clean AGZ_E_INVALID with a message, nothing allocated, no call into
+    RCCL (the checks come first), and the n = 1 path still works afterwards."""
+    import ctypes as C
+    import agogo_amd as A
+    from agogo_amd import capi
+    L = capi.lib()
+    E_INVALID = -1                                             # AGZ_E_INVALID (include/agz.h)
+    last = lambda: L.agz_last_error().decode(errors="replace")
+    ctx2 = A.Ctx(0)                                            # a second context on the SAME device
+    two = (C.c_void_p * 2)(ctx.h, ctx2.h)
+    out = (C.c_void_p * 2)()
+    assert L.agz_comm_init_all(two, 2, out) == E_INVALID
+    assert "appears twice" in last()
+    assert not out[0] and not out[1]
+    hole = (C.c_void_p * 2)(ctx.h, None)
+    assert L.agz_comm_init_all(hole, 2, out) == E_INVALID
+    assert "ctxs[1] is NULL" in last()
+    assert L.agz_comm_init_all(two, 0, out) == E_INVALID
+    assert L.agz_comm_init_all(two, 65, out) == E_INVALID
+    assert L.agz_comm_init_all(two, 2, None) == E_INVALID
+    comms = A.Comm.init_all([ctx])
+    assert comms[0].size() == 1
+    comms[0].close()
+    ctx2.close()
