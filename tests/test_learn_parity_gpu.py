@@ -74,3 +74,32 @@ def test_az_learn_epoch_log_matches_the_oracle(threshold, ev, kills_want):
     for nid in stats:
         want = ["%d/%d/%d" % (d["a_wins"], d["b_wins"], d["draws"]) for d in dev if d["a_id"] == nid]
         assert stats[nid] == want
+
+
+@pytest.mark.parametrize("threshold", [0.20, 0.83])
+def test_az_learn_with_the_trained_networks_playing_the_evaluation_games(threshold):
+    """the same composition with eval_inf = (NET, NET) — the freshly trained B really PLAYS A in the evaluation games
+    (device: agz_trainer_export -> agz_net_commit -> arena with two networks; oracle: its own trainer's row 0 in its own inference net).
+    Self-play stays on the synthetic inferencers, so examples and batches are exact; an evaluation game can in principle be flipped by
+    fp32 rounding of a network output (device and oracle trainers agree to 1e-4, not bit for bit), so the A / B / draw tables are held to
+    +-3 of 24 games and the thresholds sit far from any observed rate: the gating decision, killedA, A's identity and the Statistics
+    keys must be identical."""
+    iters, episodes, nniters, games, budget, seed, batch = 3, 48, 2, 24, 30, 4242, 32
+    sp = (capi.INF_HASH, capi.INF_HASH)
+    ev = (capi.INF_NET, capi.INF_NET)
+    dev, stats = _device_log(iters, episodes, nniters, games, budget, threshold, seed, sp, ev, batch)
+    orc = O.learn_run(O.MNK, 3, 3, 3, 0.0, O.ENC_TWOPLANE, 3, 3, 8, batch, 2, 10, 1.0, budget, threshold, seed, iters, episodes, nniters, games,
+                      sp_inf=sp, eval_inf=ev)
+    assert len(dev) == len(orc) == iters
+    print("threshold", threshold, "device", [(d["a_wins"], d["b_wins"], d["draws"]) for d in dev], "oracle", [(o["a_wins"], o["b_wins"], o["a_draw"]) for o in orc])
+    for d, o in zip(dev, orc):
+        assert d["examples"] == o["examples"] and d["batches"] == o["batches"]
+        assert d["a_wins"] + d["b_wins"] + d["draws"] == games == o["a_wins"] + o["b_wins"] + o["a_draw"]
+        for kd, ko in (("a_wins", "a_wins"), ("b_wins", "b_wins"), ("draws", "a_draw")):
+            assert abs(d[kd] - o[ko]) <= 3, (d, o)
+        decided = d["a_wins"] + d["b_wins"]
+        rate = d["b_wins"] / decided if decided else 0.0
+        assert abs(rate - threshold) > 0.15 or decided == 0, (rate, threshold)     # far from the gate: rounding cannot decide it
+        assert bool(d["killedA"]) == bool(o["killedA"]) and d["a_id"] == o["a_id"], (d, o)
+        assert abs(d["cost"] - o["cost"]) <= 2e-3 * max(1.0, abs(o["cost"]))
+    assert sorted(stats) == sorted({d["a_id"] for d in dev})

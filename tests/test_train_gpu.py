@@ -13,7 +13,7 @@ from agogo_amd import capi
 pytestmark = pytest.mark.gpu
 
 
-def make_pair(ctx, K, L, FC, W, H, F, Aspace, B, seed=5):
+def make_pair(ctx, K, L, FC, W, H, F, Aspace, B, seed=5, wscale=3.0):
     ot = O.TrainNet(K, L, FC, W, H, F, Aspace, B)
     ot.init_random(seed)
     rng = np.random.default_rng(seed)
@@ -25,7 +25,7 @@ def make_pair(ctx, K, L, FC, W, H, F, Aspace, B, seed=5):
         elif nm.endswith("_beta") or nm.endswith("_b"):
             p = rng.normal(0, 0.1, p.size).astype(np.float32)
         else:
-            p = (p * 3.0).astype(np.float32)
+            p = (p * wscale).astype(np.float32)
         ot.set_param(i, p)
     dt = A.Trainer(ctx, K, L, FC, W, H, F, Aspace, B)
     assert dt.num_params() == ot.num_params()
@@ -161,6 +161,161 @@ def test_sgd_steps_and_export(ctx):
     x = batch_data(3, F, H, W, Aspace, seed=7)[0]
     pg, vg = net.infer(x)
     assert np.all(np.isfinite(pg)) and np.all(np.isfinite(vg))
+    # ... and the exported network COMPUTES what the oracle's does.  Under the degenerate-eps reading every BatchNorm multiplies by 316 and
+    # the heads saturate (nothing to compare), and three lr-0.1 steps on the pair's 3x-Glorot filters blow the head weights up to ~40: the
+    # comparison runs on a second pair with Glorot-scale filters, under IDENTITY statistics (gamma * x + beta with the TRAINED row-0
+    # gamma / beta).  The two parameter sets agree to 1e-4 (three SGD steps on two arithmetic paths), the outputs accordingly.
+    ot2, dt2 = make_pair(ctx, K, L, FC, W, H, F, Aspace, B, seed=9, wscale=1.0)
+    for step in range(3):
+        xb, pib, vb = batch_data(B, F, H, W, Aspace, seed=100 + step)
+        ot2.batch(xb, pib, vb, lr=0.1)
+        dt2.batch(xb, pib, vb, lr=0.1)
+    net2 = A.Net(ctx, K, L, FC, W, H, F, Aspace, bn_mode=capi.BN_IDENTITY)
+    dt2.export(net2)
+    onet2 = O.Net(K, L, FC, W, H, F, Aspace, bn_mode=2)
+    for i in range(onet2.num_params()):
+        onet2.set_param(i, ot2.get_param(i)[: onet2.get_param(i).size])
+    pg2, vg2 = net2.infer(x)
+    po2, vo2 = onet2.infer(x)
+    assert 1.5 / Aspace < float(po2.max()) < 0.9 and 1e-3 < float(np.abs(vo2).max()) < 0.9, (float(po2.max()), float(np.abs(vo2).max()))   # not saturated
+    np.testing.assert_allclose(pg2, po2, atol=2e-5, rtol=1e-3)
+    np.testing.assert_allclose(vg2, vo2, atol=1e-4)
+
+
+_DEEP = {}
+
+
+def _deep_oracle(beta0):
+    """the oracle's gradients of ONE batch at the headline tower's depth (K=256, 19x19, L=20, two boards: ~20 s of oracle time per
+    regime), shared by the modes.  beta0 is added to every BatchNorm beta: 4.0 keeps every ReLU unit active (see the test)."""
+    if beta0 not in _DEEP:
+        K, L, FC, W, H, F, Aspace, B = 256, 20, 32, 19, 19, 18, 362, 2
+        ot = O.TrainNet(K, L, FC, W, H, F, Aspace, B)
+        ot.init_random(5)
+        rng = np.random.default_rng(5)
+        params = []
+        for i in range(ot.num_params()):
+            nm = ot.param_name(i)
+            p = ot.get_param(i)
+            if nm.endswith("_gamma"):
+                p = rng.uniform(0.5, 1.5, p.size).astype(np.float32)
+            elif nm.endswith("_beta") or nm.endswith("_b"):
+                p = (rng.normal(0, 0.1, p.size) + (beta0 if nm.endswith("_beta") else 0.0)).astype(np.float32)
+            ot.set_param(i, p)
+            params.append(p)
+        x, pi, v = batch_data(B, F, H, W, Aspace, seed=77)
+        cost = ot.batch(x, pi, v, lr=0.0)
+        _DEEP[beta0] = dict(shape=(K, L, FC, W, H, F, Aspace, B), params=params, names=[ot.param_name(i) for i in range(ot.num_params())],
+                            grads=[ot.get_grad(i).copy() for i in range(ot.num_params())], data=(x, pi, v), cost=cost)
+    return _DEEP[beta0]
+
+
+def _deep_errors(ctx, D, mode):
+    K, L, FC, W, H, F, Aspace, B = D["shape"]
+    dt = A.Trainer(ctx, K, L, FC, W, H, F, Aspace, B)
+    for i, p in enumerate(D["params"]):
+        dt.set_param(i, p)
+    if mode != "f32":
+        dt.set_compute_mode((capi.COMPUTE_BF16X3 if mode == "bf16x3" else capi.COMPUTE_WINO_H2) | capi.COMPUTE_FORCE)
+    cd = dt.forward_backward(*D["data"])
+    rel, l2 = [], []
+    for i, go in enumerate(D["grads"]):
+        e = np.abs(dt.get_grad(i) - go).astype(np.float64)
+        rel.append(float(e.max()) / (float(np.abs(go).max()) + 1e-30))
+        l2.append(float(np.sqrt((e ** 2).sum() / ((go.astype(np.float64) ** 2).sum() + 1e-300))))
+    dt.close()
+    return cd, rel, l2
+
+
+def test_forward_backward_headline_depth_l20(ctx):
+    """the trainer's measured arithmetic (AGZ_COMPUTE_WINO_H2: fp16x2 forward convolutions, Winograd fp16x2 data
+    gradient, fp16x2 three-tap weight gradient; and bf16x3) at the depth train_leg times — K=256, 19x19, TWENTY dual blocks — against the
+    oracle trainer, all 129 gradient tensors, so that error compounding through 20 layers of backward is observed, not assumed.
+
+    What was observed (scripts/r5_deep_grad_probe.py, profiles/r05/deep_gradient_probe.log): with ordinary BatchNorm shifts the
+    comparison at this depth is decided by ReLU units whose pre-activation rounds to the other side of zero — a handful among 7.4 M
+    units, in EVERY mode including the true-fp32 kernels: every tensor then differs coherently by ~1e-2 (relative L2: fp32-MFMA 1.2-1.7e-2,
+    bf16x3 5e-3) although the cost agrees to 1e-4.  That is the function's discontinuity, not arithmetic.  The arithmetic's own compounding
+    is measured where the function is smooth: beta + 4 keeps every unit active (the tower is then 20 blocks of convolution and training-
+    mode BatchNorm, forward and backward).  There fp32-MFMA — summation order alone — reaches 2.4-2.7e-5 of a tensor's maximum at depth
+    20 (2e-5 is the bar of the one-block test) and the split modes stay within twice that.  Bars: 5e-5 per tensor in every mode, and
+    no split mode worse than 2x the fp32-MFMA path's own worst tensor.  The ordinary-shift regime is reported, with a gross-error bar."""
+    D = _deep_oracle(4.0)
+    worst = {}
+    for mode in ("f32", "bf16x3", "wino_h2"):
+        cd, rel, l2 = _deep_errors(ctx, D, mode)
+        assert abs(cd - D["cost"]) <= 1e-4 * max(1.0, abs(D["cost"])), (mode, cd, D["cost"])
+        w = int(np.argmax(rel))
+        worst[mode] = rel[w]
+        print("trainer %s at K=256 / 19x19 / L=20, every unit active: worst gradient tensor %s at %.2e of its maximum; relative L2 median %.1e max %.1e"
+              % (mode, D["names"][w], rel[w], float(np.median(l2)), max(l2)))
+        for i, r in enumerate(rel):
+            assert r <= 5e-5, (mode, D["names"][i], r)
+    assert worst["bf16x3"] <= 2.0 * worst["f32"] and worst["wino_h2"] <= 2.0 * worst["f32"], worst
+    Dn = _deep_oracle(0.0)
+    for mode in ("f32", "wino_h2"):
+        cd, rel, l2 = _deep_errors(ctx, Dn, mode)
+        assert abs(cd - Dn["cost"]) <= 1e-3 * max(1.0, abs(Dn["cost"])), (mode, cd, Dn["cost"])
+        print("trainer %s at L=20, ordinary shifts (ReLU flips decide): relative L2 per tensor median %.1e max %.1e, worst element %.1e of its tensor's maximum"
+              % (mode, float(np.median(l2)), max(l2), max(rel)))
+        assert max(l2) <= 0.15, (mode, max(l2))      # gross-error bar only: see the docstring
+
+
+def test_trained_weights_through_the_measured_inference_arithmetic(ctx):
+    """the inference modes had only ever seen Glorot weights.  Three agz_trainer_batch steps (lr 0.1) at K=128 / 9x9 /
+    four blocks, then export -> commit (which proves the range bound g1 * max|x| + g0 of DESIGN 4a on THESE weights) -> inference under
+    AGZ_COMPUTE_WINO_H2 (chained blocks), bf16x3 and fp32-MFMA against the oracle inference net holding the same exported row-0
+    parameters: the full network tolerance."""
+    from test_net_gpu import POL_ATOL, POL_RTOL, VAL_ATOL
+    K, L, FC, W, H, F, Aspace, B = 128, 4, 64, 9, 9, 18, 82, 8
+    ot = O.TrainNet(K, L, FC, W, H, F, Aspace, B)
+    ot.init_random(13)
+    rng = np.random.default_rng(13)
+    start = []
+    # (gamma ~ U(0.3, 0.9): with the reference's N(0, sigma) gamma a four-block tower's output is constant, with gamma ~ 1 three lr-0.1 steps
+    #  at this width saturate the softmax under identity statistics — explored with the oracle alone; here the policy peaks at ~5x uniform)
+    for i in range(ot.num_params()):
+        nm, p = ot.param_name(i), ot.get_param(i)
+        if nm.endswith("_gamma"):
+            p = (0.6 * rng.uniform(0.5, 1.5, p.size)).astype(np.float32)
+        elif nm.endswith("_beta") or nm.endswith("_b"):
+            p = rng.normal(0, 0.1, p.size).astype(np.float32)
+        ot.set_param(i, p)
+        start.append(p.copy())
+    dt = A.Trainer(ctx, K, L, FC, W, H, F, Aspace, B)
+    for i in range(ot.num_params()):
+        dt.set_param(i, ot.get_param(i))
+    dt.set_compute_mode(capi.COMPUTE_WINO_H2 | capi.COMPUTE_FORCE)
+    for step in range(3):
+        x, pi, v = batch_data(B, F, H, W, Aspace, seed=500 + step)
+        co = ot.batch(x, pi, v, lr=0.1)
+        cd = dt.batch(x, pi, v, lr=0.1)
+        assert abs(cd - co) <= 2e-3 * max(1.0, abs(co)), (step, cd, co)
+    moved = 0.0
+    # (648 samples per channel and 1.3 M ReLU units: a unit whose pre-activation rounds to the other side of zero moves a filter gradient
+    #  by ~1 % — see test_forward_backward_headline_depth_l20 — so the two trainers' parameters are only held to a gross-error bar here;
+    #  the strict trainer parity lives in the tests above, this test is about the INFERENCE arithmetic on weights SGD has moved)
+    for i in range(ot.num_params()):
+        po, pd = ot.get_param(i), dt.get_param(i)
+        assert float(np.abs(pd - po).max()) <= 5e-2 * float(np.abs(po).max()) + 1e-7, ot.param_name(i)
+    net = A.Net(ctx, K, L, FC, W, H, F, Aspace, bn_mode=capi.BN_IDENTITY)
+    dt.export(net)                                         # (export commits)
+    onet = O.Net(K, L, FC, W, H, F, Aspace, bn_mode=2)
+    for i in range(onet.num_params()):
+        onet.set_param(i, net.get_param(i))                # the SAME exported parameters on both sides
+        moved = max(moved, float(np.abs(net.get_param(i) - start[i][: net.get_param(i).size]).max()))
+    assert moved > 1e-3                                    # SGD really moved them
+    xs = batch_data(40, F, H, W, Aspace, seed=9)[0]
+    po, vo = onet.infer(xs[:6])
+    assert 2.0 / Aspace < float(po.max()) < 0.95 and float(np.abs(vo).max()) < 0.95, (float(po.max()), float(np.abs(vo).max()))   # a real comparison
+    for mode in (capi.COMPUTE_F32_MFMA, capi.COMPUTE_BF16X3 | capi.COMPUTE_FORCE, capi.COMPUTE_WINO_H2 | capi.COMPUTE_FORCE):
+        net.set_compute_mode(mode)
+        pg, vg = net.infer(xs)
+        np.testing.assert_allclose(pg[:6], po, atol=POL_ATOL, rtol=POL_RTOL, err_msg="mode %d" % mode)
+        np.testing.assert_allclose(vg[:6], vo, atol=VAL_ATOL, err_msg="mode %d" % mode)
+        print("trained weights, mode %d: max |dpolicy| vs oracle %.2e" % (mode, float(np.abs(pg[:6] - po).max())))
+    net.close()
+    dt.close()
 
 
 def test_agz_train_loop_runs_and_shuffles(ctx):
