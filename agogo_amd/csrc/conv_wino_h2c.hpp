@@ -24,7 +24,8 @@
 #pragma once
 // (included by net.hip INSIDE namespace agz, after conv_wino_h2.hpp)
 
-__device__ __forceinline__ unsigned h2c_img(int row, int slot) { return (unsigned)(row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)); }
+// (every offset of the two DMA GEMMs below comes from gemm_maps.hpp — plain constexpr functions a CPU test checks, tests/test_gemm_maps_cpu.py)
+__device__ __forceinline__ unsigned h2c_img(int row, int slot) { return maps::h2c_img(row, slot); }
 
 // ---- the transform-domain GEMMs on the chained layouts: 128 x 256 tile, A (HBM) fetched PFA K steps ahead into rotating register
 // sets, B (L2) one step ahead — wino_gemm_h2d_kernel's pipeline; every global access of a wave is one contiguous KB.
@@ -163,10 +164,8 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_h2g_kernel(WinoH2Args h) {
   // DMA: wave w fills rows 32 w .. 32 w + 31 of the A image (4 instructions of 8 rows) and rows 64 w .. + 63 of the B image (8);
   // LDS unit (row r, slot q') receives global unit (r, q' ^ ((r >> 1) & 7)); (r >> 1) & 7 = (4 j + lane / 16) & 7 for instruction j
   const __amdgpu_buffer_rsrc_t ar = h2_rsrc(a.V), br = h2_rsrc(h.U2c);
-  const unsigned sw0 = (unsigned)(lane >> 4) & 7u, sw1 = (4u + (unsigned)(lane >> 4)) & 7u;
-  const unsigned l8 = (unsigned)(lane >> 3) * 128u, q8 = (unsigned)(lane & 7);
-  const unsigned vo_e = l8 + ((q8 ^ sw0) << 4), vo_o = l8 + 1024u + ((q8 ^ sw1) << 4);   // instructions j even / odd: + (j / 2) * 2048
-  const unsigned a_w = (unsigned)wid * 4096u, b_w = (unsigned)wid * 8192u;               // the wave's part of a chunk (bytes)
+  const unsigned vo_e = maps::h2c_dma_src(lane, 0), vo_o = maps::h2c_dma_src(lane, 1);   // instructions j even / odd: + (j / 2) * 2048 (scalar)
+  const unsigned a_w = maps::h2c_wave_part(wid, 128), b_w = maps::h2c_wave_part(wid, 256);   // the wave's part of a chunk (bytes)
   unsigned a_so = (unsigned)(((size_t)m_tile * h.npos + pos) * (size_t)NK * SA) + a_w;
   unsigned b_so = (unsigned)((((size_t)pos * NK) * n_nt + n_tile) * (size_t)SB) + b_w;
   const unsigned b_step = (unsigned)n_nt * SB;
@@ -181,33 +180,30 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_h2g_kernel(WinoH2Args h) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  const int kh = lane >> 5, sw = (lane >> 1) & 7;
-  const unsigned fa = (unsigned)((wm * 64 + (lane & 31)) * 128);
-  const unsigned fb = (unsigned)(SA + (wn * 128 + (lane & 31)) * 128);
-
 #pragma nounroll
   for (int it = 0; it < NK; it++) {
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (h2c_lds_ptr_t)(la + j * 1024), 16, (j & 1) ? vo_o : vo_e, a_so + (unsigned)(j >> 1) * 2048u, 0, 0);
+    for (int j = 0; j < maps::h2c_wave_instrs(128); j++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (h2c_lds_ptr_t)(la + maps::h2c_dma_dst(0, j)), 16, (j & 1) ? vo_o : vo_e,
+                                               a_so + (maps::h2c_dma_src(0, j) - maps::h2c_dma_src(0, j & 1)), 0, 0);
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (h2c_lds_ptr_t)(lb + j * 1024), 16, (j & 1) ? vo_o : vo_e, b_so + (unsigned)(j >> 1) * 2048u, 0, 0);
+    for (int j = 0; j < maps::h2c_wave_instrs(256); j++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (h2c_lds_ptr_t)(lb + maps::h2c_dma_dst(0, j)), 16, (j & 1) ? vo_o : vo_e,
+                                               b_so + (maps::h2c_dma_src(0, j) - maps::h2c_dma_src(0, j & 1)), 0, 0);
     a_so += SA; b_so += b_step;
     __syncthreads();                                  // (its fence waits vmcnt(0): this wave's DMA has landed; then every wave's)
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       f16x8_t A_[2][2];
-      const unsigned so0 = (unsigned)(((2 * ks + kh) ^ sw) << 4), so1 = (unsigned)(((4 + 2 * ks + kh) ^ sw) << 4);
 #pragma unroll
       for (int i = 0; i < 2; i++) {
-        A_[i][0] = *reinterpret_cast<const f16x8_t*>(lds + fa + i * 4096 + so0);
-        A_[i][1] = *reinterpret_cast<const f16x8_t*>(lds + fa + i * 4096 + so1);
+        A_[i][0] = *reinterpret_cast<const f16x8_t*>(lds + maps::h2c_frag(wm * 64 + i * 32, lane, 0, ks));
+        A_[i][1] = *reinterpret_cast<const f16x8_t*>(lds + maps::h2c_frag(wm * 64 + i * 32, lane, 1, ks));
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) {                   // B fragments just in time: 8 registers live instead of 32
-        const f16x8_t b0 = *reinterpret_cast<const f16x8_t*>(lds + fb + j * 4096 + so0);
-        const f16x8_t b1 = *reinterpret_cast<const f16x8_t*>(lds + fb + j * 4096 + so1);
+        const f16x8_t b0 = *reinterpret_cast<const f16x8_t*>(lds + SA + maps::h2c_frag(wn * 128 + j * 32, lane, 0, ks));
+        const f16x8_t b1 = *reinterpret_cast<const f16x8_t*>(lds + SA + maps::h2c_frag(wn * 128 + j * 32, lane, 1, ks));
 #pragma unroll
         for (int i = 0; i < 2; i++) {                 // small terms first: lo*hi, hi*lo, hi*hi
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[i][1], b0, acc[i][j], 0, 0, 0);
@@ -219,7 +215,9 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_h2g_kernel(WinoH2Args h) {
     __syncthreads();                                  // every wave has read the stage before the next DMA overwrites it
   }
 
-  float* mbase = a.Mb + ((((size_t)m_tile * h.npos + pos) * (size_t)(a.Ntot >> 6) + (size_t)n_tile * 4 + wn * 2) * 128 + (size_t)(wm * 64)) * 64 + lane;
+  // M: after v_permlane32_swap of two neighbouring column tiles a register holds all 64 columns of one row (lanes = columns): w0 = row
+  // mfma_row(r), w1 = that row + 4; every store instruction writes one 256-byte run of Mc
+  float* mbase = a.Mb + maps::mc_index(m_tile, h.npos, pos, a.Ntot >> 6, n_tile * 4 + wn * 2, wm * 64, lane);
 #pragma unroll
   for (int qq = 0; qq < 2; qq++)
 #pragma unroll
@@ -229,9 +227,9 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_h2g_kernel(WinoH2Args h) {
         const unsigned x0 = __float_as_uint(acc[i][2 * qq][r]), x1 = __float_as_uint(acc[i][2 * qq + 1][r]);
         const auto s32 = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);
         const unsigned w0 = s32[0], w1 = s32[1];
-        float* d = mbase + (size_t)qq * 8192 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * 64;
+        float* d = mbase + maps::mc_index(0, 0, 0, 0, qq, i * 32 + maps::mfma_row(r), 0);
         d[0] = __uint_as_float(w0);
-        d[4 * 64] = __uint_as_float(w1);
+        d[maps::mc_index(0, 0, 0, 0, 0, 4, 0)] = __uint_as_float(w1);
       }
 }
 
@@ -261,30 +259,23 @@ __device__ __forceinline__ void h2p_dma16(h2p_rsrc_t rsrc, unsigned lds_addr, un
                : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 #define H2P_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-constexpr int H2P_D = 10;                          // DMA lookahead in stages (ring: 16)
-// unit u of a team's list -> byte offset of its K step 0 in V2c (half tile hm of position pos: rows 64 (hm & 1) .. of m-tile hm >> 1)
-__host__ __device__ constexpr unsigned h2p_v_base(int pos, int hm, int npos) {
-  return (unsigned)(((hm >> 1) * npos + pos) * (8 * 16384) + (hm & 1) * 8192);
-}
 // MODE (decomposition runs only, agz_net_set_wino_h2_gemm(net, 2 + 16 * MODE)): bit 0 = no M stores, bit 1 = no DMA (the ring holds whatever LDS held)
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
   const WinoArgs& a = h.w;
-  constexpr int NK = 8, R = 16, SA = 64 * 128, D = H2P_D;
-  static_assert(D == 10, "the ring slot / K step arithmetic below is written for D = 10");
+  constexpr int NK = maps::H2P_NK, R = maps::H2P_R, SA = 64 * 128, D = maps::H2P_D;   // (ring / look-ahead arithmetic: gemm_maps.hpp)
   __shared__ __attribute__((aligned(1024))) unsigned char lds[R * SA];   // 128 KB
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
   const int n_slabs = a.Ntot >> 7, n_nt = a.Ntot >> 8;
-  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-  const int tpx = (int)(gridDim.x >> 3) / n_slabs;           // teams per XCD
-  if (slot >= tpx * n_slabs) return;
-  const int team = xcd * tpx + slot / n_slabs, slab = slot % n_slabs, nteams = 8 * tpx;
+  const maps::H2pTeam tm = maps::h2p_team((int)blockIdx.x, (int)gridDim.x, n_slabs);
+  if (tm.idle) return;
+  const int team = tm.team, slab = tm.slab, nteams = tm.nteams;
   // units are dealt in PAIRS (n_half is even): a team's range starts at an even unit and holds an even number, so the two tiles
   // of a pair (ring halves / accumulator sets 0 and 1) always share a position
   const int n_half = a.n_mtiles * 2, U2 = h.npos * a.n_mtiles;
-  const int u0 = 2 * (int)((long)team * U2 / nteams), nT = 2 * (int)((long)(team + 1) * U2 / nteams) - u0;
+  const int u0 = maps::h2p_u0(team, nteams, U2), nT = maps::h2p_u0(team + 1, nteams, U2) - u0;
   if (nT <= 0) return;
 
   h2p_rsrc_t ar;
@@ -295,21 +286,19 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
   }
   // DMA of an 8 KB stage: wave w fills rows 16 w .. 16 w + 15 (2 instructions of 8 rows); LDS unit (row r, slot q') receives global
   // unit (r, q' ^ ((r >> 1) & 7)) — h2c_img's swizzle on the SOURCE address, (r >> 1) & 7 = (4 j + lane / 16) & 7 for instruction j
-  const unsigned sw0 = (unsigned)(lane >> 4) & 7u, sw1 = (4u + (unsigned)(lane >> 4)) & 7u;
-  const unsigned l8 = (unsigned)(lane >> 3) * 128u, q8 = (unsigned)(lane & 7);
-  const unsigned vo_e = l8 + ((q8 ^ sw0) << 4), vo_o = l8 + 1024u + ((q8 ^ sw1) << 4);
-  const unsigned a_w = (unsigned)wid * 2048u;
+  const unsigned vo_e = maps::h2c_dma_src(lane, 0), vo_o = maps::h2c_dma_src(lane, 1);
+  static_assert(maps::h2c_wave_instrs(64) == 2, "two DMA instructions per wave and stage");
+  const unsigned a_w = maps::h2c_wave_part(wid, 64);
   const unsigned dma_l = (unsigned)(size_t)(h2c_lds_ptr_t)lds + a_w;
   auto issue = [&](unsigned vb, int kk, int rslot) {
     if (MODE & 2) return;
     const unsigned so = vb + (unsigned)kk * 16384u + a_w;
-    h2p_dma16(ar, dma_l + (unsigned)rslot * SA, vo_e, so);
-    h2p_dma16(ar, dma_l + (unsigned)rslot * SA + 1024u, vo_o, so);
+    h2p_dma16(ar, dma_l + (unsigned)rslot * SA + maps::h2c_dma_dst(0, 0), vo_e, so);
+    h2p_dma16(ar, dma_l + (unsigned)rslot * SA + maps::h2c_dma_dst(0, 1), vo_o, so);
   };
-  const int kh = lane >> 5, sw = (lane >> 1) & 7;
-  const unsigned fa = (unsigned)((wm * 32 + (lane & 31)) * 128);
+  const int kh = lane >> 5;
   auto frag = [&](int rslot, int ks, int p) -> f16x8_t {
-    return *reinterpret_cast<const f16x8_t*>(lds + rslot * SA + fa + (unsigned)(((p * 4 + 2 * ks + kh) ^ sw) << 4));
+    return *reinterpret_cast<const f16x8_t*>(lds + rslot * SA + maps::h2c_frag(wm * 32, lane, p, ks));
   };
 
   // B fragments of this wave's 64 columns, every K step: Bf[kk][ks][j][piece]
@@ -338,16 +327,16 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
           for (int p = 0; p < 2; p++) asm volatile("" : "+a"(Bf[kk][ks][j][p]));
   };
   auto m_base = [&](int pos, int hm) -> float* {
-    return a.Mb + ((((size_t)(hm >> 1) * h.npos + pos) * (size_t)(a.Ntot >> 6) + (size_t)(slab * 2 + wn)) * 128 + (size_t)((hm & 1) * 64 + wm * 32)) * 64 + lane;
+    return a.Mb + maps::mc_index(hm >> 1, h.npos, pos, a.Ntot >> 6, slab * 2 + wn, (hm & 1) * 64 + wm * 32, lane);
   };
   auto store_rows = [&](const f32x16 (&ac)[2], float* mb, int r) {     // accumulator register r of both column tiles: rows R and R + 4
     const unsigned x0 = __float_as_uint(ac[0][r]), x1 = __float_as_uint(ac[1][r]);
     const auto s32 = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);
     const unsigned w0 = s32[0], w1 = s32[1];
-    float* d = mb + (size_t)((r & 3) + 8 * (r >> 2)) * 64;
+    float* d = mb + maps::mc_index(0, 0, 0, 0, 0, maps::mfma_row(r), 0);
     if (MODE & 1) { asm volatile("" ::"v"(w0), "v"(w1)); return; }
     d[0] = __uint_as_float(w0);
-    d[4 * 64] = __uint_as_float(w1);
+    d[maps::mc_index(0, 0, 0, 0, 0, 4, 0)] = __uint_as_float(w1);
   };
 
   int pos = u0 / n_half;
@@ -356,12 +345,12 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
   auto unit_base = [&](int tt) -> unsigned {
     int m = u0 + (tt < nT ? tt : nT - 1) - pos * n_half, p = pos;
     if (m >= n_half) { m -= n_half; p++; }
-    return h2p_v_base(p, m, h.npos);
+    return maps::h2p_v_base(p, m, h.npos);
   };
   {                                                          // prologue: stages 0 .. D - 1 (units 0 and 1)
     const unsigned vb0 = unit_base(0), vb1 = unit_base(1);
 #pragma unroll
-    for (int g = 0; g < D; g++) issue(g < NK ? vb0 : vb1, g & 7, g);
+    for (int g = 0; g < D; g++) issue(g < NK ? vb0 : vb1, g % NK, maps::h2p_slot(g / NK, g % NK));
   }
   f32x16 accA[2], accB[2];
 #pragma unroll
@@ -369,12 +358,12 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
 #pragma unroll
     for (int r = 0; r < 16; r++) accB[j][r] = 0.f;
   f16x8_t Fc[2][2];                                          // A fragments of the step about to run: [ks][piece]
-  H2P_WAIT((D - 1) * 2);                                     // stage 0 has landed (this wave's part; after the barrier every wave's)
+  H2P_WAIT(maps::h2p_wait_early() + 2);                      // stage 0 has landed (this wave's part; after the barrier every wave's)
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-    for (int p = 0; p < 2; p++) Fc[ks][p] = frag(0, ks, p);
+    for (int p = 0; p < 2; p++) Fc[ks][p] = frag(maps::h2p_slot(0, 0), ks, p);
   // tile 0 has no predecessor: its store slots write the zeros of accB to its OWN rows (overwritten by its results during tile 1:
   // a wave's stores to one address stay in order) — every step of the kernel then issues the same 2 DMAs + 4 stores
   float* mprev = m_base(pos, u0 - pos * n_half);
@@ -385,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
     const int hm = u0 + t - pos * n_half;
     const unsigned vb1 = unit_base(t + 1), vb2 = unit_base(t + 2);
     float* const mcur = m_base(pos, hm);
-    const unsigned early = (unsigned)__builtin_amdgcn_readfirstlane((t < 2 || (MODE & 1)) ? 1 : 0);
+    const unsigned early = (unsigned)__builtin_amdgcn_readfirstlane((maps::h2p_early(t) || (MODE & 1)) ? 1 : 0);
 #pragma unroll
     for (int j = 0; j < 2; j++) {
 #pragma unroll
@@ -396,15 +385,15 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
     for (int kk = 0; kk < NK; kk++) {
       // stage g + 1 has landed: younger operations than its two DMAs = 4 stores of the issuing step + 8 steps x (2 DMA + 4 stores)
       // = 52; in the first pair the younger operations are prologue DMAs: >= (D - 2) x 2 (a count that is too small only waits longer)
-      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lh2p_steady_%=\n\ts_waitcnt vmcnt(16)\n\ts_branch .Lh2p_done_%=\n"
-                   ".Lh2p_steady_%=:\n\ts_waitcnt vmcnt(52)\n.Lh2p_done_%=:" ::"s"(early) : "memory", "scc");
+      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lh2p_steady_%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lh2p_done_%=\n"
+                   ".Lh2p_steady_%=:\n\ts_waitcnt vmcnt(%2)\n.Lh2p_done_%=:" ::"s"(early), "n"(maps::h2p_wait_early()), "n"(maps::h2p_wait_steady()) : "memory", "scc");
       __builtin_amdgcn_s_barrier();
-      issue((kk + D) / NK == 1 ? vb1 : vb2, (kk + D) % NK, (PAR * NK + kk + D) % R);
+      issue(maps::h2p_tiles_ahead(kk) == 1 ? vb1 : vb2, maps::h2p_kk_ahead(kk), maps::h2p_slot_ahead(PAR, kk));
       f16x8_t Fn[2][2];
 #pragma unroll
       for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-        for (int p = 0; p < 2; p++) Fn[ks][p] = frag((PAR * NK + kk + 1) % R, ks, p);
+        for (int p = 0; p < 2; p++) Fn[ks][p] = frag(maps::h2p_slot_next(PAR, kk), ks, p);
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {                       // small terms first: lo*hi, hi*lo, hi*hi (per accumulator as h2g)
         accC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][1], Bf[kk][ks][0][0], accC[0], 0, 0, 0);

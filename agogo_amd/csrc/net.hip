@@ -20,6 +20,7 @@
 //   16-byte-chunk XOR swizzle ((row>>1)&7) so the ds_read_b128 operand reads are bank-conflict free.
 //   Algorithmic FLOPs per launch: 2 * M * N * 9 * Cin.
 #include "net.hpp"
+#include "gemm_maps.hpp"
 
 #include <cmath>
 #include <cstdio>

@@ -11,7 +11,7 @@ from test_train_gpu import batch_data
 
 ctx = A.Ctx(0)
 K, L, FC, W, H, F, Aspace, B = 256, int(os.environ.get("PROBE_L", "20")), 32, 19, 19, 18, 362, 2
-for wscale, beta0 in ((1.0, 8.0), (1.0, 4.0)):
+for wscale, beta0 in ((1.0, 0.0), (1.0, 4.0), (1.0, 8.0)):
     ot = O.TrainNet(K, L, FC, W, H, F, Aspace, B)
     ot.init_random(5)
     rng = np.random.default_rng(5)
@@ -48,12 +48,14 @@ for wscale, beta0 in ((1.0, 8.0), (1.0, 4.0)):
             rel.append(float(e.max()) / mx)
             frac5.append(float((e > 2e-5 * mx).mean())); frac3.append(float((e > 1e-3 * mx).mean()))
             l2.append(float(np.sqrt((e.astype(np.float64) ** 2).sum() / ((go[i].astype(np.float64) ** 2).sum() + 1e-300))))
+        stat_lines = []
         for kind in ("Filter", "_gamma", "_beta"):
             idx = [i for i in range(len(go)) if (names[i].startswith(kind) if kind == "Filter" else names[i].endswith(kind))]
-            print("    %-7s frac>2e-5: median %.1e max %.1e | frac>1e-3: median %.1e max %.1e | rel L2: median %.1e max %.1e" % (
+            stat_lines.append("    %-7s frac>2e-5: median %.1e max %.1e | frac>1e-3: median %.1e max %.1e | rel L2: median %.1e max %.1e" % (
                 kind, np.median([frac5[i] for i in idx]), max(frac5[i] for i in idx), np.median([frac3[i] for i in idx]), max(frac3[i] for i in idx),
                 np.median([l2[i] for i in idx]), max(l2[i] for i in idx)))
         filt = [(names[i], rel[i]) for i in range(len(go)) if names[i].startswith("Filter")]
         print(" ", mode, "dcost %.2e" % abs(cd - co), "worst %.2e (%s)" % (max(rel), names[int(np.argmax(rel))]))
         print("    filters top->bottom:", " ".join("%.0e" % r for _, r in filt[::-1][:44:2]))
+        print("\n".join(stat_lines))
         dt.close()
