@@ -24,10 +24,10 @@ package agzhip
 import "C"
 
 import (
-	"time"
 	"errors"
 	"runtime"
 	"sync"
+	"time"
 	"unsafe"
 
 	"github.com/gorgonia/agogo"
@@ -394,28 +394,41 @@ func NewMCTS(ctx *Ctx, kind GameKind, g game.State, k int, komi float32, encoder
 		kindInf, h = C.int(C.AGZ_INF_NET), nn.h
 	}
 	if err := lastErr(C.agz_mcts_set_inferencer(t.h, kindInf, h)); err != nil {
+		C.agz_mcts_destroy(t.h) // (the handle exists from here on: no error path may leak it)
 		return nil, err
 	}
 	// mcts.Config.Timeout is what a reference caller actually sets (Budget is inert there, search.go:183-185): a conf without a
 	// Budget keeps the reference's own stopping rule — search by wall clock, not deterministic; with a Budget the search runs
 	// exactly Budget simulations (the declared, bit-reproducible semantics)
 	if conf.Budget <= 0 && conf.Timeout > 0 {
-		ms := int(conf.Timeout / time.Millisecond)
-		if ms < 1 {
-			ms = 1
-		}
-		if err := lastErr(C.agz_mcts_set_timeout_ms(t.h, C.int(ms))); err != nil {
+		if err := lastErr(C.agz_mcts_set_timeout_ms(t.h, timeoutMs(conf.Timeout))); err != nil {
+			C.agz_mcts_destroy(t.h)
 			return nil, err
 		}
 	}
 	return t, nil
 }
 
+// timeoutMs: a positive duration below one millisecond is one millisecond (0 would silently mean "exactly Budget simulations").
+func timeoutMs(d time.Duration) C.int {
+	if d <= 0 {
+		return 0
+	}
+	if d < time.Millisecond {
+		return 1
+	}
+	return C.int(d / time.Millisecond)
+}
+
 // SetTimeout: mcts.Config.Timeout on a live tree (0 restores "exactly Budget simulations").
 func (t *MCTS) SetTimeout(d time.Duration) error {
 	defer t.ctx.enter()()
-	return lastErr(C.agz_mcts_set_timeout_ms(t.h, C.int(d/time.Millisecond)))
+	return lastErr(C.agz_mcts_set_timeout_ms(t.h, timeoutMs(d)))
 }
+
+// Log (mcts/debug.go:40, release.go): the reference's release build logs nothing; the device tree keeps no log either.  Present so that
+// *MCTS has the whole method set Agent / Arena use on their tree (SetGame, Search, Policies, Reset, Log — INTEGRATION.md section 2).
+func (t *MCTS) Log() string { return "" }
 
 // SetGame (tree.go:120-124).
 func (t *MCTS) SetGame(g game.State) { t.current = g }
@@ -669,6 +682,19 @@ func (c *Comm) AllReduceGradients(t *Trainer, lr float32) error {
 		return err
 	}
 	return lastErr(C.agz_trainer_apply(t.h, C.float(lr), C.float(1.0/float32(C.agz_comm_size(c.h)))))
+}
+
+// BatchStep: one data-parallel dual.Train inner step (meta.go:33-40) on this rank's batch — forward / backward with every slice of the
+// flat gradient buffer summed over the ranks while the rest of the backward runs (agz_trainer_forward_backward_allreduce), then the
+// averaged SGD step.  Every rank calls it for the same step.
+func (c *Comm) BatchStep(t *Trainer, planes, pi, v []float32, lr float32) (cost float32, err error) {
+	defer c.ctx.enter()()
+	var cc C.float
+	if err := lastErr(C.agz_trainer_forward_backward_allreduce(c.h, t.h, (*C.float)(unsafe.Pointer(&planes[0])), (*C.float)(unsafe.Pointer(&pi[0])),
+		(*C.float)(unsafe.Pointer(&v[0])), &cc)); err != nil {
+		return 0, err
+	}
+	return float32(cc), lastErr(C.agz_trainer_apply(t.h, C.float(lr), C.float(1.0/float32(C.agz_comm_size(c.h)))))
 }
 
 func (c *Comm) Close() error { defer c.ctx.enter()(); C.agz_comm_destroy(c.h); c.h = nil; return nil }
