@@ -737,8 +737,9 @@ class Mcts:
         _check(lib().agz_mcts_last_simulations(self.h, C.byref(n)), "agz_mcts_last_simulations")
         return n.value
 
-    def to_dot(self, max_nodes=200):
-        """(*MCTS).ToDot (mcts/graph.go:34): Graphviz text of the live tree"""
+    def to_dot(self, max_nodes=0):
+        """(*MCTS).ToDot (mcts/graph.go:34): Graphviz text of the live tree.  max_nodes = 0 (default, as the reference and the Go shim):
+        the whole tree — hundreds of MB for a deep 19x19 tree; max_nodes > 0: the first max_nodes nodes (a top of the tree)"""
         need = C.c_size_t(0)
         _check(lib().agz_mcts_to_dot(self.h, int(max_nodes), None, 0, C.byref(need)), "agz_mcts_to_dot")
         buf = C.create_string_buffer(need.value)

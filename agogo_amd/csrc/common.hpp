@@ -54,6 +54,9 @@ struct agz_ctx {
   agz::ProfClass prof[AGZ_PROF_NCLASS];
   int prof_open = 0;   // scopes begun and not yet ended (classes nest: a layer scope around its kernels' scopes)
   int num_cus = 256;
+  // per-DEVICE function attributes set through this context (hipFuncSetAttribute applies to the current device only): bit 0 = the
+  // fused out->in kernel's 80 KB of dynamic LDS is available, bit 1 = the attempt was made (conv_wino_h2c.hpp)
+  unsigned func_attr_state = 0;
 
   // record a start event for a kernel class (no-op unless profiling)
   void prof_begin(int klass);

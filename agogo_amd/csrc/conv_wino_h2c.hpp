@@ -962,16 +962,18 @@ static void wino_h2c_oi(agz_ctx* ctx, WinoH2Args& h, bool last, hipStream_t st, 
   const size_t shm = last ? 0 : (size_t)(16 / a.TPB) * a.H * a.W * 32 * sizeof(float);
   // (the pipelined kernel addresses M and V through one buffer descriptor each: 31-bit byte offsets)
   const bool fits31 = wino_h2_rows(h.npos, (size_t)a.T) * a.Ntot * 4 < ((size_t)1 << 31);
-  if (variant == 4 && !last && fits31) {   // persistent, software-pipelined
+  // up to 80 KB of dynamic LDS (wino_h2c_ok): a function attribute of the CURRENT DEVICE — kept per context (several contexts / devices in
+  // one process: agz_comm_init_all), its result checked; where it cannot be set the plain out->in kernel below runs instead
+  if (variant == 4 && !last && fits31 && !(ctx->func_attr_state & 2u)) {
+    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_oip_h2c_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_oip_h2c_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    ctx->func_attr_state |= 2u | (ok ? 1u : 0u);
+  }
+  if (variant == 4 && !last && fits31 && (ctx->func_attr_state & 1u)) {   // persistent, software-pipelined
     const size_t shp = (size_t)(16 / a.TPB) * (h.tm * a.nty + 2) * (h.tm * a.ntx + 2) * 32 * sizeof(float);
     const int items = ceil_div(a.T, 16) * (a.C >> 5);
     const dim3 gp((unsigned)std::min(items, 2 * ctx->num_cus));
-    static bool attr_set = false;
-    if (!attr_set) {   // up to 80 KB of dynamic LDS (wino_h2c_ok)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_oip_h2c_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_oip_h2c_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      attr_set = true;
-    }
     if (h.tm == 5) hipLaunchKernelGGL((wino_oip_h2c_kernel<5>), gp, dim3(256), shp, st, h);
     else hipLaunchKernelGGL((wino_oip_h2c_kernel<4>), gp, dim3(256), shp, st, h);
     return;

@@ -2095,6 +2095,7 @@ int agz_mcts_set_parallel(agz_mcts* m, int lanes) {
 
 int agz_mcts_set_game(agz_mcts* m, const agz_state* st) {
   AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
+  m->dot_cache.clear(); m->dot_cache.shrink_to_fit();   // (a ToDot text kept between its size query and its fill dies with the tree it printed)
   int r = agz_arena_set_state(m->arena, 0, st);
   if (r == AGZ_OK) m->have_game = true;
   return r;
@@ -2104,6 +2105,7 @@ int agz_mcts_search(agz_mcts* m, int player, int32_t* best) {
   AGZ_REQUIRE(m && best, AGZ_E_INVALID, "agz_mcts_search: NULL argument");
   AGZ_REQUIRE(player == AGZ_BLACK || player == AGZ_WHITE, AGZ_E_INVALID, "agz_mcts_search: player %d", player);
   agz_arena* a = m->arena;
+  m->dot_cache.clear(); m->dot_cache.shrink_to_fit();
   AGZ_REQUIRE(!a->in_move, AGZ_E_STATE, "agz_mcts_search: a search is in progress");
   // (t.current is nil before SetGame in the reference, tree.go:107-111: Search would dereference it)
   AGZ_REQUIRE(m->have_game, AGZ_E_STATE, "agz_mcts_search: no game — call agz_mcts_set_game first (mcts.SetGame, tree.go:107)");
@@ -2355,6 +2357,7 @@ int agz_mcts_reset(agz_mcts* m) {
   AGZ_HIP_TRY(hipMemsetAsync(a->d.counters, 0, CNT_N * sizeof(unsigned long long), s));
   AGZ_HIP_TRY(hipStreamSynchronize(s));
   a->prep_expand_seen = 0;
+  m->dot_cache.clear(); m->dot_cache.shrink_to_fit();
   m->have_game = false;      // a fresh mcts.New has no game: SetGame comes first
   return AGZ_OK;
 }

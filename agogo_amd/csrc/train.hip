@@ -1733,6 +1733,9 @@ int agz_trainer_grads_dev(agz_trainer* t, float** dev_ptr, size_t* n_floats) {
   return AGZ_OK;
 }
 
+// the learn rate dual.Train builds its solver with: gorgonia.NewVanillaSolver(gorgonia.WithLearnRate(0.1)) (dualnet/meta.go:22)
+static constexpr float DUAL_TRAIN_LR = 0.1f;
+
 // dual.Train (dualnet/meta.go:16-54): iterations x batches of BatchSize rows; shuffleBatch (meta.go:57-102) after every
 // iteration with the build's SplitMix64 (Fisher-Yates j = r.Intn(i+1) pattern).  Xs/policies/values are shuffled IN PLACE
 // like the reference does.
@@ -1746,7 +1749,7 @@ int agz_train(agz_trainer* t, float* Xs, float* policies, float* values, int bat
   for (int it = 0; it < iterations; it++) {
     for (int b = 0; b < batches; b++) {
       size_t s0 = (size_t)b * t->B;
-      int r = agz_trainer_batch(t, Xs + s0 * xs, policies + s0 * ps, values + s0, 0.1f, &c);
+      int r = agz_trainer_batch(t, Xs + s0 * xs, policies + s0 * ps, values + s0, DUAL_TRAIN_LR, &c);
       if (r != AGZ_OK) return r;
     }
     for (size_t i = 0; i < n; i++) {
@@ -1787,11 +1790,11 @@ int agz_train_dev(agz_trainer* t, const float* Xs_dev, const float* policies_dev
       hipLaunchKernelGGL(k_gather_rows_t, dim3(nblk((size_t)t->B * xs)), dim3(256), 0, s, Xs_dev, ib, t->d_planes, (int)xs, (size_t)t->B * xs);
       hipLaunchKernelGGL(k_gather_rows_t, dim3(nblk((size_t)t->B * ps)), dim3(256), 0, s, policies_dev, ib, t->d_pi, (int)ps, (size_t)t->B * ps);
       hipLaunchKernelGGL(k_gather_rows_t, dim3(nblk((size_t)t->B)), dim3(256), 0, s, values_dev, ib, t->d_v, 1, (size_t)t->B);
-      t->fuse_lr = 0.1f;
+      t->fuse_lr = DUAL_TRAIN_LR;
       rc = t->forward_backward_dev(t->d_planes, t->d_pi, t->d_v);
       t->fused_done = rc == AGZ_OK;
       t->fuse_lr = 0.f;
-      if (rc == AGZ_OK) rc = agz_trainer_apply(t, 0.1f, 1.0f);
+      if (rc == AGZ_OK) rc = agz_trainer_apply(t, DUAL_TRAIN_LR, 1.0f);
     }
     for (size_t i = 0; i < n; i++) {  // shuffleBatch (meta.go:57-102) on the row index
       size_t j = (size_t)(rng.next() % (uint64_t)(i + 1));

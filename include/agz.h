@@ -190,7 +190,13 @@ int agz_trainer_get_param(const agz_trainer* t, int index, float* host, size_t n
 int agz_trainer_get_grad(const agz_trainer* t, int index, float* host, size_t n);
 int agz_trainer_init_random(agz_trainer* t, uint64_t seed);
 /* One batch of dual.Train's inner loop (dualnet/meta.go:33-40): Let planes/Pi/V, RunAll, solver.Step(lr).
- * planes [B,F,H,W], pi [B,ActionSpace], v [B] host buffers; *cost = xent(logits,Pi) + mean((o-V)^2) (dual.go:113-121). */
+ * planes [B,F,H,W], pi [B,ActionSpace], v [B] host buffers; *cost = xent(logits,Pi) + mean((o-V)^2) (dual.go:113-121).
+ * NOTE (gradient read-back): with lr != 0 this call — and agz_train / agz_train_dev, which are loops of it — takes the SGD step of the
+ * tower's batch-shaped gamma / beta INSIDE the BatchNorm backward kernel (98 % of the learnables: no gradient round trip), so their
+ * gradients are NOT materialised: agz_trainer_get_grad / agz_trainer_grads_dev then return what an earlier forward_backward left there
+ * for those tensors (zeros on a fresh trainer); filter and head gradients are current.  To read every gradient, run
+ * agz_trainer_forward_backward (or agz_trainer_batch with lr = 0).  A step that fails part-way may have stepped some layers' gamma / beta
+ * already: treat the trainer's parameters as undefined after an error (reload a checkpoint, agz_trainer_load). */
 int agz_trainer_batch(agz_trainer* t, const float* planes, const float* pi, const float* v, float lr, float* cost);
 /* Split form for data-parallel training: forward_backward fills the flat gradient buffer; all-reduce it over RCCL
  * (agz_trainer_grads_dev gives the device pointer: ONE collective per step); apply does w -= lr*grad_scale*grad. */

@@ -340,7 +340,8 @@ def test_to_dot_renders_the_live_tree(ctx):
     dot = dev.to_dot(max_nodes=0)                      # 0: the whole tree, as the reference's ToDot
     assert dot.startswith("digraph G {") and dot.rstrip().endswith("}")
     n = dev.nodes()
-    assert n > 200 and dev.to_dot().count("[ fontname") == 200   # the wrapper's default is bounded (a 1600-simulation 19x19 tree is hundreds of MB of HTML)
+    assert n > 200 and dev.to_dot().count("[ fontname") == n     # the wrapper's default is the reference's: the whole tree
+    assert dev.to_dot(max_nodes=200).count("[ fontname") == 200
     ids = [int(x) for x in re.findall(r"^\t(\d+) \[ fontname", dot, flags=re.M)]
     assert ids == list(range(n))
     edges = [(int(a), int(b)) for a, b in re.findall(r"^\t(\d+)->(\d+);", dot, flags=re.M)]
