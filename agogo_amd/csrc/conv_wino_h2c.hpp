@@ -258,6 +258,13 @@ __device__ __forceinline__ void h2p_dma16(h2p_rsrc_t rsrc, unsigned lds_addr, un
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
+// the two DMA instructions of a wave's part of a stage: one save / restore of M0
+__device__ __forceinline__ void h2p_dma16x2(h2p_rsrc_t rsrc, unsigned lds_a, unsigned lds_b, unsigned voff_a, unsigned voff_b, unsigned soff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+               "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_a), "s"(lds_b), "v"(voff_a), "v"(voff_b), "s"(rsrc), "s"(soff) : "memory");
+}
 #define H2P_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 // MODE (decomposition runs only, agz_net_set_wino_h2_gemm(net, 2 + 16 * MODE)): bit 0 = no M stores, bit 1 = no DMA (the ring holds whatever LDS held)
 template <int MODE>
@@ -293,8 +300,7 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
   auto issue = [&](unsigned vb, int kk, int rslot) {
     if (MODE & 2) return;
     const unsigned so = vb + (unsigned)kk * 16384u + a_w;
-    h2p_dma16(ar, dma_l + (unsigned)rslot * SA + maps::h2c_dma_dst(0, 0), vo_e, so);
-    h2p_dma16(ar, dma_l + (unsigned)rslot * SA + maps::h2c_dma_dst(0, 1), vo_o, so);
+    h2p_dma16x2(ar, dma_l + (unsigned)rslot * SA + maps::h2c_dma_dst(0, 0), dma_l + (unsigned)rslot * SA + maps::h2c_dma_dst(0, 1), vo_e, vo_o, so);
   };
   const int kh = lane >> 5;
   auto frag = [&](int rslot, int ks, int p) -> f16x8_t {
@@ -326,6 +332,8 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
 #pragma unroll
           for (int p = 0; p < 2; p++) asm volatile("" : "+a"(Bf[kk][ks][j][p]));
   };
+  // (M stores WITHOUT the lane swap — two whole 128-byte lines per instruction straight from the accumulation registers, 288 fewer
+  //  instructions per tile pair — measured SLOWER: 0.325 vs 0.312 ms; the 256-byte runs matter to the memory system, profiles/r05)
   auto m_base = [&](int pos, int hm) -> float* {
     return a.Mb + maps::mc_index(hm >> 1, h.npos, pos, a.Ntot >> 6, slab * 2 + wn, (hm & 1) * 64 + wm * 32, lane);
   };
@@ -375,12 +383,9 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
     const unsigned vb1 = unit_base(t + 1), vb2 = unit_base(t + 2);
     float* const mcur = m_base(pos, hm);
     const unsigned early = (unsigned)__builtin_amdgcn_readfirstlane((maps::h2p_early(t) || (MODE & 1)) ? 1 : 0);
+    f32x16 zero16;                                             // the tile's first product takes a zero C operand (an inline constant: nothing to clear)
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) accC[j][r] = 0.f;
-      asm volatile("" : "+v"(accC[j]));
-    }
+    for (int r = 0; r < 16; r++) zero16[r] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < NK; kk++) {
       // stage g + 1 has landed: younger operations than its two DMAs = 4 stores of the issuing step + 8 steps x (2 DMA + 4 stores)
@@ -396,8 +401,8 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
         for (int p = 0; p < 2; p++) Fn[ks][p] = frag(maps::h2p_slot_next(PAR, kk), ks, p);
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {                       // small terms first: lo*hi, hi*lo, hi*hi (per accumulator as h2g)
-        accC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][1], Bf[kk][ks][0][0], accC[0], 0, 0, 0);
-        accC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][1], Bf[kk][ks][1][0], accC[1], 0, 0, 0);
+        accC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][1], Bf[kk][ks][0][0], (kk | ks) ? accC[0] : zero16, 0, 0, 0);
+        accC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][1], Bf[kk][ks][1][0], (kk | ks) ? accC[1] : zero16, 0, 0, 0);
         accC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][0], Bf[kk][ks][0][1], accC[0], 0, 0, 0);
         accC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fc[ks][0], Bf[kk][ks][1][1], accC[1], 0, 0, 0);
         store_rows(accP, mprev, 2 * kk + ks);                // the previous tile's M, two row groups per K step

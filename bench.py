@@ -262,19 +262,25 @@ def config0_leg():
             "seconds": wall, "ok": "AZ_LEARN OK" in out.stdout, "epochs": lines}
 
 
-def latency_leg(ctx, lanes_list=(1, 16), moves=3, sims=1600):
+def latency_leg(ctx, lanes_list=(1, 8, 16), moves=3, sims=1600):
     """BASELINE config #5 (tournament Agent.Search): 19x19, K=256, 40 blocks, 1600 sims/move, ONE tree through the single-tree
-    boundary's engine; p50 wall time of a move (begin_move + simulate(Budget) + end_move + sync) on a short sample: the
-    sequential search (lanes 1, the declared semantics; AGZ_COMPUTE_AUTO: the fp16x2 one-launch-per-layer tower) and lane rounds of 16 (deterministic, bit-exact vs
-    the oracle's parallelRound) with the Winograd fp16x2 tower kept at every batch size (AGZ_COMPUTE_FORCE)."""
+    boundary's engine; p50 wall time of a move (begin_move + simulate(Budget) + end_move + sync) on a short sample, at three operating
+    points side by side: the sequential search (lanes 1, the declared semantics) and lane rounds of 8 and 16 — the
+    deterministic restatement of what the reference itself does (runtime.NumCPU() goroutines on one tree with a stored virtual loss,
+    mcts/search.go:112-131; bit-exact vs the oracle's parallelRound).  Towers: lanes 1 and 8 run the fp16x2 one-launch-per-layer kernel
+    (AGZ_COMPUTE_AUTO, conv_lat.hpp: up to 8-11 boards), lanes 16 the Winograd fp16x2 tower kept at every batch size (AGZ_COMPUTE_FORCE).
+    Each point carries the per-simulation kernel split (HIP events on ONE extra move, outside the timed ones) and the roofline of the
+    tower layer: a 19x19 / K=256 dual layer reads its 4.72 MB fp16 hi/lo weight image first touch, 188.7 MB per 40-block evaluation."""
     S, K, L = 19, 256, 40
     net = A.Net(ctx, K, L, 2 * K, S, S, 18, S * S + 1, BatchSize=1, bn_mode=capi.BN_IDENTITY)
     net.init_random(1337)
     standard_bn_init(net)
     net.commit()
-    out = {"workload": "config #5: 19x19 wq Agent.Search, K=256, 40 blocks, %d sims/move, one tree" % sims, "moves_timed": moves}
+    w_layer = (K // 32) * 9 * 2 * (2 * K) * 32 * 2           # bytes of one layer's latency-regime weight image [c/32][tap][2][2K][32] fp16
+    out = {"workload": "config #5: 19x19 wq Agent.Search, K=256, 40 blocks, %d sims/move, one tree" % sims, "moves_timed": moves,
+           "tower_weight_bytes_per_eval": L * w_layer}
     for lanes in lanes_list:
-        net.set_compute_mode((capi.COMPUTE_WINO_H2 | capi.COMPUTE_FORCE) if lanes > 1 else capi.COMPUTE_AUTO)   # AUTO at batch 1: the fp16x2 latency kernel (F32_MFMA keeps exact fp32 products)
+        net.set_compute_mode((capi.COMPUTE_WINO_H2 | capi.COMPUTE_FORCE) if lanes > 8 else capi.COMPUTE_AUTO)   # AUTO up to 8 boards: the fp16x2 latency kernel (F32_MFMA keeps exact fp32 products)
         arena = A.Arena(ctx, capi.GAME_WQ, S, S, komi=7.5, encoder=capi.ENC_WQ, n_games=1, seed=7, Budget=sims)
         arena.set_inferencer(0, capi.INF_NET, net)
         arena.set_inferencer(1, capi.INF_NET, net)
@@ -290,9 +296,30 @@ def latency_leg(ctx, lanes_list=(1, 16), moves=3, sims=1600):
             ctx.sync()
             if mv >= 1:
                 lat.append(time.perf_counter() - t0)
+        # one extra move with every kernel class bracketed by HIP events: where a simulation's time goes (not part of the p50)
+        ctx.prof_enable(True)
+        arena.begin_move()
+        arena.simulate(sims)
+        arena.end_move(False)
+        ctx.sync()
+        ctx.prof_enable(False)
+        split = {}
+        for name, k in (("tower", capi.PROF_CONV), ("input_layer", capi.PROF_CONV_INIT), ("heads", capi.PROF_HEADS), ("select", capi.PROF_SELECT), ("expand", capi.PROF_EXPAND)):
+            n, ms = ctx.prof_read(k)
+            split[name + "_us_per_sim"] = ms * 1e3 / sims
+        rounds = sims / lanes
+        tower_ms_per_eval = split["tower_us_per_sim"] * 1e-3 * lanes       # one tower pass serves `lanes` simulations
+        latency_tower = lanes <= 8
         out["lanes_%d" % lanes] = {"p50_move_s": float(np.percentile(lat, 50)), "max_move_s": float(np.max(lat)),
-                                   "ms_per_sim": float(np.median(lat)) / sims * 1e3,
-                                   "tower": "winograd fp16x2 (forced at every batch size)" if lanes > 1 else "fp16x2 one-launch-per-layer kernel (latency regime, conv_lat.hpp)"}
+                                   "ms_per_sim": float(np.median(lat)) / sims * 1e3, "rounds_per_move": rounds,
+                                   "kernel_split": split,
+                                   "tower": "fp16x2 one-launch-per-layer kernel (latency regime, conv_lat.hpp)" if latency_tower else "winograd fp16x2 (forced at every batch size)",
+                                   "roofline": ({"bound": "hbm", "kernel": "conv3x3_lat_h2_kernel (one launch per dual layer)", "bytes_per_eval": L * w_layer,
+                                                 "tower_ms_per_eval": tower_ms_per_eval, "us_per_layer": tower_ms_per_eval * 1e3 / L,
+                                                 "achieved_GBs": L * w_layer / (tower_ms_per_eval * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                                                 "frac": L * w_layer / (tower_ms_per_eval * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 "note": "first-touch weight stream of a batch-%d evaluation; the layer is bound by its launch boundary + first-byte latency + 64 B/clk "
+                                                         "LDS fill per CU, not by HBM (DESIGN 4c)" % lanes} if latency_tower else None)}
         arena.close()
     net.close()
     return out
@@ -632,6 +659,29 @@ def main():
     gather_ms = gather
 
     if rank == 0:
+        # the search kernels of one step: algorithmic bytes from the live tree statistics of the timed region (SURVEY 8(d):
+        # Select reads path nodes x children x 12 B — prior, visits, blackScores; expansion writes n_legal x 20 B of new nodes and the
+        # leaf's encoded planes), duration from the HIP-event steps after the timed region; HBM counters QUOTED from the committed pass
+        path_per_sim = (st1["path_nodes"] - st0["path_nodes"]) / max(1, sims_all)
+        kids_per_node = (st1["children_read"] - st0["children_read"]) / max(1, (st1["path_nodes"] - st0["path_nodes"]) - sims_all)
+        sel_ms, exp_ms = prof["select"]["avg_ms"], prof["expand"]["avg_ms"]
+        sel_bytes = G * ((path_per_sim - 1) * kids_per_node * 12.0 + 18 * S * S * 4.0)      # child blocks read + the leaf's 18 planes written
+        exp_bytes = G * ((S * S + 1) * 20.0 + (S * S + 1) * 4.0)                                # <= A new nodes + the policy row read
+        pmc_mcts = None
+        try:
+            pmc_mcts = {k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "GBps": v["GBps"], "frac_of_8TBps": v["frac_of_8TBps"]}
+                        for k, v in json.load(open(os.path.join(ROOT, "profiles", "r05", "pmc_mcts_kernels.json")))["kernels"].items()}
+        except Exception:
+            pass
+        mcts_detail = {"mean_path_nodes": path_per_sim, "mean_children_per_select": kids_per_node,
+                       "k_select": {"avg_ms": sel_ms, "algorithmic_bytes": sel_bytes, "GBps": (sel_bytes / (sel_ms * 1e-3) / 1e9) if sel_ms else None,
+                                    "frac_of_8TBps": (sel_bytes / (sel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sel_ms else None},
+                       "k_expand": {"avg_ms": exp_ms, "algorithmic_bytes": exp_bytes, "GBps": (exp_bytes / (exp_ms * 1e-3) / 1e9) if exp_ms else None,
+                                    "frac_of_8TBps": (exp_bytes / (exp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if exp_ms else None},
+                       "counters": pmc_mcts, "counters_source": "profiles/r05/pmc_mcts_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; quoted)",
+                       "note": "one 64-lane wavefront per game walks its own tree with the board in LDS: latency-bound by construction, 1-2 % of the HBM peak, "
+                               "~1.3 % of the step; measured on near-uniform priors (BatchNorm gamma = 1 / beta = 0, identity statistics: config.weights) — trees are wide "
+                               "(~250 children per visited node, paths ~3 nodes)"}
         flops_eval = nets[0].flops_per_eval()
         hw = S * S
         conv_flops_launch = 2.0 * (G * hw) * (2 * K) * (9 * K)  # algorithmic FLOPs of one dual-block launch
@@ -696,6 +746,14 @@ def main():
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        traffic_source = os.path.relpath(pmc_path, ROOT) if traffic is not None else None
+        # the memory system's own ceiling for this kernel's byte mix, MEASURED (scripts/probes/rw_probe.hip) and committed — not a constant
+        stream_ceiling, stream_src = None, None
+        try:
+            rw = json.load(open(os.path.join(ROOT, "profiles", "r05", "rw_probe.json")))
+            stream_ceiling, stream_src = [float(x) * 1e3 for x in rw["gemm_mix_1_2_TBps"]], "profiles/r05/rw_probe.json (gemm_mix_1_2_TBps: every box and grid measured)"
+        except Exception:
+            pass
         for mode, leg in legs.items():
             if leg.get("conv_dual_avg_ms"):
                 leg["conv_dual_tflops"] = conv_flops_launch / (leg["conv_dual_avg_ms"] * 1e-3) / 1e12
@@ -744,20 +802,23 @@ def main():
                        "tower_queues": 2 if two_queues else 1},
             "roofline": ({"bound": "hbm", "achieved": wino_detail["wino_gemm"]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": wino_detail["wino_gemm"]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                          "traffic_source": (traffic_source + " (PMC pass of an earlier run of this kernel on this shape: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE; QUOTED, not collected in this run)") if traffic_source else None,
+                          "measured_in_this_run": ["achieved", "frac", "avg_launch_ms", "launches", "block"],
                           "algorithmic_bytes_per_launch": wino_detail["wino_gemm"]["algorithmic_bytes"],
                           # the whole dual block (all its kernels, one-queue HIP events around the block): VERDICT r3 item 2
                           "block": {"algorithmic_bytes": wino_detail["block_algorithmic_bytes"], "avg_ms": wino_detail["block_avg_ms"],
                                     "achieved": wino_detail["block_achieved_GBs"], "unit": "GB/s",
                                     "frac": (wino_detail["block_achieved_GBs"] / HBM_PEAK_GBS) if wino_detail["block_achieved_GBs"] else None,
                                     "kernels": "wino_gemm_h2g_kernel + wino_oip_h2c_kernel (chained)" if wino_detail.get("chained") else "in + GEMM + out"},
-                          # measured context for `frac` (scripts/probes/rw_probe.hip on 2 GB streams, profiles/r04/rw_probe.log): a bare
-                          # streaming kernel with this kernel's byte mix (1 part read : 2 parts written, nothing re-used) reaches 4.87-5.12 TB/s
-                          # on this part, pure reads 5.55-5.81, pure writes 4.30-4.44 — not a claim about `peak`, which stays the guide's 8 TB/s
-                          "stream_ceiling_same_mix_GBs": [4870.0, 5120.0],
-                          "frac_of_stream_ceiling": wino_detail["wino_gemm"]["achieved_GBs"] / 5000.0}
+                          # measured context for `frac` (scripts/probes/rw_probe.hip on 2 GB streams): what a bare streaming kernel with this
+                          # kernel's byte mix (1 part read : 2 parts written, nothing re-used) reaches on this part, box to box — read from the
+                          # committed probe results; not a claim about `peak`, which stays the guide's 8 TB/s
+                          "stream_ceiling_same_mix_GBs": stream_ceiling, "stream_ceiling_source": stream_src,
+                          "frac_of_stream_ceiling": ([wino_detail["wino_gemm"]["achieved_GBs"] / max(stream_ceiling), wino_detail["wino_gemm"]["achieved_GBs"] / min(stream_ceiling)]
+                                                     if stream_ceiling else None)}
                          if (args.compute == "wino_h2" and wino_detail) else
                          {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": (achieved / peak) if achieved else None, "traffic": traffic}) | {
+                         "frac": (achieved / peak) if achieved else None, "traffic": traffic, "traffic_source": traffic_source}) | {
                          "kernel": kernels[args.compute], "peak_note": notes[args.compute],
                          "flops_per_launch": flops_launch, "avg_launch_ms": launch_ms,
                          "launches": n_launch,
@@ -768,6 +829,10 @@ def main():
                                     "where the half-batch chains overlap and a kernel's own duration is not defined; "
                                     "`bench.py --tower-queues 1` measures the same kernel inside the timed region" % n_launch) if two_queues else
                                    "HIP events on the launch stream, steps after the timed region (--prof-stride 0)"},
+            # a WHOLE move of all games on this rank (begin_move + Budget simulations + end_move), measured before the timed region:
+            # `value`'s K steps carry one move boundary (1 in K instead of 1 in Budget), so `value` reads a little low
+            "full_move_sims_per_s": (full_move or {}).get("sims_per_s"),
+            "full_move_note": "rank 0's whole move (extra.full_move_19x19): re-root / prepareRoot + %d simulations + bestMove / Apply for all %d games; not aggregated over ranks" % (args.budget, G),
             # N > 1 self-checks, top level: every rank's simulations, and what the RCCL exchange leg (extra.examples_allgather) saw
             "per_rank_sims": per_rank_sims, "world_size": world,
             "rccl_ranks": (gather or {}).get("rccl_ranks") if world > 1 else None,
@@ -786,6 +851,7 @@ def main():
                                        "note": "every game on its own random opening; trees pre-grown so the timed steps cross a move "
                                                "boundary (end_move + begin_move of all games inside the timed region)"},
                       "full_move_19x19": full_move,
+                      "mcts": mcts_detail,
                       "games_per_s_19x19": ({"value": full_move["moves_per_s"] / (2 * hw), "moves_per_game": 2 * hw,
                                              "note": "MEASURED moves/s of a whole move (full_move_19x19) / the 2*M*N move cap: random-init nets "
                                                      "almost never pass twice, so a game runs to the cap; complete 19x19 games are not played in "
