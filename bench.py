@@ -313,6 +313,7 @@ def latency_leg(ctx, lanes_list=(1, 8, 16), moves=3, sims=1600):
         out["lanes_%d" % lanes] = {"p50_move_s": float(np.percentile(lat, 50)), "max_move_s": float(np.max(lat)),
                                    "ms_per_sim": float(np.median(lat)) / sims * 1e3, "rounds_per_move": rounds,
                                    "kernel_split": split,
+                                   "kernel_split_note": "HIP events around every launch on one extra move: each launch pays ~2-3 us of event overhead, so the classes sum to more than ms_per_sim (the timed moves run without events)",
                                    "tower": "fp16x2 one-launch-per-layer kernel (latency regime, conv_lat.hpp)" if latency_tower else "winograd fp16x2 (forced at every batch size)",
                                    "roofline": ({"bound": "hbm", "kernel": "conv3x3_lat_h2_kernel (one launch per dual layer)", "bytes_per_eval": L * w_layer,
                                                  "tower_ms_per_eval": tower_ms_per_eval, "us_per_layer": tower_ms_per_eval * 1e3 / L,
