@@ -10,10 +10,18 @@
 // GEMM rows.  All learnables live in one flat buffer P and all gradients in one flat buffer G (same offsets):
 // the SGD step is a single axpy and a data-parallel run needs ONE all-reduce over G (agz_trainer_grads_dev).
 //
-// Kernels: forward conv and data-gradient conv reuse conv3x3_mfma_kernel (raw epilogue; the data gradient is the
-// same GEMM with tap-flipped, transposed weights); the weight gradient is its own fp32 MFMA kernel (k_wgrad);
-// BatchNorm statistics / apply / backward and the heads are bandwidth-bound elementwise + reduction kernels.
-// Status: correct (parity vs oracle/train.hpp within fp32 tolerance); k_wgrad is not tuned yet.
+// Kernels, per compute mode (agz_trainer_set_compute_mode; every mode inside the same gradient tolerance against oracle/train.hpp):
+//   AGZ_COMPUTE_F32_MFMA  forward and data-gradient convolutions through conv3x3_mfma_kernel (raw epilogue; the data gradient is the
+//                         same GEMM with tap-flipped, transposed weights), weight gradient k_wgrad (fp32 MFMA)            125 ms / G19 step
+//   AGZ_COMPUTE_BF16X3    the three GEMMs on the bf16 pipe with exact three-way operand splits (conv3x3_x3 raw, k_wgrad_x3)    82 ms
+//   AGZ_COMPUTE_WINO_H2   forward = the DIRECT fp16x2 convolution (conv_h2.hpp's 128x256 kernel, raw store, weight image split on
+//                         the device every step), data gradient = the Winograd fp16x2 path (conv_wino_h2.hpp) with device-built
+//                         weights, weight gradient = k_wgrad_h2t3 (both operands split once per layer into hi / lo fp16 planes,
+//                         LDS-DMA, three taps per workgroup from one x image, ds_read_b64_tr_b16): 0.53-0.64 ms per layer, 0.48 of
+//                         the fp16x2 MFMA roof                                                                              47-49 ms
+// BatchNorm statistics / apply / backward and the heads are bandwidth-bound elementwise + reduction kernels (k_bn_bwd1 0.66 of HBM);
+// the batch-shaped gamma / beta take their SGD step inside k_bn_bwd1 on single-process steps; the weight gradient runs on its own
+// stream; a data-parallel step reduces every layer's slice of the flat gradient buffer under the backward pass (on_slice, comm.hip).
 #include <cmath>
 #include <cstring>
 #include <thread>
