@@ -435,3 +435,4 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h2w_kernel(ConvArgs a, const _
     }
   }
 }
+

@@ -116,6 +116,7 @@ struct WinoH2Args {
   unsigned* amax_next;       // [B] bits of the proven bound on max |y| of this block's output: the range word of V2(l+1)
   float g1, g0;              // that bound = g1 * max|x| + g0 (agz_net::build_wino_h2_weights)
   int gemm_variant;          // 0: default, 1: wino_gemm_h2g_kernel, 2: wino_gemm_h2p_kernel (agz_net_set_wino_h2_gemm, agz_debug.h)
+  int row_pad;               // three-kernel form: extra rows after every position's 128 tile rows of V and M (wino_h2_launch: rB = 128 + row_pad)
 };
 __device__ __forceinline__ size_t h2_row(const WinoH2Args& h, int pos, int t) {
   return (size_t)(t >> h.rsh) * h.rA + (size_t)pos * h.rB + (size_t)(t & h.rmask);
@@ -1208,7 +1209,7 @@ static inline int wino_h2_pick_tm(int H, int W) {
 }
 
 // rows of V (and of M) the launch below addresses for `tiles` tiles: what the caller sizes the buffers by
-static inline size_t wino_h2_rows(int npos, size_t tiles) { return (size_t)npos * (((tiles + 127) / 128) * 128); }
+static inline size_t wino_h2_rows(int npos, size_t tiles, int row_pad = 0) { return (size_t)npos * (((tiles + 127) / 128) * (size_t)(128 + row_pad)); }
 
 // launches the stages of one block for a chunk of boards (h.w.V / Mb sized by the caller: wino_h2_rows())
 static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, hipStream_t st = nullptr) {
@@ -1217,7 +1218,7 @@ static void wino_h2_launch(agz_ctx* ctx, WinoH2Args& h, bool wide, hipStream_t s
   const int tm = h.tm == 5 ? 5 : 4;
   h.tm = tm; h.npos = (tm + 2) * (tm + 2);
   a.nty = ceil_div(a.H, tm); a.ntx = ceil_div(a.W, tm); a.TPB = a.nty * a.ntx; a.T = a.B * a.TPB;
-  h.rsh = 7; h.rmask = 127; h.rA = (unsigned)h.npos * 128u; h.rB = 128u;   // V and M in blocks of 128 tiles: [tile / 128][position][tile % 128]
+  h.rsh = 7; h.rmask = 127; h.rB = 128u + (unsigned)h.row_pad; h.rA = (unsigned)h.npos * h.rB;   // V and M in blocks of 128 tiles: [tile / 128][position][tile % 128 (+ pad)]
   a.n_mtiles = ceil_div(a.T, 128); a.n_ntiles = ceil_div(a.Ntot, 128);
   h.in_swap = a.C % 128 == 0 ? 1 : 0;   // a wave = 64 channel pairs of ONE tile
   // Forms of the output transform: 0 = thread per (tile, channel), both branches at once;

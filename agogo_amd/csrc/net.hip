@@ -847,6 +847,9 @@ int agz::conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, 
   a.n_ntiles = Cout_p / 256; a.n_mtiles = ceil_div(a.M, 128); a.splits = 1;
   a.amax_in = ranges ? ranges : sc->h2_words; a.w_unscale = 1.f; a.w_amax_dev = wmax;
   ProfScope ps(ctx, AGZ_PROF_CONV_INIT);
+  // (Round 5, measured and dropped: the same kernel on 256 x 256 tiles — 512 threads, two 64 KB stages, one barrier per K step, half the
+  // weight re-reads through L2 -> CU (3.4 instead of 5 GB per G19 layer): 0.665 against 0.67 ms.  The kernel is bound by the split of its
+  // activations — VALU and LDS-write issue per staged element — not by operand bytes.)
   hipLaunchKernelGGL(conv3x3_h2w_kernel, dim3(a.n_mtiles * a.n_ntiles), dim3(256), 0, s, a, (const _Float16*)sc->w2);
   AGZ_HIP_TRY(hipGetLastError());
   return AGZ_OK;
@@ -877,7 +880,8 @@ int agz::conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float
   hipStream_t s = ctx->stream;
   const int tm = wino_h2_pick_tm(H, W), npos = (tm + 2) * (tm + 2);
   const size_t tiles = (size_t)B * ceil_div(H, tm) * ceil_div(W, tm);
-  const size_t v_need = wino_h2_rows(npos, tiles) * Cin_p, m_need = wino_h2_rows(npos, tiles) * Cout_p;
+  const int row_pad = 0;   // (rows of padding after every position's 128 tile rows: 1 / 4 / 16 measured no different from 0 at C = 512)
+  const size_t v_need = wino_h2_rows(npos, tiles, row_pad) * Cin_p, m_need = wino_h2_rows(npos, tiles, row_pad) * Cout_p;
   const size_t u_need = (size_t)npos * (Cin_p / 32) * 2 * Cout_p * 32;   // fp16 elements
   if (v_need > sc->v_cap || m_need > sc->m_cap || u_need > sc->u_cap || B > sc->b_cap) {
     AGZ_HIP_TRY(hipStreamSynchronize(s));
@@ -909,7 +913,7 @@ int agz::conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float
   wa.x = x; wa.y = y; wa.V = sc->V; wa.Mb = sc->M; wa.ep = nullptr;
   wa.B = B; wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Cin_p; wa.Cout_p = Cout_p; wa.Ntot = Cout_p;
   hh.U2 = (const _Float16*)sc->U2; hh.w_unscale = 1.f; hh.w_unscale_dev = unscale; hh.raw = 1; hh.tm = tm;
-  hh.amax_in = ranges ? ranges : sc->words; hh.amax_out = nullptr; hh.wave_max = nullptr; hh.fuse_prev = 0;
+  hh.amax_in = ranges ? ranges : sc->words; hh.amax_out = nullptr; hh.wave_max = nullptr; hh.fuse_prev = 0; hh.row_pad = row_pad;
   wino_h2_launch(ctx, hh, Cout_p % 256 == 0, s);
   AGZ_HIP_TRY(hipGetLastError());
   return AGZ_OK;
