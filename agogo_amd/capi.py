@@ -181,6 +181,7 @@ def lib():
     sig("agz_net_set_wino_h2_form", i32, vp, i32)
     sig("agz_net_set_wino_h2_gemm", i32, vp, i32)
     sig("agz_arena_set_prep_compact", i32, vp, i32)
+    sig("agz_trainer_set_dma_forward", i32, vp, i32)
     sig("agz_arena_last_prep_batch", i32, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
     sig("agz_wino_h2_chained", i32, i32, i32, i32)
     sig("agz_arena_random_moves", i32, vp, pi, u64)
@@ -465,6 +466,10 @@ class Trainer:
 
     def set_compute_mode(self, mode):
         _check(lib().agz_trainer_set_compute_mode(self.h, int(mode)), "agz_trainer_set_compute_mode")
+
+    def set_dma_forward(self, on=True):
+        """agz_debug.h A/B hook: WINO_H2 forward convolutions through the DMA GEMM on pre-split planes (default) or the staging-split kernel"""
+        _check(lib().agz_trainer_set_dma_forward(self.h, int(on)), "agz_trainer_set_dma_forward")
 
     def grads_dev(self):
         ptr, n = C.c_void_p(), C.c_size_t(0)

@@ -817,9 +817,8 @@ __global__ __launch_bounds__(256) void split_w2_kernel(const float* __restrict__
 bool agz::conv3x3_raw_h2_fits(int B, int H, int W, int Cin_p, int Cout_p) {
   return Cin_p % 32 == 0 && Cout_p % 256 == 0 && (size_t)B * (H + 2) * (W + 2) * (size_t)std::max(Cin_p, Cout_p) * sizeof(float) < ((size_t)1 << 32);
 }
-int agz::conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc,
-                        const unsigned* ranges) {
-  AGZ_REQUIRE(conv3x3_raw_h2_fits(B, H, W, Cin_p, Cout_p), AGZ_E_UNSUPPORTED, "conv3x3_raw_h2: shape %d x %dx%d, %d -> %d not supported", B, H, W, Cin_p, Cout_p);
+// max|w| word + fp16x2 weight image of one layer (also clears the B board-range words of sc for a range sweep that may follow)
+static int raw_h2_weights(agz_ctx* ctx, const float* w, int B, int Cin_p, int Cout_p, WinoRawScratch* sc, unsigned** wmax_out) {
   hipStream_t s = ctx->stream;
   const size_t w_elems = (size_t)9 * Cout_p * Cin_p;
   if (sc->w2_cap < w_elems * 2) {
@@ -840,6 +839,23 @@ int agz::conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, 
   sc->h2_flip ^= 1;
   hipLaunchKernelGGL(w_absmax_kernel, dim3((unsigned)std::min<size_t>((w_elems + 255) / 256, 256)), dim3(256), 0, s, w, w_elems, wmax);
   hipLaunchKernelGGL(split_w2_kernel, dim3((unsigned)((w_elems + 255) / 256)), dim3(256), 0, s, w, (_Float16*)sc->w2, Cout_p, Cin_p, wmax, sc->h2_words, B, wmax_next);
+  *wmax_out = wmax;
+  return AGZ_OK;
+}
+int agz::conv3x3_raw_h2_weights(agz_ctx* ctx, const float* w, int Cin_p, int Cout_p, WinoRawScratch* sc, const void** w2, const unsigned** w_amax) {
+  unsigned* wmax = nullptr;
+  int r = raw_h2_weights(ctx, w, std::max(sc->h2_b_cap, 1), Cin_p, Cout_p, sc, &wmax);
+  if (r != AGZ_OK) return r;
+  *w2 = sc->w2; *w_amax = wmax;
+  AGZ_HIP_TRY(hipGetLastError());
+  return AGZ_OK;
+}
+int agz::conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc,
+                        const unsigned* ranges) {
+  AGZ_REQUIRE(conv3x3_raw_h2_fits(B, H, W, Cin_p, Cout_p), AGZ_E_UNSUPPORTED, "conv3x3_raw_h2: shape %d x %dx%d, %d -> %d not supported", B, H, W, Cin_p, Cout_p);
+  hipStream_t s = ctx->stream;
+  unsigned* wmax = nullptr;
+  { int r = raw_h2_weights(ctx, w, B, Cin_p, Cout_p, sc, &wmax); if (r != AGZ_OK) return r; }
   if (!ranges) hipLaunchKernelGGL(board_amax_parts_kernel, dim3(B * 8), dim3(256), 0, s, x, sc->h2_words, H * W, W, W + 2, (H + 2) * (W + 2), Cin_p, 8);
   ConvArgs a{};
   a.M = B * H * W; a.HW = H * W; a.W = W; a.Wp = W + 2; a.HpWp = (H + 2) * (W + 2);

@@ -33,6 +33,9 @@ struct WinoRawScratch {
 int conv3x3_raw_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc,
                    const unsigned* ranges = nullptr);
 bool conv3x3_raw_h2_fits(int B, int H, int W, int Cin_p, int Cout_p);
+// the weight half of conv3x3_raw_h2 alone: max|w| word + the fp16x2 image w2[c/32][tap][piece][n][32] in sc (the trainer's DMA forward
+// convolution, train.hip, brings its own activation planes and kernel)
+int conv3x3_raw_h2_weights(agz_ctx* ctx, const float* w, int Cin_p, int Cout_p, WinoRawScratch* sc, const void** w2, const unsigned** w_amax);
 int conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc,
                         const unsigned* ranges = nullptr);
 bool conv3x3_raw_wino_h2_fits(int B, int H, int W, int Cin_p, int Cout_p);

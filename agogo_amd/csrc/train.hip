@@ -1119,11 +1119,153 @@ __global__ void k_head_conv_bwd_x(TGeo g, const float* __restrict__ dzh, const f
 
 using namespace agz;
 
+// ---- forward convolution of a dual block with BOTH operands DMA'd into LDS (AGZ_COMPUTE_WINO_H2, round 5) -------------------------------
+// conv_h2.hpp's conv3x3_h2w_kernel splits its fp32 activations while staging them: every element is scaled, split and written to LDS once
+// per tap and column tile (18 times per layer), and that VALU + ds_write issue — not operand bytes — bounds it (0.67 ms per G19 layer; the
+// same kernel on 256-row tiles, with half the weight re-reads, ran 0.665).  Measured here: 0.583 ms per G19 layer.  The layer input is
+// split ONCE into hi / lo fp16 planes
+// (k_split_h2p, the tensor's own power-of-two range from the BatchNorm pass that wrote it) — the very planes the weight gradient of the
+// same layer reads in the backward pass, which therefore no longer splits x itself — and the convolution is a pure DMA GEMM like
+// wino_gemm_h2g_kernel: 128 x 256 tile, K step = 32 channels of one tap, `buffer_load ... lds` of 16 bytes per lane for both operands
+// (A rows gathered by padded pixel: one lane offset per 16-row instruction, the tap and the channel chunk in the scalar offset), single
+// 48 KB stage, plain __syncthreads(), three workgroups per CU (two, without the 3 spilled registers: 0.596 against 0.583 ms).  LDS image:
+// four pieces (A hi, A lo, B hi, B lo) of 64-byte rows, 16-byte
+// units XOR-swizzled with (row >> 2) & 3 — on the SOURCE address, the DMA writes lane-linearly.  Products as everywhere: lo*hi, hi*lo, hi*hi.
+// (conv_h2.hpp's scale rule for the weight image: s = 2^(13 - floor(log2(amax))), exact inverse)
+__device__ __forceinline__ void h2_scales(unsigned amax_bits, float* s, float* inv) {
+  int e = (int)((amax_bits >> 23) & 0xffu);
+  if (amax_bits == 0u) { *s = 1.f; *inv = 1.f; return; }
+  e = e < 30 ? 30 : (e > 230 ? 230 : e);
+  *s = __uint_as_float((unsigned)(267 - e) << 23);
+  *inv = __uint_as_float((unsigned)(e - 13) << 23);
+}
+struct ConvDmaArgs {
+  const _Float16 *xh, *xl;   // [B][Hp][Wp][Cin] hi / lo planes of the layer input (zero halo)
+  const _Float16* w2;        // [Cin/32][tap][piece][Ntot][32]
+  float* y;                  // [B][Hp][Wp][Ntot] raw GEMM result (halo untouched)
+  const unsigned* x_amax;    // bits of max|x| (the planes' scale: wg_h2_scale)
+  const unsigned* w_amax;    // bits of max|w| (the weight image's scale: h2_scales of conv_h2.hpp)
+  TGeo g;
+  int Cin, Ntot, n_mtiles, n_ntiles;
+};
+__device__ __forceinline__ unsigned cd_lds_off(int row, int unit) { return (unsigned)(row * 64 + ((unit ^ ((row >> 2) & 3)) << 4)); }
+__global__ __launch_bounds__(256, 3) void k_conv_h2dma(ConvDmaArgs a) {
+  constexpr int PA = 128 * 64, PB = 256 * 64;          // bytes of one A / B piece image
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PA + 2 * PB];   // 48 KB
+
+  const int nblk = a.n_mtiles * a.n_ntiles;
+  const int id = blockIdx.x;
+  int q = nblk >> 3, rr = nblk & 7, xcd = id & 7, slot = id >> 3;
+  int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
+  const int m_tile = tile / a.n_ntiles, n_tile = tile - m_tile * a.n_ntiles;
+  const int m0 = m_tile * 128, n0 = n_tile * 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+
+  const size_t plane_bytes = (size_t)a.g.B * a.g.Hp * a.g.Wp * a.Cin * 2;
+  const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.xh), 0, (int)plane_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.xl), 0, (int)plane_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w2), 0, 0x7fffffff, 0x00020000);
+
+  // DMA lane mapping: an instruction lands 16 rows x 64 bytes; lane l -> row 16 j + (l >> 2), LDS unit l & 3, source unit (l & 3) ^ ((l >> 4) & 3)
+  const unsigned src_unit = (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+  unsigned voa[2];                                       // A: rows 32 wid + 16 j + (lane >> 2) -> padded pixel, shifted by -(Wp + 1) (the taps add 0 .. 2 Wp + 2)
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    int m = m0 + 32 * wid + 16 * j + (lane >> 2);
+    if (m >= a.g.M) m = a.g.M - 1;
+    voa[j] = (unsigned)((pix_off(a.g, m) - (size_t)(a.g.Wp + 1)) * (size_t)a.Cin * 2) + src_unit;
+  }
+  int nrow = n0 + 64 * wid + (lane >> 2);                // B: rows 64 wid + 16 j + (lane >> 2): + j KB in the scalar offset
+  const unsigned vob = (unsigned)(nrow < a.Ntot ? nrow : a.Ntot - 1) * 64u + src_unit;
+  const unsigned piece_bytes = (unsigned)a.Ntot * 64u;
+  unsigned char* const la = lds + wid * 2048;            // this wave's 32 rows of an A piece
+  unsigned char* const lb = lds + 2 * PA + wid * 4096;   // this wave's 64 rows of a B piece
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  int ra[2], rb[4];
+#pragma unroll
+  for (int i = 0; i < 2; i++) ra[i] = (wm * 2 + i) * 32 + (lane & 31);
+  // columns of this wave inside the 256-column tile: j = 0..3 -> 32-column groups of its 128 columns (the weight image's own order)
+#pragma unroll
+  for (int j = 0; j < 4; j++) rb[j] = wn * 128 + j * 32 + (lane & 31);
+  const int kh = lane >> 5;
+
+  const int NC = a.Cin >> 5;
+  unsigned wso = 0;                                      // weight image: K steps in [chunk][tap] order, 2 pieces each
+#pragma nounroll
+  for (int cc = 0; cc < NC; cc++) {
+#pragma nounroll
+    for (int tap = 0; tap < 9; tap++) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const unsigned aso = (unsigned)((ky * a.g.Wp + kx) * a.Cin * 2 + cc * 64);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (wg_lds_ptr_t)(la + j * 1024), 16, voa[j], aso, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (wg_lds_ptr_t)(la + PA + j * 1024), 16, voa[j], aso, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (wg_lds_ptr_t)(lb + j * 1024), 16, vob, wso + (unsigned)j * 1024u, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (wg_lds_ptr_t)(lb + PB + j * 1024), 16, vob, wso + piece_bytes + (unsigned)j * 1024u, 0, 0);
+      }
+      wso += 2u * piece_bytes;
+      __syncthreads();                                   // (its fence waits vmcnt(0): this wave's DMA has landed; then every wave's)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        wg_f16x8_t A_[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+          for (int i = 0; i < 2; i++) A_[i][p] = *reinterpret_cast<const wg_f16x8_t*>(lds + p * PA + cd_lds_off(ra[i], 2 * ks + kh));
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                    // B fragments just in time
+          const wg_f16x8_t b0 = *reinterpret_cast<const wg_f16x8_t*>(lds + 2 * PA + cd_lds_off(rb[j], 2 * ks + kh));
+          const wg_f16x8_t b1 = *reinterpret_cast<const wg_f16x8_t*>(lds + 2 * PA + PB + cd_lds_off(rb[j], 2 * ks + kh));
+#pragma unroll
+          for (int i = 0; i < 2; i++) {                  // small terms first: lo*hi, hi*lo, hi*hi
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[i][1], b0, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[i][0], b1, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[i][0], b0, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();                                   // every wave has read the stage before the next DMA overwrites it
+    }
+  }
+  // raw result, un-scaled by the two exact powers of two
+  float sw_, unw_;
+  h2_scales(*a.w_amax, &sw_, &unw_);
+  const float un = unw_ / wg_h2_scale(*a.x_amax);
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= a.g.M) continue;
+      float* yr = a.y + pix_off(a.g, m) * (size_t)a.Ntot;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int c = n0 + rb[j];
+        if (c < a.Ntot) yr[c] = acc[i][j][r] * un;
+      }
+    }
+}
+
 struct TLayer {
   int Cin_p, Cout_p, nbr;
   size_t o_wf, o_gamma, o_beta;   // offsets in the flat P / G buffers
   float *wt = nullptr, *z = nullptr, *out = nullptr, *mean = nullptr, *inv = nullptr;
   unsigned short *w3f = nullptr, *w3t = nullptr;   // bf16x3 images of the forward / transposed filter (AGZ_COMPUTE_BF16X3)
+  _Float16* xh2 = nullptr;                         // AGZ_COMPUTE_WINO_H2: hi plane then lo plane of the layer INPUT (forward DMA convolution + weight gradient)
+  bool x_planes = false;                           // ... and they hold this step's input (set by the forward pass, read by the backward pass)
 };
 struct TParamRef { std::string name; int kind; std::vector<int> shape; int layer; int sub; };  // sub: 0 filter(a) 1 gamma 2 beta, for dual +10 = branch b
 
@@ -1196,6 +1338,7 @@ struct agz_trainer {
   // as the kernels that write it have been ENQUEUED — heads first, then layer L .. 0 (the order of the backward pass, the same on
   // every rank) — with the stream whose completion means "slice written"; the slices tile [0, n_flat) exactly
   std::function<int(size_t off, size_t n, hipStream_t ready)> on_slice;
+  bool dma_fwd = true;      // AGZ_COMPUTE_WINO_H2 forward convolutions through k_conv_h2dma (agz_trainer_set_dma_forward, agz_debug.h: A/B hook)
   float fuse_lr = 0.f;      // != 0 during a fused step: k_bn_bwd1 updates gamma / beta in place, apply() skips them
   bool fused_done = false;  // the backward that just ran took the fused path
 };
@@ -1224,7 +1367,22 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   for (int l = 0; l <= L; l++) {
     TLayer& ly = layers[l];
     int r;
-    if (use_h2_fwd(ly.Cin_p, ly.Cout_p)) {
+    ly.x_planes = false;
+    const size_t n_x_fwd = (size_t)B * g.Hp * g.Wp * ly.Cin_p;
+    if (use_h2_fwd(ly.Cin_p, ly.Cout_p) && dma_fwd && x_amax_ready[l] && ly.Cin_p % 32 == 0 && ly.Cout_p % 256 == 0 && g.W >= 16 && n_x_fwd * 2 < ((size_t)1 << 31)) {
+      // planes of the layer input (its range word came out of the previous layer's BatchNorm pass), then the DMA GEMM
+      if (!ly.xh2) { r = alloc(&ly.xh2, 2 * n_x_fwd); if (r != AGZ_OK) return r; }
+      const unsigned gs = (unsigned)std::min<size_t>(nblk(n_x_fwd / 4), (size_t)ctx->num_cus * 8);
+      hipLaunchKernelGGL(k_split_h2p, dim3(gs), dim3(256), 0, s, cur, ly.xh2, ly.xh2 + n_x_fwd, n_x_fwd / 4, amax_words + 2 * l + 1);
+      const void* w2 = nullptr; const unsigned* wmax = nullptr;
+      if ((r = conv3x3_raw_h2_weights(ctx, P + ly.o_wf, ly.Cin_p, ly.Cout_p, &wsc, &w2, &wmax)) != AGZ_OK) return r;
+      ConvDmaArgs ca{};
+      ca.xh = ly.xh2; ca.xl = ly.xh2 + n_x_fwd; ca.w2 = (const _Float16*)w2; ca.y = ly.z; ca.x_amax = amax_words + 2 * l + 1; ca.w_amax = wmax;
+      ca.g = g; ca.Cin = ly.Cin_p; ca.Ntot = ly.Cout_p; ca.n_mtiles = ceil_div(g.M, 128); ca.n_ntiles = ly.Cout_p / 256;
+      hipLaunchKernelGGL(k_conv_h2dma, dim3(ca.n_mtiles * ca.n_ntiles), dim3(256), 0, s, ca);
+      ly.x_planes = true;
+      r = AGZ_OK;
+    } else if (use_h2_fwd(ly.Cin_p, ly.Cout_p)) {
       r = conv3x3_raw_h2(ctx, cur, P + ly.o_wf, ly.z, B, g.H, g.W, ly.Cin_p, ly.Cout_p, &wsc, xb_ready[l] ? board_words + (size_t)l * B : nullptr);
     } else if (use_x3(ly, ly.Cin_p, ly.Cout_p)) {
       if ((r = split_w3(ctx, P + ly.o_wf, ly.w3f, ly.Cout_p, ly.Cin_p)) != AGZ_OK) return r;
@@ -1325,10 +1483,10 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
       if (g.W >= 16 && C % 8 == 0 && ly.Cin_p % 8 == 0) {
         // three taps per workgroup from hi / lo fp16 planes (k_wgrad_h2t3)
         _Float16* dzh = (_Float16*)dz_h2; _Float16* dzl = dzh + n_dz;
-        _Float16* xh = (_Float16*)x_h2; _Float16* xl = xh + n_x;
+        _Float16* xh = ly.x_planes ? ly.xh2 : (_Float16*)x_h2; _Float16* xl = xh + n_x;   // (the forward pass's planes of this input, if it made them)
         hipLaunchKernelGGL(k_split_h2p, dim3(gs), dim3(256), 0, sw, dz, dzh, dzl, n_dz / 4, wg_amax);
         if (sw != s) { AGZ_HIP_TRY(hipEventRecord(ev_split, sw)); split_recorded = true; }
-        hipLaunchKernelGGL(k_split_h2p, dim3(gs), dim3(256), 0, sw, xin, xh, xl, n_x / 4, wg_amax + 1);
+        if (!ly.x_planes) hipLaunchKernelGGL(k_split_h2p, dim3(gs), dim3(256), 0, sw, xin, xh, xl, n_x / 4, wg_amax + 1);
         WgH2t3Args w3{};
         w3.dzh = dzh; w3.dzl = dzl; w3.xh = xh; w3.xl = xl; w3.amax = wg_amax; w3.dw = wa.dw; w3.g = g; w3.N = wa.N; w3.Cin = wa.Cin;
         w3.n_tiles = wa.n_tiles; w3.c_tiles = wa.c_tiles; w3.steps_per_board = ceil_div(g.HW, 32);
@@ -1732,6 +1890,12 @@ int agz_trainer_set_compute_mode(agz_trainer* t, int mode) {
       }
   t->x3 = mode == AGZ_COMPUTE_BF16X3 || mode == AGZ_COMPUTE_WINO_H2;
   t->wino = mode == AGZ_COMPUTE_WINO_H2;
+  return AGZ_OK;
+}
+
+int agz_trainer_set_dma_forward(agz_trainer* t, int on) {
+  AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
+  t->dma_fwd = on != 0;
   return AGZ_OK;
 }
 

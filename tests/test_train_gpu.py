@@ -81,7 +81,7 @@ def test_forward_backward_matches_oracle(ctx, K, L, FC, W, H, F, Aspace, B, mode
     assert any(np.abs(ot.get_grad(i)).max() > 1e-6 for i in range(ot.num_params()))
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "wino_h2"])
+@pytest.mark.parametrize("mode", ["bf16x3", "wino_h2", "wino_h2_staged_fwd"])
 def test_forward_backward_headline_width_19x19(ctx, mode):
     """the trainer's fast modes at the headline tower's width and board (K=256, 19x19, 18 planes, 362 actions; one dual block,
     two boards so the oracle finishes in seconds): the shapes the G19 step runs — 128-multiple tiles, F(5x5,3x3) with the ragged
@@ -93,6 +93,8 @@ def test_forward_backward_headline_width_19x19(ctx, mode):
     K, L, FC, W, H, F, Aspace, B = 256, 1, 32, 19, 19, 18, 362, 2
     ot, dt = make_pair(ctx, K, L, FC, W, H, F, Aspace, B)
     dt.set_compute_mode((capi.COMPUTE_BF16X3 if mode == "bf16x3" else capi.COMPUTE_WINO_H2) | capi.COMPUTE_FORCE)
+    if mode == "wino_h2_staged_fwd":     # round 5: the forward convolutions default to the DMA GEMM on pre-split planes (k_conv_h2dma); this keeps
+        dt.set_dma_forward(False)        # the staging-split kernel (conv3x3_h2w_kernel) under the same bar
     report = []
     for seed in (77, 78, 79, 80):
         x, pi, v = batch_data(B, F, H, W, Aspace, seed=seed)
