@@ -295,6 +295,66 @@ def test_prepare_root_packed_batch_equals_the_whole_batch(ctx, mode):
     net.close()
 
 
+@pytest.mark.parametrize("kind,m,n,k,enc,K,L,G,budget,plies", [
+    (capi.GAME_MNK, 3, 3, 3, capi.ENC_TWOPLANE, 32, 2, 37, 200, 6),        # tic-tac-toe: games END inside the run (restarts, fresh roots)
+    (capi.GAME_C4, 6, 7, 4, capi.ENC_TWOPLANE, 64, 3, 100, 150, 6),        # connect-4 at a batch where the half-tile fp32 kernels run
+    (capi.GAME_WQ, 9, 9, 0, capi.ENC_WQ, 128, 3, 300, 160, 5),             # 9x9 Go, the chained Winograd tower at 300 boards
+    (capi.GAME_MNK, 5, 5, 4, capi.ENC_TWOPLANE, 32, 1, 9, 90, 6),          # a handful of games: the packed batch may be 1..9 boards
+], ids=["ttt", "c4", "go9", "mnk5"])
+def test_prepare_root_packed_batch_on_other_games_and_sizes(ctx, kind, m, n, k, enc, K, L, G, budget, plies):
+    """The packed prepareRoot batch against the whole-batch forward across games, network widths and arena sizes — wherever
+    agz_net::min_same_batch finds a smaller batch with the whole batch's kernels the trees must stay identical, wherever it does not the
+    forward must simply be the whole batch.  AGZ_COMPUTE_AUTO (what a user gets), every game's root statistics after every ply."""
+    F = 18 if enc == capi.ENC_WQ else 2
+    A1 = n + 1 if kind == capi.GAME_C4 else m * n + 1      # (c4: one entry per column + pass, as bench.py's config #2 net)
+    net = A.Net(ctx, K, L, 64, n, m, F, A1, bn_mode=capi.BN_IDENTITY)
+    net.init_random(7)
+    for i in range(net.num_params()):
+        name, cnt = net.param_info(i)
+        if name.endswith("_gamma"):
+            net.set_param(i, np.ones(cnt, np.float32))
+        elif name.endswith("_beta"):
+            net.set_param(i, np.zeros(cnt, np.float32))
+    net.commit()
+    net.set_compute_mode(capi.COMPUTE_AUTO)
+    arenas = []
+    for packed in (True, False):
+        dev = A.Arena(ctx, kind, m, n, k, 5.5 if kind in (capi.GAME_WQ, capi.GAME_KOMI) else 0.0, encoder=enc, n_games=G, seed=99, Budget=budget)
+        dev.set_inferencer(0, capi.INF_NET, net)
+        dev.set_inferencer(1, capi.INF_NET, net)
+        dev.reset()
+        # every game on its own position (identical games would need the network all together or not at all)
+        dev.random_moves(np.random.default_rng(5).integers(0, max(2, (n if kind == capi.GAME_C4 else m * n) // 3), size=G).astype(np.int32), 5)
+        dev.set_prep_compact(packed)
+        arenas.append(dev)
+    seen_packed, batches = False, []
+    for ply in range(plies):
+        for dev in arenas:
+            dev.begin_move()
+        (b1, r1), (b0, r0) = arenas[0].last_prep_batch(), arenas[1].last_prep_batch()
+        assert r1 == r0 and b0 in (0, G) and (b1 == 0) == (r1 == 0) and r1 <= b1 <= G, (ply, b1, r1, b0, r0)
+        seen_packed = seen_packed or (0 < b1 < G)
+        batches.append((b1, r1))
+        for dev in arenas:
+            dev.simulate(budget)
+            dev.end_move(True)
+        for g in range(G):
+            for agent in (0, 1):
+                a, b = arenas[0].root_children(g, agent), arenas[1].root_children(g, agent)
+                np.testing.assert_array_equal(a[0], b[0], err_msg="game %d agent %d ply %d" % (g, agent, ply))
+                np.testing.assert_array_equal(a[1], b[1])
+                np.testing.assert_array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+                np.testing.assert_array_equal(a[3].view(np.uint32), b[3].view(np.uint32))
+            np.testing.assert_array_equal(arenas[0].history(g), arenas[1].history(g))
+    s1, s0 = arenas[0].stats(), arenas[1].stats()
+    for key in ("sims_total", "sims_nonnull", "nn_evals", "moves_played", "games_finished", "examples", "tree_full"):
+        assert s1[key] == s0[key], key
+    print("packed batch used:", seen_packed, "batches", batches)
+    for dev in arenas:
+        dev.close()
+    net.close()
+
+
 def test_config4_l40_network_batch1_and_lane_batches_vs_oracle(ctx):
     """(iii-a) BASELINE configs[4] tower (40 blocks): batch 1 (the split-K latency regime), batches 8 and 16 (one lane round)
     against the oracle on three mid-game boards."""
