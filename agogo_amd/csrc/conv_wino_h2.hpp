@@ -116,6 +116,7 @@ struct WinoH2Args {
   unsigned* amax_next;       // [B] bits of the proven bound on max |y| of this block's output: the range word of V2(l+1)
   float g1, g0;              // that bound = g1 * max|x| + g0 (agz_net::build_wino_h2_weights)
   int gemm_variant;          // 0: default, 1: wino_gemm_h2g_kernel, 2: wino_gemm_h2p_kernel (agz_net_set_wino_h2_gemm, agz_debug.h)
+  int temporal_stores;       // A/B (agz_net_set_wino_h2_gemm + 64): 1 = M and V2c stored with the default cache policy (round 4); 0: non-temporal
   int row_pad;               // three-kernel form: extra rows after every position's 128 tile rows of V and M (wino_h2_launch: rB = 128 + row_pad)
 };
 __device__ __forceinline__ size_t h2_row(const WinoH2Args& h, int pos, int t) {
@@ -900,8 +901,9 @@ __global__ __launch_bounds__(256) void wino_out_seq_h2_kernel(WinoH2Args h) {
 // the AL columns from LDS, un-scale, the block epilogue on float4 parameters, TM float4 stores of y.  Same arithmetic in the same
 // order as the thread-per-channel kernel (bit-identical results, checked on a 300-board K=256 network).  Measured 0.251 -> 0.215 ms on
 // the headline block = 4.7 TB/s, 0.95 of the stream ceiling of its mix.  LDS: 72 KB per tile for F(5x5,3x3), two workgroups per CU.
+template <int AUX = 0>   // AUX = 2: non-temporal (a stream read once)
 __device__ __forceinline__ float4 h2_ldf4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
   const unsigned x = v[0], y = v[1], z = v[2], w = v[3];
   return make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
 }

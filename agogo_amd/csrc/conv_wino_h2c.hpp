@@ -142,7 +142,11 @@ typedef __attribute__((address_space(3))) void* h2c_lds_ptr_t;
 // one 4-byte buffer_load ... lds per thread and 64 bytes — 0.298-0.315 ms against 0.300-0.304: the HBM round trip of A is not what a
 // K step waits for.  What the kernel runs into is the L2 -> CU operand stream: 2.4 GB per launch, 11 TB/s at the all-from-cache
 // floor of 0.215 ms — the rate round 3's l2_probe measured for a GEMM's mixed hit/miss stream.)
-template <int NK>
+// NT: M is stored NON-TEMPORALLY (round 5).  M (0.82 GB per launch) is written once and read once, by the next kernel: stored with the
+// default policy it displaces the operands this kernel and its neighbour on the other queue re-read from L2 (V2c by both column tiles, the
+// weight image by every row tile).  The GEMM itself does not get faster (0.311 vs 0.311 ms), the out->in kernel that follows does (0.286 ->
+// 0.270 ms), and with V2c stored the same way by that kernel the two-queue pass goes 12.27 -> 11.95 ms on one box (profiles/r05).
+template <int NK, bool NT = true>
 __global__ __launch_bounds__(256, 3) void wino_gemm_h2g_kernel(WinoH2Args h) {
   const WinoArgs& a = h.w;
   constexpr int SA = 128 * 128, SB = 256 * 128;
@@ -228,8 +232,13 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_h2g_kernel(WinoH2Args h) {
         const auto s32 = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);
         const unsigned w0 = s32[0], w1 = s32[1];
         float* d = mbase + maps::mc_index(0, 0, 0, 0, qq, i * 32 + maps::mfma_row(r), 0);
-        d[0] = __uint_as_float(w0);
-        d[maps::mc_index(0, 0, 0, 0, 0, 4, 0)] = __uint_as_float(w1);
+        if (NT) {
+          __builtin_nontemporal_store(__uint_as_float(w0), d);
+          __builtin_nontemporal_store(__uint_as_float(w1), d + maps::mc_index(0, 0, 0, 0, 0, 4, 0));
+        } else {
+          d[0] = __uint_as_float(w0);
+          d[maps::mc_index(0, 0, 0, 0, 0, 4, 0)] = __uint_as_float(w1);
+        }
       }
 }
 
@@ -343,8 +352,8 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2p_kernel(WinoH2Args h) {
     const unsigned w0 = s32[0], w1 = s32[1];
     float* d = mb + maps::mc_index(0, 0, 0, 0, 0, maps::mfma_row(r), 0);
     if (MODE & 1) { asm volatile("" ::"v"(w0), "v"(w1)); return; }
-    d[0] = __uint_as_float(w0);
-    d[maps::mc_index(0, 0, 0, 0, 0, 4, 0)] = __uint_as_float(w1);
+    __builtin_nontemporal_store(__uint_as_float(w0), d);          // (non-temporal, as wino_gemm_h2g_kernel's)
+    __builtin_nontemporal_store(__uint_as_float(w1), d + maps::mc_index(0, 0, 0, 0, 0, 4, 0));
   };
 
   int pos = u0 / n_half;
@@ -686,8 +695,10 @@ template <int TM> __device__ __forceinline__ void wino_btv_p(const f2c* d, f2c* 
 }
 
 // grid: any number of workgroups <= items (2 per CU); 256 threads; dynamic LDS [16 / TPB boards][TM nty + 2][TM ntx + 2][32] fp32
-template <int TM>
+// NT: V2c stored non-temporally (see wino_gemm_h2g_kernel; M loads non-temporal as well measured no better: 11.99 vs 11.95 ms per pass)
+template <int TM, bool NT = true>
 __global__ __launch_bounds__(256, 2) void wino_oip_h2c_kernel(WinoH2Args h) {
+  constexpr int MAUX = 0, VAUX = NT ? 2 : 0;
   using WT = WinoT<TM>;
   constexpr int AL = WT::AL, NPRE = AL - 3;
   const WinoArgs& a = h.w;
@@ -722,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void wino_oip_h2c_kernel(WinoH2Args h) {
 #pragma unroll
     for (int nu = 0; nu < NPRE; nu++)
 #pragma unroll
-      for (int xi = 0; xi < AL; xi++) m[nu][xi] = h2_ldf4(mr, m_lane, m_soff(g, s, xi * AL + nu));
+      for (int xi = 0; xi < AL; xi++) m[nu][xi] = h2_ldf4<MAUX>(mr, m_lane, m_soff(g, s, xi * AL + nu));
   }
   __syncthreads();
   for (; item < n_items; item += gridDim.x) {
@@ -748,7 +759,7 @@ __global__ __launch_bounds__(256, 2) void wino_oip_h2c_kernel(WinoH2Args h) {
       }
       if (nu + NPRE < AL) {
 #pragma unroll
-        for (int xi = 0; xi < AL; xi++) m[nu % NPRE][xi] = h2_ldf4(mr, m_lane, m_soff(g, s, xi * AL + nu + NPRE));
+        for (int xi = 0; xi < AL; xi++) m[nu % NPRE][xi] = h2_ldf4<MAUX>(mr, m_lane, m_soff(g, s, xi * AL + nu + NPRE));
       }
       wino_atv_p<TM>(c0, o0);
       wino_atv_p<TM>(c1, o1);
@@ -828,7 +839,7 @@ __global__ __launch_bounds__(256, 2) void wino_oip_h2c_kernel(WinoH2Args h) {
 #pragma unroll
       for (int nu = 0; nu < NPRE; nu++)
 #pragma unroll
-        for (int xi = 0; xi < AL; xi++) m[nu][xi] = h2_ldf4(mr, m_lane, m_soff(g2, s2, xi * AL + nu));
+        for (int xi = 0; xi < AL; xi++) m[nu][xi] = h2_ldf4<MAUX>(mr, m_lane, m_soff(g2, s2, xi * AL + nu));
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- input transform of the next block, one output row at a time (column pass recomputed per row from LDS)
@@ -869,8 +880,8 @@ __global__ __launch_bounds__(256, 2) void wino_oip_h2c_kernel(WinoH2Args h) {
           const unsigned e0 = s16[0], e1 = s16[1];
           const auto s32 = __builtin_amdgcn_permlane32_swap(e0, e1, false, false);
           const unsigned w0 = s32[0], w1 = s32[1];
-          __builtin_amdgcn_raw_buffer_store_b32(w0, vr, v_lane, v_base + (unsigned)(i * AL + j) * v_pos, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(w1, vr, v_lane + 256u, v_base + (unsigned)(i * AL + j) * v_pos, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(w0, vr, v_lane, v_base + (unsigned)(i * AL + j) * v_pos, VAUX);
+          __builtin_amdgcn_raw_buffer_store_b32(w1, vr, v_lane + 256u, v_base + (unsigned)(i * AL + j) * v_pos, VAUX);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -931,7 +942,7 @@ static void wino_h2c_gemm(agz_ctx* ctx, WinoH2Args& h, hipStream_t st) {
   // persistent form (wino_gemm_h2p_kernel; gemm_variant 2, AGZ_WINO_H2_GEMM=2): K = 256, whole 128-column slabs, one workgroup per CU
   static const int gemm_env = [] { const char* e = getenv("AGZ_WINO_H2_GEMM"); return e ? atoi(e) : 0; }();
   const int variant_all = h.gemm_variant > 0 ? h.gemm_variant : (gemm_env > 0 ? gemm_env : WINO_H2_GEMM_DEFAULT);
-  const int variant = variant_all & 15, mode = variant_all >> 4;   // (mode: agz_debug.h decomposition runs — results are then NOT valid)
+  const int variant = variant_all & 15, mode = (variant_all >> 4) & 3;   // (mode: agz_debug.h decomposition runs — results are then NOT valid)
   const int n_slabs = h.w.Ntot >> 7;
   if (variant == 2 && dma_ok && (h.w.C >> 5) == 8 && h.w.Ntot % 256 == 0 && ctx->num_cus / 8 >= n_slabs) {
     const dim3 gp((unsigned)(8 * ((ctx->num_cus / 8) / n_slabs) * n_slabs));
@@ -943,6 +954,7 @@ static void wino_h2c_gemm(agz_ctx* ctx, WinoH2Args& h, hipStream_t st) {
     }
     return;
   }
+  if (dma_ok && h.temporal_stores && (h.w.C >> 5) == 8) { hipLaunchKernelGGL((wino_gemm_h2g_kernel<8, false>), g, dim3(256), 0, st, h); return; }   // (A/B: round 4's stores)
   if (dma_ok) {
     switch (h.w.C >> 5) {
       case 4: hipLaunchKernelGGL((wino_gemm_h2g_kernel<4>), g, dim3(256), 0, st, h); return;
@@ -979,6 +991,11 @@ static void wino_h2c_oi(agz_ctx* ctx, WinoH2Args& h, bool last, hipStream_t st, 
     const size_t shp = (size_t)(16 / a.TPB) * (h.tm * a.nty + 2) * (h.tm * a.ntx + 2) * 32 * sizeof(float);
     const int items = ceil_div(a.T, 16) * (a.C >> 5);
     const dim3 gp((unsigned)std::min(items, 2 * ctx->num_cus));
+    if (h.tm == 5 && h.temporal_stores) {   // A/B instance (F(5x5,3x3) shapes only): round 4's stores
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_oip_h2c_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      hipLaunchKernelGGL((wino_oip_h2c_kernel<5, false>), gp, dim3(256), shp, st, h);
+      return;
+    }
     if (h.tm == 5) hipLaunchKernelGGL((wino_oip_h2c_kernel<5>), gp, dim3(256), shp, st, h);
     else hipLaunchKernelGGL((wino_oip_h2c_kernel<4>), gp, dim3(256), shp, st, h);
     return;

@@ -1277,7 +1277,7 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         hh.amax_true = l == 0 ? reinterpret_cast<const float*>(d_amax + b0) : nullptr;  // block 0: board_amax_kernel's exact word
         hh.wm_prev = d_wave_max + ((size_t)((l + 1) & 1) * B + b0) * wmb;
         hh.wm_out = d_wave_max + ((size_t)(l & 1) * B + b0) * wmb;
-        hh.g1 = wino_g1[l]; hh.g0 = wino_g0[l]; hh.gemm_variant = wino_gemm;
+        hh.g1 = wino_g1[l]; hh.g0 = wino_g0[l]; hh.gemm_variant = wino_gemm & 63; hh.temporal_stores = (wino_gemm >> 6) & 1;   // (A/B: + 64 = round 4's stores)
         if (l == 0) agz::wino_h2c_in(ctx, hh, st);
         agz::wino_h2c_gemm(ctx, hh, st);
         agz::wino_h2c_oi(ctx, hh, last, st, form_want == 1 ? 1 : 4);   // (A/B hook: form 1 = the plain out->in kernel)
@@ -1798,7 +1798,7 @@ int agz_net_set_wino_h2_form(agz_net* n, int form) {
 
 int agz_net_set_wino_h2_gemm(agz_net* n, int variant) {
   AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_wino_h2_gemm: null net");
-  AGZ_REQUIRE((variant >= 0 && variant <= 2) || ((variant & 15) == 2 && (variant >> 4) <= 3), AGZ_E_INVALID, "agz_net_set_wino_h2_gemm: variant %d (want 0, 1, 2 or 2 + 16 * mode)", variant);
+  AGZ_REQUIRE(((variant & 63) <= 2 && (variant >> 6) <= 1) || ((variant & 15) == 2 && (variant >> 4) <= 3), AGZ_E_INVALID, "agz_net_set_wino_h2_gemm: variant %d (want 0, 1, 2, + 64, or 2 + 16 * mode)", variant);
   n->wino_gemm = variant;
   return AGZ_OK;
 }

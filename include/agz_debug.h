@@ -53,7 +53,8 @@ int agz_net_set_wino_h2_form(agz_net* net, int form);
  * (128 x 256 tile, both operands streamed, three workgroups per CU); 2: wino_gemm_h2p_kernel (persistent, the weight slab stationary in
  * registers, M stores under the next tile's arithmetic; K = 256 only, other shapes keep kernel 1).  Results are bit-identical.  The
  * environment switch AGZ_WINO_H2_GEMM=1|2 (agz.h) does the same for a whole process.  Decomposition runs (timing only, the results are
- * NOT valid): 2 + 16 * mode with mode bit 0 = kernel 2 without its M stores, bit 1 = without its operand DMA (profiles/r05). */
+ * NOT valid): 2 + 16 * mode with mode bit 0 = kernel 2 without its M stores, bit 1 = without its operand DMA (profiles/r05).
+ * + 64 (with 0, 1 or 2): M and V2c stored with the default cache policy, as in round 4, instead of non-temporally (bit-identical; A/B). */
 int agz_net_set_wino_h2_gemm(agz_net* net, int variant);
 
 /* prepareRoot (mcts/search.go:392-408) evaluates the network only for roots without children.  agz_arena_begin_move packs those roots to

@@ -326,6 +326,9 @@ def test_persistent_gemm_is_bit_identical(ctx, S, L, B):
     gnet.set_wino_h2_gemm(2)
     p2, v2 = gnet.infer(x)
     p3, v3 = gnet.infer(x)
+    gnet.set_wino_h2_gemm(1 + 64)                          # round 4's store policy (A/B hook): the same bits
+    p4, v4 = gnet.infer(x)
+    np.testing.assert_array_equal(p4, p1)
     np.testing.assert_array_equal(p2, p1)
     np.testing.assert_array_equal(v2, v1)
     np.testing.assert_array_equal(p3, p2)
@@ -334,7 +337,7 @@ def test_persistent_gemm_is_bit_identical(ctx, S, L, B):
     np.testing.assert_allclose(p2[:nb], po, atol=POL_ATOL, rtol=POL_RTOL)
     np.testing.assert_allclose(v2[:nb], vo, atol=VAL_ATOL)
     with pytest.raises(A.AgzError):
-        gnet.set_wino_h2_gemm(3)
+        gnet.set_wino_h2_gemm(5)
     gnet.close()
 
 
