@@ -940,8 +940,7 @@ static void wino_h2c_gemm(agz_ctx* ctx, WinoH2Args& h, hipStream_t st) {
   // (the DMA form addresses V and U2c through buffer descriptors: 31-bit byte offsets)
   const bool dma_ok = wino_h2_rows(h.npos, (size_t)h.w.T) * h.w.C * 4 < ((size_t)1 << 31) && (size_t)h.npos * h.w.C * h.w.Ntot * 4 < ((size_t)1 << 31);
   // persistent form (wino_gemm_h2p_kernel; gemm_variant 2, AGZ_WINO_H2_GEMM=2): K = 256, whole 128-column slabs, one workgroup per CU
-  static const int gemm_env = [] { const char* e = getenv("AGZ_WINO_H2_GEMM"); return e ? atoi(e) : 0; }();
-  const int variant_all = h.gemm_variant > 0 ? h.gemm_variant : (gemm_env > 0 ? gemm_env : WINO_H2_GEMM_DEFAULT);
+  const int variant_all = h.gemm_variant > 0 ? h.gemm_variant : WINO_H2_GEMM_DEFAULT;   // (the environment switch is resolved by the caller: net.hip)
   const int variant = variant_all & 15, mode = (variant_all >> 4) & 3;   // (mode: agz_debug.h decomposition runs — results are then NOT valid)
   const int n_slabs = h.w.Ntot >> 7;
   if (variant == 2 && dma_ok && (h.w.C >> 5) == 8 && h.w.Ntot % 256 == 0 && ctx->num_cus / 8 >= n_slabs) {

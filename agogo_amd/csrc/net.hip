@@ -1277,7 +1277,12 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         hh.amax_true = l == 0 ? reinterpret_cast<const float*>(d_amax + b0) : nullptr;  // block 0: board_amax_kernel's exact word
         hh.wm_prev = d_wave_max + ((size_t)((l + 1) & 1) * B + b0) * wmb;
         hh.wm_out = d_wave_max + ((size_t)(l & 1) * B + b0) * wmb;
-        hh.g1 = wino_g1[l]; hh.g0 = wino_g0[l]; hh.gemm_variant = wino_gemm & 63; hh.temporal_stores = (wino_gemm >> 6) & 1;   // (A/B: + 64 = round 4's stores)
+        hh.g1 = wino_g1[l]; hh.g0 = wino_g0[l];
+        {   // which GEMM kernel / store policy: agz_net_set_wino_h2_gemm, else AGZ_WINO_H2_GEMM (1 | 2, + 64 = round 4's stores), else the default
+          static const int gemm_env = [] { const char* e = getenv("AGZ_WINO_H2_GEMM"); return e ? atoi(e) : 0; }();
+          const int gv = wino_gemm > 0 ? wino_gemm : gemm_env;
+          hh.gemm_variant = gv & 63; hh.temporal_stores = (gv >> 6) & 1;
+        }
         if (l == 0) agz::wino_h2c_in(ctx, hh, st);
         agz::wino_h2c_gemm(ctx, hh, st);
         agz::wino_h2c_oi(ctx, hh, last, st, form_want == 1 ? 1 : 4);   // (A/B hook: form 1 = the plain out->in kernel)
