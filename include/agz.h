@@ -29,7 +29,8 @@
  *                             block l+1 in one kernel); same tolerance       [tests/test_wino_gpu.py knobs test]
  *   AGZ_WINO_H2_GEMM=1|2      the GEMM kernel of the chained AGZ_COMPUTE_WINO_H2 block: 1 = 128 x 256 tiles, both operands streamed,
  *                             three workgroups per CU (default); 2 = persistent, the weight slab stationary in registers (K = 256);
- *                             bit-identical                              [tests/test_wino_gpu.py knobs test]
+ *                             + 64: M / V2c stored with the default cache policy instead of non-temporally (round 4's behaviour);
+ *                             all bit-identical                          [tests/test_wino_gpu.py knobs test]
  *   AGZ_WINO_CHUNK=<n>        boards per chunk of the AGZ_COMPUTE_WINO tower; bit-identical
  *                             [tests/test_wino_gpu.py::test_wino_board_chunks_in_a_subprocess]
  */

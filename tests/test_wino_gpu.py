@@ -265,6 +265,7 @@ H2_KNOBS = [
     {"AGZ_WINO_H2_FORM": "0"},                                     # the three-kernel block instead of the chained one
     {"AGZ_WINO_H2_GEMM": "2"},                                     # the persistent GEMM (weight slab stationary in registers; K = 256)
     {"AGZ_WINO_H2_GEMM": "2", "AGZ_WINO_H2_CHUNK": "16", "AGZ_WINO_H2_QUEUES": "2"},   # ... on short per-team unit lists, two queues
+    {"AGZ_WINO_H2_GEMM": "65"},                                    # the default GEMM with round 4's store policy (default: non-temporal M / V2c stores)
 ]
 
 
