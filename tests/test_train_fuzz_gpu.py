@@ -41,7 +41,11 @@ def test_random_trainer_shape(ctx, seed):
         # cost: the device and the oracle are each within 2e-5 of the float64 value (weights x3 make the logits large and the
         # mean cancels); in a 1200-shape soak two draws had them on opposite sides of it, 2.4e-5 apart
         # (profiles/r01/fuzz_soak.txt) -> mutual tolerance 4e-5
-        assert abs(cd - co) <= 4e-5 * max(1.0, abs(co)), (cd, co, shape)
+        # ... and with fewer than 64 samples per channel (BatchSize 1 on a 6x4 board: training-mode BatchNorm over 24 values) the
+        # fp32-MFMA path itself sits 2.8e-5 from the oracle and the split modes 5.9e-5 on one draw of a 2006-shape soak
+        # (profiles/r05/fuzz_soak.txt, seed 560359): 1e-4 there
+        cost_tol = 4e-5 if B * H * W >= 64 else 1e-4
+        assert abs(cd - co) <= cost_tol * max(1.0, abs(co)), (cd, co, shape)
         bad = []
         for i in range(ot.num_params()):
             go, gd = ot.get_grad(i), dt.get_grad(i)
