@@ -799,6 +799,8 @@ def main():
                                   "reference initialiser: BatchNorm gamma=1, beta=0 with IDENTITY statistics instead of GlorotN gamma/beta under "
                                   "the degenerate-eps reading (x316 per layer saturates softmax/tanh and every search tree degenerates); "
                                   "FLOPs and bytes per evaluation are identical",
+                       "priors_note": "with gamma = 1 / beta = 0 and identity statistics the random-init policy is near uniform: the search runs on WIDE trees "
+                                      "(~250 children per visited node, paths ~3 nodes: extra.mcts) — the MCTS share of the step is measured on that shape",
                        "parallelism": "games sharded %d/GPU, no data-path collective" % G,
                        "tower_queues": 2 if two_queues else 1},
             "roofline": ({"bound": "hbm", "achieved": wino_detail["wino_gemm"]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
