@@ -130,3 +130,39 @@ def test_mcts_and_inferer_method_sets_match_the_reference():
     # mcts.New's parameter list (tree.go:80) is what NewMCTS mirrors after the device-side arguments
     assert re.search(r"func New\(game game\.State, conf Config, nn Inferencer\) \*MCTS", tree)
     assert re.search(r"func NewMCTS\(ctx \*Ctx, kind GameKind, g game\.State, .*conf mcts\.Config, nn \*Net, seed uint64\) \(\*MCTS, error\)", shim)
+
+
+def _c_prototypes():
+    """name -> number of parameters, for every function include/agz.h declares"""
+    hdr = open(os.path.join(ROOT, "include", "agz.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"^[\w \*]+?\b(agz_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.M | re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(_split(args))
+    return protos
+
+
+def _go_calls(src):
+    """(name, number of arguments) of every C.agz_xxx(...) call in the shim, by balanced-parenthesis scanning"""
+    out = []
+    for m in re.finditer(r"C\.(agz_\w+)\(", src):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        args = src[m.end():i - 1].strip()
+        out.append((m.group(1), 0 if not args else len(_split(args)), src.count("\n", 0, m.start()) + 1))
+    return out
+
+
+def test_every_cgo_call_passes_as_many_arguments_as_the_header_declares():
+    """A poor man's type check of the cgo calls (no Go toolchain here): every C.agz_* call names a function of include/agz.h and passes
+    exactly as many arguments as its prototype has parameters."""
+    protos = _c_prototypes()
+    assert len(protos) > 90 and protos["agz_net_infer"] == 5 and protos["agz_last_error"] == 0, len(protos)
+    calls = _go_calls(open(SHIM).read())
+    assert len(calls) > 60
+    for name, n, line in calls:
+        assert name in protos, "agzhip.go:%d calls C.%s, which include/agz.h does not declare" % (line, name)
+        assert n == protos[name], "agzhip.go:%d: C.%s called with %d argument(s), the prototype has %d" % (line, name, n, protos[name])
