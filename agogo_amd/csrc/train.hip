@@ -163,11 +163,19 @@ __device__ __forceinline__ void board_amax_commit(unsigned m0, unsigned m1, int 
 // The same apply, four channels per thread and a fixed channel quad per thread (Kp % 4 == 0, (Kp / 4) divides 256), with max|out| of
 // the whole tensor as a by-product: the NEXT layer's weight gradient splits this tensor into fp16 pieces and needs its range — a
 // separate sweep (k_absmax) re-read it.  Same expressions per element as k_bn_apply.
+// ph != nullptr (round 5): the fp16 hi / lo planes of `out` that the NEXT layer's DMA convolution and weight gradient read are written
+// here as well, scaled by the power of two of `est_bits` — the exact range of the same tensor one step earlier.  The exact range of THIS
+// step comes out of this very pass; k_split_h2p_cond then keeps the planes if both ranges have the same exponent (the usual case: the
+// scale is what the exact range prescribes, the results do not depend on the history) and re-splits the tensor otherwise.
+__device__ __forceinline__ float wg_h2_scale(unsigned amax_bits);
+typedef _Float16 bn_f16x4_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_bn_apply_v(TGeo g, const float* __restrict__ z, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, const float* __restrict__ mean,
                                                     const float* __restrict__ inv, float* __restrict__ out, int Kp, int nbr,
-                                                    int rows_per_block, unsigned* __restrict__ amax_bits, unsigned* __restrict__ board_bits) {
+                                                    int rows_per_block, unsigned* __restrict__ amax_bits, unsigned* __restrict__ board_bits,
+                                                    _Float16* __restrict__ ph = nullptr, _Float16* __restrict__ pl = nullptr, const unsigned* __restrict__ est_bits = nullptr) {
   const int q = Kp >> 2, tpr = 256 / q, cq = threadIdx.x % q, rs = threadIdx.x / q;
+  const float ps = ph ? wg_h2_scale(*est_bits) : 1.f;
   const int C = nbr * Kp;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, g.M);
   float4 mu[2], iv[2];
@@ -204,6 +212,17 @@ __global__ __launch_bounds__(256) void k_bn_apply_v(TGeo g, const float* __restr
     mx = rowm > mx ? rowm : mx;
     if (r >= r_next) mb[1] = rowm > mb[1] ? rowm : mb[1]; else mb[0] = rowm > mb[0] ? rowm : mb[0];
     reinterpret_cast<float4*>(out + po * Kp)[cq] = make_float4(o[0], o[1], o[2], o[3]);
+    if (ph) {
+      bn_f16x4_t hh, ll;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float xs = o[k] * ps;
+        hh[k] = (_Float16)xs;
+        ll[k] = (_Float16)(xs - (float)hh[k]);
+      }
+      reinterpret_cast<bn_f16x4_t*>(ph + po * Kp)[cq] = hh;
+      reinterpret_cast<bn_f16x4_t*>(pl + po * Kp)[cq] = ll;
+    }
   }
   block_amax_commit(mx, amax_bits);
   if (board_bits) board_amax_commit(mb[0], mb[1], bf, g.B, board_bits);
@@ -728,6 +747,25 @@ __global__ __launch_bounds__(256) void k_split_h2p(const float* __restrict__ x, 
     reinterpret_cast<wg_f16x4_t*>(yl)[i] = l;
   }
 }
+// the same split, skipped when the planes already hold it: written by k_bn_apply_v under the previous step's range `est_bits`, valid when
+// that range and this step's exact one prescribe the same power of two
+__global__ __launch_bounds__(256) void k_split_h2p_cond(const float* __restrict__ x, _Float16* __restrict__ yh, _Float16* __restrict__ yl, size_t n4,
+                                                        const unsigned* __restrict__ amax_bits, const unsigned* __restrict__ est_bits) {
+  if (est_bits && *est_bits != 0u && wg_h2_scale(*est_bits) == wg_h2_scale(*amax_bits)) return;
+  const float s = wg_h2_scale(*amax_bits);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float in[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+    wg_f16x4_t h, l;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      h[k] = (_Float16)in[k];
+      l[k] = (_Float16)(in[k] - (float)h[k]);
+    }
+    reinterpret_cast<wg_f16x4_t*>(yh)[i] = h;
+    reinterpret_cast<wg_f16x4_t*>(yl)[i] = l;
+  }
+}
 struct WgH2t3Args {
   const _Float16 *dzh, *dzl, *xh, *xl;
   const unsigned* amax;
@@ -1115,6 +1153,254 @@ __global__ void k_head_conv_bwd_x(TGeo g, const float* __restrict__ dzh, const f
   dx[pix_off(g, r) * Kp + c] = dzh[r * 3] * hc[c] + dzh[r * 3 + 1] * hc[Kp + c] + dzh[r * 3 + 2] * hc[2 * Kp + c];
 }
 
+
+// ---- heads, second form (round 5): the same arithmetic with the memory behaviour fixed.  The nine kernels above cost 1.85 ms of a 47 ms
+// G19 step, serially between the forward and the backward pass: three-block BatchNorm passes over 92 416 rows, a single-block cost sum,
+// one thread per output walking strided operands.  Below: wave-per-row reductions, multi-block partial sums (double atomics), and FC
+// kernels that load each weight once for eight batch rows (resp. eight weight rows) from LDS tiles.  Wherever an output is a sequential sum
+// over i / b / j the ORDER is the old kernel's (bit-identical outputs: the FC forward, dWp, dW1, d(yh)); the BatchNorm sums, the head
+// convolution and the cost are now tree / atomic sums (differences at 1e-7 of the value).
+__global__ __launch_bounds__(256) void k_head_conv2(TGeo g, const float* __restrict__ x, const float* __restrict__ hc, float* __restrict__ zh, int Kp) {
+  const int lane = threadIdx.x & 63, wv = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), nw = (int)(gridDim.x * 4u);
+  for (int r = wv; r < g.M; r += nw) {
+    const float* xp = x + pix_off(g, r) * Kp;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < Kp; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + c);
+      const float4 a = *reinterpret_cast<const float4*>(hc + c), b = *reinterpret_cast<const float4*>(hc + Kp + c), d = *reinterpret_cast<const float4*>(hc + 2 * Kp + c);
+      s0 += v.x * a.x + v.y * a.y + v.z * a.z + v.w * a.w;
+      s1 += v.x * b.x + v.y * b.y + v.z * b.z + v.w * b.w;
+      s2 += v.x * d.x + v.y * d.y + v.z * d.z + v.w * d.w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (lane == 0) { zh[(size_t)r * 3] = s0; zh[(size_t)r * 3 + 1] = s1; zh[(size_t)r * 3 + 2] = s2; }
+  }
+}
+// sums [3] and sums of squares [3] of zh's channels -> hacc[0..5] (zeroed by the caller), then mean / inv
+__global__ __launch_bounds__(256) void k_head_stats_part(TGeo g, const float* __restrict__ zh, double* __restrict__ hacc) {
+  __shared__ double red[6][4];
+  double s[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < g.M; r += gridDim.x * 256) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) { const double v = zh[(size_t)r * 3 + j]; s[j] += v; q[j] += v * v; }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s[j] += __shfl_xor(s[j], o, 64); q[j] += __shfl_xor(q[j], o, 64); }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { for (int j = 0; j < 3; j++) { red[j][w] = s[j]; red[3 + j][w] = q[j]; } }
+  __syncthreads();
+  if (threadIdx.x < 6) atomicAdd(&hacc[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+__global__ void k_head_stats_fin(TGeo g, const double* __restrict__ hacc, float eps, float* __restrict__ mean, float* __restrict__ inv) {
+  const int j = threadIdx.x;
+  if (j >= 3) return;
+  const double mu = hacc[j] / g.M;
+  double var = hacc[3 + j] / g.M - mu * mu;
+  if (var < 0) var = 0;
+  mean[j] = (float)mu;
+  inv[j] = 1.0f / sqrtf((float)var + eps);
+}
+// out[b][j] = sum_i y[b][i] * Wt[i][j] + bias[b][j] for eight batch rows per block: grid (ceil(N / 256), ceil(B / 8), 2); z = 0: the policy
+// logits (y = channels 0, 1 of yh flattened, K = 2 HW), z = 1: the value head's hidden layer (y = channel 2, K = HW)
+__global__ __launch_bounds__(256) void k_fc_fwd2(HeadT h) {
+  extern __shared__ float ys[];                      // [8][K]
+  const bool pol = blockIdx.z == 0;
+  const int N = pol ? h.A : h.FC, K = pol ? 2 * h.HW : h.HW;
+  const int j = blockIdx.x * 256 + threadIdx.x, b0 = blockIdx.y * 8;
+  if (blockIdx.x * 256 >= N) return;
+  const float* W = pol ? h.Wp : h.W1;
+  for (int e = threadIdx.x; e < 8 * K; e += 256) {
+    const int t = e / K, i = e - t * K, b = b0 + t;
+    ys[e] = b < h.B ? h.yh[((size_t)b * 3 + (pol ? 0 : 2)) * h.HW + i] : 0.f;
+  }
+  __syncthreads();
+  if (j >= N) return;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < K; i++) {
+    const float w = W[(size_t)i * N + j];
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] += ys[t * K + i] * w;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    const int b = b0 + t;
+    if (b >= h.B) break;
+    const size_t o = (size_t)b * N + j;
+    if (pol) h.logits[o] = acc[t] + h.bp[o]; else h.hpre[o] = acc[t] + h.b1[o];
+  }
+}
+__global__ __launch_bounds__(64) void k_value_out2(HeadT h) {   // one wave per batch row
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int j = lane; j < h.FC; j += 64) { const float hv = h.hpre[(size_t)b * h.FC + j]; s += (hv > 0.f ? hv : 0.f) * h.W2[j]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) h.o[b] = s + h.b2[b];
+}
+// cost sums -> hacc[6] (policy), hacc[7] (value), zeroed by the caller; k_cost_fin writes cost[0..1]
+__global__ __launch_bounds__(256) void k_cost_part(HeadT h, double* __restrict__ hacc) {
+  __shared__ double red[2][4];
+  double sp = 0, sv = 0;
+  const int n = h.B * h.A;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) sp += -(double)(h.Pi[i] * h.logits[i] + (1.f - h.Pi[i]) * (1.f - h.logits[i]));
+  for (int b = blockIdx.x * 256 + threadIdx.x; b < h.B; b += gridDim.x * 256) { const double d = h.o[b] - h.V[b]; sv += d * d; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sp += __shfl_xor(sp, o, 64); sv += __shfl_xor(sv, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sp; red[1][threadIdx.x >> 6] = sv; }
+  __syncthreads();
+  if (threadIdx.x < 2) atomicAdd(&hacc[6 + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+__global__ void k_cost_fin(HeadT h, const double* __restrict__ hacc) {
+  if (threadIdx.x == 0) { h.cost[0] = (float)(hacc[6] / ((double)h.B * h.A)); h.cost[1] = (float)(hacc[7] / h.B); }
+}
+// dW[i][j] = sum_b y[b][i] * d[b][j], eight rows i per block: grid (ceil(N / 256), ceil(K / 8), 2); z = 0: dWp (d = the xent gradient),
+// z = 1: dW1 (d = the value head's hidden-layer gradient).  The b loop is the old kernel's.
+__global__ __launch_bounds__(256) void k_fc_bwd_w(HeadT h) {
+  extern __shared__ float ys[];                      // [B][8]
+  const bool pol = blockIdx.z == 0;
+  const int N = pol ? h.A : h.FC, K = pol ? 2 * h.HW : h.HW;
+  const int j = blockIdx.x * 256 + threadIdx.x, i0 = blockIdx.y * 8;
+  if (blockIdx.x * 256 >= N || i0 >= K) return;
+  for (int e = threadIdx.x; e < h.B * 8; e += 256) {
+    const int b = e >> 3, t = e & 7, i = i0 + t;
+    ys[e] = i < K ? h.yh[((size_t)b * 3 + (pol ? 0 : 2)) * h.HW + i] : 0.f;
+  }
+  __syncthreads();
+  if (j >= N) return;
+  const float sc = 1.0f / ((float)h.B * (float)h.A);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < h.B; b++) {
+    float d;
+    if (pol) d = (1.f - 2.f * h.Pi[(size_t)b * h.A + j]) * sc;
+    else { const float dob = 2.f * (h.o[b] - h.V[b]) / (float)h.B; d = h.hpre[(size_t)b * h.FC + j] > 0.f ? dob * h.W2[j] : 0.f; }
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] += ys[b * 8 + t] * d;
+  }
+  float* dW = pol ? h.dWp : h.dW1;
+#pragma unroll
+  for (int t = 0; t < 8; t++) if (i0 + t < K) dW[(size_t)(i0 + t) * N + j] = acc[t];
+}
+// the elementwise / small parts of the FC backward: dbp, db1, dW2, db2
+__global__ void k_fc_bwd_small(HeadT h) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const float sc = 1.0f / ((float)h.B * (float)h.A);
+  const int n_bp = h.B * h.A, n_b1 = h.B * h.FC, n_w2 = h.FC, n_b2 = h.B;
+  if (idx < n_bp) { h.dbp[idx] = (1.f - 2.f * h.Pi[idx]) * sc; return; }
+  idx -= n_bp;
+  if (idx < n_b1) {
+    const int b = idx / h.FC, j = idx - b * h.FC;
+    const float dob = 2.f * (h.o[b] - h.V[b]) / (float)h.B;
+    h.db1[idx] = h.hpre[idx] > 0.f ? dob * h.W2[j] : 0.f;
+    return;
+  }
+  idx -= n_b1;
+  if (idx < n_w2) {
+    float s = 0.f;
+    for (int b = 0; b < h.B; b++) { const float hv = h.hpre[(size_t)b * h.FC + idx]; s += (2.f * (h.o[b] - h.V[b]) / (float)h.B) * (hv > 0.f ? hv : 0.f); }
+    h.dW2[idx] = s;
+    return;
+  }
+  idx -= n_w2;
+  if (idx < n_b2) h.db2[idx] = 2.f * (h.o[idx] - h.V[idx]) / (float)h.B;
+}
+// d(yh)[b][q] for eight batch rows per block: grid (ceil(Q / 256), ceil(B / 8), 2); z = 0: q < 2 HW (sum over the A logits), z = 1: the value
+// channel (sum over the FC hidden units).  The j loop is the old kernel's; the per-(b, j) factor comes from an LDS tile.
+__global__ __launch_bounds__(256) void k_fc_bwd_y(HeadT h) {
+  extern __shared__ float ds[];                      // [8][J]
+  const bool pol = blockIdx.z == 0;
+  const int J = pol ? h.A : h.FC, Q = pol ? 2 * h.HW : h.HW;
+  const int q = blockIdx.x * 256 + threadIdx.x, b0 = blockIdx.y * 8;
+  if (blockIdx.x * 256 >= Q) return;
+  const float sc = 1.0f / ((float)h.B * (float)h.A);
+  for (int e = threadIdx.x; e < 8 * J; e += 256) {
+    const int t = e / J, j = e - t * J, b = b0 + t;
+    float d = 0.f;
+    if (b < h.B) {
+      if (pol) d = (1.f - 2.f * h.Pi[(size_t)b * h.A + j]) * sc;
+      else { const float dob = 2.f * (h.o[b] - h.V[b]) / (float)h.B; d = h.hpre[(size_t)b * h.FC + j] > 0.f ? dob * h.W2[j] : 0.f; }
+    }
+    ds[e] = d;
+  }
+  __syncthreads();
+  if (q >= Q) return;
+  const float* Wr = (pol ? h.Wp : h.W1) + (size_t)q * J;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < J; j++) {
+    const float w = Wr[j];
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] += ds[t * J + j] * w;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    const int b = b0 + t;
+    if (b < h.B) h.dyh[(size_t)b * 3 * h.HW + (pol ? 0 : 2 * h.HW) + q] = acc[t];
+  }
+}
+// head BatchNorm backward in two passes over all rows: (1) dgamma / dbeta, dxh -> dzh, the two channel sums -> hacc[8..13] (zeroed by the
+// caller); (2) dzh = inv * (dxh - s1 / m - xh * s2 / m)
+__global__ __launch_bounds__(256) void k_head_bn_bwd_a(TGeo g, const float* __restrict__ zh, const float* __restrict__ yh, const float* __restrict__ dyh,
+                                                       const float* __restrict__ hg, const float* __restrict__ mean, const float* __restrict__ inv,
+                                                       float* __restrict__ dhg, float* __restrict__ dhb, float* __restrict__ dzh, double* __restrict__ hacc) {
+  __shared__ double red[6][4];
+  double a1[3] = {0, 0, 0}, a2[3] = {0, 0, 0};
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < g.M; r += gridDim.x * 256) {
+    const int b = r / g.HW, p = r - b * g.HW;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const size_t o = ((size_t)b * 3 + j) * g.HW + p;
+      const float gg = yh[o] > 0.f ? dyh[o] : 0.f;
+      const float xh = (zh[(size_t)r * 3 + j] - mean[j]) * inv[j];
+      dhg[o] = gg * xh; dhb[o] = gg;
+      const float dxh = gg * hg[o];
+      dzh[(size_t)r * 3 + j] = dxh;
+      a1[j] += dxh; a2[j] += (double)dxh * xh;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a1[j] += __shfl_xor(a1[j], o, 64); a2[j] += __shfl_xor(a2[j], o, 64); }
+  if ((threadIdx.x & 63) == 0) { for (int j = 0; j < 3; j++) { red[j][threadIdx.x >> 6] = a1[j]; red[3 + j][threadIdx.x >> 6] = a2[j]; } }
+  __syncthreads();
+  if (threadIdx.x < 6) atomicAdd(&hacc[8 + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+__global__ __launch_bounds__(256) void k_head_bn_bwd_b(TGeo g, const float* __restrict__ zh, const float* __restrict__ mean, const float* __restrict__ inv,
+                                                       float* __restrict__ dzh, const double* __restrict__ hacc) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)g.M * 3) return;
+  const int j = (int)(idx % 3);
+  const float s1 = (float)hacc[8 + j], s2 = (float)hacc[11 + j], m = (float)g.M;
+  const float xh = (zh[idx] - mean[j]) * inv[j];
+  dzh[idx] = inv[j] * (dzh[idx] - s1 / m - xh * (s2 / m));
+}
+// dhc[j][c] += sum over the block's rows: one thread per channel, the three j at once (x read once), four rows in flight
+__global__ __launch_bounds__(256) void k_head_conv_bwd_w2(TGeo g, const float* __restrict__ x, const float* __restrict__ dzh, float* __restrict__ dhc, int Kp,
+                                                          int rows_per_block) {
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, g.M);
+  for (int c = threadIdx.x; c < Kp; c += 256) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int r = r0; r < r1; r++) {
+      const float xv = x[pix_off(g, r) * Kp + c];
+      s0 += dzh[(size_t)r * 3] * xv; s1 += dzh[(size_t)r * 3 + 1] * xv; s2 += dzh[(size_t)r * 3 + 2] * xv;
+    }
+    atomicAdd(&dhc[c], s0); atomicAdd(&dhc[Kp + c], s1); atomicAdd(&dhc[2 * Kp + c], s2);
+  }
+}
+__global__ __launch_bounds__(256) void k_head_conv_bwd_x2(TGeo g, const float* __restrict__ dzh, const float* __restrict__ hc, float* __restrict__ dx, int Kp) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // one float4 of one row
+  const int k4 = Kp >> 2;
+  if (idx >= (size_t)g.M * k4) return;
+  const int r = (int)(idx / k4), c = (int)(idx - (size_t)r * k4) * 4;
+  const float d0 = dzh[(size_t)r * 3], d1 = dzh[(size_t)r * 3 + 1], d2 = dzh[(size_t)r * 3 + 2];
+  const float4 a = *reinterpret_cast<const float4*>(hc + c), b = *reinterpret_cast<const float4*>(hc + Kp + c), e = *reinterpret_cast<const float4*>(hc + 2 * Kp + c);
+  float4 o;
+  o.x = d0 * a.x + d1 * b.x + d2 * e.x; o.y = d0 * a.y + d1 * b.y + d2 * e.y; o.z = d0 * a.z + d1 * b.z + d2 * e.z; o.w = d0 * a.w + d1 * b.w + d2 * e.w;
+  *reinterpret_cast<float4*>(dx + pix_off(g, r) * Kp + c) = o;
+}
+
 }  // namespace agz
 
 using namespace agz;
@@ -1310,6 +1596,12 @@ struct agz_trainer {
   hipStream_t wg_stream = nullptr;
   hipEvent_t ev_dz = nullptr, ev_split = nullptr, ev_join = nullptr;
   size_t dz_h2_cap = 0, x_h2_cap = 0;
+  std::vector<char> planes_fused;      // layer l's input planes were written by the previous layer's k_bn_apply_v this step
+  bool dma_layer(int l) const {        // layer l's forward convolution runs as the DMA GEMM on pre-split planes (k_conv_h2dma)
+    const TLayer& ly = layers[l];
+    return dma_fwd && use_h2_fwd(ly.Cin_p, ly.Cout_p) && ly.Cin_p % 32 == 0 && ly.Cout_p % 256 == 0 && g.W >= 16 &&
+           (size_t)B * g.Hp * g.Wp * ly.Cin_p * 2 < ((size_t)1 << 31);
+  }
   bool use_wino(int cin, int cout) const {
     return wino && cin % 32 == 0 && cin >= 64 && conv3x3_raw_wino_h2_fits(B, g.H, g.W, cin, cout) &&
            (x3_force || (size_t)((g.M + 127) / 128) * ((cout + 127) / 128) >= (size_t)ctx->num_cus);
@@ -1338,6 +1630,9 @@ struct agz_trainer {
   // as the kernels that write it have been ENQUEUED — heads first, then layer L .. 0 (the order of the backward pass, the same on
   // every rank) — with the stream whose completion means "slice written"; the slices tile [0, n_flat) exactly
   std::function<int(size_t off, size_t n, hipStream_t ready)> on_slice;
+  unsigned* amax_prev = nullptr;   // [(L + 2) * 2] last step's amax_words: the range estimates k_bn_apply_v writes the next layer's planes under
+  double* head_acc = nullptr;   // [16] partial sums of the head kernels' second form (statistics, cost, BatchNorm backward)
+  bool fast_heads = true;   // agz_trainer_set_dma_forward(t, on | 2 * heads): the second form of the head kernels (A/B hook)
   bool dma_fwd = true;      // AGZ_COMPUTE_WINO_H2 forward convolutions through k_conv_h2dma (agz_trainer_set_dma_forward, agz_debug.h: A/B hook)
   float fuse_lr = 0.f;      // != 0 during a fused step: k_bn_bwd1 updates gamma / beta in place, apply() skips them
   bool fused_done = false;  // the backward that just ran took the fused path
@@ -1360,6 +1655,7 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   hipLaunchKernelGGL(k_zero_regions, dim3(64, L + 1), dim3(256), 0, s, G, zero_tab, L + 1);
   AGZ_HIP_TRY(hipMemsetAsync(G + o_hc, 0, (n_flat - o_hc) * sizeof(float), s));
   AGZ_HIP_TRY(hipMemsetAsync(acc_b, 0, (size_t)(L + 1) * 2048 * sizeof(double), s));
+  AGZ_HIP_TRY(hipMemcpyAsync(amax_prev, amax_words, (size_t)(L + 2) * 2 * sizeof(unsigned), hipMemcpyDeviceToDevice, s));   // (last step's ranges: estimates for the fused plane split)
   AGZ_HIP_TRY(hipMemsetAsync(amax_words, 0, (size_t)(L + 2) * 2 * sizeof(unsigned), s));
   AGZ_HIP_TRY(hipMemsetAsync(board_words, 0, (size_t)2 * (L + 2) * B * sizeof(unsigned), s));
   // ---- forward, training-mode BN
@@ -1369,11 +1665,13 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     int r;
     ly.x_planes = false;
     const size_t n_x_fwd = (size_t)B * g.Hp * g.Wp * ly.Cin_p;
-    if (use_h2_fwd(ly.Cin_p, ly.Cout_p) && dma_fwd && x_amax_ready[l] && ly.Cin_p % 32 == 0 && ly.Cout_p % 256 == 0 && g.W >= 16 && n_x_fwd * 2 < ((size_t)1 << 31)) {
-      // planes of the layer input (its range word came out of the previous layer's BatchNorm pass), then the DMA GEMM
-      if (!ly.xh2) { r = alloc(&ly.xh2, 2 * n_x_fwd); if (r != AGZ_OK) return r; }
+    if (dma_layer(l) && x_amax_ready[l]) {
+      // planes of the layer input (its range word came out of the previous layer's BatchNorm pass, and so did the planes themselves
+      // unless the range's exponent moved since the last step), then the DMA GEMM
+      if (!ly.xh2) { r = alloc(&ly.xh2, 2 * n_x_fwd); if (r != AGZ_OK) return r; planes_fused[l] = 0; }
       const unsigned gs = (unsigned)std::min<size_t>(nblk(n_x_fwd / 4), (size_t)ctx->num_cus * 8);
-      hipLaunchKernelGGL(k_split_h2p, dim3(gs), dim3(256), 0, s, cur, ly.xh2, ly.xh2 + n_x_fwd, n_x_fwd / 4, amax_words + 2 * l + 1);
+      hipLaunchKernelGGL(k_split_h2p_cond, dim3(gs), dim3(256), 0, s, cur, ly.xh2, ly.xh2 + n_x_fwd, n_x_fwd / 4, amax_words + 2 * l + 1,
+                         planes_fused[l] ? (const unsigned*)(amax_prev + 2 * l + 1) : (const unsigned*)nullptr);
       const void* w2 = nullptr; const unsigned* wmax = nullptr;
       if ((r = conv3x3_raw_h2_weights(ctx, P + ly.o_wf, ly.Cin_p, ly.Cout_p, &wsc, &w2, &wmax)) != AGZ_OK) return r;
       ConvDmaArgs ca{};
@@ -1405,13 +1703,25 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     if (wino && Kp % 4 == 0 && Kp / 4 <= 256 && 256 % (Kp / 4) == 0 && ly.nbr <= 2) {
       const int tpr = 256 / (Kp / 4), rpb = round_up(std::max(tpr, ceil_div(g.M, 2048)), tpr);
       const bool per_board = rpb <= g.HW;   // (a block's rows then lie in at most two boards)
+      // the next layer's DMA convolution reads `out` as fp16 hi / lo planes: written here, under last step's range (k_split_h2p_cond checks)
+      _Float16* nph = nullptr;
+      if (l < L && dma_layer(l + 1) && layers[l + 1].Cin_p == Kp) {
+        TLayer& nx = layers[l + 1];
+        const size_t n_nx = (size_t)B * g.Hp * g.Wp * nx.Cin_p;
+        if (!nx.xh2) { int r2 = alloc(&nx.xh2, 2 * n_nx); if (r2 != AGZ_OK) return r2; }
+        nph = nx.xh2;
+        planes_fused[l + 1] = 1;
+      } else if (l < L) planes_fused[l + 1] = 0;
       hipLaunchKernelGGL(k_bn_apply_v, dim3(nblk(g.M, rpb)), dim3(256), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean, ly.inv, ly.out,
-                         Kp, ly.nbr, rpb, amax_words + 2 * (l + 1) + 1, per_board ? board_words + (size_t)(l + 1) * B : nullptr);
+                         Kp, ly.nbr, rpb, amax_words + 2 * (l + 1) + 1, per_board ? board_words + (size_t)(l + 1) * B : nullptr,
+                         nph, nph ? nph + (size_t)B * g.Hp * g.Wp * Kp : nullptr, (const unsigned*)(amax_prev + 2 * (l + 1) + 1));
       x_amax_ready[l + 1] = 1;
       xb_ready[l + 1] = per_board;
-    } else
+    } else {
+      if (l < L) planes_fused[l + 1] = 0;
       hipLaunchKernelGGL(k_bn_apply, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, ly.z, P + ly.o_gamma, P + ly.o_beta, ly.mean,
                          ly.inv, ly.out, Kp, ly.nbr);
+    }
     cur = ly.out;
   }
   // ---- heads forward
@@ -1419,20 +1729,45 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   h.B = B; h.HW = g.HW; h.A = A; h.FC = FC; h.yh = yh; h.Wp = P + o_Wp; h.bp = P + o_bp; h.W1 = P + o_W1; h.b1 = P + o_b1;
   h.W2 = P + o_W2; h.b2 = P + o_b2; h.Pi = pi; h.V = v; h.logits = logits; h.hpre = hpre; h.o = o;
   h.dWp = G + o_Wp; h.dbp = G + o_bp; h.dW1 = G + o_W1; h.db1 = G + o_b1; h.dW2 = G + o_W2; h.db2 = G + o_b2; h.dyh = dyh; h.cost = cost;
+  // (second form of the head kernels: see k_head_conv2 ... above; fast_heads = 0, agz_debug.h, keeps the first form for A/B)
+  const int fcK = 2 * g.HW > FC ? 2 * g.HW : FC, fcJ = A > FC ? A : FC;
+  const bool fh = fast_heads && (size_t)8 * (2 * g.HW) * 4 <= 60000 && (size_t)B * 8 * 4 <= 60000 && (size_t)8 * fcJ * 4 <= 60000 && fcK > 0;
+  if (fh) {
+    AGZ_HIP_TRY(hipMemsetAsync(head_acc, 0, 16 * sizeof(double), s));
+    hipLaunchKernelGGL(k_head_conv2, dim3(std::min(nblk(g.M, 4), ctx->num_cus * 16)), dim3(256), 0, s, g, cur, P + o_hc, zh, Kp);
+    hipLaunchKernelGGL(k_head_stats_part, dim3(std::min(nblk(g.M), ctx->num_cus)), dim3(256), 0, s, g, zh, head_acc);
+    hipLaunchKernelGGL(k_head_stats_fin, dim3(1), dim3(64), 0, s, g, head_acc, conf.bn_eps, hmean, hinv);
+    hipLaunchKernelGGL(k_head_apply, dim3(nblk((size_t)g.M * 3)), dim3(256), 0, s, g, zh, P + o_hg, P + o_hb, hmean, hinv, yh);
+    hipLaunchKernelGGL(k_fc_fwd2, dim3(nblk(std::max(A, FC)), nblk(B, 8), 2), dim3(256), (size_t)8 * 2 * g.HW * sizeof(float), s, h);
+    hipLaunchKernelGGL(k_value_out2, dim3(B), dim3(64), 0, s, h);
+    hipLaunchKernelGGL(k_cost_part, dim3(std::min(nblk((size_t)B * A), 64)), dim3(256), 0, s, h, head_acc);
+    hipLaunchKernelGGL(k_cost_fin, dim3(1), dim3(64), 0, s, h, head_acc);
+  } else {
   hipLaunchKernelGGL(k_head_conv, dim3(nblk((size_t)g.M * 3)), dim3(256), 0, s, g, cur, P + o_hc, zh, Kp);
   hipLaunchKernelGGL(k_head_stats, dim3(3), dim3(256), 0, s, g, zh, conf.bn_eps, hmean, hinv);
   hipLaunchKernelGGL(k_head_apply, dim3(nblk((size_t)g.M * 3)), dim3(256), 0, s, g, zh, P + o_hg, P + o_hb, hmean, hinv, yh);
   hipLaunchKernelGGL(k_fc_fwd, dim3(nblk((size_t)B * A + (size_t)B * FC)), dim3(256), 0, s, h);
   hipLaunchKernelGGL(k_value_out, dim3(nblk(B)), dim3(256), 0, s, h);
   hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, s, h);
+  }
   // ---- heads backward
   size_t n_fc = (size_t)2 * g.HW * A + (size_t)B * A + (size_t)g.HW * FC + (size_t)B * FC + FC + B + (size_t)B * 3 * g.HW;
+  if (fh) {
+    hipLaunchKernelGGL(k_fc_bwd_w, dim3(nblk(std::max(A, FC)), nblk(2 * g.HW, 8), 2), dim3(256), (size_t)B * 8 * sizeof(float), s, h);
+    hipLaunchKernelGGL(k_fc_bwd_small, dim3(nblk((size_t)B * A + (size_t)B * FC + FC + B)), dim3(256), 0, s, h);
+    hipLaunchKernelGGL(k_fc_bwd_y, dim3(nblk(2 * g.HW), nblk(B, 8), 2), dim3(256), (size_t)8 * fcJ * sizeof(float), s, h);
+    hipLaunchKernelGGL(k_head_bn_bwd_a, dim3(std::min(nblk(g.M), ctx->num_cus)), dim3(256), 0, s, g, zh, yh, dyh, P + o_hg, hmean, hinv, G + o_hg, G + o_hb, dzh, head_acc);
+    hipLaunchKernelGGL(k_head_bn_bwd_b, dim3(nblk((size_t)g.M * 3)), dim3(256), 0, s, g, zh, hmean, hinv, dzh, head_acc);
+    hipLaunchKernelGGL(k_head_conv_bwd_w2, dim3(nblk(g.M, RPB)), dim3(256), 0, s, g, cur, dzh, G + o_hc, Kp, RPB);
+  } else {
   hipLaunchKernelGGL(k_fc_bwd, dim3(nblk(n_fc)), dim3(256), 0, s, h);
   hipLaunchKernelGGL(k_head_bn_bwd, dim3(3), dim3(256), 0, s, g, zh, yh, dyh, P + o_hg, hmean, hinv, G + o_hg, G + o_hb, dzh);
   hipLaunchKernelGGL(k_head_conv_bwd_w, dim3(nblk(g.M, RPB)), dim3(256), 0, s, g, cur, dzh, G + o_hc, Kp, RPB);
+  }
   float* dcur = dA;
   float* dnext = dB;
-  hipLaunchKernelGGL(k_head_conv_bwd_x, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, dzh, P + o_hc, dcur, Kp);
+  if (fh) hipLaunchKernelGGL(k_head_conv_bwd_x2, dim3(nblk((size_t)g.M * (Kp / 4))), dim3(256), 0, s, g, dzh, P + o_hc, dcur, Kp);
+  else hipLaunchKernelGGL(k_head_conv_bwd_x, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, dzh, P + o_hc, dcur, Kp);
   if (on_slice) { int r = on_slice(o_hc, n_flat - o_hc, s); if (r != AGZ_OK) return r; }   // the heads' gradients are final
   // ---- tower backward
   if (!wg_stream) {
@@ -1587,7 +1922,7 @@ int agz_trainer_create(agz_ctx* ctx, const agz_net_conf* c, agz_trainer** out) {
   TAL(x0, px * t->Fp) TAL(dA, px * Kp) TAL(dB, px * Kp) TAL(dz, px * 2 * Kp) TAL(dz0, px * Kp) TAL(acc, 2048)   /* [2][1024] channel sums of the forward BatchNorm (self-clearing) */
   TAL(acc_b, (size_t)(t->L + 1) * 2048) TAL(amax_words, (size_t)(t->L + 2) * 2) TAL(zero_tab, (size_t)(t->L + 1) * 2)
   TAL(board_words, (size_t)2 * (t->L + 2) * B)
-  t->x_amax_ready.assign(t->L + 2, 0); t->xb_ready.assign(t->L + 2, 0);
+  t->x_amax_ready.assign(t->L + 2, 0); t->xb_ready.assign(t->L + 2, 0); t->planes_fused.assign(t->L + 2, 0);
   {
     std::vector<size_t> tab((size_t)(t->L + 1) * 2);
     for (int l = 0; l <= t->L; l++) {
@@ -1604,7 +1939,7 @@ int agz_trainer_create(agz_ctx* ctx, const agz_net_conf* c, agz_trainer** out) {
         (r = t->alloc(&ly.wt, (size_t)9 * ly.Cout_p * ly.Cin_p)) != AGZ_OK) { agz_trainer_destroy(t); return r; }
   }
   TAL(zh, (size_t)g.M * 3) TAL(yh, (size_t)g.M * 3) TAL(dyh, (size_t)g.M * 3) TAL(dzh, (size_t)g.M * 3) TAL(hmean, 4) TAL(hinv, 4)
-  TAL(logits, (size_t)B * A) TAL(hpre, (size_t)B * FCn) TAL(o, B) TAL(cost, 2)
+  TAL(logits, (size_t)B * A) TAL(hpre, (size_t)B * FCn) TAL(o, B) TAL(cost, 2) TAL(head_acc, 16) TAL(amax_prev, (size_t)(t->L + 2) * 2)
   TAL(d_planes, (size_t)B * F * HW) TAL(d_pi, (size_t)B * A) TAL(d_v, B)
 #undef TAL
   AGZ_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1895,7 +2230,8 @@ int agz_trainer_set_compute_mode(agz_trainer* t, int mode) {
 
 int agz_trainer_set_dma_forward(agz_trainer* t, int on) {
   AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
-  t->dma_fwd = on != 0;
+  t->dma_fwd = (on & 1) != 0;
+  t->fast_heads = (on & 4) == 0;      // bit 2: the FIRST form of the head kernels (A/B)
   return AGZ_OK;
 }
 

@@ -65,7 +65,8 @@ int agz_arena_set_prep_compact(agz_arena* arena, int on);
 int agz_arena_last_prep_batch(agz_arena* arena, int* boards, int* roots);
 
 /* A/B hook: the trainer's AGZ_COMPUTE_WINO_H2 forward convolutions through the DMA GEMM on pre-split fp16 planes (k_conv_h2dma, train.hip;
- * default on) or through conv3x3_h2w_kernel, which splits the fp32 activations while staging them (on = 0).  Same tolerance. */
+ * default on) or through conv3x3_h2w_kernel, which splits the fp32 activations while staging them (bit 0 of `on` clear).  Bit 2 of `on` set:
+ * the first form of the head kernels (one thread per output, three-block BatchNorm passes) instead of the second (default).  Same tolerance. */
 int agz_trainer_set_dma_forward(agz_trainer* t, int on);
 
 #ifdef __cplusplus
