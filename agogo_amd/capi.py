@@ -468,7 +468,8 @@ class Trainer:
         _check(lib().agz_trainer_set_compute_mode(self.h, int(mode)), "agz_trainer_set_compute_mode")
 
     def set_dma_forward(self, on=True):
-        """agz_debug.h A/B hook: WINO_H2 forward convolutions through the DMA GEMM on pre-split planes (default) or the staging-split kernel"""
+        """agz_debug.h A/B hook: bit 0 WINO_H2 forward convolutions through the DMA GEMM on pre-split planes (default) or the staging-split
+        kernel; bit 2 the first form of the head kernels; bit 3 weight images per layer in line instead of at the start of the step"""
         _check(lib().agz_trainer_set_dma_forward(self.h, int(on)), "agz_trainer_set_dma_forward")
 
     def grads_dev(self):

@@ -890,15 +890,60 @@ void agz::wino_raw_scratch_free(WinoRawScratch* sc) {
   *sc = WinoRawScratch{};
 }
 
+static int raw_weights_reserve(RawWeights* rw, size_t bytes) {
+  if (rw->cap >= bytes && rw->words) return AGZ_OK;
+  raw_weights_free(rw);
+  AGZ_HIP_TRY(hipMalloc(&rw->img, bytes));
+  AGZ_HIP_TRY(hipMalloc(&rw->words, 4 * sizeof(unsigned)));
+  rw->cap = bytes;
+  return AGZ_OK;
+}
+void agz::raw_weights_free(RawWeights* rw) {
+  if (rw->img) hipFree(rw->img);
+  if (rw->words) hipFree(rw->words);
+  *rw = RawWeights{};
+}
+int agz::conv3x3_raw_h2_weights_to(agz_ctx* ctx, hipStream_t st, const float* w, int Cin_p, int Cout_p, RawWeights* out) {
+  (void)ctx;
+  const size_t w_elems = (size_t)9 * Cout_p * Cin_p;
+  int r = raw_weights_reserve(out, w_elems * 2 * sizeof(_Float16));
+  if (r != AGZ_OK) return r;
+  AGZ_HIP_TRY(hipMemsetAsync(out->words, 0, 4 * sizeof(unsigned), st));
+  hipLaunchKernelGGL(w_absmax_kernel, dim3((unsigned)std::min<size_t>((w_elems + 255) / 256, 256)), dim3(256), 0, st, w, w_elems, out->words);
+  hipLaunchKernelGGL(split_w2_kernel, dim3((unsigned)((w_elems + 255) / 256)), dim3(256), 0, st, w, (_Float16*)out->img, Cout_p, Cin_p, out->words, out->words + 2, 1,
+                     out->words + 3);
+  AGZ_HIP_TRY(hipGetLastError());
+  return AGZ_OK;
+}
+int agz::conv3x3_raw_wino_h2_weights_to(agz_ctx* ctx, hipStream_t st, const float* w, int H, int W, int Cin_p, int Cout_p, RawWeights* out) {
+  (void)ctx;
+  const int tm = wino_h2_pick_tm(H, W), npos = (tm + 2) * (tm + 2);
+  const size_t u_need = (size_t)npos * (Cin_p / 32) * 2 * Cout_p * 32;   // fp16 elements
+  int r = raw_weights_reserve(out, u_need * sizeof(_Float16));
+  if (r != AGZ_OK) return r;
+  AGZ_HIP_TRY(hipMemsetAsync(out->words, 0, 4 * sizeof(unsigned), st));
+  const unsigned gw = (unsigned)(((size_t)Cout_p * Cin_p + 255) / 256);
+  float* unscale = reinterpret_cast<float*>(out->words + 1);
+  if (tm == 5) {
+    hipLaunchKernelGGL(wino_u_absmax_kernel<5>, dim3(gw), dim3(256), 0, st, w, Cout_p, Cin_p, out->words);
+    hipLaunchKernelGGL(wino_u_build_kernel<5>, dim3(gw), dim3(256), 0, st, w, Cout_p, Cin_p, out->words, (_Float16*)out->img, unscale);
+  } else {
+    hipLaunchKernelGGL(wino_u_absmax_kernel<4>, dim3(gw), dim3(256), 0, st, w, Cout_p, Cin_p, out->words);
+    hipLaunchKernelGGL(wino_u_build_kernel<4>, dim3(gw), dim3(256), 0, st, w, Cout_p, Cin_p, out->words, (_Float16*)out->img, unscale);
+  }
+  AGZ_HIP_TRY(hipGetLastError());
+  return AGZ_OK;
+}
+
 int agz::conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc,
-                             const unsigned* ranges) {
+                             const unsigned* ranges, const RawWeights* pre) {
   AGZ_REQUIRE(conv3x3_raw_wino_h2_fits(B, H, W, Cin_p, Cout_p), AGZ_E_UNSUPPORTED, "conv3x3_raw_wino_h2: shape %d x %dx%d, %d -> %d not supported", B, H, W, Cin_p, Cout_p);
   hipStream_t s = ctx->stream;
   const int tm = wino_h2_pick_tm(H, W), npos = (tm + 2) * (tm + 2);
   const size_t tiles = (size_t)B * ceil_div(H, tm) * ceil_div(W, tm);
   const int row_pad = 0;   // (rows of padding after every position's 128 tile rows: 1 / 4 / 16 measured no different from 0 at C = 512)
   const size_t v_need = wino_h2_rows(npos, tiles, row_pad) * Cin_p, m_need = wino_h2_rows(npos, tiles, row_pad) * Cout_p;
-  const size_t u_need = (size_t)npos * (Cin_p / 32) * 2 * Cout_p * 32;   // fp16 elements
+  const size_t u_need = pre ? 0 : (size_t)npos * (Cin_p / 32) * 2 * Cout_p * 32;   // fp16 elements
   if (v_need > sc->v_cap || m_need > sc->m_cap || u_need > sc->u_cap || B > sc->b_cap) {
     AGZ_HIP_TRY(hipStreamSynchronize(s));
     if (v_need > sc->v_cap) { if (sc->V) hipFree(sc->V); sc->V = nullptr; sc->v_cap = 0; AGZ_HIP_TRY(hipMalloc(&sc->V, v_need * 4)); sc->v_cap = v_need; }
@@ -907,17 +952,20 @@ int agz::conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float
     if (B > sc->b_cap) { if (sc->words) hipFree(sc->words); sc->words = nullptr; sc->b_cap = 0; AGZ_HIP_TRY(hipMalloc(&sc->words, ((size_t)B + 2) * 4)); sc->b_cap = B; }
   }
   unsigned* umax = sc->words + sc->b_cap;
-  float* unscale = reinterpret_cast<float*>(sc->words + sc->b_cap + 1);
+  const float* unscale = pre ? reinterpret_cast<const float*>(pre->words + 1) : reinterpret_cast<const float*>(sc->words + sc->b_cap + 1);
   const int Hp = H + 2, Wp = W + 2;
   // the layer's Winograd-domain weights and their scale
-  AGZ_HIP_TRY(hipMemsetAsync(umax, 0, 4, s));
-  const unsigned gw = (unsigned)(((size_t)Cout_p * Cin_p + 255) / 256);
-  if (tm == 5) {
-    hipLaunchKernelGGL(wino_u_absmax_kernel<5>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax);
-    hipLaunchKernelGGL(wino_u_build_kernel<5>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax, (_Float16*)sc->U2, unscale);
-  } else {
-    hipLaunchKernelGGL(wino_u_absmax_kernel<4>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax);
-    hipLaunchKernelGGL(wino_u_build_kernel<4>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax, (_Float16*)sc->U2, unscale);
+  if (!pre) {
+    float* un = reinterpret_cast<float*>(sc->words + sc->b_cap + 1);
+    AGZ_HIP_TRY(hipMemsetAsync(umax, 0, 4, s));
+    const unsigned gw = (unsigned)(((size_t)Cout_p * Cin_p + 255) / 256);
+    if (tm == 5) {
+      hipLaunchKernelGGL(wino_u_absmax_kernel<5>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax);
+      hipLaunchKernelGGL(wino_u_build_kernel<5>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax, (_Float16*)sc->U2, un);
+    } else {
+      hipLaunchKernelGGL(wino_u_absmax_kernel<4>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax);
+      hipLaunchKernelGGL(wino_u_build_kernel<4>, dim3(gw), dim3(256), 0, s, w, Cout_p, Cin_p, umax, (_Float16*)sc->U2, un);
+    }
   }
   // per-board range of the input (training activations are signed: the kernel takes |x|)
   if (!ranges) {
@@ -928,7 +976,7 @@ int agz::conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float
   WinoArgs& wa = hh.w;
   wa.x = x; wa.y = y; wa.V = sc->V; wa.Mb = sc->M; wa.ep = nullptr;
   wa.B = B; wa.H = H; wa.W = W; wa.Hp = Hp; wa.Wp = Wp; wa.C = Cin_p; wa.Cout_p = Cout_p; wa.Ntot = Cout_p;
-  hh.U2 = (const _Float16*)sc->U2; hh.w_unscale = 1.f; hh.w_unscale_dev = unscale; hh.raw = 1; hh.tm = tm;
+  hh.U2 = (const _Float16*)(pre ? pre->img : sc->U2); hh.w_unscale = 1.f; hh.w_unscale_dev = unscale; hh.raw = 1; hh.tm = tm;
   hh.amax_in = ranges ? ranges : sc->words; hh.amax_out = nullptr; hh.wave_max = nullptr; hh.fuse_prev = 0; hh.row_pad = row_pad;
   wino_h2_launch(ctx, hh, Cout_p % 256 == 0, s);
   AGZ_HIP_TRY(hipGetLastError());

@@ -36,8 +36,15 @@ bool conv3x3_raw_h2_fits(int B, int H, int W, int Cin_p, int Cout_p);
 // the weight half of conv3x3_raw_h2 alone: max|w| word + the fp16x2 image w2[c/32][tap][piece][n][32] in sc (the trainer's DMA forward
 // convolution, train.hip, brings its own activation planes and kernel)
 int conv3x3_raw_h2_weights(agz_ctx* ctx, const float* w, int Cin_p, int Cout_p, WinoRawScratch* sc, const void** w2, const unsigned** w_amax);
+// The weight halves of the two raw convolutions on a stream of the CALLER's choosing, into buffers the caller owns: the trainer's filters
+// do not change inside a step, so it builds every layer's images on its side stream while the forward pass runs (train.hip)
+struct RawWeights { void* img = nullptr; unsigned* words = nullptr; size_t cap = 0; };   // words: [0] range bits, [1] Winograd 1 / scale (float), [2..3] spare
+int conv3x3_raw_h2_weights_to(agz_ctx* ctx, hipStream_t st, const float* w, int Cin_p, int Cout_p, RawWeights* out);        // words[0] = max|w|
+int conv3x3_raw_wino_h2_weights_to(agz_ctx* ctx, hipStream_t st, const float* w, int H, int W, int Cin_p, int Cout_p, RawWeights* out);
+void raw_weights_free(RawWeights* rw);
+// pre != nullptr: conv3x3_raw_wino_h2_weights_to's image of w (then w is not read)
 int conv3x3_raw_wino_h2(agz_ctx* ctx, const float* x, const float* w, float* y, int B, int H, int W, int Cin_p, int Cout_p, WinoRawScratch* sc,
-                        const unsigned* ranges = nullptr);
+                        const unsigned* ranges = nullptr, const RawWeights* pre = nullptr);
 bool conv3x3_raw_wino_h2_fits(int B, int H, int W, int Cin_p, int Cout_p);
 void wino_raw_scratch_free(WinoRawScratch* sc);
 }  // namespace agz

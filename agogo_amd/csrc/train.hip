@@ -1552,6 +1552,11 @@ struct TLayer {
   unsigned short *w3f = nullptr, *w3t = nullptr;   // bf16x3 images of the forward / transposed filter (AGZ_COMPUTE_BF16X3)
   _Float16* xh2 = nullptr;                         // AGZ_COMPUTE_WINO_H2: hi plane then lo plane of the layer INPUT (forward DMA convolution + weight gradient)
   bool x_planes = false;                           // ... and they hold this step's input (set by the forward pass, read by the backward pass)
+  // weight images of the step, built on the side stream beside the forward pass (prep_weights): fw = fp16x2 image of the filter for the DMA
+  // forward convolution, bw = Winograd image of the transposed filter for the data gradient
+  agz::RawWeights fw, bw;
+  hipEvent_t ev_fw = nullptr;
+  bool fw_ready = false, bw_ready = false;         // ... built for THIS step
 };
 struct TParamRef { std::string name; int kind; std::vector<int> shape; int layer; int sub; };  // sub: 0 filter(a) 1 gamma 2 beta, for dual +10 = branch b
 
@@ -1634,6 +1639,10 @@ struct agz_trainer {
   double* head_acc = nullptr;   // [16] partial sums of the head kernels' second form (statistics, cost, BatchNorm backward)
   bool fast_heads = true;   // agz_trainer_set_dma_forward(t, on | 2 * heads): the second form of the head kernels (A/B hook)
   bool dma_fwd = true;      // AGZ_COMPUTE_WINO_H2 forward convolutions through k_conv_h2dma (agz_trainer_set_dma_forward, agz_debug.h: A/B hook)
+  bool hoist_w = true;      // ... every layer's weight images at the start of the step on the side stream (bit 3 of the same hook: per layer, in line)
+  hipEvent_t ev_w0 = nullptr, ev_bw = nullptr;
+  int side_stream();
+  int prep_weights();
   float fuse_lr = 0.f;      // != 0 during a fused step: k_bn_bwd1 updates gamma / beta in place, apply() skips them
   bool fused_done = false;  // the backward that just ran took the fused path
 };
@@ -1646,9 +1655,53 @@ __global__ __launch_bounds__(256) void k_zero_regions(float* __restrict__ base, 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (size_t)gridDim.x * 256) base[off + i] = 0.f;
 }
 
+int agz_trainer::side_stream() {
+  if (wg_stream) return AGZ_OK;
+  AGZ_HIP_TRY(hipStreamCreateWithFlags(&wg_stream, hipStreamNonBlocking));
+  AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_dz, hipEventDisableTiming));
+  AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_split, hipEventDisableTiming));
+  AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_w0, hipEventDisableTiming));
+  AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_bw, hipEventDisableTiming));
+  return AGZ_OK;
+}
+
+// AGZ_COMPUTE_WINO_H2: the filters are constant inside a step (apply() runs after the backward pass), so the per-layer weight passes — range
+// word + fp16 hi / lo image for the DMA forward convolution (2 kernels), transpose + Winograd image for the data gradient (3 kernels), each a
+// few MB of work that cannot fill the chip: 17 + 73 us per layer in line at G19 — are queued here on the side stream, which is otherwise
+// idle until the backward pass: forward images first, in layer order with an event each, then the data gradient's with one event
+int agz_trainer::prep_weights() {
+  for (auto& ly : layers) { ly.fw_ready = false; ly.bw_ready = false; }
+  if (!wino || !hoist_w) return AGZ_OK;
+  int r = side_stream();
+  if (r != AGZ_OK) return r;
+  hipStream_t s = ctx->stream, sw = wg_stream;
+  AGZ_HIP_TRY(hipEventRecord(ev_w0, s));              // (the previous step's apply() and its readers of the images)
+  AGZ_HIP_TRY(hipStreamWaitEvent(sw, ev_w0, 0));
+  for (int l = 0; l <= L; l++) {
+    TLayer& ly = layers[l];
+    if (!dma_layer(l)) continue;
+    if (!ly.ev_fw) AGZ_HIP_TRY(hipEventCreateWithFlags(&ly.ev_fw, hipEventDisableTiming));
+    if ((r = agz::conv3x3_raw_h2_weights_to(ctx, sw, P + ly.o_wf, ly.Cin_p, ly.Cout_p, &ly.fw)) != AGZ_OK) return r;
+    AGZ_HIP_TRY(hipEventRecord(ly.ev_fw, sw));
+    ly.fw_ready = true;
+  }
+  for (int l = L; l >= 1; l--) {
+    TLayer& ly = layers[l];
+    const int C = ly.Cout_p;
+    if (!use_wino(C, ly.Cin_p)) continue;
+    hipLaunchKernelGGL(k_make_wt, dim3((unsigned)(((size_t)9 * C * ly.Cin_p + 255) / 256)), dim3(256), 0, sw, P + ly.o_wf, ly.wt, C, ly.Cin_p);
+    if ((r = agz::conv3x3_raw_wino_h2_weights_to(ctx, sw, ly.wt, g.H, g.W, C, ly.Cin_p, &ly.bw)) != AGZ_OK) return r;
+    ly.bw_ready = true;
+  }
+  AGZ_HIP_TRY(hipEventRecord(ev_bw, sw));
+  return AGZ_OK;
+}
+
 int agz_trainer::forward_backward_dev(const float* planes, const float* pi, const float* v) {
   hipStream_t s = ctx->stream;
   const int RPB = 64;
+  { int r0 = prep_weights(); if (r0 != AGZ_OK) return r0; }
   hipLaunchKernelGGL(k_pack_planes_t, dim3(nblk((size_t)g.M * Fp)), dim3(256), 0, s, planes, x0, g, F, Fp);
   // zero the gradient regions that are ACCUMULATED into (filters: atomics; heads).  The batch-shaped gamma / beta gradients — 98 % of
   // the flat buffer — are plain stores of every element (k_bn_bwd1) and need no clearing (one 7.7 GB memset per G19 step saved)
@@ -1673,7 +1726,8 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
       hipLaunchKernelGGL(k_split_h2p_cond, dim3(gs), dim3(256), 0, s, cur, ly.xh2, ly.xh2 + n_x_fwd, n_x_fwd / 4, amax_words + 2 * l + 1,
                          planes_fused[l] ? (const unsigned*)(amax_prev + 2 * l + 1) : (const unsigned*)nullptr);
       const void* w2 = nullptr; const unsigned* wmax = nullptr;
-      if ((r = conv3x3_raw_h2_weights(ctx, P + ly.o_wf, ly.Cin_p, ly.Cout_p, &wsc, &w2, &wmax)) != AGZ_OK) return r;
+      if (ly.fw_ready) { AGZ_HIP_TRY(hipStreamWaitEvent(s, ly.ev_fw, 0)); w2 = ly.fw.img; wmax = ly.fw.words; }
+      else if ((r = conv3x3_raw_h2_weights(ctx, P + ly.o_wf, ly.Cin_p, ly.Cout_p, &wsc, &w2, &wmax)) != AGZ_OK) return r;
       ConvDmaArgs ca{};
       ca.xh = ly.xh2; ca.xl = ly.xh2 + n_x_fwd; ca.w2 = (const _Float16*)w2; ca.y = ly.z; ca.x_amax = amax_words + 2 * l + 1; ca.w_amax = wmax;
       ca.g = g; ca.Cin = ly.Cin_p; ca.Ntot = ly.Cout_p; ca.n_mtiles = ceil_div(g.M, 128); ca.n_ntiles = ly.Cout_p / 256;
@@ -1770,13 +1824,9 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   else hipLaunchKernelGGL(k_head_conv_bwd_x, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, dzh, P + o_hc, dcur, Kp);
   if (on_slice) { int r = on_slice(o_hc, n_flat - o_hc, s); if (r != AGZ_OK) return r; }   // the heads' gradients are final
   // ---- tower backward
-  if (!wg_stream) {
-    AGZ_HIP_TRY(hipStreamCreateWithFlags(&wg_stream, hipStreamNonBlocking));
-    AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_dz, hipEventDisableTiming));
-    AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_split, hipEventDisableTiming));
-    AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-  }
+  { int r = side_stream(); if (r != AGZ_OK) return r; }
   hipStream_t sw = wg_stream;
+  if (wino && hoist_w) AGZ_HIP_TRY(hipStreamWaitEvent(s, ev_bw, 0));   // the data gradient's weight images (prep_weights; long done)
   for (int l = L; l >= 0; l--) {
     TLayer& ly = layers[l];
     int C = ly.Cout_p;
@@ -1850,10 +1900,11 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
     // layer l's slice [filter | gamma | beta] is final once its weight gradient has run (sw: it started after this layer's BatchNorm backward)
     if (on_slice) { int r = on_slice(ly.o_wf, (l < L ? layers[l + 1].o_wf : o_hc) - ly.o_wf, sw); if (r != AGZ_OK) return r; }
     if (l > 0) {  // data gradient: the forward GEMM with flipped/transposed weights over the [a|b] channels of dz
-      hipLaunchKernelGGL(k_make_wt, dim3(nblk((size_t)9 * C * ly.Cin_p)), dim3(256), 0, s, P + ly.o_wf, ly.wt, C, ly.Cin_p);
+      if (!ly.bw_ready) hipLaunchKernelGGL(k_make_wt, dim3(nblk((size_t)9 * C * ly.Cin_p)), dim3(256), 0, s, P + ly.o_wf, ly.wt, C, ly.Cin_p);
       int r;
       if (use_wino(C, ly.Cin_p)) {
-        r = conv3x3_raw_wino_h2(ctx, dz, ly.wt, dnext, B, g.H, g.W, C, ly.Cin_p, &wsc, dzb_ready ? board_words + (size_t)(L + 2 + l) * B : nullptr);
+        r = conv3x3_raw_wino_h2(ctx, dz, ly.wt, dnext, B, g.H, g.W, C, ly.Cin_p, &wsc, dzb_ready ? board_words + (size_t)(L + 2 + l) * B : nullptr,
+                                ly.bw_ready ? &ly.bw : nullptr);
       } else if (use_x3(ly, C, ly.Cin_p)) {
         if ((r = split_w3(ctx, ly.wt, ly.w3t, ly.Cin_p, C)) != AGZ_OK) return r;
         r = conv3x3_raw_x3(ctx, dz, ly.w3t, dnext, B, g.H, g.W, C, ly.Cin_p);
@@ -1952,6 +2003,9 @@ void agz_trainer_destroy(agz_trainer* t) {
   hipSetDevice(t->ctx->device);
   hipStreamSynchronize(t->ctx->stream);
   if (t->wg_stream) { hipStreamSynchronize(t->wg_stream); hipStreamDestroy(t->wg_stream); }
+  for (auto& ly : t->layers) { agz::raw_weights_free(&ly.fw); agz::raw_weights_free(&ly.bw); if (ly.ev_fw) hipEventDestroy(ly.ev_fw); }
+  if (t->ev_w0) hipEventDestroy(t->ev_w0);
+  if (t->ev_bw) hipEventDestroy(t->ev_bw);
   if (t->ev_dz) hipEventDestroy(t->ev_dz);
   if (t->ev_split) hipEventDestroy(t->ev_split);
   if (t->ev_join) hipEventDestroy(t->ev_join);
@@ -2232,6 +2286,7 @@ int agz_trainer_set_dma_forward(agz_trainer* t, int on) {
   AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
   t->dma_fwd = (on & 1) != 0;
   t->fast_heads = (on & 4) == 0;      // bit 2: the FIRST form of the head kernels (A/B)
+  t->hoist_w = (on & 8) == 0;         // bit 3: weight images per layer in line, not at the start of the step on the side stream (A/B)
   return AGZ_OK;
 }
 

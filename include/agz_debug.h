@@ -66,7 +66,9 @@ int agz_arena_last_prep_batch(agz_arena* arena, int* boards, int* roots);
 
 /* A/B hook: the trainer's AGZ_COMPUTE_WINO_H2 forward convolutions through the DMA GEMM on pre-split fp16 planes (k_conv_h2dma, train.hip;
  * default on) or through conv3x3_h2w_kernel, which splits the fp32 activations while staging them (bit 0 of `on` clear).  Bit 2 of `on` set:
- * the first form of the head kernels (one thread per output, three-block BatchNorm passes) instead of the second (default).  Same tolerance. */
+ * the first form of the head kernels (one thread per output, three-block BatchNorm passes) instead of the second (default).  Bit 3 set: every
+ * layer's weight images (fp16 hi / lo filter image of the forward convolution, Winograd image of the data gradient) built per layer in line
+ * instead of at the start of the step on the trainer's side stream (default).  Same tolerance; bit 3 does not change a single product. */
 int agz_trainer_set_dma_forward(agz_trainer* t, int on);
 
 #ifdef __cplusplus

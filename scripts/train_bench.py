@@ -10,6 +10,7 @@ ap.add_argument("--B", type=int, default=256); ap.add_argument("--size", type=in
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--x3", action="store_true", help="AGZ_COMPUTE_BF16X3 forward / data-gradient / weight-gradient GEMMs")
 ap.add_argument("--wino-h2", action="store_true", help="AGZ_COMPUTE_WINO_H2 forward / data-gradient convolutions (bf16x3 weight gradient)")
+ap.add_argument("--hooks", default="", help="comma list of agz_trainer_set_dma_forward values (agz_debug.h) to time in turn in this process, e.g. 1,9,1,9")
 args = ap.parse_args()
 S = args.size
 ctx = A.Ctx(0)
@@ -28,6 +29,16 @@ t0 = time.perf_counter()
 for _ in range(args.steps):
     c = t.batch(x, pi, v)
 dt = (time.perf_counter() - t0) / args.steps
+if args.hooks:
+    ab = []
+    for hv in [int(q) for q in args.hooks.split(",")]:
+        t.set_dma_forward(hv)
+        t.batch(x, pi, v)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            c2 = t.batch(x, pi, v)
+        ab.append({"hook": hv, "step_ms": round((time.perf_counter() - t0) / args.steps * 1e3, 3), "cost": c2})
+    print(json.dumps({"ab": ab}))
 hw = S * S
 flops = 3 * (2.0 * 18 * args.K * 9 * hw + args.L * 2 * 2.0 * args.K * args.K * 9 * hw) * args.B  # fwd + dgrad + wgrad
 print(json.dumps({"B": args.B, "K": args.K, "L": args.L, "step_ms": dt * 1e3, "examples_per_s": args.B / dt,
