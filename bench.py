@@ -742,6 +742,8 @@ def main():
         if args.compute == "wino_h2" and capi.wino_h2_chained(S, S, K) == 1:
             pmc_name = "pmc_wino_h2c.json"   # the chained block's GEMM (wino_gemm_h2g_kernel), round 4
         pmc_path = os.path.join(ROOT, "profiles", pmc_name)
+        if os.path.exists(os.path.join(ROOT, "profiles", "r05", pmc_name)):   # the newest pass of the same kernel (scripts/r5_pmc_tower.sh)
+            pmc_path = os.path.join(ROOT, "profiles", "r05", pmc_name)
         if os.path.exists(pmc_path) and (S, K, L, G) == (19, 256, 20, 512):  # the PMC pass was taken on this exact shape
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
@@ -805,7 +807,7 @@ def main():
                        "tower_queues": 2 if two_queues else 1},
             "roofline": ({"bound": "hbm", "achieved": wino_detail["wino_gemm"]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": wino_detail["wino_gemm"]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                          "traffic_source": (traffic_source + " (PMC pass of an earlier run of this kernel on this shape: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE; QUOTED, not collected in this run)") if traffic_source else None,
+                          "traffic_source": (traffic_source + " (separate rocprofv3 --pmc passes over this kernel on this shape, scripts/r5_pmc_tower.sh: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE; QUOTED, not collected in this run)") if traffic_source else None,
                           "measured_in_this_run": ["achieved", "frac", "avg_launch_ms", "launches", "block"],
                           "algorithmic_bytes_per_launch": wino_detail["wino_gemm"]["algorithmic_bytes"],
                           # the whole dual block (all its kernels, one-queue HIP events around the block): VERDICT r3 item 2
