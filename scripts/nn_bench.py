@@ -23,6 +23,7 @@ ap.add_argument("--wino", action="store_true", help="AGZ_COMPUTE_WINO (AGZ_WINO_
 ap.add_argument("--wino-h2", action="store_true", help="AGZ_COMPUTE_WINO_H2")
 ap.add_argument("--force", action="store_true", help="AGZ_COMPUTE_FORCE: take the split kernels below the chip-filling threshold")
 ap.add_argument("--no-latency", action="store_true", help="agz_net_set_latency_mode(0)")
+ap.add_argument("--host", action="store_true", help="also time the host-buffer boundary agz_net_infer (pageable and agz_host_alloc buffers): the PCIe-inclusive rate")
 ap.add_argument("--zero", action="store_true", help="all-zero weights (DVFS probe: same instruction stream, low toggle power)")
 args = ap.parse_args()
 ctx = A.Ctx(0)
@@ -66,7 +67,23 @@ if args.wino or args.wino_h2:
         wino[nm + "_launches"] = n_
 flops = net.flops_per_eval() * args.B
 dt = (t1 - t0) / args.iters
+host = {}
+if args.host:
+    from agogo_amd.capi import lib, _pf, _check
+    xh0 = x.cpu().numpy()
+    for kind in ("pageable", "pinned"):
+        mk = (lambda shp: np.zeros(shp, np.float32)) if kind == "pageable" else (lambda shp: ctx.host_array(shp))
+        xh = mk((args.B, 18, S, S)); xh[...] = xh0
+        ph = mk((args.B, S * S + 1)); vh = mk((args.B,))
+        for _ in range(2):
+            _check(lib().agz_net_infer(net.h, _pf(xh), args.B, _pf(ph), _pf(vh)), "agz_net_infer")
+        th = time.perf_counter()
+        for _ in range(args.iters):
+            _check(lib().agz_net_infer(net.h, _pf(xh), args.B, _pf(ph), _pf(vh)), "agz_net_infer")
+        dh = (time.perf_counter() - th) / args.iters
+        host[kind] = {"ms_per_pass": dh * 1e3, "evals_per_s": args.B / dh, "bytes_in": int(xh.nbytes), "bytes_out": int(ph.nbytes + vh.nbytes),
+                      "policy_equal_to_device_path": bool(np.array_equal(ph, pol.cpu().numpy()))}
 print(json.dumps({"B": args.B, "K": args.K, "L": args.L, "ms_per_pass": dt * 1e3, "evals_per_s": args.B / dt,
                   "tflops": flops / dt / 1e12, "frac_fp32_peak": flops / dt / 157.3e12,
                   "conv_launches": n_conv, "conv_ms_avg": ms_conv / max(n_conv, 1), "heads_ms_avg": ms_head / max(n_head, 1), "init_ms_avg": ms_init / max(n_init, 1),
-                  "wino": wino, "policy_sum": float(pol.sum().item()), "value_mean": float(val.mean().item())}))
+                  "wino": wino, "host_boundary": host, "policy_sum": float(pol.sum().item()), "value_mean": float(val.mean().item())}))
