@@ -1640,6 +1640,7 @@ struct agz_trainer {
   bool fast_heads = true;   // agz_trainer_set_dma_forward(t, on | 2 * heads): the second form of the head kernels (A/B hook)
   bool dma_fwd = true;      // AGZ_COMPUTE_WINO_H2 forward convolutions through k_conv_h2dma (agz_trainer_set_dma_forward, agz_debug.h: A/B hook)
   bool hoist_w = true;      // ... every layer's weight images at the start of the step on the side stream (bit 3 of the same hook: per layer, in line)
+  bool one_stream = false;  // bit 4 of the same hook: no side stream at all (diagnostic: a kernel table without overlap shows every kernel's own duration)
   hipEvent_t ev_w0 = nullptr, ev_bw = nullptr;
   int side_stream();
   int prep_weights();
@@ -1672,7 +1673,7 @@ int agz_trainer::side_stream() {
 // idle until the backward pass: forward images first, in layer order with an event each, then the data gradient's with one event
 int agz_trainer::prep_weights() {
   for (auto& ly : layers) { ly.fw_ready = false; ly.bw_ready = false; }
-  if (!wino || !hoist_w) return AGZ_OK;
+  if (!wino || !hoist_w || one_stream) return AGZ_OK;
   int r = side_stream();
   if (r != AGZ_OK) return r;
   hipStream_t s = ctx->stream, sw = wg_stream;
@@ -1825,8 +1826,8 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   if (on_slice) { int r = on_slice(o_hc, n_flat - o_hc, s); if (r != AGZ_OK) return r; }   // the heads' gradients are final
   // ---- tower backward
   { int r = side_stream(); if (r != AGZ_OK) return r; }
-  hipStream_t sw = wg_stream;
-  if (wino && hoist_w) AGZ_HIP_TRY(hipStreamWaitEvent(s, ev_bw, 0));   // the data gradient's weight images (prep_weights; long done)
+  hipStream_t sw = one_stream ? s : wg_stream;
+  if (wino && hoist_w && !one_stream) AGZ_HIP_TRY(hipStreamWaitEvent(s, ev_bw, 0));   // the data gradient's weight images (prep_weights; long done)
   for (int l = L; l >= 0; l--) {
     TLayer& ly = layers[l];
     int C = ly.Cout_p;
@@ -2286,6 +2287,7 @@ int agz_trainer_set_dma_forward(agz_trainer* t, int on) {
   AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
   t->dma_fwd = (on & 1) != 0;
   t->fast_heads = (on & 4) == 0;      // bit 2: the FIRST form of the head kernels (A/B)
+  t->one_stream = (on & 16) != 0;     // bit 4: everything on the step's stream (diagnostic)
   t->hoist_w = (on & 8) == 0;         // bit 3: weight images per layer in line, not at the start of the step on the side stream (A/B)
   return AGZ_OK;
 }

@@ -68,7 +68,8 @@ int agz_arena_last_prep_batch(agz_arena* arena, int* boards, int* roots);
  * default on) or through conv3x3_h2w_kernel, which splits the fp32 activations while staging them (bit 0 of `on` clear).  Bit 2 of `on` set:
  * the first form of the head kernels (one thread per output, three-block BatchNorm passes) instead of the second (default).  Bit 3 set: every
  * layer's weight images (fp16 hi / lo filter image of the forward convolution, Winograd image of the data gradient) built per layer in line
- * instead of at the start of the step on the trainer's side stream (default).  Same tolerance; bit 3 does not change a single product. */
+ * instead of at the start of the step on the trainer's side stream (default).  Bit 4 set: no side stream at all
+ * (diagnostic: per-kernel durations without overlap).  Same tolerance; bits 3 and 4 do not change a single product. */
 int agz_trainer_set_dma_forward(agz_trainer* t, int on);
 
 #ifdef __cplusplus

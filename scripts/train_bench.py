@@ -10,6 +10,7 @@ ap.add_argument("--B", type=int, default=256); ap.add_argument("--size", type=in
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--x3", action="store_true", help="AGZ_COMPUTE_BF16X3 forward / data-gradient / weight-gradient GEMMs")
 ap.add_argument("--wino-h2", action="store_true", help="AGZ_COMPUTE_WINO_H2 forward / data-gradient convolutions (bf16x3 weight gradient)")
+ap.add_argument("--hook", type=int, default=-1, help="agz_trainer_set_dma_forward value for the whole run (agz_debug.h)")
 ap.add_argument("--hooks", default="", help="comma list of agz_trainer_set_dma_forward values (agz_debug.h) to time in turn in this process, e.g. 1,9,1,9")
 args = ap.parse_args()
 S = args.size
@@ -20,6 +21,8 @@ if args.wino_h2:
     t.set_compute_mode(A.capi.COMPUTE_WINO_H2)
 elif args.x3:
     t.set_compute_mode(A.capi.COMPUTE_BF16X3)
+if args.hook >= 0:
+    t.set_dma_forward(args.hook)
 rng = np.random.default_rng(0)
 x = rng.choice(np.array([-1, 0, 1], np.float32), size=(args.B, 18, S, S)).astype(np.float32)
 pi = np.zeros((args.B, S * S + 1), np.float32); pi[np.arange(args.B), rng.integers(0, S * S + 1, args.B)] = 1
