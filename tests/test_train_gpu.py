@@ -98,7 +98,7 @@ def test_first_form_of_the_head_kernels_still_matches_the_oracle(ctx, K, L, FC, 
         assert float(np.abs(gd - go).max()) <= 2e-5 * scale + 1e-7, ot.param_name(i)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "wino_h2", "wino_h2_staged_fwd", "wino_h2_weights_in_line"])
+@pytest.mark.parametrize("mode", ["bf16x3", "wino_h2", "wino_h2_staged_fwd", "wino_h2_weights_in_line", "wino_h2_one_stream"])
 def test_forward_backward_headline_width_19x19(ctx, mode):
     """the trainer's fast modes at the headline tower's width and board (K=256, 19x19, 18 planes, 362 actions; one dual block,
     two boards so the oracle finishes in seconds): the shapes the G19 step runs — 128-multiple tiles, F(5x5,3x3) with the ragged
@@ -114,6 +114,8 @@ def test_forward_backward_headline_width_19x19(ctx, mode):
         dt.set_dma_forward(False)        # the staging-split kernel (conv3x3_h2w_kernel) under the same bar
     if mode == "wino_h2_weights_in_line":  # ... and every layer's weight images are built at the start of the step on the side stream
         dt.set_dma_forward(1 | 8)          # (prep_weights, train.hip); bit 3 keeps the per-layer in-line passes under the same bar
+    if mode == "wino_h2_one_stream":       # diagnostic form (bit 4): no side stream, every kernel on the step's stream
+        dt.set_dma_forward(1 | 16)
     report = []
     for seed in (77, 78, 79, 80):
         x, pi, v = batch_data(B, F, H, W, Aspace, seed=seed)
