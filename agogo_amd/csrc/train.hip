@@ -14,14 +14,17 @@
 //   AGZ_COMPUTE_F32_MFMA  forward and data-gradient convolutions through conv3x3_mfma_kernel (raw epilogue; the data gradient is the
 //                         same GEMM with tap-flipped, transposed weights), weight gradient k_wgrad (fp32 MFMA)            125 ms / G19 step
 //   AGZ_COMPUTE_BF16X3    the three GEMMs on the bf16 pipe with exact three-way operand splits (conv3x3_x3 raw, k_wgrad_x3)    82 ms
-//   AGZ_COMPUTE_WINO_H2   forward = the DIRECT fp16x2 convolution (conv_h2.hpp's 128x256 kernel, raw store, weight image split on
-//                         the device every step), data gradient = the Winograd fp16x2 path (conv_wino_h2.hpp) with device-built
-//                         weights, weight gradient = k_wgrad_h2t3 (both operands split once per layer into hi / lo fp16 planes,
-//                         LDS-DMA, three taps per workgroup from one x image, ds_read_b64_tr_b16): 0.53-0.64 ms per layer, 0.48 of
-//                         the fp16x2 MFMA roof                                                                              47-49 ms
-// BatchNorm statistics / apply / backward and the heads are bandwidth-bound elementwise + reduction kernels (k_bn_bwd1 0.66 of HBM);
-// the batch-shaped gamma / beta take their SGD step inside k_bn_bwd1 on single-process steps; the weight gradient runs on its own
-// stream; a data-parallel step reduces every layer's slice of the flat gradient buffer under the backward pass (on_slice, comm.hip).
+//   AGZ_COMPUTE_WINO_H2   forward = the DIRECT fp16x2 convolution as a pure DMA GEMM (k_conv_h2dma below: fp16 hi / lo planes of the layer
+//                         input — written by the BatchNorm pass that produces the tensor, shared with the weight gradient — and the
+//                         fp16x2 weight image, both by LDS-DMA; 0.55-0.58 ms per layer), data gradient = the Winograd fp16x2 path
+//                         (conv_wino_h2.hpp), weight gradient = k_wgrad_h2t3 (hi / lo fp16 planes of both operands, LDS-DMA, three taps
+//                         per workgroup from one x image, ds_read_b64_tr_b16): 0.55 ms per layer alone, 0.48 of the fp16x2 MFMA roof;
+//                         every layer's weight images are built at the start of the step on the side stream (prep_weights)  42.5-43.3 ms
+// BatchNorm statistics / apply / backward are bandwidth-bound elementwise + reduction kernels at ~5 TB/s (43 % of a layer's time: the
+// reference's batch-shaped gamma / beta fix their bytes); the heads run as wave-per-row reductions and LDS-tiled FC kernels (second form,
+// 0.35 ms per step); the batch-shaped gamma / beta take their SGD step inside k_bn_bwd1 on single-process steps; the weight gradient
+// runs on its own stream; a data-parallel step reduces every layer's slice of the flat gradient buffer under the backward pass
+// (on_slice, comm.hip).
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -1578,10 +1581,10 @@ struct agz_trainer {
   float *logits = nullptr, *hpre = nullptr, *o = nullptr, *cost = nullptr;
   float *d_planes = nullptr, *d_pi = nullptr, *d_v = nullptr;
   bool x3 = false, x3_force = false;   // agz_trainer_set_compute_mode (FORCE: also below the chip-filling threshold, tests)
-  // AGZ_COMPUTE_WINO_H2: the DATA-GRADIENT convolutions of the dual blocks through conv_wino_h2.hpp; the forward convolutions
-  // stay on the bf16x3 kernels.  (Round 2 also ran the forward convolutions through the Winograd path: 72 instead of 87 ms per
-  // G19 step, but its rounding — 2e-6 of the output rms against 2e-7 — flips a ReLU unit against the reference arithmetic on every
-  // other data draw at K = 256 / 19x19, which moves that unit's gradients by percent: outside the stated tolerance, removed.)
+  // AGZ_COMPUTE_WINO_H2: the DATA-GRADIENT convolutions of the dual blocks through conv_wino_h2.hpp; the forward convolutions are DIRECT
+  // fp16x2 convolutions (use_h2_fwd / dma_layer below).  (Round 2 also ran the forward convolutions through the Winograd path: 72 instead
+  // of 87 ms per G19 step, but its rounding — 2e-6 of the output rms against 2e-7 — flips a ReLU unit against the reference arithmetic on
+  // every other data draw at K = 256 / 19x19, which moves that unit's gradients by percent: outside the stated tolerance, removed.)
   bool wino = false;
   WinoRawScratch wsc;
   // ... and the weight gradient with fp16x2 products: both operands split once per layer (k_wgrad_h2)
