@@ -469,7 +469,8 @@ class Trainer:
 
     def set_dma_forward(self, on=True):
         """agz_debug.h A/B hook: bit 0 WINO_H2 forward convolutions through the DMA GEMM on pre-split planes (default) or the staging-split
-        kernel; bit 2 the first form of the head kernels; bit 3 weight images per layer in line instead of at the start of the step"""
+        kernel; bit 2 the first form of the head kernels; bit 3 weight images per layer in line instead of at the start of the step;
+        bit 4 no side stream; bit 5 k_conv_h2dma instead of k_conv_h2dma3; bits 6, 7 timing-only decomposition of the latter (wrong results)"""
         _check(lib().agz_trainer_set_dma_forward(self.h, int(on)), "agz_trainer_set_dma_forward")
 
     def grads_dev(self):

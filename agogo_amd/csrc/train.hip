@@ -1548,6 +1548,159 @@ __global__ __launch_bounds__(256, 3) void k_conv_h2dma(ConvDmaArgs a) {
     }
 }
 
+// ---- the same convolution, nine taps from ONE x image (round 5, second form) ---------------------------------------------------------------
+// k_conv_h2dma above streams 48 KB through L2 -> LDS per K step of 6.3 MFLOP: 5 GB per G19 layer, which at the ~10 TB/s the L2 delivers to
+// the CUs is the whole 0.56 ms (46 % of the fp16x2 MFMA roof).  Here a workgroup computes 256 output pixels x 128 output channels and
+// lands, per 32-channel chunk, ONE image of its input: the padded pixels from (first output pixel) - Wp - 1 to (last output pixel) + Wp + 1,
+// hi and lo plane — tap (ky, kx) of output pixel m reads image row ra(m) + ky Wp + kx, ra(m) = padded distance of m from the tile's first
+// pixel (row ends and one board crossing included: <= 372 rows for 19x19) — 47 KB for nine taps; the weights stream per tap (16 KB,
+// double-buffered, landing under the tap before).  21 KB per K step instead of 48.  Same products in the same order per accumulator
+// (chunks ascending, taps ascending, lo*hi, hi*lo, hi*hi): results are k_conv_h2dma's bit for bit.  80 KB of LDS: two workgroups per CU;
+// assembly DMA + counted waits as in k_wgrad_h2t3 (the compiler's own LDS-DMA bookkeeping would drain the weight prefetch before every tap).
+// Measured: G19 step 43.1 -> 42.2 ms (forward_backward, same box; 0.565 -> ~0.52 ms per layer), far from the 2.3x fewer bytes.  Decomposition
+// (MODE, scripts/train_bench.py --fb --hooks 1,65,129,193; ms per step): everything 42.2, no x image after chunk 0 41.9, no weight DMA
+// 37.5, neither 36.9 — the arithmetic alone runs AT the MFMA rate (0.255 ms per layer), the image costs 17 us per layer, the weights' 16 KB
+// per tap 235 us.  That cost did not move with: no look-ahead at all (+0.2 ms per step); no wait for the weights (-2.3 of the 4.7 ms, wrong
+// results); an XCD per n-tile (its quarter of the weights resident in its L2); every K step landing the SAME lines; a different chunk
+// order per m-tile; nor with the weights loaded straight into registers one tap ahead (lane = output channel, no LDS, no barrier inside a
+// chunk: 42.1 ms, and 45.8 on every other run).  Vector-memory traffic beside 48 MFMAs + 24 fragment reads per tap slows the tap whatever
+// its source, latency and path; what remains is fewer weight bytes per product (a 256 x 256 tile: one workgroup per CU, another kernel).
+constexpr int CD3_IMG = 372;
+template <int MODE>   // (decomposition runs only — WRONG results: bit 0 = the x image lands for chunk 0 only, bit 1 = no weight DMA after K step 0)
+__global__ __launch_bounds__(256, 2) void k_conv_h2dma3(ConvDmaArgs a) {
+  constexpr int PA = CD3_IMG * 64;          // bytes of one piece (hi or lo) of the x image
+  constexpr int PB = 128 * 64, SB = 2 * PB;  // one piece of a tap's weights; a weight stage (hi, lo)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * PA + 2 * SB];   // 47 616 + 32 768 bytes
+
+  const int nblk = a.n_mtiles * a.n_ntiles;
+  const int id = blockIdx.x;
+  int q = nblk >> 3, rr = nblk & 7, xcd = id & 7, slot = id >> 3;
+  int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
+  const int m_tile = tile / a.n_ntiles, n_tile = tile - m_tile * a.n_ntiles;   // (the n-tiles of an m-tile are neighbours on one XCD: one x image in its L2)
+  const int m0 = m_tile * 256, n0 = n_tile * 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+
+  const size_t plane_bytes = (size_t)a.g.B * a.g.Hp * a.g.Wp * a.Cin * 2;
+  auto mk = [](const void* p, size_t bytes) -> wg_rsrc_t {
+    const unsigned long long u = (unsigned long long)p;
+    wg_rsrc_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)u); r[1] = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes); r[3] = 0x00020000u;
+    return r;
+  };
+  const wg_rsrc_t rxh = mk(a.xh, plane_bytes), rxl = mk(a.xl, plane_bytes);
+  const wg_rsrc_t rw = mk(a.w2, (size_t)(a.Cin >> 5) * 9 * 2 * a.Ntot * 64);
+  const unsigned lds0 = (unsigned)(size_t)(wg_lds_ptr_t)lds;
+
+  // DMA lane mapping (both operands): an instruction lands 16 rows x 64 bytes lane-linearly; lane l -> row 16 j + (l >> 2), LDS unit l & 3,
+  // SOURCE unit (l & 3) ^ ((l >> 4) & 3) (the read side's swizzle, cd_lds_off)
+  const unsigned src_unit = (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+  const int pb = (int)pix_off(a.g, m0) - a.g.Wp - 1;                       // padded pixel of image row 0 (>= 0)
+  const unsigned va0 = (unsigned)(pb + (lane >> 2)) * (unsigned)(a.Cin * 2) + src_unit;
+  const unsigned vb0 = (unsigned)(n0 + 32 * wid + (lane >> 2)) * 64u + src_unit;
+  const unsigned piece_bytes = (unsigned)a.Ntot * 64u;
+  auto issue_A = [&](int cc) {                       // instructions j = wid, wid + 4, .. < 24; rows >= CD3_IMG stay unwritten (lanes off)
+#pragma unroll
+    for (int jj = 0; jj < 6; jj++) {
+      const int j = wid + 4 * jj;
+      if (16 * j + (lane >> 2) < CD3_IMG) {
+        const unsigned vo = va0 + (unsigned)j * (unsigned)(16 * a.Cin * 2) + (unsigned)cc * 64u;
+        wg_dma16(rxh, lds0 + (unsigned)j * 1024u, vo);
+        wg_dma16(rxl, lds0 + (unsigned)PA + (unsigned)j * 1024u, vo);
+      }
+    }
+  };
+  auto issue_B = [&](int kstep, int buf) {           // K step = chunk * 9 + tap: the weight image's own order, two pieces each
+    const unsigned so = (unsigned)kstep * 2u * piece_bytes;
+    const unsigned d = lds0 + 2u * PA + (unsigned)buf * SB + (unsigned)wid * 2048u;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      wg_dma16(rw, d + (unsigned)j * 1024u, vb0 + so + (unsigned)j * 1024u);
+      wg_dma16(rw, d + PB + (unsigned)j * 1024u, vb0 + so + piece_bytes + (unsigned)j * 1024u);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  int ra[4];                                           // image row of this lane's output pixel under tap (0, 0)
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int m = m0 + (wm * 4 + i) * 32 + (lane & 31);
+    if (m >= a.g.M) m = a.g.M - 1;
+    ra[i] = (int)pix_off(a.g, m) - (pb + a.g.Wp + 1);
+  }
+  const int kh = lane >> 5;
+  unsigned ob[2][2];                                   // weight fragment offsets inside a stage piece
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) ob[j][ks] = cd_lds_off(wn * 64 + j * 32 + (lane & 31), 2 * ks + kh);
+
+  const int NC = a.Cin >> 5, NS = NC * 9;
+  issue_B(0, 0);
+  int t = 0;
+#pragma nounroll
+  for (int cc = 0; cc < NC; cc++) {
+    if (cc > 0) __builtin_amdgcn_s_barrier();          // every wave is done with the image of chunk cc - 1
+    if (!(MODE & 1) || cc == 0) issue_A(cc);
+#pragma nounroll
+    for (int tap = 0; tap < 9; tap++) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the tap's weights (and, at tap 0, of the image) has landed
+      __builtin_amdgcn_s_barrier();                      // ... every wave's; and every wave is done with the tap before
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(MODE & 2) && t + 1 < NS) issue_B(t + 1, (t + 1) & 1);
+      const unsigned char* bs = lds + 2 * PA + (t & 1) * SB;
+      const int ky = (tap * 11) >> 5;                    // tap / 3 for tap < 9
+      const int toff = ky * a.g.Wp + (tap - 3 * ky);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        wg_f16x8_t B_[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          B_[j][0] = *reinterpret_cast<const wg_f16x8_t*>(bs + ob[j][ks]);
+          B_[j][1] = *reinterpret_cast<const wg_f16x8_t*>(bs + PB + ob[j][ks]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int row = ra[i] + toff;
+          const unsigned o = (unsigned)(row * 64) + ((unsigned)((2 * ks + kh) ^ ((row >> 2) & 3)) << 4);
+          const wg_f16x8_t ah = *reinterpret_cast<const wg_f16x8_t*>(lds + o);
+          const wg_f16x8_t al = *reinterpret_cast<const wg_f16x8_t*>(lds + PA + o);
+#pragma unroll
+          for (int j = 0; j < 2; j++) {                  // small terms first: lo*hi, hi*lo, hi*hi
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, B_[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, B_[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, B_[j][0], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      t++;
+    }
+  }
+  // raw result, un-scaled by the two exact powers of two
+  float sw_, unw_;
+  h2_scales(*a.w_amax, &sw_, &unw_);
+  const float un = unw_ / wg_h2_scale(*a.x_amax);
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = m0 + (wm * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= a.g.M) continue;
+      float* yr = a.y + pix_off(a.g, m) * (size_t)a.Ntot + n0 + wn * 64 + (lane & 31);
+#pragma unroll
+      for (int j = 0; j < 2; j++) yr[j * 32] = acc[i][j][r] * un;
+    }
+}
+
 struct TLayer {
   int Cin_p, Cout_p, nbr;
   size_t o_wf, o_gamma, o_beta;   // offsets in the flat P / G buffers
@@ -1643,6 +1796,20 @@ struct agz_trainer {
   bool fast_heads = true;   // agz_trainer_set_dma_forward(t, on | 2 * heads): the second form of the head kernels (A/B hook)
   bool dma_fwd = true;      // AGZ_COMPUTE_WINO_H2 forward convolutions through k_conv_h2dma (agz_trainer_set_dma_forward, agz_debug.h: A/B hook)
   bool hoist_w = true;      // ... every layer's weight images at the start of the step on the side stream (bit 3 of the same hook: per layer, in line)
+  bool conv3 = true;        // bit 5 of the same hook set: k_conv_h2dma (a K step = one tap) instead of k_conv_h2dma3 (nine taps from one x image)
+  int conv3_mode = 0;       // bits 6, 7 of the hook: k_conv_h2dma3<MODE> (decomposition runs: WRONG results)
+  int conv3_span = -1;      // rows of k_conv_h2dma3's largest x image for this geometry (<= CD3_IMG or the kernel is not used)
+  bool conv3_layer(int l) {
+    const TLayer& ly = layers[l];
+    if (!conv3 || !dma_layer(l) || ly.Cout_p % 128 != 0) return false;
+    if (conv3_span < 0) {
+      auto po = [&](int m) -> long { const int b = m / g.HW, p = m - b * g.HW, h = p / g.W, w = p - h * g.W; return ((long)b * g.Hp + h + 1) * g.Wp + w + 1; };
+      int mx = 0;
+      for (int m0 = 0; m0 < g.M; m0 += 256) mx = std::max(mx, (int)(po(std::min(m0 + 255, g.M - 1)) - po(m0)) + 2 * g.Wp + 3);
+      conv3_span = mx;
+    }
+    return conv3_span <= CD3_IMG;
+  }
   bool one_stream = false;  // bit 4 of the same hook: no side stream at all (diagnostic: a kernel table without overlap shows every kernel's own duration)
   hipEvent_t ev_w0 = nullptr, ev_bw = nullptr;
   int side_stream();
@@ -1734,8 +1901,19 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
       else if ((r = conv3x3_raw_h2_weights(ctx, P + ly.o_wf, ly.Cin_p, ly.Cout_p, &wsc, &w2, &wmax)) != AGZ_OK) return r;
       ConvDmaArgs ca{};
       ca.xh = ly.xh2; ca.xl = ly.xh2 + n_x_fwd; ca.w2 = (const _Float16*)w2; ca.y = ly.z; ca.x_amax = amax_words + 2 * l + 1; ca.w_amax = wmax;
-      ca.g = g; ca.Cin = ly.Cin_p; ca.Ntot = ly.Cout_p; ca.n_mtiles = ceil_div(g.M, 128); ca.n_ntiles = ly.Cout_p / 256;
-      hipLaunchKernelGGL(k_conv_h2dma, dim3(ca.n_mtiles * ca.n_ntiles), dim3(256), 0, s, ca);
+      ca.g = g; ca.Cin = ly.Cin_p; ca.Ntot = ly.Cout_p;
+      if (conv3_layer(l)) {
+        ca.n_mtiles = ceil_div(g.M, 256); ca.n_ntiles = ly.Cout_p / 128;
+        switch (conv3_mode) {
+          case 1: hipLaunchKernelGGL(k_conv_h2dma3<1>, dim3(ca.n_mtiles * ca.n_ntiles), dim3(256), 0, s, ca); break;
+          case 2: hipLaunchKernelGGL(k_conv_h2dma3<2>, dim3(ca.n_mtiles * ca.n_ntiles), dim3(256), 0, s, ca); break;
+          case 3: hipLaunchKernelGGL(k_conv_h2dma3<3>, dim3(ca.n_mtiles * ca.n_ntiles), dim3(256), 0, s, ca); break;
+          default: hipLaunchKernelGGL(k_conv_h2dma3<0>, dim3(ca.n_mtiles * ca.n_ntiles), dim3(256), 0, s, ca); break;
+        }
+      } else {
+        ca.n_mtiles = ceil_div(g.M, 128); ca.n_ntiles = ly.Cout_p / 256;
+        hipLaunchKernelGGL(k_conv_h2dma, dim3(ca.n_mtiles * ca.n_ntiles), dim3(256), 0, s, ca);
+      }
       ly.x_planes = true;
       r = AGZ_OK;
     } else if (use_h2_fwd(ly.Cin_p, ly.Cout_p)) {
@@ -2290,6 +2468,8 @@ int agz_trainer_set_dma_forward(agz_trainer* t, int on) {
   AGZ_REQUIRE(t, AGZ_E_INVALID, "trainer is NULL");
   t->dma_fwd = (on & 1) != 0;
   t->fast_heads = (on & 4) == 0;      // bit 2: the FIRST form of the head kernels (A/B)
+  t->conv3_mode = (on >> 6) & 3;
+  t->conv3 = (on & 32) == 0;          // bit 5: the forward DMA convolution with one tap per K step (k_conv_h2dma) (A/B)
   t->one_stream = (on & 16) != 0;     // bit 4: everything on the step's stream (diagnostic)
   t->hoist_w = (on & 8) == 0;         // bit 3: weight images per layer in line, not at the start of the step on the side stream (A/B)
   return AGZ_OK;

@@ -69,7 +69,10 @@ int agz_arena_last_prep_batch(agz_arena* arena, int* boards, int* roots);
  * the first form of the head kernels (one thread per output, three-block BatchNorm passes) instead of the second (default).  Bit 3 set: every
  * layer's weight images (fp16 hi / lo filter image of the forward convolution, Winograd image of the data gradient) built per layer in line
  * instead of at the start of the step on the trainer's side stream (default).  Bit 4 set: no side stream at all
- * (diagnostic: per-kernel durations without overlap).  Same tolerance; bits 3 and 4 do not change a single product. */
+ * (diagnostic: per-kernel durations without overlap).  Bit 5 set: the DMA forward convolution with one tap per K step (k_conv_h2dma, 128 x 256
+ * tile) instead of nine taps from one x image (k_conv_h2dma3, 256 x 128 tile; default where the image fits its 372 rows).  Same tolerance;
+ * bits 3, 4 and 5 do not change a single product.  Bits 6, 7: decomposition runs of k_conv_h2dma3 (no x image after chunk 0 / no weight DMA):
+ * WRONG results, timing only. */
 int agz_trainer_set_dma_forward(agz_trainer* t, int on);
 
 #ifdef __cplusplus

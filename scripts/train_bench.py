@@ -11,6 +11,7 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--x3", action="store_true", help="AGZ_COMPUTE_BF16X3 forward / data-gradient / weight-gradient GEMMs")
 ap.add_argument("--wino-h2", action="store_true", help="AGZ_COMPUTE_WINO_H2 forward / data-gradient convolutions (bf16x3 weight gradient)")
 ap.add_argument("--hook", type=int, default=-1, help="agz_trainer_set_dma_forward value for the whole run (agz_debug.h)")
+ap.add_argument("--fb", action="store_true", help="--hooks: time forward_backward (no SGD step: decomposition hooks that compute garbage leave the weights alone)")
 ap.add_argument("--hooks", default="", help="comma list of agz_trainer_set_dma_forward values (agz_debug.h) to time in turn in this process, e.g. 1,9,1,9")
 args = ap.parse_args()
 S = args.size
@@ -36,10 +37,11 @@ if args.hooks:
     ab = []
     for hv in [int(q) for q in args.hooks.split(",")]:
         t.set_dma_forward(hv)
-        t.batch(x, pi, v)
+        step = (lambda: t.forward_backward(x, pi, v)) if args.fb else (lambda: t.batch(x, pi, v))
+        step()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            c2 = t.batch(x, pi, v)
+            c2 = step()
         ab.append({"hook": hv, "step_ms": round((time.perf_counter() - t0) / args.steps * 1e3, 3), "cost": c2})
     print(json.dumps({"ab": ab}))
 hw = S * S

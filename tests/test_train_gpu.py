@@ -98,7 +98,31 @@ def test_first_form_of_the_head_kernels_still_matches_the_oracle(ctx, K, L, FC, 
         assert float(np.abs(gd - go).max()) <= 2e-5 * scale + 1e-7, ot.param_name(i)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "wino_h2", "wino_h2_staged_fwd", "wino_h2_weights_in_line", "wino_h2_one_stream"])
+def test_forward_dma_convolution_forms_agree(ctx):
+    """k_conv_h2dma3 (nine taps of a 32-channel chunk from one x image, 256 x 128 tile; default) against k_conv_h2dma (one tap per K step,
+    128 x 256 tile; agz_trainer_set_dma_forward bit 5): the same products in the same order per accumulator, so the forward pass — the cost —
+    is identical, and the gradients agree to the weight gradient's atomics.  K=256 / 19x19, three boards: 1083 rows = four whole 256-row
+    tiles and a partial one, board crossings inside tiles 1 and 2; two dual blocks."""
+    K, L, FC, W, H, F, Aspace, B = 256, 2, 32, 19, 19, 18, 362, 3
+    ot, d3 = make_pair(ctx, K, L, FC, W, H, F, Aspace, B)
+    d1 = A.Trainer(ctx, K, L, FC, W, H, F, Aspace, B)
+    for i in range(ot.num_params()):
+        d1.set_param(i, ot.get_param(i))
+    for dt in (d3, d1):
+        dt.set_compute_mode(capi.COMPUTE_WINO_H2 | capi.COMPUTE_FORCE)
+    d1.set_dma_forward(1 | 32)
+    for seed in (5, 6):
+        x, pi, v = batch_data(B, F, H, W, Aspace, seed=seed)
+        c3 = d3.forward_backward(x, pi, v)
+        c1 = d1.forward_backward(x, pi, v)
+        assert c3 == c1, (seed, c3, c1)
+        for i in range(ot.num_params()):
+            g3, g1 = d3.get_grad(i), d1.get_grad(i)
+            scale = float(np.abs(g1).max())
+            assert float(np.abs(g3 - g1).max()) <= 2e-6 * scale + 1e-9, (seed, ot.param_name(i))
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "wino_h2", "wino_h2_staged_fwd", "wino_h2_weights_in_line", "wino_h2_one_stream", "wino_h2_one_tap_per_step"])
 def test_forward_backward_headline_width_19x19(ctx, mode):
     """the trainer's fast modes at the headline tower's width and board (K=256, 19x19, 18 planes, 362 actions; one dual block,
     two boards so the oracle finishes in seconds): the shapes the G19 step runs — 128-multiple tiles, F(5x5,3x3) with the ragged
@@ -114,6 +138,8 @@ def test_forward_backward_headline_width_19x19(ctx, mode):
         dt.set_dma_forward(False)        # the staging-split kernel (conv3x3_h2w_kernel) under the same bar
     if mode == "wino_h2_weights_in_line":  # ... and every layer's weight images are built at the start of the step on the side stream
         dt.set_dma_forward(1 | 8)          # (prep_weights, train.hip); bit 3 keeps the per-layer in-line passes under the same bar
+    if mode == "wino_h2_one_tap_per_step":  # the first form of the DMA forward convolution (k_conv_h2dma; the default is k_conv_h2dma3)
+        dt.set_dma_forward(1 | 32)
     if mode == "wino_h2_one_stream":       # diagnostic form (bit 4): no side stream, every kernel on the step's stream
         dt.set_dma_forward(1 | 16)
     report = []
