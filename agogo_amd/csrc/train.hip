@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "net.hpp"
+#include "conv_maps.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1437,7 +1438,7 @@ struct ConvDmaArgs {
   TGeo g;
   int Cin, Ntot, n_mtiles, n_ntiles;
 };
-__device__ __forceinline__ unsigned cd_lds_off(int row, int unit) { return (unsigned)(row * 64 + ((unit ^ ((row >> 2) & 3)) << 4)); }
+__device__ __forceinline__ unsigned cd_lds_off(int row, int unit) { return cmaps::lds_off(row, unit); }   // (conv_maps.hpp: shared with the CPU check)
 __global__ __launch_bounds__(256, 3) void k_conv_h2dma(ConvDmaArgs a) {
   constexpr int PA = 128 * 64, PB = 256 * 64;          // bytes of one A / B piece image
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PA + 2 * PB];   // 48 KB
@@ -1565,7 +1566,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_h2dma(ConvDmaArgs a) {
 // order per m-tile; nor with the weights loaded straight into registers one tap ahead (lane = output channel, no LDS, no barrier inside a
 // chunk: 42.1 ms, and 45.8 on every other run).  Vector-memory traffic beside 48 MFMAs + 24 fragment reads per tap slows the tap whatever
 // its source, latency and path; what remains is fewer weight bytes per product (a 256 x 256 tile: one workgroup per CU, another kernel).
-constexpr int CD3_IMG = 372;
+constexpr int CD3_IMG = cmaps::CD3_IMG;
 template <int MODE>   // (decomposition runs only — WRONG results: bit 0 = the x image lands for chunk 0 only, bit 1 = no weight DMA after K step 0)
 __global__ __launch_bounds__(256, 2) void k_conv_h2dma3(ConvDmaArgs a) {
   constexpr int PA = CD3_IMG * 64;          // bytes of one piece (hi or lo) of the x image
@@ -1596,19 +1597,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2dma3(ConvDmaArgs a) {
 
   // DMA lane mapping (both operands): an instruction lands 16 rows x 64 bytes lane-linearly; lane l -> row 16 j + (l >> 2), LDS unit l & 3,
   // SOURCE unit (l & 3) ^ ((l >> 4) & 3) (the read side's swizzle, cd_lds_off)
-  const unsigned src_unit = (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) << 4;
-  const int pb = (int)pix_off(a.g, m0) - a.g.Wp - 1;                       // padded pixel of image row 0 (>= 0)
-  const unsigned va0 = (unsigned)(pb + (lane >> 2)) * (unsigned)(a.Cin * 2) + src_unit;
-  const unsigned vb0 = (unsigned)(n0 + 32 * wid + (lane >> 2)) * 64u + src_unit;
+  const unsigned src_unit = cmaps::dma_src_unit(lane);
+  const size_t pix0 = pix_off(a.g, m0);
+  const int pb = cmaps::cd3_base(pix0, a.g.Wp);                             // padded pixel of image row 0 (>= 0)
+  const unsigned va0 = (unsigned)(pb + cmaps::dma_row(lane, 0)) * (unsigned)(a.Cin * 2) + src_unit;
+  const unsigned vb0 = (unsigned)(n0 + 32 * wid + cmaps::dma_row(lane, 0)) * 64u + src_unit;
   const unsigned piece_bytes = (unsigned)a.Ntot * 64u;
   auto issue_A = [&](int cc) {                       // instructions j = wid, wid + 4, .. < 24; rows >= CD3_IMG stay unwritten (lanes off)
 #pragma unroll
     for (int jj = 0; jj < 6; jj++) {
       const int j = wid + 4 * jj;
-      if (16 * j + (lane >> 2) < CD3_IMG) {
+      if (cmaps::dma_row(lane, j) < CD3_IMG) {
         const unsigned vo = va0 + (unsigned)j * (unsigned)(16 * a.Cin * 2) + (unsigned)cc * 64u;
-        wg_dma16(rxh, lds0 + (unsigned)j * 1024u, vo);
-        wg_dma16(rxl, lds0 + (unsigned)PA + (unsigned)j * 1024u, vo);
+        wg_dma16(rxh, lds0 + cmaps::dma_dst(0, j), vo);
+        wg_dma16(rxl, lds0 + (unsigned)PA + cmaps::dma_dst(0, j), vo);
       }
     }
   };
@@ -1617,8 +1619,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2dma3(ConvDmaArgs a) {
     const unsigned d = lds0 + 2u * PA + (unsigned)buf * SB + (unsigned)wid * 2048u;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-      wg_dma16(rw, d + (unsigned)j * 1024u, vb0 + so + (unsigned)j * 1024u);
-      wg_dma16(rw, d + PB + (unsigned)j * 1024u, vb0 + so + piece_bytes + (unsigned)j * 1024u);
+      wg_dma16(rw, d + cmaps::dma_dst(0, j), vb0 + so + (unsigned)j * 1024u);
+      wg_dma16(rw, d + PB + cmaps::dma_dst(0, j), vb0 + so + piece_bytes + (unsigned)j * 1024u);
     }
   };
 
@@ -1634,7 +1636,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2dma3(ConvDmaArgs a) {
   for (int i = 0; i < 4; i++) {
     int m = m0 + (wm * 4 + i) * 32 + (lane & 31);
     if (m >= a.g.M) m = a.g.M - 1;
-    ra[i] = (int)pix_off(a.g, m) - (pb + a.g.Wp + 1);
+    ra[i] = cmaps::cd3_row0(pix_off(a.g, m), pix0);
   }
   const int kh = lane >> 5;
   unsigned ob[2][2];                                   // weight fragment offsets inside a stage piece
@@ -1658,7 +1660,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2dma3(ConvDmaArgs a) {
       if (!(MODE & 2) && t + 1 < NS) issue_B(t + 1, (t + 1) & 1);
       const unsigned char* bs = lds + 2 * PA + (t & 1) * SB;
       const int ky = (tap * 11) >> 5;                    // tap / 3 for tap < 9
-      const int toff = ky * a.g.Wp + (tap - 3 * ky);
+      const int toff = cmaps::cd3_tap(ky, tap - 3 * ky, a.g.Wp);
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
         wg_f16x8_t B_[2][2];
@@ -1670,7 +1672,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2dma3(ConvDmaArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int row = ra[i] + toff;
-          const unsigned o = (unsigned)(row * 64) + ((unsigned)((2 * ks + kh) ^ ((row >> 2) & 3)) << 4);
+          const unsigned o = cmaps::lds_off(row, 2 * ks + kh);
           const wg_f16x8_t ah = *reinterpret_cast<const wg_f16x8_t*>(lds + o);
           const wg_f16x8_t al = *reinterpret_cast<const wg_f16x8_t*>(lds + PA + o);
 #pragma unroll
@@ -1803,9 +1805,9 @@ struct agz_trainer {
     const TLayer& ly = layers[l];
     if (!conv3 || !dma_layer(l) || ly.Cout_p % 128 != 0) return false;
     if (conv3_span < 0) {
-      auto po = [&](int m) -> long { const int b = m / g.HW, p = m - b * g.HW, h = p / g.W, w = p - h * g.W; return ((long)b * g.Hp + h + 1) * g.Wp + w + 1; };
       int mx = 0;
-      for (int m0 = 0; m0 < g.M; m0 += 256) mx = std::max(mx, (int)(po(std::min(m0 + 255, g.M - 1)) - po(m0)) + 2 * g.Wp + 3);
+      for (int m0 = 0; m0 < g.M; m0 += 256)
+        mx = std::max(mx, cmaps::cd3_rows(cmaps::pix(m0, g.HW, g.W, g.Hp, g.Wp), cmaps::pix(std::min(m0 + 255, g.M - 1), g.HW, g.W, g.Hp, g.Wp), g.Wp));
       conv3_span = mx;
     }
     return conv3_span <= CD3_IMG;
