@@ -40,11 +40,19 @@ namespace agz {
 
 struct TGeo { int B, H, W, HW, Hp, Wp, M; };  // M = B*HW rows
 
-__device__ __forceinline__ size_t pix_off(const TGeo& g, int r) {  // padded pixel index of GEMM row r
+__host__ __device__ constexpr __forceinline__ size_t pix_off(const TGeo& g, int r) {  // padded pixel index of GEMM row r
   int b = r / g.HW, p = r - b * g.HW;
   int h = p / g.W, w = p - h * g.W;
   return ((size_t)b * g.Hp + h + 1) * g.Wp + w + 1;
 }
+// (the same function as conv_maps.hpp's pix, which the CPU check of k_conv_h2dma3's image geometry uses: compared at compile time)
+constexpr bool pix_off_is_cmaps_pix(int B, int H, int W) {
+  const TGeo g{B, H, W, H * W, H + 2, W + 2, B * H * W};
+  for (int m = 0; m < g.M; m++)
+    if (pix_off(g, m) != cmaps::pix(m, g.HW, g.W, g.Hp, g.Wp)) return false;
+  return true;
+}
+static_assert(pix_off_is_cmaps_pix(3, 19, 19) && pix_off_is_cmaps_pix(2, 16, 17) && pix_off_is_cmaps_pix(5, 3, 4), "pix_off != cmaps::pix");
 
 // ---- BatchNorm statistics: per-channel sums over the M interior rows of z [pix][C] -----------------------------
 // pass 0: sum(z)                    -> acc[c]
