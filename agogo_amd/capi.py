@@ -14,7 +14,7 @@ PASS, RESIGN = -1, -2
 NO_MOVE = -32768
 GAME_MNK, GAME_C4, GAME_KOMI, GAME_WQ = 0, 1, 2, 3
 ENC_TWOPLANE, ENC_WQ = 0, 1
-INF_NET, INF_DUMMY, INF_SCRIPT, INF_HASH, INF_UNIFORM = 0, 1, 2, 3, 4
+INF_NET, INF_DUMMY, INF_SCRIPT, INF_HASH, INF_UNIFORM, INF_CALLBACK = 0, 1, 2, 3, 4, 5
 BN_DEGENERATE_EPS, BN_RUNNING, BN_IDENTITY = 0, 1, 2
 COMPUTE_F32_MFMA, COMPUTE_BF16X3, COMPUTE_FP16X2, COMPUTE_WINO, COMPUTE_AUTO, COMPUTE_WINO_H2 = 0, 1, 2, 3, 4, 5
 COMPUTE_FORCE = 0x100
@@ -65,6 +65,44 @@ class GameState(C.Structure):
     _fields_ = [("to_move", C.c_int32), ("move_number", C.c_int32), ("passes", C.c_int32), ("ended", C.c_int32),
                 ("winner", C.c_int32), ("a_is_black", C.c_int32), ("last_move", C.c_int32), ("reserved", C.c_int32),
                 ("score_black", C.c_float), ("score_white", C.c_float)]
+
+
+class LeafBatch(C.Structure):
+    """agz_leaf_batch (include/agz.h): the leaves a host inferencer (AGZ_INF_CALLBACK) is handed in one call"""
+    _fields_ = [("n", C.c_int32), ("features", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("policy_len", C.c_int32),
+                ("planes", C.POINTER(C.c_float)), ("board", C.POINTER(C.c_int32)), ("to_move", C.POINTER(C.c_int32)),
+                ("move_number", C.POINTER(C.c_int32)), ("game", C.POINTER(C.c_int32)), ("policy", C.POINTER(C.c_float)),
+                ("value", C.POINTER(C.c_float))]
+
+
+INFER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(LeafBatch))
+
+
+def make_infer_fn(py):
+    """agz_infer_fn around a Python function  leaves -> (policy [n, policy_len], value [n]);  leaves = dict(planes [n, F, H, W], board
+    [n, H*W], to_move [n], move_number [n], game [n]).  An exception inside `py` is reported to libagz as a failed call (the search aborts
+    with AGZ_E_CALLBACK) and re-raised by the binding afterwards."""
+    box = {"exc": None}
+
+    def tramp(_user, bp):
+        try:
+            b = bp.contents
+            n, F, H, W, pl = b.n, b.features, b.height, b.width, b.policy_len
+            as_np = np.ctypeslib.as_array
+            leaves = {"planes": as_np(b.planes, shape=(n, F, H, W)), "board": as_np(b.board, shape=(n, H * W)),
+                      "to_move": as_np(b.to_move, shape=(n,)), "move_number": as_np(b.move_number, shape=(n,)),
+                      "game": as_np(b.game, shape=(n,)), "policy_len": pl}
+            pol, val = py(leaves)
+            as_np(b.policy, shape=(n, pl))[...] = np.asarray(pol, np.float32).reshape(n, pl)
+            as_np(b.value, shape=(n,))[...] = np.asarray(val, np.float32).reshape(n)
+            return 0
+        except BaseException as e:   # never let an exception unwind through the C frames
+            box["exc"] = e
+            return 1
+
+    fn = INFER_FN(tramp)
+    fn._box = box
+    return fn
 
 
 def lib_path():
@@ -180,6 +218,7 @@ def lib():
     sig("agz_wino_h2_tile", i32, i32, i32)
     sig("agz_net_set_wino_h2_form", i32, vp, i32)
     sig("agz_net_set_wino_h2_gemm", i32, vp, i32)
+    sig("agz_net_min_same_batch", i32, vp, i32, i32, C.POINTER(C.c_int))
     sig("agz_arena_set_prep_compact", i32, vp, i32)
     sig("agz_trainer_set_dma_forward", i32, vp, i32)
     sig("agz_arena_last_prep_batch", i32, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
@@ -190,6 +229,8 @@ def lib():
     sig("agz_mcts_create", i32, vp, C.POINTER(GameConf), C.POINTER(MctsConf), u64, i32, pvp)
     sig("agz_mcts_destroy", None, vp)
     sig("agz_mcts_set_inferencer", i32, vp, i32, vp)
+    sig("agz_mcts_set_inferencer_callback", i32, vp, INFER_FN, vp, i32)
+    sig("agz_arena_set_inferencer_callback", i32, vp, i32, INFER_FN, vp, i32)
     sig("agz_mcts_set_parallel", i32, vp, i32)
     sig("agz_mcts_set_game", i32, vp, C.POINTER(State))
     sig("agz_mcts_search", i32, vp, i32, pi)
@@ -209,6 +250,7 @@ def lib():
     sig("agz_trainer_allreduce", i32, vp, vp)
     sig("agz_trainer_forward_backward_allreduce", i32, vp, vp, pf, pf, pf, pf)
     sig("agz_trainer_forward_backward_allreduce_dev", i32, vp, vp, vp, vp, vp, pf)
+    sig("agz_comm_debug_fail_slice", i32, vp, i32)
     _LIB = L
     return L
 
@@ -377,6 +419,12 @@ class Net:
         """agz_debug.h A/B hook: 0 default, 1 wino_gemm_h2g_kernel, 2 wino_gemm_h2p_kernel (persistent; K = 256)"""
         _check(lib().agz_net_set_wino_h2_gemm(self.h, int(variant)), "agz_net_set_wino_h2_gemm")
 
+    def min_same_batch(self, n, G):
+        """agz_debug.h: the smallest batch >= n whose per-board outputs equal those of a G-board batch bit for bit"""
+        b = C.c_int(0)
+        _check(lib().agz_net_min_same_batch(self.h, int(n), int(G), C.byref(b)), "agz_net_min_same_batch")
+        return b.value
+
     def infer_dev(self, planes_ptr, B, policy_ptr, value_ptr):
         """device pointers (ints); asynchronous on the ctx stream"""
         _check(lib().agz_net_infer_dev(self.h, C.c_void_p(planes_ptr), B, C.c_void_p(policy_ptr),
@@ -537,6 +585,12 @@ class Arena:
                "agz_arena_set_inferencer")
         if net is not None:
             self._nets.append(net)
+
+    def set_inferencer_callback(self, agent, fn, policy_len):
+        """AGZ_INF_CALLBACK: agent `agent` evaluates its leaves through the Python function fn(leaves) -> (policy, value) (make_infer_fn)"""
+        cfn = make_infer_fn(fn)
+        _check(lib().agz_arena_set_inferencer_callback(self.h, agent, cfn, None, int(policy_len)), "agz_arena_set_inferencer_callback")
+        self._nets.append(cfn)      # keeps the trampoline alive as long as the arena
 
     def reset(self, a_is_black=None):
         if a_is_black is None:
@@ -700,6 +754,12 @@ class Mcts:
         if net is not None:
             self._nets.append(net)
 
+    def set_inferencer_callback(self, fn, policy_len):
+        """mcts.New(game, conf, nn) with a caller-supplied Inferencer: fn(leaves) -> (policy, value) (make_infer_fn)"""
+        cfn = make_infer_fn(fn)
+        _check(lib().agz_mcts_set_inferencer_callback(self.h, cfn, None, int(policy_len)), "agz_mcts_set_inferencer_callback")
+        self._nets.append(cfn)
+
     def set_parallel(self, lanes):
         _check(lib().agz_mcts_set_parallel(self.h, int(lanes)), "agz_mcts_set_parallel")
 
@@ -837,6 +897,10 @@ class Comm:
         _check(lib().agz_trainer_forward_backward_allreduce(self.h, trainer.h, _pf(x), _pf(p), _pf(vv), C.byref(c)),
                "agz_trainer_forward_backward_allreduce")
         return c.value
+
+    def debug_fail_slice(self, k):
+        """agz_debug.h: this rank's next data-parallel step fails right before slice k (failure injection for the N > 1 tests)"""
+        _check(lib().agz_comm_debug_fail_slice(self.h, int(k)), "agz_comm_debug_fail_slice")
 
     def forward_backward_allreduce_dev(self, trainer, planes_ptr, pi_ptr, v_ptr, want_cost=True):
         c = C.c_float(0)

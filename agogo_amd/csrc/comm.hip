@@ -120,7 +120,7 @@ void agz_comm_destroy(agz_comm* c) {
   const Rccl* R = rccl();
   if (R && c->comm) { hipSetDevice(c->ctx->device); hipStreamSynchronize(c->ctx->stream); R->CommDestroy(c->comm); }
   if (c->d_words) { hipSetDevice(c->ctx->device); hipFree(c->d_words); }
-  if (c->ar_stream) { hipSetDevice(c->ctx->device); hipStreamSynchronize(c->ar_stream); hipStreamDestroy(c->ar_stream); hipEventDestroy(c->ev_ready); hipEventDestroy(c->ev_done); }
+  if (c->ar_stream) { hipSetDevice(c->ctx->device); hipStreamSynchronize(c->ar_stream); hipStreamDestroy(c->ar_stream); hipEventDestroy(c->ev_ready); hipEventDestroy(c->ev_done); if (c->h_status) hipHostFree(c->h_status); }
   delete c;
 }
 
@@ -154,27 +154,62 @@ static int dp_begin(agz_comm* c, agz_trainer* t, const Rccl* R) {
     AGZ_HIP_TRY(hipStreamCreateWithFlags(&c->ar_stream, hipStreamNonBlocking));
     AGZ_HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     AGZ_HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    AGZ_HIP_TRY(hipHostMalloc((void**)&c->h_status, 16, hipHostMallocDefault));
   }
   float* g = nullptr;
   size_t n_all = 0;
   int r = agz_trainer_grads_dev(t, &g, &n_all);
   if (r != AGZ_OK) return r;
+  agz_trainer_slices(t, c->dp_slices);
+  c->dp_issued = 0;
   agz_trainer_set_slice_hook(t, [c, g, n_all, R](size_t off, size_t n, hipStream_t ready) -> int {
     AGZ_REQUIRE(off + n <= n_all, AGZ_E_STATE, "data-parallel step: slice [%zu, %zu) outside the gradient buffer", off, off + n);
+    AGZ_REQUIRE(c->dp_issued < c->dp_slices.size() && c->dp_slices[c->dp_issued] == std::make_pair(off, n), AGZ_E_STATE,
+                "data-parallel step: slice %zu is not the one the slice table announces", c->dp_issued);
+    if (c->debug_fail_slice == (int)c->dp_issued) { c->debug_fail_slice = -1; set_error("injected failure before slice %zu (agz_comm_debug_fail_slice)", c->dp_issued); return AGZ_E_STATE; }
     AGZ_HIP_TRY(hipEventRecord(c->ev_ready, ready));
     AGZ_HIP_TRY(hipStreamWaitEvent(c->ar_stream, c->ev_ready, 0));
     AGZ_NCCL_TRY(R->AllReduce(g + off, g + off, n, ncclFloat32, ncclSum, c->comm, c->ar_stream));
+    c->dp_issued++;
     return AGZ_OK;
   });
   return AGZ_OK;
 }
-static int dp_end(agz_comm* c, agz_trainer* t, int r) {
+// End of the step on every rank, whatever happened on this one: a rank that failed part-way (an allocation, a launch, a
+// collective) still ENTERS the slices it has not issued — its peers are inside them or about to be, and a collective one rank never
+// enters is a hang — and then all ranks exchange one status word (the number of ranks that failed).  A non-zero word makes the call fail on EVERY
+// rank (AGZ_E_PEER where this rank itself was fine): the gradients of such a step are undefined everywhere and must not be applied.
+// A failure of RCCL itself (a collective that returns an error here) is fatal for the process group: tear the communicator down.
+static int dp_end(agz_comm* c, agz_trainer* t, const Rccl* R, int r) {
   agz_trainer_set_slice_hook(t, nullptr);
+  float* g = nullptr;
+  size_t n_all = 0;
+  const bool have_g = agz_trainer_grads_dev(t, &g, &n_all) == AGZ_OK;
+  std::string first_error = r != AGZ_OK ? agz_last_error() : "";
+  if (have_g)
+    for (; c->dp_issued < c->dp_slices.size(); c->dp_issued++) {   // only ever non-empty after a local failure
+      const auto& sl = c->dp_slices[c->dp_issued];
+      if (R->AllReduce(g + sl.first, g + sl.first, sl.second, ncclFloat32, ncclSum, c->comm, c->ar_stream) != ncclSuccess && r == AGZ_OK) r = AGZ_E_HIP;
+    }
+  c->h_status[0] = r != AGZ_OK ? 1ull : 0ull;
+  c->h_status[1] = 0;
+  unsigned long long* dw = c->d_words + c->size + 2;   // the last exchange word of the communicator (allocated with it)
+  bool ok = hipMemcpyAsync(dw, &c->h_status[0], 8, hipMemcpyHostToDevice, c->ar_stream) == hipSuccess &&
+            R->AllReduce(dw, dw, 1, ncclUint64, ncclSum, c->comm, c->ar_stream) == ncclSuccess &&
+            hipMemcpyAsync(&c->h_status[1], dw, 8, hipMemcpyDeviceToHost, c->ar_stream) == hipSuccess &&
+            hipStreamSynchronize(c->ar_stream) == hipSuccess;
   // the step's stream carries everything again: whatever comes next (agz_trainer_apply) sees the summed gradients
-  if (hipEventRecord(c->ev_done, c->ar_stream) != hipSuccess || hipStreamWaitEvent(c->ctx->stream, c->ev_done, 0) != hipSuccess) {
-    if (r == AGZ_OK) { set_error("data-parallel step: joining the reduction queue failed"); r = AGZ_E_HIP; }
-  }
-  return r;
+  ok = ok && hipEventRecord(c->ev_done, c->ar_stream) == hipSuccess && hipStreamWaitEvent(c->ctx->stream, c->ev_done, 0) == hipSuccess;
+  if (r != AGZ_OK) { set_error("data-parallel step failed on this rank (its peers are told; gradients undefined): %s", first_error.c_str()); return r; }
+  if (!ok) { set_error("data-parallel step: the status exchange / joining the reduction queue failed (fatal for the process group)"); return AGZ_E_HIP; }
+  if (c->h_status[1] != 0) { set_error("data-parallel step: another rank failed in this step; the gradients are undefined and must not be applied"); return AGZ_E_PEER; }
+  return AGZ_OK;
+}
+
+int agz_comm_debug_fail_slice(agz_comm* c, int k) {
+  AGZ_REQUIRE(c, AGZ_E_INVALID, "agz_comm_debug_fail_slice: NULL communicator");
+  c->debug_fail_slice = k;
+  return AGZ_OK;
 }
 
 int agz_trainer_forward_backward_allreduce(agz_comm* c, agz_trainer* t, const float* planes, const float* pi, const float* v, float* cost) {
@@ -185,7 +220,7 @@ int agz_trainer_forward_backward_allreduce(agz_comm* c, agz_trainer* t, const fl
   AGZ_HIP_TRY(hipSetDevice(c->ctx->device));
   int r = dp_begin(c, t, R);
   if (r != AGZ_OK) return r;
-  return dp_end(c, t, agz_trainer_forward_backward(t, planes, pi, v, cost));
+  return dp_end(c, t, R, agz_trainer_forward_backward(t, planes, pi, v, cost));
 }
 
 int agz_trainer_forward_backward_allreduce_dev(agz_comm* c, agz_trainer* t, const float* planes_dev, const float* pi_dev, const float* v_dev, float* cost) {
@@ -196,7 +231,7 @@ int agz_trainer_forward_backward_allreduce_dev(agz_comm* c, agz_trainer* t, cons
   AGZ_HIP_TRY(hipSetDevice(c->ctx->device));
   int r = dp_begin(c, t, R);
   if (r != AGZ_OK) return r;
-  return dp_end(c, t, agz_trainer_forward_backward_dev(t, planes_dev, pi_dev, v_dev, cost));
+  return dp_end(c, t, R, agz_trainer_forward_backward_dev(t, planes_dev, pi_dev, v_dev, cost));
 }
 
 }  // extern "C"

@@ -8,6 +8,8 @@
 #include <rccl/rccl.h>
 
 #include <functional>
+#include <utility>
+#include <vector>
 
 #include "common.hpp"
 
@@ -31,6 +33,7 @@ const Rccl* rccl();
 // (train.hip) the context a trainer was created on; the per-slice hook of a data-parallel step (agz_trainer::on_slice)
 agz_ctx* agz_trainer_ctx(const agz_trainer* t);
 void agz_trainer_set_slice_hook(agz_trainer* t, std::function<int(size_t off, size_t n, hipStream_t ready)> f);
+void agz_trainer_slices(const agz_trainer* t, std::vector<std::pair<size_t, size_t>>& out);   // (offset, count) in issue order
 
 struct agz_comm {
   agz_ctx* ctx = nullptr;
@@ -42,6 +45,12 @@ struct agz_comm {
   // the gradient slices of a data-parallel step are reduced on their own queue while the backward pass goes on (comm.hip)
   hipStream_t ar_stream = nullptr;
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  // one data-parallel step: the slice table of the trainer, how many of its collectives this rank has entered, and the status word
+  // every rank exchanges at the end of the step (dp_end) so that a failure on ONE rank is an error on ALL of them
+  std::vector<std::pair<size_t, size_t>> dp_slices;
+  size_t dp_issued = 0;
+  unsigned long long* h_status = nullptr;   // pinned
+  int debug_fail_slice = -1;                // agz_comm_debug_fail_slice (agz_debug.h)
 };
 
 #define AGZ_NCCL_TRY(expr)                                                                                   \

@@ -338,7 +338,9 @@ __global__ __launch_bounds__(64) void k_begin_move(Dev d, GameCfg c, MctsCfg mc)
   int player = d.to_move[g];
   St st;
   load_state(c, d, g, s, st, false, lane);
-  if (lane == 0) d.stalled[t] = 0;
+  // a search is judged by what IT adds: the overflow mark of an earlier search (the tree was re-rooted and compacted since) must not
+  // hide this one's from CNT_FULL (a wall-clock search ends on it, a Budget search reports AGZ_E_TREE_FULL)
+  if (lane == 0) { d.stalled[t] = 0; d.overflow[t] = 0; }
   int pool = d.cur_pool[t];
   size_t base = pool_base(d, t, pool);
   bool ok = d.has_root[t] && d.has_prev[t] && c.kind != AGZ_GAME_C4;  // c4: Eq() can never hold (App. C c2)
@@ -487,6 +489,7 @@ __global__ __launch_bounds__(64) void k_select(Dev d, GameCfg c, MctsCfg mc, flo
       float* act = agent == 0 ? act_in0 : act_in1;
       // NN slots are lane-major ([lane][game slot]) so that a round of nl lanes is one dense batch of nl*G rows
       if (act) encode_nhwc(c, s, st, act + ((size_t)l * d.G + d.slot_of_game[g]) * (c.m + 2) * (c.n + 2) * 32, lane);
+      if (d.cb_planes && ((d.cb_mask >> agent) & 1)) encode_nchw(c, s, st, d.cb_planes + q * (size_t)c.F * c.cells, lane);   // AGZ_INF_CALLBACK
     }
     if (lane == 0) {
       d.leaf_kind[q] = kind;
@@ -593,6 +596,7 @@ __global__ __launch_bounds__(64) void k_leaf(Dev d, GameCfg c, MctsCfg mc, float
   for (int i = lane; i < c.cells; i += WAVE) d.leaf_board[q * CELLS_PAD + i] = s.board[i];
   float* act = agent == 0 ? act_in0 : act_in1;
   if (act) encode_nhwc(c, s, st, act + ((size_t)l * d.G + d.slot_of_game[g]) * (c.m + 2) * (c.n + 2) * 32, lane);
+  if (d.cb_planes && ((d.cb_mask >> agent) & 1)) encode_nchw(c, s, st, d.cb_planes + q * (size_t)c.F * c.cells, lane);
 }
 
 // one workgroup per (game, lane): the evaluation and the renormalised, sorted expansion list of an expandable leaf
@@ -1307,6 +1311,20 @@ struct agz_arena {
   bool in_move = false;
   bool restart = false;  // continuous self-play: finished games restart immediately
   int moves_done = 0;
+  // AGZ_INF_CALLBACK (mcts.Inferencer as a host function, mcts/mcts.go:15-18): the callee, its policy width, page-locked staging
+  agz_infer_fn cb_fn[2] = {nullptr, nullptr};
+  void* cb_user[2] = {nullptr, nullptr};
+  int cb_plen[2] = {0, 0};
+  std::vector<void*> host_allocs;
+  int cb_rows = 0;                                   // G * V the staging below was sized for
+  int32_t *h_kind = nullptr, *h_player = nullptr, *h_ply = nullptr, *h_tomove = nullptr, *h_ab = nullptr, *h_ended = nullptr;
+  int8_t* h_lboard = nullptr;
+  float* h_planes = nullptr;                         // [G*V][F*cells] as the device wrote them
+  float *h_pk_planes = nullptr, *h_pk_policy = nullptr, *h_pk_value = nullptr;   // the packed batch handed to the callee
+  int32_t *h_pk_board = nullptr, *h_pk_tomove = nullptr, *h_pk_mn = nullptr, *h_pk_game = nullptr;
+  float* h_policy[2] = {nullptr, nullptr};           // [G*V][policy_len] in NN-slot order, uploaded for k_expand
+  float* h_value[2] = {nullptr, nullptr};
+  int64_t cb_calls = 0, cb_leaves = 0;
 
   template <typename T>
   int alloc(T** p, size_t n) {
@@ -1318,6 +1336,16 @@ struct agz_arena {
     return AGZ_OK;
   }
   bool split_nets() const { return inf_kind[0] == AGZ_INF_NET && inf_kind[1] == AGZ_INF_NET && net[0] != net[1]; }
+  template <typename T>
+  int halloc(T** p, size_t n) {
+    void* q = nullptr;
+    AGZ_HIP_TRY(hipHostMalloc(&q, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault));
+    host_allocs.push_back(q);
+    *p = (T*)q;
+    return AGZ_OK;
+  }
+  int cb_setup();                    // (re)allocate the callback staging for G * V leaves
+  int cb_run(int nl);                // leaves of callback agents -> host function -> d_policy / d_value
   int update_slots();
   int nn_step(int prep, int nl = 1);   // nl lanes per tree in this round (<= d.V)
 };
@@ -1339,6 +1367,103 @@ __global__ __launch_bounds__(256) void k_prep_compact(Dev d, float* act, int slo
     if (src != rank && i < slot_f4) a4[(size_t)rank * slot_f4 + i] = a4[(size_t)src * slot_f4 + i];
     rank++;
   }
+}
+
+// ---- AGZ_INF_CALLBACK ------------------------------------------------------------------------------------------------------------
+// mcts.New(game, conf, nn Inferencer) takes ANY implementation of `Infer(state) (policy, value)` (mcts/mcts.go:15-18, tree.go:80).  The
+// device search meets such an inferencer between its two kernels: k_select leaves every expandable leaf's encoded planes (NCHW, the
+// arena's encoder), board, mover and move number; the leaves of the callback agents are packed into ONE batch, the host function fills
+// policy [n][policy_len] and value [n], and k_expand consumes the rows exactly as it consumes a network's.  One host round trip per
+// simulation step (all games at once): the boundary for caller-supplied networks and a network-independent differential hook — not
+// the measured path (AGZ_INF_NET keeps everything on the device).
+int agz_arena::cb_setup() {
+  const int rows = G * d.V;
+  const size_t pl = (size_t)gc.F * gc.cells;
+  if (!d.cb_planes || cb_rows != rows) {
+    int r;
+    // (the previous, smaller staging stays on the allocation lists and is released with the arena, as agz_arena_set_parallel's scratch)
+    if ((r = alloc(&d.cb_planes, (size_t)rows * pl)) != AGZ_OK) return r;
+    if ((r = halloc(&h_kind, rows)) != AGZ_OK || (r = halloc(&h_player, rows)) != AGZ_OK || (r = halloc(&h_ply, rows)) != AGZ_OK ||
+        (r = halloc(&h_tomove, G)) != AGZ_OK || (r = halloc(&h_ab, G)) != AGZ_OK || (r = halloc(&h_ended, G)) != AGZ_OK ||
+        (r = halloc(&h_lboard, (size_t)rows * CELLS_PAD)) != AGZ_OK || (r = halloc(&h_planes, (size_t)rows * pl)) != AGZ_OK ||
+        (r = halloc(&h_pk_planes, (size_t)rows * pl)) != AGZ_OK || (r = halloc(&h_pk_value, rows)) != AGZ_OK ||
+        (r = halloc(&h_pk_board, (size_t)rows * gc.cells)) != AGZ_OK || (r = halloc(&h_pk_tomove, rows)) != AGZ_OK ||
+        (r = halloc(&h_pk_mn, rows)) != AGZ_OK || (r = halloc(&h_pk_game, rows)) != AGZ_OK)
+      return r;
+    cb_rows = rows;
+  }
+  { int r = halloc(&h_pk_policy, (size_t)rows * std::max(std::max(cb_plen[0], cb_plen[1]), 1)); if (r != AGZ_OK) return r; }
+  for (int a = 0; a < 2; a++) {
+    if (inf_kind[a] != AGZ_INF_CALLBACK) continue;
+    if (d_policy[a]) { hipFree(d_policy[a]); d_policy[a] = nullptr; }
+    if (d_value[a]) { hipFree(d_value[a]); d_value[a] = nullptr; }
+    AGZ_HIP_TRY(hipMalloc(&d_policy[a], (size_t)rows * cb_plen[a] * sizeof(float)));
+    AGZ_HIP_TRY(hipMalloc(&d_value[a], (size_t)rows * sizeof(float)));
+    int r;
+    if ((r = halloc(&h_policy[a], (size_t)rows * cb_plen[a])) != AGZ_OK || (r = halloc(&h_value[a], rows)) != AGZ_OK) return r;
+    memset(h_policy[a], 0, (size_t)rows * cb_plen[a] * sizeof(float));
+    memset(h_value[a], 0, (size_t)rows * sizeof(float));
+  }
+  return AGZ_OK;
+}
+
+int agz_arena::cb_run(int nl) {
+  hipStream_t s = ctx->stream;
+  const int rows = G * d.V;
+  const size_t pl = (size_t)gc.F * gc.cells;
+  AGZ_HIP_TRY(hipMemcpyAsync(h_kind, d.leaf_kind, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(h_player, d.leaf_player, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(h_ply, d.leaf_ply, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(h_tomove, d.to_move, (size_t)G * 4, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(h_ab, d.a_is_black, (size_t)G * 4, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(h_ended, d.ended, (size_t)G * 4, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(h_lboard, d.leaf_board, (size_t)rows * CELLS_PAD, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipMemcpyAsync(h_planes, d.cb_planes, (size_t)rows * pl * 4, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  for (int a = 0; a < 2; a++) {
+    if (inf_kind[a] != AGZ_INF_CALLBACK) continue;
+    if (a == 1 && inf_kind[0] == AGZ_INF_CALLBACK && cb_fn[0] == cb_fn[1] && cb_user[0] == cb_user[1] && cb_plen[0] == cb_plen[1]) continue;   // one callee for both agents: served below in ONE call
+    const bool both = a == 0 && inf_kind[1] == AGZ_INF_CALLBACK && cb_fn[0] == cb_fn[1] && cb_user[0] == cb_user[1] && cb_plen[0] == cb_plen[1];
+    const int plen = cb_plen[a];
+    int n = 0;
+    std::vector<int> qs, ags;
+    for (int g = 0; g < G; g++) {
+      if (h_ended[g]) continue;
+      const int agent = ((h_tomove[g] == AGZ_BLACK) == (h_ab[g] != 0)) ? 0 : 1;
+      if (agent != a && !(both && agent == 1)) continue;
+      for (int l = 0; l < nl; l++) {
+        const int q = g * d.V + l;
+        if (h_kind[q] != LEAF_EXPAND) continue;
+        memcpy(h_pk_planes + (size_t)n * pl, h_planes + (size_t)q * pl, pl * sizeof(float));
+        for (int i = 0; i < gc.cells; i++) h_pk_board[(size_t)n * gc.cells + i] = h_lboard[(size_t)q * CELLS_PAD + i];
+        h_pk_tomove[n] = h_player[q]; h_pk_mn[n] = h_ply[q]; h_pk_game[n] = g;
+        qs.push_back(q); ags.push_back(agent);
+        n++;
+      }
+    }
+    if (n == 0) continue;
+    agz_leaf_batch b{};
+    b.n = n; b.features = gc.F; b.height = gc.m; b.width = gc.n; b.policy_len = plen;
+    b.planes = h_pk_planes; b.board = h_pk_board; b.to_move = h_pk_tomove; b.move_number = h_pk_mn; b.game = h_pk_game;
+    b.policy = h_pk_policy; b.value = h_pk_value;
+    memset(h_pk_policy, 0, (size_t)n * plen * sizeof(float));
+    memset(h_pk_value, 0, (size_t)n * sizeof(float));
+    const int rc = cb_fn[a](cb_user[a], &b);
+    cb_calls++; cb_leaves += n;
+    if (rc != 0) { agz::set_error("the host inferencer (AGZ_INF_CALLBACK, agent %d) returned %d for a batch of %d leaves: the search is aborted, reset the arena", a, rc, n); return AGZ_E_CALLBACK; }
+    for (int i = 0; i < n; i++) {
+      const int q = qs[i], g = q / d.V, l = q - g * d.V, ag = ags[i];
+      const size_t slot = (size_t)l * G + slot_host[g];     // lane-major NN slots, as k_select / k_expand index them
+      memcpy(h_policy[ag] + slot * plen, h_pk_policy + (size_t)i * plen, (size_t)plen * sizeof(float));
+      h_value[ag][slot] = h_pk_value[i];
+    }
+  }
+  for (int a = 0; a < 2; a++) {
+    if (inf_kind[a] != AGZ_INF_CALLBACK) continue;
+    AGZ_HIP_TRY(hipMemcpyAsync(d_policy[a], h_policy[a], (size_t)rows * cb_plen[a] * sizeof(float), hipMemcpyHostToDevice, s));
+    AGZ_HIP_TRY(hipMemcpyAsync(d_value[a], h_value[a], (size_t)rows * sizeof(float), hipMemcpyHostToDevice, s));
+  }
+  return AGZ_OK;
 }
 
 // NN batch slots.  One shared net (or synthetic inferencers): slot = game.  Two different nets: games whose
@@ -1418,6 +1543,7 @@ int agz_arena::nn_step(int prep, int nl) {
       case AGZ_INF_DUMMY: inf.policy_len[a] = gc.A; break;
       case AGZ_INF_SCRIPT: inf.policy_len[a] = 10; break;
       case AGZ_INF_HASH: inf.policy_len[a] = gc.A + 1; break;
+      case AGZ_INF_CALLBACK: inf.kind[a] = AGZ_INF_NET; inf.policy_len[a] = cb_plen[a]; break;   // k_expand reads rows the host function filled
       default: inf.policy_len[a] = 25; break;
     }
   }
@@ -1443,6 +1569,9 @@ int agz_arena::nn_step(int prep, int nl) {
       if (r != AGZ_OK) return r;
     }
   }
+  // host inferencers (AGZ_INF_CALLBACK) AFTER the network pass of the other agent is enqueued: the callee may itself call into a net of
+  // this context (its input buffer held this step's leaves until now)
+  if (d.cb_mask && need_forward) { int r = cb_run(nl); if (r != AGZ_OK) return r; }
   {
     ProfScope ps(ctx, AGZ_PROF_EXPAND);
     if (split_lanes) {
@@ -1500,7 +1629,10 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
   d.G = G; d.T = T;
   // (a single tree with Budget <= 0 = a search that stops on the wall clock, agz_mcts_set_timeout_ms: no simulation count to size by —
   // room for 65536 expansions, at most the 8 M-node ceiling; a full pool ends such a search, agz_mcts_search)
-  const long long size_by = mcts->Budget > 0 || n_games > 1 ? mcts->Budget : 65536;
+  // (an arena of several games with neither a Budget nor a pool size has nothing to size its trees by: refused, not guessed — ADVICE r5)
+  AGZ_REQUIRE(mcts->Budget > 0 || n_games == 1 || max_nodes > 0, AGZ_E_INVALID,
+              "agz_arena_create: %d games with Budget <= 0 need an explicit max_nodes (node pool per tree)", n_games);
+  const long long size_by = mcts->Budget > 0 ? mcts->Budget : 65536;
   long long cap = max_nodes > 0 ? max_nodes : (long long)(2 * (size_by + 2)) * (c.A + 1) + 16;
   if (cap > 8000000) cap = 8000000;
   d.cap = (int)cap;
@@ -1552,6 +1684,7 @@ void agz_arena_destroy(agz_arena* a) {
   hipSetDevice(a->ctx->device);
   hipStreamSynchronize(a->ctx->stream);
   for (void* p : a->allocs) hipFree(p);
+  for (void* p : a->host_allocs) hipHostFree(p);
   for (int i = 0; i < 2; i++) { if (a->d_policy[i]) hipFree(a->d_policy[i]); if (a->d_value[i]) hipFree(a->d_value[i]); }
   if (a->d_forced) hipFree(a->d_forced);
   if (a->d_remaining) hipFree(a->d_remaining);
@@ -1560,7 +1693,7 @@ void agz_arena_destroy(agz_arena* a) {
 
 int agz_arena_set_inferencer(agz_arena* a, int agent, int kind, agz_net* net) {
   AGZ_REQUIRE(a && (agent == 0 || agent == 1), AGZ_E_INVALID, "agz_arena_set_inferencer: bad agent");
-  AGZ_REQUIRE(kind >= AGZ_INF_NET && kind <= AGZ_INF_UNIFORM, AGZ_E_INVALID, "unknown inferencer kind %d", kind);
+  AGZ_REQUIRE(kind >= AGZ_INF_NET && kind <= AGZ_INF_UNIFORM, AGZ_E_INVALID, "unknown inferencer kind %d%s", kind, kind == AGZ_INF_CALLBACK ? " (AGZ_INF_CALLBACK is set by agz_arena_set_inferencer_callback)" : "");
   if (kind == AGZ_INF_NET) {
     AGZ_REQUIRE(net && net->committed, AGZ_E_STATE, "AGZ_INF_NET needs a committed net");
     AGZ_REQUIRE(net->ctx == a->ctx, AGZ_E_INVALID, "net belongs to another ctx");
@@ -1584,6 +1717,25 @@ int agz_arena_set_inferencer(agz_arena* a, int agent, int kind, agz_net* net) {
   }
   a->inf_kind[agent] = kind;
   a->net[agent] = kind == AGZ_INF_NET ? net : nullptr;
+  a->cb_fn[agent] = nullptr; a->cb_user[agent] = nullptr; a->cb_plen[agent] = 0;
+  a->d.cb_mask &= ~(1 << agent);
+  return a->update_slots();
+}
+
+int agz_arena_set_inferencer_callback(agz_arena* a, int agent, agz_infer_fn fn, void* user, int policy_len) {
+  AGZ_REQUIRE(a && (agent == 0 || agent == 1), AGZ_E_INVALID, "agz_arena_set_inferencer_callback: bad agent");
+  AGZ_REQUIRE(fn, AGZ_E_INVALID, "agz_arena_set_inferencer_callback: NULL function");
+  AGZ_REQUIRE(!a->in_move, AGZ_E_STATE, "agz_arena_set_inferencer_callback: a search is in progress");
+  AGZ_REQUIRE(policy_len >= a->gc.A && policy_len <= 4096, AGZ_E_INVALID,
+              "agz_arena_set_inferencer_callback: policy_len %d (the game's ActionSpace is %d; the pass probability is the LAST entry, search.go:276)", policy_len, a->gc.A);
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  a->inf_kind[agent] = AGZ_INF_CALLBACK;
+  a->net[agent] = nullptr;
+  a->cb_fn[agent] = fn; a->cb_user[agent] = user; a->cb_plen[agent] = policy_len;
+  a->d.cb_mask |= 1 << agent;
+  int r = a->cb_setup();
+  if (r != AGZ_OK) return r;
   return a->update_slots();
 }
 
@@ -1608,6 +1760,7 @@ int agz_arena_set_parallel(agz_arena* a, int lanes) {
   AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
   for (int agent = 0; agent < 2; agent++)   // network batch and output buffers grow to G*lanes rows
     if (a->inf_kind[agent] == AGZ_INF_NET) { r = agz_arena_set_inferencer(a, agent, AGZ_INF_NET, a->net[agent]); if (r != AGZ_OK) return r; }
+  if (a->d.cb_mask) { r = a->cb_setup(); if (r != AGZ_OK) return r; }   // host-callback agents: staging for G * lanes leaves
   return AGZ_OK;
 }
 
@@ -2086,6 +2239,13 @@ int agz_mcts_set_inferencer(agz_mcts* m, int kind, agz_net* net) {
   int r = agz_arena_set_inferencer(m->arena, 0, kind, net);
   if (r != AGZ_OK) return r;
   return agz_arena_set_inferencer(m->arena, 1, kind, net);   // agent B's tree is never searched; same inferencer keeps one NN batch
+}
+
+int agz_mcts_set_inferencer_callback(agz_mcts* m, agz_infer_fn fn, void* user, int policy_len) {
+  AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
+  int r = agz_arena_set_inferencer_callback(m->arena, 0, fn, user, policy_len);
+  if (r != AGZ_OK) return r;
+  return agz_arena_set_inferencer_callback(m->arena, 1, fn, user, policy_len);
 }
 
 int agz_mcts_set_parallel(agz_mcts* m, int lanes) {

@@ -124,6 +124,9 @@ struct Dev {
   int32_t* best_out;      // [G] result of a search-only end of move (agz_mcts_search: Search does not Apply, search.go:151-163)
   int ex_cap;
   int moves_stride;       // max_moves + 4
+  // ---- AGZ_INF_CALLBACK: the leaf states a host inferencer is handed between k_select and k_expand
+  float* cb_planes;       // [G*V][F*cells] the encoder's NCHW tensor of leaf q (what Agent.Infer encodes, agent.go:60-74); nullptr: no callback agent
+  int cb_mask;            // bit a set: agent a holds a callback inferencer
 };
 
 enum { CNT_SIMS = 0, CNT_NONNULL = 1, CNT_EVALS = 2, CNT_MOVES = 3, CNT_GAMES = 4, CNT_EXAMPLES = 5, CNT_FULL = 6, CNT_A_WINS = 7, CNT_B_WINS = 8,

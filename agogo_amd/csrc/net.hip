@@ -1327,7 +1327,15 @@ int agz_net::forward_packed(int B, float* policy_dev, float* value_dev) {
         hh.wm_out = d_wave_max + ((size_t)(l & 1) * B + b0) * wmb;
         hh.g1 = wino_g1[l]; hh.g0 = wino_g0[l];
         {   // which GEMM kernel / store policy: agz_net_set_wino_h2_gemm, else AGZ_WINO_H2_GEMM (1 | 2, + 64 = round 4's stores), else the default
-          static const int gemm_env = [] { const char* e = getenv("AGZ_WINO_H2_GEMM"); return e ? atoi(e) : 0; }();
+          // (the environment reaches the two product kernels only: 1 | 2, + 64; anything else — 2 + 16 * mode are the persistent kernel's
+          //  timing-only decomposition instances, wrong results by design, agz_debug.h — is ignored with one line on stderr)
+          static const int gemm_env = [] {
+            const char* e = getenv("AGZ_WINO_H2_GEMM");
+            const int v = e ? atoi(e) : 0;
+            if (v == 0 || (((v & 63) == 1 || (v & 63) == 2) && (v >> 6) <= 1)) return v;
+            fprintf(stderr, "libagz: AGZ_WINO_H2_GEMM=%s ignored (want 1 or 2, optionally + 64)\n", e);
+            return 0;
+          }();
           const int gv = wino_gemm > 0 ? wino_gemm : gemm_env;
           hh.gemm_variant = gv & 63; hh.temporal_stores = (gv >> 6) & 1;
         }
@@ -1846,6 +1854,13 @@ int agz_net_set_wino_h2_form(agz_net* n, int form) {
   AGZ_REQUIRE(n, AGZ_E_INVALID, "agz_net_set_wino_h2_form: null net");
   AGZ_REQUIRE(form >= -1 && form <= 2, AGZ_E_INVALID, "agz_net_set_wino_h2_form: form %d (want -1, 0 or 1)", form);
   n->wino_form = form;
+  return AGZ_OK;
+}
+
+int agz_net_min_same_batch(agz_net* n, int k, int G, int* batch) {
+  AGZ_REQUIRE(n && batch && k >= 1 && G >= k, AGZ_E_INVALID, "agz_net_min_same_batch: bad argument");
+  AGZ_REQUIRE(n->committed, AGZ_E_STATE, "agz_net_min_same_batch: commit the net first");
+  *batch = n->min_same_batch(k, G);
   return AGZ_OK;
 }
 

@@ -2014,6 +2014,17 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
   float* dnext = dB;
   if (fh) hipLaunchKernelGGL(k_head_conv_bwd_x2, dim3(nblk((size_t)g.M * (Kp / 4))), dim3(256), 0, s, g, dzh, P + o_hc, dcur, Kp);
   else hipLaunchKernelGGL(k_head_conv_bwd_x, dim3(nblk((size_t)g.M * Kp)), dim3(256), 0, s, g, dzh, P + o_hc, dcur, Kp);
+  if (wino) {
+    // the weight gradient's fp16 scratch at its largest layer, BEFORE the first slice goes to the reduction queue: an allocation failure
+    // between two slices would leave the peers waiting in the collectives this rank never enters
+    size_t need_dz = 0, need_x = 0;
+    for (int l = 0; l <= L; l++) {
+      need_dz = std::max(need_dz, (size_t)B * g.Hp * g.Wp * layers[l].Cout_p);
+      need_x = std::max(need_x, (size_t)B * g.Hp * g.Wp * layers[l].Cin_p);
+    }
+    if (dz_h2_cap < need_dz) { if (dz_h2) hipFree(dz_h2); dz_h2 = nullptr; dz_h2_cap = 0; AGZ_HIP_TRY(hipMalloc(&dz_h2, need_dz * 4)); dz_h2_cap = need_dz; }
+    if (x_h2_cap < need_x) { if (x_h2) hipFree(x_h2); x_h2 = nullptr; x_h2_cap = 0; AGZ_HIP_TRY(hipMalloc(&x_h2, need_x * 4)); x_h2_cap = need_x; }
+  }
   if (on_slice) { int r = on_slice(o_hc, n_flat - o_hc, s); if (r != AGZ_OK) return r; }   // the heads' gradients are final
   // ---- tower backward
   { int r = side_stream(); if (r != AGZ_OK) return r; }
@@ -2115,6 +2126,13 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
 // (comm.hip) the context a trainer was created on
 agz_ctx* agz_trainer_ctx(const agz_trainer* t) { return t ? t->ctx : nullptr; }
 void agz_trainer_set_slice_hook(agz_trainer* t, std::function<int(size_t, size_t, hipStream_t)> f) { t->on_slice = std::move(f); }
+// the slices forward_backward_dev hands to on_slice, in the order it issues them: the heads, then layer L .. 0 ([filter | gamma | beta])
+void agz_trainer_slices(const agz_trainer* t, std::vector<std::pair<size_t, size_t>>& out) {
+  out.clear();
+  out.emplace_back(t->o_hc, t->n_flat - t->o_hc);
+  const int L = (int)t->layers.size() - 1;
+  for (int l = L; l >= 0; l--) out.emplace_back(t->layers[l].o_wf, (l < L ? t->layers[l + 1].o_wf : t->o_hc) - t->layers[l].o_wf);
+}
 
 extern "C" {
 

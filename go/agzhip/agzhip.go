@@ -25,6 +25,7 @@ import "C"
 
 import (
 	"errors"
+	"fmt"
 	"runtime"
 	"sync"
 	"time"
@@ -386,7 +387,7 @@ func NewMCTS(ctx *Ctx, kind GameKind, g game.State, k int, komi float32, encoder
 		Budget: C.int32_t(conf.Budget), RandomMinVisits: C.uint32_t(conf.RandomMinVisits), RandomTemperature: C.float(conf.RandomTemperature),
 		DumbPass: C.int32_t(dumb), ResignPercentage: C.float(conf.ResignPercentage), PassPreference: C.int32_t(conf.PassPreference)}
 	t := &MCTS{ctx: ctx, cells: m * n, action: g.ActionSpace(), current: g}
-	if err := lastErr(C.agz_mcts_create(ctx.h, &gc, &mc, C.uint64_t(seed), 0, &t.h)); err != nil {
+	if err := lastErr(C.agz_mcts_create(ctx.h, &gc, &mc, C.uint64_t(seed), C.int(poolNodes(conf, g.ActionSpace(), nn != nil)), &t.h)); err != nil {
 		return nil, err
 	}
 	kindInf, h := C.int(C.AGZ_INF_DUMMY), (*C.agz_net)(nil)
@@ -407,6 +408,32 @@ func NewMCTS(ctx *Ctx, kind GameKind, g game.State, k int, komi float32, encoder
 		}
 	}
 	return t, nil
+}
+
+// poolNodes: the node pool of a tree whose conf has no Budget (the reference's callers set Timeout only).  Sized from the time-out —
+// a search cannot expand more leaves than it has time for: a batch-1 evaluation of a residual tower takes >= 0.25 ms on the device
+// (4000 simulations/s), a synthetic inferencer ~16 us (60000/s) — times ActionSpace+1 children per expansion, at least 64 expansions,
+// at most the library's 8 M-node ceiling.  A conf with a Budget returns 0: the library sizes the pool from the Budget.  (Round 5 let the
+// library default to 65536 expansions for every such handle: about a GB of device memory per Agent.)  A pool that fills before the clock
+// runs out ENDS the search with the best move so far (agz_mcts_search).
+func poolNodes(conf mcts.Config, actionSpace int, withNet bool) int {
+	if conf.Budget > 0 {
+		return 0
+	}
+	rate := 60000.0
+	if withNet {
+		rate = 4000.0
+	}
+	d := conf.Timeout
+	if d <= 0 {
+		d = 100 * time.Millisecond // the reference's DefaultConfig
+	}
+	exp := int(d.Seconds()*rate) + 64
+	nodes := int64(exp) * int64(actionSpace+1)
+	if nodes > 8000000 {
+		nodes = 8000000
+	}
+	return int(nodes)
 }
 
 // timeoutMs: a positive duration below one millisecond is one millisecond (0 would silently mean "exactly Budget simulations").
@@ -602,6 +629,11 @@ func NewTrainer(ctx *Ctx, d *dual.Dual) (*Trainer, error) {
 // into d.Model() so the rest of AZ.Learn (SwitchToInference, Save) sees the trained network.  Xs [rows, F, H, W], policies
 // [rows, ActionSpace], values [rows] as flat float32 slices (tensor.Dense.Data()).
 func (t *Trainer) Train(Xs, policies, values []float32, batches, iterations int, seed uint64) error {
+	rows := batches * t.d.BatchSize
+	if batches < 1 || len(Xs) < rows*t.d.Features*t.d.Height*t.d.Width || len(policies) < rows*t.d.ActionSpace || len(values) < rows {
+		return fmt.Errorf("agzhip: Train: %d batches of %d rows need %d / %d / %d values, got %d / %d / %d", batches, t.d.BatchSize,
+			rows*t.d.Features*t.d.Height*t.d.Width, rows*t.d.ActionSpace, rows, len(Xs), len(policies), len(values))
+	}
 	defer t.ctx.enter()()
 	var cost C.float
 	if err := lastErr(C.agz_train(t.h, (*C.float)(unsafe.Pointer(&Xs[0])), (*C.float)(unsafe.Pointer(&policies[0])),
@@ -688,6 +720,18 @@ func (c *Comm) AllReduceGradients(t *Trainer, lr float32) error {
 // flat gradient buffer summed over the ranks while the rest of the backward runs (agz_trainer_forward_backward_allreduce), then the
 // averaged SGD step.  Every rank calls it for the same step.
 func (c *Comm) BatchStep(t *Trainer, planes, pi, v []float32, lr float32) (cost float32, err error) {
+	// (lengths first: the C side reads exactly one batch from each slice, and an error returned here comes BEFORE this rank enters the
+	// step's collectives — its peers must be stopped by the caller, as after any programming error on one rank)
+	b := t.d.BatchSize
+	if want := b * t.d.Features * t.d.Height * t.d.Width; len(planes) < want {
+		return 0, fmt.Errorf("agzhip: BatchStep: planes has %d values, one batch is %d", len(planes), want)
+	}
+	if want := b * t.d.ActionSpace; len(pi) < want {
+		return 0, fmt.Errorf("agzhip: BatchStep: pi has %d values, one batch is %d", len(pi), want)
+	}
+	if len(v) < b {
+		return 0, fmt.Errorf("agzhip: BatchStep: v has %d values, one batch is %d", len(v), b)
+	}
 	defer c.ctx.enter()()
 	var cc C.float
 	if err := lastErr(C.agz_trainer_forward_backward_allreduce(c.h, t.h, (*C.float)(unsafe.Pointer(&planes[0])), (*C.float)(unsafe.Pointer(&pi[0])),

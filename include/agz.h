@@ -51,6 +51,8 @@ extern "C" {
 #define AGZ_E_STATE (-4)     /* call sequence error (e.g. infer before commit) */
 #define AGZ_E_TREE_FULL (-5) /* a tree's node pool overflowed (reference cap: MAXTREESIZE, mcts/search.go:23) */
 #define AGZ_E_UNSUPPORTED (-6)
+#define AGZ_E_CALLBACK (-8)  /* a host inferencer (AGZ_INF_CALLBACK) returned non-zero: the search was aborted */
+#define AGZ_E_PEER (-7)      /* a data-parallel step failed on ANOTHER rank (agz_trainer_forward_backward_allreduce): gradients undefined */
 
 typedef struct agz_ctx agz_ctx;
 typedef struct agz_net agz_net;
@@ -270,6 +272,30 @@ typedef struct agz_mcts_conf {
 #define AGZ_INF_SCRIPT 2 /* mcts/example_test.go:40-72 dummyNN (tic-tac-toe script by move number) */
 #define AGZ_INF_HASH 3   /* deterministic synthetic inferencer (integer hash of the position): parity tests */
 #define AGZ_INF_UNIFORM 4 /* mcts/example_test.go:158-166 dummyNN2: 1/25 policy (len 25), value 1/25 */
+#define AGZ_INF_CALLBACK 5 /* ANY mcts.Inferencer as a host function (agz_arena_set_inferencer_callback / agz_mcts_set_inferencer_callback) */
+
+/* The `nn Inferencer` argument of mcts.New is an interface: Infer(state game.State) (policy []float32, value float32)
+ * (mcts/mcts.go:15-18; tree.go:80).  A host inferencer meets the device search between its two kernels: after the descent every
+ * expandable leaf of the agents that hold one is handed over as ONE batch — per leaf the encoder's input tensor (what Agent.Infer builds from
+ * the state, agent.go:60-74), the board, the mover and MoveNumber() — and the callee fills one policy row and one value per leaf, exactly
+ * what Infer returns: policy_len probabilities whose LAST entry is the pass probability (search.go:276), and the value as the
+ * network reports it (the search itself turns it into `1 - value` for White, search.go:278-280).  The rows are consumed by the same
+ * expansion kernel that reads a network's.  One host round trip per simulation step for all games of the arena: the boundary for
+ * caller-supplied networks and a network-independent differential hook; AGZ_INF_NET keeps the whole step on the device.
+ * Return 0; anything else aborts the search (AGZ_E_CALLBACK; reset the arena).  The function runs on the thread that called into libagz. */
+typedef struct agz_leaf_batch {
+  int32_t n;                  /* leaves in this call (>= 1) */
+  int32_t features, height, width; /* geometry of `planes` (the arena's encoder) */
+  int32_t policy_len;         /* floats per policy row (the value given at registration) */
+  const float* planes;        /* [n][features][height][width] */
+  const int32_t* board;       /* [n][height*width]  AGZ_NONE / AGZ_BLACK / AGZ_WHITE */
+  const int32_t* to_move;     /* [n] the leaf state's ToMove() */
+  const int32_t* move_number; /* [n] the leaf state's MoveNumber() */
+  const int32_t* game;        /* [n] which game of the arena the leaf belongs to */
+  float* policy;              /* OUT [n][policy_len] */
+  float* value;               /* OUT [n] */
+} agz_leaf_batch;
+typedef int (*agz_infer_fn)(void* user, const agz_leaf_batch* batch);
 
 /* MakeArena × n_games (arena.go:42-70): n_games independent games, each with agents A and B, each
  * agent with its own search tree (mcts.New, mcts/tree.go:80-103).  max_nodes = node-pool capacity per
@@ -280,6 +306,9 @@ void agz_arena_destroy(agz_arena* arena);
 /* Agent.NN / SwitchToInference / useDummy (agent.go:42-57,105-113): agent 0 = A, 1 = B. net may be NULL
  * for the non-NET kinds. */
 int agz_arena_set_inferencer(agz_arena* arena, int agent, int kind, agz_net* net);
+/* agent `agent` holds a host inferencer (AGZ_INF_CALLBACK, above).  policy_len >= the game's ActionSpace (<= 4096).  Setting another
+ * kind with agz_arena_set_inferencer removes it. */
+int agz_arena_set_inferencer_callback(agz_arena* arena, int agent, agz_infer_fn fn, void* user, int policy_len);
 /* Start new games: fresh trees, empty boards, colour assignment.  a_is_black: per game 0/1, or NULL to
  * draw it from the arena RNG (arena.go:81-89 draws a.r.Intn(2)). */
 int agz_arena_reset(agz_arena* arena, const uint8_t* a_is_black);
@@ -401,6 +430,9 @@ int agz_mcts_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_conf
 void agz_mcts_destroy(agz_mcts* mcts);
 /* the `nn Inferencer` argument of mcts.New (mcts/mcts.go:15-18): AGZ_INF_* (net may be NULL for the synthetic kinds) */
 int agz_mcts_set_inferencer(agz_mcts* mcts, int kind, agz_net* net);
+/* mcts.New(game, conf, nn) with a caller-supplied Inferencer: `fn` is called once per simulation with the one leaf state (lane rounds:
+ * up to `lanes` leaves) — the reference's own dummyNN (mcts/example_test.go:40-72) runs through this as it runs through mcts.New */
+int agz_mcts_set_inferencer_callback(agz_mcts* mcts, agz_infer_fn fn, void* user, int policy_len);
 /* lanes per round (BUILD EXTENSION, see agz_arena_set_parallel) */
 int agz_mcts_set_parallel(agz_mcts* mcts, int lanes);
 /* (*MCTS).SetGame (tree.go:120-124) */
@@ -501,7 +533,10 @@ int agz_trainer_allreduce(agz_comm* comm, agz_trainer* t);
  * backward runs (the G19 trainer's buffer is 7.7 GB: as one call after the backward it would cost about as much xGMI time as the
  * whole compute step).  On return (asynchronous on the ctx stream, like agz_trainer_allreduce) the gradients are the sums; the result
  * equals forward_backward + agz_trainer_allreduce.  Follow with agz_trainer_apply(t, lr, 1.0f / agz_comm_size(comm)).  Every rank
- * must call it for the same step (the slices are collectives, issued in the same order everywhere).  dualnet/meta.go:16-54. */
+ * must call it for the same step (the slices are collectives, issued in the same order everywhere).  Errors: a rank that fails part-way
+ * still enters every collective of the step, and the step ends with a one-word status exchange — the call then fails on EVERY rank
+ * (AGZ_E_PEER on the ranks that were fine themselves) and the gradients must not be applied; an error of RCCL itself is fatal for the
+ * process group (destroy the communicator).  dualnet/meta.go:16-54. */
 int agz_trainer_forward_backward_allreduce(agz_comm* comm, agz_trainer* t, const float* planes, const float* pi, const float* v, float* cost);
 int agz_trainer_forward_backward_allreduce_dev(agz_comm* comm, agz_trainer* t, const float* planes_dev, const float* pi_dev, const float* v_dev, float* cost);
 

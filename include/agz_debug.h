@@ -75,6 +75,17 @@ int agz_arena_last_prep_batch(agz_arena* arena, int* boards, int* roots);
  * WRONG results, timing only. */
 int agz_trainer_set_dma_forward(agz_trainer* t, int on);
 
+/* The smallest batch >= n that runs the kernels of a batch of G boards on this net in its current compute mode (agz_net::min_same_batch, what
+ * prepareRoot's packed forward uses): per board the outputs of such a batch are those of the G-board batch bit for bit.  The parity tests
+ * evaluate single leaves for the oracle with it instead of G copies of the board. */
+int agz_net_min_same_batch(agz_net* net, int n, int G, int* batch);
+
+/* Failure injection (tests): the data-parallel step of this communicator fails on THIS rank right before it would enter the collective of
+ * slice k (0 = the heads, 1 .. = layer L .. 0; k < 0: off).  One shot: cleared by the step it hits.  What the test checks is the rule of
+ * agz_trainer_forward_backward_allreduce: the failing rank still enters every collective, every rank's call fails (AGZ_E_PEER on the
+ * healthy ones), nobody hangs, and the next step is a normal one. */
+int agz_comm_debug_fail_slice(agz_comm* comm, int k);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,90 @@ def test_allgather_and_allreduce_over_n_ranks_on_one_gpu(counts, tmp_path):
     assert not np.array_equal(R[0]["local0"], R[1]["local0"])
 
 
+FAIL_WORKER = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import agogo_amd as A
+rank, n, out, bad_rank, bad_slice = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+ctx = A.Ctx(0)
+idf = out + ".uid"
+if rank == 0:
+    uid = A.Comm.unique_id()
+    with open(idf + ".tmp", "wb") as f:
+        f.write(uid)
+    os.replace(idf + ".tmp", idf)
+else:
+    t0 = time.time()
+    while not os.path.exists(idf):
+        assert time.time() - t0 < 60
+        time.sleep(0.01)
+    uid = open(idf, "rb").read()
+comm = A.Comm.init_rank(ctx, n, rank, uid)
+tr = A.Trainer(ctx, 32, 2, 16, 3, 3, 2, 10, 4)          # slices: heads, layer 2, layer 1, layer 0
+tr.init_random(3)
+rng = np.random.default_rng(100 + rank)
+x = rng.choice(np.array([-1, 0.001, 1], np.float32), size=(4, 2, 3, 3)).astype(np.float32)
+pi = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 4)]
+val = rng.choice(np.array([-1, 0, 1], np.float32), size=4).astype(np.float32)
+tr.forward_backward(x, pi, val)
+local = [tr.get_grad(i).copy() for i in range(tr.num_params())]
+if rank == bad_rank:
+    comm.debug_fail_slice(bad_slice)
+msg = ""
+try:
+    comm.forward_backward_allreduce(tr, x, pi, val)
+except A.AgzError as e:
+    msg = str(e)
+ctx.sync()
+# the next step is an ordinary one on every rank
+comm.forward_backward_allreduce(tr, x, pi, val)
+ctx.sync()
+summed = [tr.get_grad(i).copy() for i in range(tr.num_params())]
+np.savez(out + ".r%d.npz" % rank, msg=np.array(msg), nparams=tr.num_params(),
+         **{"local%d" % i: g for i, g in enumerate(local)}, **{"sum%d" % i: g for i, g in enumerate(summed)})
+comm.close()
+"""
+
+
+@pytest.mark.parametrize("n,bad_rank,bad_slice", [(2, 1, 1), (3, 0, 0), (2, 0, 3)])
+def test_a_rank_that_fails_inside_the_data_parallel_step_does_not_hang_its_peers(n, bad_rank, bad_slice, tmp_path):
+    """agz_trainer_forward_backward_allreduce issues L + 2 collectives from inside the backward pass; a rank that
+    failed after the first one used to return with the rest un-entered — its peers blocked for ever.  Now the failing rank still enters every
+    collective of the step and all ranks exchange a status word: the call fails on EVERY rank (AGZ_E_PEER = -7 on the healthy ones), nobody
+    hangs, and the following step reduces normally (bit-identical to the sum of the ranks' own gradients).  Failure injected by
+    agz_comm_debug_fail_slice before the first, a middle and the last slice."""
+    assert os.path.exists(FAKE)
+    out = str(tmp_path / "f")
+    env = dict(os.environ, AGZ_RCCL_LIB=FAKE)
+    procs = [subprocess.Popen([sys.executable, "-c", FAIL_WORKER, str(r), str(n), out, str(bad_rank), str(bad_slice)], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(n)]
+    logs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    for r, pr in enumerate(procs):
+        assert pr.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-3000:])
+    R = [np.load(out + ".r%d.npz" % r) for r in range(n)]
+    for r in range(n):
+        msg = str(R[r]["msg"])
+        if r == bad_rank:
+            assert "(-4)" in msg and "injected failure before slice %d" % bad_slice in msg, msg
+        else:
+            assert "(-7)" in msg and "another rank failed" in msg, msg
+    for i in range(int(R[0]["nparams"])):
+        s_ = R[0]["local%d" % i].astype(np.float32).copy()
+        for r in range(1, n):
+            s_ = (s_ + R[r]["local%d" % i]).astype(np.float32)
+        for r in range(n):
+            np.testing.assert_array_equal(R[r]["sum%d" % i], s_)
+
+
 def test_fake_rccl_is_test_infrastructure_only():
     """the product never names the double: it only honours AGZ_RCCL_LIB"""
     for d, _, fs in os.walk(os.path.join(ROOT, "agogo_amd")):

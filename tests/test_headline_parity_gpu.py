@@ -133,8 +133,8 @@ def test_headline_network_l20_b512_midgame_boards_vs_oracle(ctx, mode):
 @pytest.mark.parametrize("mode", ["wino"] + (["wino_h2"] if "wino_h2" in MODES else []))
 def test_headline_engine_512_games_on_their_own_positions_bit_exact(ctx, mode):
     """(ii) configs[3] per GPU as bench.py runs it: 512 games, each on its own random opening, the measured arithmetic,
-    two searched plies; games 0, 1 and 311 against oracle arenas whose inferencer is the same GPU network evaluated as a
-    512-row batch of the one board (same kernels; the arithmetic is batch independent bit for bit, test above)."""
+    two searched plies; 32 watched games against oracle arenas whose inferencer is the same GPU network evaluated as a batch of copies
+    of the one board (agz_net_min_same_batch rows: the kernels of the 512-row batch; the arithmetic is batch independent bit for bit)."""
     L, G, budget, seed = 20, 512, 12, 1337
     net = std_net(ctx, L)
     net.set_compute_mode(MODES[mode])
@@ -149,14 +149,23 @@ def test_headline_engine_512_games_on_their_own_positions_bit_exact(ctx, mode):
     dev.random_moves(n_moves, seed)
     assert len({dev.game(g)[0].tobytes() for g in range(0, G, 16)}) == G // 16
 
+    nb = net.min_same_batch(1, G)      # the smallest batch with the G-board batch's kernels: per board the same bits (asserted below)
+
     def cb(planes):
-        p, v = net.infer(np.repeat(planes.reshape(1, F, S, S), G, axis=0))
+        p, v = net.infer(np.repeat(planes.reshape(1, F, S, S), nb, axis=0))
         return p[0], float(v[0])
 
-    watch = (0, 1, 311)
+    x0 = cached_midgame(512)[0][7:8]
+    pa, va = net.infer(np.repeat(x0, nb, axis=0))
+    pb, vb = net.infer(np.repeat(x0, G, axis=0))
+    np.testing.assert_array_equal(pa[0], pb[G - 1])
+    np.testing.assert_array_equal(va[0], vb[0])
+    # 32 watched games (round 5: 3) spread over the arena — both colour assignments, openings from 0 to 216 moves
+    watch = tuple(sorted(set([0, 1, 311] + [int(x) for x in np.linspace(2, G - 1, 29).round()])))
+    assert len(watch) == 32
     orcs = {}
     for g in watch:
-        o = O.Arena(O.WQ, S, S, 0, 7.5, enc=O.ENC_WQ, Budget=budget)
+        o = O.Arena(O.WQ, S, S, 0, 7.5, enc=O.ENC_WQ, Budget=budget, seed=seed + g)
         o.set_callback(0, cb, ASPACE)
         o.set_callback(1, cb, ASPACE)
         o.begin(int(ab[g]))
@@ -436,5 +445,180 @@ def test_config4_one_tree_search_bit_exact_vs_oracle(ctx, lanes, latency, forced
         boards.append(g.board())
         player = O.WHITE if player == O.BLACK else O.BLACK
         g.set_to_move(player)
+    dev.close()
+    net.close()
+
+
+# ---- the search pinned at the depth bench.py measures -------------------------------------------------------------
+
+def _replay_opening(o, seed, g, n):
+    for _ in range(int(n)):
+        o.random_move(seed, g)
+
+
+def test_headline_budget_800_three_plies_on_the_measured_network_bit_exact(ctx):
+    """1(a): BASELINE configs[3] per GPU AT ITS OWN BUDGET — 19x19, K=256, 20 blocks, 512 games, AGZ_COMPUTE_WINO_H2, **800 simulations per
+    move**, the node pools bench.py runs with (max_nodes = 0: the library's default from the Budget), three searched plies: the third ply
+    searches a tree RE-ROOTED from an 800-visit tree through the packed prepareRoot batch (mcts/search.go:92-164, 424-500).  One watched
+    game against an oracle arena fed the same network (agz_net_min_same_batch copies of the leaf: the 512-board batch's kernels) —
+    children, visit counts, blackScores bits, prior bits, the move — and no pool of any of the 1024 trees may overflow."""
+    L, G, budget, seed, g = 20, 512, 800, 4242, 137
+    net = std_net(ctx, L)
+    net.set_compute_mode(MODES["wino_h2"])
+    dev = A.Arena(ctx, capi.GAME_WQ, S, S, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=seed, Budget=budget)
+    dev.set_inferencer(0, capi.INF_NET, net)
+    dev.set_inferencer(1, capi.INF_NET, net)
+    ab = np.array([(i % 2) == 0 for i in range(G)], dtype=np.uint8)
+    dev.reset(ab)
+    rng = np.random.default_rng(seed)
+    n_moves = rng.integers(0, 217, size=G).astype(np.int32)
+    n_moves[g] = 120
+    dev.random_moves(n_moves, seed)
+    nb = net.min_same_batch(1, G)
+
+    def cb(planes):
+        p, v = net.infer(np.repeat(planes.reshape(1, F, S, S), nb, axis=0))
+        return p[0], float(v[0])
+
+    o = O.Arena(O.WQ, S, S, 0, 7.5, enc=O.ENC_WQ, Budget=budget, seed=seed + g)
+    o.set_callback(0, cb, ASPACE)
+    o.set_callback(1, cb, ASPACE)
+    o.begin(int(ab[g]))
+    _replay_opening(o, seed, g, n_moves[g])
+    np.testing.assert_array_equal(dev.history(g), o.history())
+    root_visits, nodes, preps = [], [], []
+    for ply in range(3):
+        dev.begin_move()
+        preps.append(dev.last_prep_batch())
+        dev.simulate(budget)
+        dev.end_move(True)
+        _, st0 = o.state()
+        agent = 0 if ((st0["to_move"] == O.BLACK) == bool(ab[g])) else 1
+        o.step(True)
+        omv, ovis, obs, opr = o.root_children(agent)
+        dmv, dvis, dbs, dpr = dev.root_children(g, agent)
+        np.testing.assert_array_equal(dmv, omv, err_msg="ply %d" % ply)
+        np.testing.assert_array_equal(dvis, ovis, err_msg="ply %d" % ply)
+        np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+        np.testing.assert_array_equal(dpr.view(np.uint32), opr.view(np.uint32))
+        assert dev.history(g)[-1] == o.history()[-1]
+        root_visits.append(int(ovis.sum()))
+        nodes.append(dev.tree_nodes(g, agent))
+    st = dev.stats()
+    assert st["tree_full"] == 0 and st["sims_total"] == 3 * G * budget
+    assert root_visits[0] >= budget and root_visits[2] > root_visits[0], root_visits   # ply 3: this search's 800 on top of the kept subtree
+    assert min(nodes) > 100000, nodes
+    assert preps[0] == (G, G) and 0 < preps[2][1] < G and preps[2][0] <= G, preps     # the re-rooted ply: only the roots without children
+    print("\n[headline depth] budget 800 x 3 plies: root visits %r, tree nodes %r, prepareRoot batches %r" % (root_visits, nodes, preps))
+    dev.close()
+    net.close()
+
+
+def test_headline_budget_800_hash_inferencer_24_watched_games_bit_exact(ctx):
+    """1(b): the same arena shape and Budget (19x19, 512 games, 800 simulations per move, three plies, default pools) with AGZ_INF_HASH — the
+    oracle's cost is then MCTS only — and 24 watched games spread over the opening depths (0 .. 216 moves) and both colours: every watched
+    root after every ply (children, visits, blackScores bits, prior bits), every move, and the finished examples of the watched games."""
+    G, budget, seed = 512, 800, 99
+    dev = A.Arena(ctx, capi.GAME_WQ, S, S, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=seed, Budget=budget)
+    dev.set_inferencer(0, capi.INF_HASH)
+    dev.set_inferencer(1, capi.INF_HASH)
+    ab = np.array([(i % 3) != 0 for i in range(G)], dtype=np.uint8)
+    dev.reset(ab)
+    rng = np.random.default_rng(seed)
+    n_moves = rng.integers(0, 217, size=G).astype(np.int32)
+    order = np.argsort(n_moves, kind="stable")
+    watch = sorted(set(int(order[i]) for i in np.linspace(0, G - 1, 24).round().astype(int)))
+    assert len(watch) == 24
+    dev.random_moves(n_moves, seed)
+    orcs = {}
+    for g in watch:
+        o = O.Arena(O.WQ, S, S, 0, 7.5, enc=O.ENC_WQ, Budget=budget, seed=seed + g)
+        o.set_inferencer(0, O.INF_HASH)
+        o.set_inferencer(1, O.INF_HASH)
+        o.begin(int(ab[g]))
+        _replay_opening(o, seed, g, n_moves[g])
+        np.testing.assert_array_equal(dev.history(g), o.history())
+        orcs[g] = o
+    from concurrent.futures import ThreadPoolExecutor
+    for ply in range(3):
+        dev.begin_move()
+        dev.simulate(budget)
+        dev.end_move(True)
+        agents = {}
+        for g, o in orcs.items():
+            _, st0 = o.state()
+            agents[g] = 0 if ((st0["to_move"] == O.BLACK) == bool(ab[g])) else 1
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:      # (the oracle calls run outside the GIL)
+            list(ex.map(lambda o: o.step(True), orcs.values()))
+        for g, o in orcs.items():
+            omv, ovis, obs, opr = o.root_children(agents[g])
+            dmv, dvis, dbs, dpr = dev.root_children(g, agents[g])
+            np.testing.assert_array_equal(dmv, omv, err_msg="game %d ply %d" % (g, ply))
+            np.testing.assert_array_equal(dvis, ovis, err_msg="game %d ply %d" % (g, ply))
+            np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+            np.testing.assert_array_equal(dpr.view(np.uint32), opr.view(np.uint32))
+            assert dev.history(g)[-1] == o.history()[-1]
+            if ply == 2:
+                assert int(ovis.sum()) > budget + len(ovis)          # the re-rooted tree kept visits from ply 0
+    st = dev.stats()
+    assert st["tree_full"] == 0 and st["sims_total"] == 3 * G * budget
+    dev.close()
+
+
+@pytest.mark.parametrize("lanes,forced", [(1, None), (8, None), (16, "wino_h2")])
+def test_config4_budget_1600_one_tree_bit_exact_vs_oracle(ctx, lanes, forced):
+    """1(c): BASELINE configs[4] AT ITS OWN BUDGET — one tree, 40 blocks, **1600 simulations per move**, the three operating points
+    bench.py's latency leg reports (sequential and lane rounds of 8 on the latency kernel, lane rounds of 16 on the forced Winograd tower),
+    two turns from a 90-move position through the single-tree boundary, the second turn re-rooting the first's tree: device tree ==
+    oracle tree given the same network outputs (children, visits, blackScores bits, priors bits, move)."""
+    L, budget = 40, 1600
+    net = std_net(ctx, L)
+    net.set_latency_mode(True)
+    if forced:
+        net.set_compute_mode(MODES[forced] | capi.COMPUTE_FORCE)
+    g = O.Game(O.WQ, S, S, 0, 7.5)
+    rng = np.random.default_rng(23)
+    player, moves, boards = O.BLACK, [], []
+    g.set_to_move(player)
+    for _ in range(90):
+        empt = np.where(g.board() == 0)[0]
+        mv = next(int(c) for c in rng.permutation(empt) if g.check(player, int(c)))
+        g.apply(player, mv)
+        moves.append(mv)
+        boards.append(g.board())
+        player = O.WHITE if player == O.BLACK else O.BLACK
+        g.set_to_move(player)
+    dev = A.Mcts(ctx, capi.GAME_WQ, S, S, 0, 7.5, encoder=capi.ENC_WQ, Budget=budget)
+    dev.set_inferencer(capi.INF_NET, net)
+    dev.set_parallel(lanes)
+    orc = O.Mcts(g, enc=O.ENC_WQ, Budget=budget, lanes=lanes)
+
+    def cb(planes):
+        p, v = net.infer(planes.reshape(1, F, S, S))
+        return p[0], float(v[0])
+
+    orc.set_callback(cb, ASPACE)
+    vis_sum = []
+    for turn in range(2):
+        dev.set_game(board=g.board(), to_move=player, n_moves=len(moves), passes=0, hash=g.hash(), last_moves=moves,
+                     historical=np.array(boards[-8:], np.int32))
+        orc.set_game(g)
+        bd, bo = dev.search(player), orc.search(player)
+        assert bd == bo
+        omv, ovis, obs, opr = orc.root_children()
+        dmv, dvis, dbs, dpr = dev.root_children()
+        np.testing.assert_array_equal(dmv, omv)
+        np.testing.assert_array_equal(dvis, ovis)
+        np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+        np.testing.assert_array_equal(dpr.view(np.uint32), opr.view(np.uint32))
+        vis_sum.append(int(ovis.sum()))
+        g.apply(player, bd)           # the next turn searches for the other colour: its root is this search's most visited child
+        moves.append(bd)
+        boards.append(g.board())
+        player = O.WHITE if player == O.BLACK else O.BLACK
+        g.set_to_move(player)
+    assert vis_sum[1] > budget + 362      # turn 2 searched a re-rooted tree (the kept subtree's visits on top of its own 1600)
+    assert dev.stats()["tree_full"] == 0
+    assert dev.nodes() > 100000
     dev.close()
     net.close()

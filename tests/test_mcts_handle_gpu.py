@@ -328,6 +328,38 @@ def test_wall_clock_search_without_a_budget(ctx):
     dev.close()
 
 
+def test_a_pool_that_fills_twice_on_one_handle(ctx):
+    """ADVICE r5 (engine.hip): the overflow mark of a tree was cleared only by a reset, so CNT_FULL moved on a handle's FIRST overflow only:
+    the second pool-filling wall-clock search spun on its stalled tree until the deadline, and a Budget handle returned AGZ_OK for its
+    second truncated search.  Now k_begin_move clears the mark (every search is judged by what it adds): two consecutive pool-filling
+    searches on one long-lived handle both end early (wall clock) / both raise (Budget)."""
+    import time
+    host = Host(O.WQ, 9, 9, 0, 7.5)
+    dev = A.Mcts(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, Budget=0, max_nodes=400)
+    dev.set_inferencer(capi.INF_HASH)
+    dev.set_timeout_ms(2000)
+    player = O.BLACK
+    for turn in range(3):
+        dev.set_game(**host.state_kw())
+        t0 = time.perf_counter()
+        mv = dev.search(player)                                    # AGZ_OK every time: a full pool ends a wall-clock search
+        dt = time.perf_counter() - t0
+        assert dt < 1.0, (turn, dt)                                # (round 5: turn 1 ran to the 2 s deadline)
+        assert dev.last_simulations() >= 1 and (mv == capi.PASS or mv in host.legal(player)), (turn, mv)
+        host.apply(player, mv)
+        player = O.WHITE if player == O.BLACK else O.BLACK
+    dev.close()
+    host = Host(O.WQ, 9, 9, 0, 7.5)
+    dev = A.Mcts(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, Budget=64, max_nodes=400)
+    dev.set_inferencer(capi.INF_HASH)
+    for turn in range(2):
+        dev.set_game(**host.state_kw())
+        with pytest.raises(A.AgzError, match="overflowed"):        # (round 5: the second search returned AGZ_OK)
+            dev.search(O.BLACK if turn == 0 else O.WHITE)
+        host.apply(O.BLACK if turn == 0 else O.WHITE, 40 + turn)
+    dev.close()
+
+
 def test_to_dot_renders_the_live_tree(ctx):
     """(*MCTS).ToDot (mcts/graph.go:34-90) over the device tree: one node per tree node with the reference's rows, one edge per
     parent/child pair, children in move order, a node's board = the moves of its path (root: Black, then alternating)."""
