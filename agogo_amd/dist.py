@@ -11,8 +11,9 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher (torch.distributed.run)."""
+def init_from_env(backend=None, timeout_s=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher (torch.distributed.run).  timeout_s: the process group's collective
+    time-out (default: torch's own)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -23,7 +24,11 @@ def init_from_env(backend=None):
             # both device types: host-side bookkeeping tensors (digests, win counts) go over gloo, device buffers over RCCL
             # (an nccl-only group raises "No backend type associated with device type cpu" on a CPU tensor: ADVICE r1)
             backend = "cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if timeout_s:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world
 
 

@@ -235,7 +235,8 @@ def test_bench_two_ranks_end_to_end_through_the_self_relaunch(tmp_path):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu", "--games", "32", "--budget", "16", "--steps", "2",
-           "--warmup", "1", "--L", "4", "--no-cpu-baseline", "--no-games-leg", "--no-go9-leg", "--no-latency-leg", "--no-train-leg", "--no-f32-leg"]
+           "--warmup", "1", "--L", "4", "--cpu-threads", "8", "--cpu-baseline-seconds", "2", "--no-games-leg", "--no-go9-leg", "--no-latency-leg",
+           "--no-train-leg", "--no-f32-leg"]
     pr = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
     lines = [l for l in pr.stdout.decode().splitlines() if l.startswith("{")]
@@ -247,8 +248,47 @@ def test_bench_two_ranks_end_to_end_through_the_self_relaunch(tmp_path):
     assert d["rccl_ranks"] == 2
     assert d["rows_check"] == "ok" and len(d["rows_per_rank"]) == 2 and sum(d["rows_per_rank"]) == d["rows_gathered"] > 0
     assert min(d["rows_per_rank"]) > 0                         # both ranks' arenas recorded examples (a move boundary inside the run)
+    # the N > 1 line is COMPLETE — the CPU baseline (rank 0, once; the other rank waits in the closing barrier), the
+    # roofline object, and every rank's device memory in use
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] and cb["value"] > 0 and cb["cores"] == 8 and "rank 0 only" in cb["ran_on"]
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["frac"] > 0 and d["roofline"]["end_to_end"]["frac_of_fp32_mfma_peak"] > 0
+    assert len(d["config"]["hbm_used_bytes_per_rank"]) == 2 and min(d["config"]["hbm_used_bytes_per_rank"]) > 0
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_n2_two_ranks_one_gpu.json"), "w") as f:
+        json.dump(d, f, indent=1)
+
+
+def test_bench_eight_ranks_rehearsal_on_one_gpu(tmp_path):
+    """the driver's N = 8 launch line rehearsed before hardware sees it — `python -m torch.distributed.run --nproc-per-node 8
+    ... bench.py --gpus 8` with all eight ranks on GPU 0 (--shared-gpu: gloo process group, the in-tree RCCL double for libagz's exchange):
+    ports, environment, the eight-way aggregation (n_gpus = 8, every rank simulated, rows_gathered = the sum of eight ranks' rows, eight
+    communicator ranks), per-rank device memory, and a clean exit of all eight processes."""
+    import json
+    import socket
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ, AGZ_RCCL_LIB=FAKE)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--shared-gpu", "--games", "16", "--budget", "8", "--steps", "2", "--warmup", "1", "--L", "2",
+           "--no-cpu-baseline", "--no-games-leg", "--no-go9-leg", "--no-latency-leg", "--no-train-leg", "--no-f32-leg"]
+    pr = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in pr.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["world_size"] == 8 and d["scaling"] == "weak"
+    assert len(d["per_rank_sims"]) == 8 and min(d["per_rank_sims"]) > 0
+    assert abs(sum(d["per_rank_sims"]) - d["value"] * d["ms_per_step"] * d["steps"] * 1e-3) < 1.0
+    assert d["rccl_ranks"] == 8 and d["rows_check"] == "ok" and len(d["rows_per_rank"]) == 8 and sum(d["rows_per_rank"]) == d["rows_gathered"] > 0
+    assert len(d["config"]["hbm_used_bytes_per_rank"]) == 8 and min(d["config"]["hbm_used_bytes_per_rank"]) > 0
+    assert d["roofline"]["frac"] > 0
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_n8_eight_ranks_one_gpu.json"), "w") as f:
         json.dump(d, f, indent=1)
 
 
