@@ -222,6 +222,7 @@ def lib():
     sig("agz_arena_set_prep_compact", i32, vp, i32)
     sig("agz_trainer_set_dma_forward", i32, vp, i32)
     sig("agz_arena_last_prep_batch", i32, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
+    sig("agz_arena_debug_counter", i32, vp, i32, C.POINTER(C.c_int64))
     sig("agz_wino_h2_chained", i32, i32, i32, i32)
     sig("agz_arena_random_moves", i32, vp, pi, u64)
     sig("agz_arena_set_state", i32, vp, i32, C.POINTER(State))
@@ -678,6 +679,12 @@ class Arena:
         b, r = C.c_int(0), C.c_int(0)
         _check(lib().agz_arena_last_prep_batch(self.h, C.byref(b), C.byref(r)), "agz_arena_last_prep_batch")
         return b.value, r.value
+
+    def max_path_nodes(self):
+        """agz_debug.h AGZ_CNT_PATHMAX: nodes on the longest descent since the last reset"""
+        v = C.c_int64(0)
+        _check(lib().agz_arena_debug_counter(self.h, 15, C.byref(v)), "agz_arena_debug_counter")
+        return v.value
 
     def tree_nodes(self, g, agent):
         n = C.c_int32(0)

@@ -501,6 +501,7 @@ __global__ __launch_bounds__(64) void k_select(Dev d, GameCfg c, MctsCfg mc, flo
       if (!prep) {   // measurement only: nodes on the path and children read by Select, summed over simulations
         atomicAdd(&d.counters[CNT_PATH], (unsigned long long)plen);
         atomicAdd(&d.counters[CNT_KIDS], (unsigned long long)kids_seen);
+        atomicMax(&d.counters[CNT_PATHMAX], (unsigned long long)plen);   // the longest descent so far (a step lasts as long as its longest path)
       }
     }
     __syncthreads();
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(64) void k_select_paths(Dev d, GameCfg c, MctsCfg m
       if (!prep) {
         atomicAdd(&d.counters[CNT_PATH], (unsigned long long)plen);
         atomicAdd(&d.counters[CNT_KIDS], (unsigned long long)kids_seen);
+        atomicMax(&d.counters[CNT_PATHMAX], (unsigned long long)plen);   // the longest descent so far (a step lasts as long as its longest path)
       }
     }
     __syncthreads();
@@ -1653,7 +1655,9 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
   {
     size_t per_ex = (size_t)c.F * c.cells + (c.A + 1) + 3;
     size_t want = std::max<size_t>((size_t)G * c.max_moves * 2, 16384);  // room for restarted games (agz_arena_selfplay)
-    size_t budget = (size_t)(2ull << 30) / (per_ex * 4);  // <= 2 GiB of examples per arena
+    // <= 12 GiB of examples per arena (round 5: 2 GiB = 78 k rows on 19x19 — 512 complete games record 370 k, and the complete-games run
+    // of round 6 dropped 276 k of them; 288 GB of HBM hold the whole epoch: 512 games x 722 moves x 27.5 KB = 10.2 GB)
+    size_t budget = (size_t)(12ull << 30) / (per_ex * 4);
     d.ex_cap = (int)std::min(want, budget);
   }
   AL(ex_planes, (size_t)d.ex_cap * c.F * c.cells) AL(ex_policy, (size_t)d.ex_cap * (c.A + 1)) AL(ex_value, d.ex_cap)
@@ -1798,6 +1802,16 @@ int agz_arena_begin_move(agz_arena* a) {
   }
   a->in_move = true;
   return a->nn_step(1);  // prepareRoot
+}
+
+int agz_arena_debug_counter(agz_arena* a, int which, int64_t* value) {
+  AGZ_REQUIRE(a && value && which >= 0 && which < CNT_N, AGZ_E_INVALID, "agz_arena_debug_counter: bad argument");
+  AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  unsigned long long v = 0;
+  AGZ_HIP_TRY(hipMemcpyAsync(&v, a->d.counters + which, 8, hipMemcpyDeviceToHost, a->ctx->stream));
+  AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  *value = (int64_t)v;
+  return AGZ_OK;
 }
 
 int agz_arena_set_prep_compact(agz_arena* a, int on) {

@@ -130,7 +130,7 @@ struct Dev {
 };
 
 enum { CNT_SIMS = 0, CNT_NONNULL = 1, CNT_EVALS = 2, CNT_MOVES = 3, CNT_GAMES = 4, CNT_EXAMPLES = 5, CNT_FULL = 6, CNT_A_WINS = 7, CNT_B_WINS = 8,
-       CNT_DRAWS = 9, CNT_ILLEGAL = 10, CNT_DROPPED = 11, CNT_PATH = 12, CNT_KIDS = 13, CNT_PREP_EXPAND = 14, CNT_N = 16 };
+       CNT_DRAWS = 9, CNT_ILLEGAL = 10, CNT_DROPPED = 11, CNT_PATH = 12, CNT_KIDS = 13, CNT_PREP_EXPAND = 14, CNT_PATHMAX = 15, CNT_N = 16 };
 
 // per-agent inferencer description passed to the expand kernel
 struct InfDesc {

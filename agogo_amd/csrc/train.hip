@@ -1820,6 +1820,13 @@ struct agz_trainer {
     }
     return conv3_span <= CD3_IMG;
   }
+  // k_wgrad_h2t3 at ONE workgroup per CU (round 6): 16 KB of unused dynamic LDS on top of its 73.7 KB make a second workgroup not fit.  Two per CU
+  // hold the whole register file (243 registers x 2 waves per SIMD) and 147 of 160 KB of LDS: nothing of the main stream's chain (the data
+  // gradient, the next layer's BatchNorm backward) could be resident beside it and the side stream overlapped 4 %.  One per CU runs 0.72 instead
+  // of 0.53 ms on its own and leaves half of every SIMD's registers: both chains now progress together (the layer's backward 1.28 -> 1.19 ms,
+  // the step 42.4 -> 41.0 ms on the same box; profiles/r06/train_overlap.md).  Bit 8 of the hook: two per CU again (A/B).
+  int wg_pad_lds = 16384;
+  bool wg_low_prio = false; // bit 9: the side stream at the lowest priority (set before the first step)
   bool one_stream = false;  // bit 4 of the same hook: no side stream at all (diagnostic: a kernel table without overlap shows every kernel's own duration)
   hipEvent_t ev_w0 = nullptr, ev_bw = nullptr;
   int side_stream();
@@ -1838,7 +1845,12 @@ __global__ __launch_bounds__(256) void k_zero_regions(float* __restrict__ base, 
 
 int agz_trainer::side_stream() {
   if (wg_stream) return AGZ_OK;
-  AGZ_HIP_TRY(hipStreamCreateWithFlags(&wg_stream, hipStreamNonBlocking));
+  if (wg_low_prio) {
+    int lo = 0, hi = 0;
+    AGZ_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (numerically larger = lower priority)
+    AGZ_HIP_TRY(hipStreamCreateWithPriority(&wg_stream, hipStreamNonBlocking, lo));
+  } else
+    AGZ_HIP_TRY(hipStreamCreateWithFlags(&wg_stream, hipStreamNonBlocking));
   AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_dz, hipEventDisableTiming));
   AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_split, hipEventDisableTiming));
   AGZ_HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
@@ -2083,7 +2095,7 @@ int agz_trainer::forward_backward_dev(const float* planes, const float* pi, cons
         // CUs; about two rounds of them (5 chunks x 24 workgroups on 64 slots at K = 256; 4 to 8 chunks per XCD measured within 5 %)
         const int slots = ctx->num_cus / 8 * 2;
         w3.n_chunks = std::min(B, 8 * std::max(1, 2 * slots / per_chunk3));
-        hipLaunchKernelGGL(k_wgrad_h2t3, dim3((unsigned)(per_chunk3 * round_up(w3.n_chunks, 8))), dim3(256), 0, sw, w3);
+        hipLaunchKernelGGL(k_wgrad_h2t3, dim3((unsigned)(per_chunk3 * round_up(w3.n_chunks, 8))), dim3(256), (size_t)wg_pad_lds, sw, w3);
       } else {
         hipLaunchKernelGGL(k_split_h2, dim3(gs), dim3(256), 0, sw, dz, dz_h2, n_dz / 4, wg_amax);
         if (sw != s) { AGZ_HIP_TRY(hipEventRecord(ev_split, sw)); split_recorded = true; }
@@ -2500,6 +2512,8 @@ int agz_trainer_set_dma_forward(agz_trainer* t, int on) {
   t->conv3 = (on & 32) == 0;          // bit 5: the forward DMA convolution with one tap per K step (k_conv_h2dma) (A/B)
   t->one_stream = (on & 16) != 0;     // bit 4: everything on the step's stream (diagnostic)
   t->hoist_w = (on & 8) == 0;         // bit 3: weight images per layer in line, not at the start of the step on the side stream (A/B)
+  t->wg_pad_lds = (on & 256) ? 0 : 16384;   // bit 8: k_wgrad_h2t3 at two workgroups per CU as in round 5 (default: one, 73.7 KB static + 16 KB dynamic LDS)
+  t->wg_low_prio = (on & 512) != 0;     // bit 9: the side stream at the lowest priority (before the first step)
   return AGZ_OK;
 }
 

@@ -156,9 +156,9 @@ def cpu_baseline(size, K, L, budget_s=30.0, max_threads=64, g19_seconds=30.0):
     t0 = time.perf_counter()
     net.infer(x)
     t_eval = time.perf_counter() - t0
-    # under T concurrent evaluations one evaluation takes ~2.5x its solo time at 64 threads on this class of host (memory
-    # bandwidth), more with every core busy: the sample is sized for ~9 s either way
-    slow = 2.5 * max(1.0, T / 64.0) ** 0.5
+    # under T concurrent evaluations one evaluation takes ~4.5x its solo time at 64 threads on this class of host (memory
+    # bandwidth), more with every core busy
+    slow = 4.5 * max(1.0, T / 64.0) ** 0.5   # (measured in round 6: 5.9 s per evaluation under 64 concurrent ones against 1.3 s solo)
     # (round 5 sized this leg for ~9 s: 2 simulations per thread, 128 in all, and the figure moved 5.2 - 7.9 sims/s between rounds on the same
     # code; now a ~30 s box, at least 4 simulations per thread — VERDICT r5 weak 10)
     sims = int(max(4, min(64, g19_seconds / max(slow * t_eval, 1e-3) - 1)))
@@ -219,8 +219,8 @@ def games_leg(ctx, compute="bf16x3"):
            "games_finished": st["games_finished"], "seconds": dt, "games_per_s": st["games_finished"] / dt,
            "sims_per_s": st["sims_nonnull"] / dt, "moves_per_s": st["moves_played"] / dt, "examples": st["examples"],
            "game_length": _length_stats(lens), "distinct_games": len({arena.history(g).tobytes() for g in range(256)}),
-           "note": "the arena runs until its LONGEST game ends (finished games idle in the batch): games_per_s is a lower bound of the continuous-self-play rate, "
-                   "games_per_s_continuous = moves_per_s_at_full_occupancy / mean length is not claimed here"}
+           **_continuous_rate(256, dt, lens),
+           "note": "the arena runs until its LONGEST game ends (finished games idle in the batch): games_per_s is a lower bound of the continuous-self-play rate"}
     arena.close()
     net.close()
     return out
@@ -230,6 +230,16 @@ def _length_stats(lens):
     lens = np.asarray(lens)
     return {"mean": float(lens.mean()), "min": int(lens.min()), "p10": float(np.percentile(lens, 10)), "p50": float(np.percentile(lens, 50)),
             "p90": float(np.percentile(lens, 90)), "max": int(lens.max()), "distinct_lengths": int(len(np.unique(lens)))}
+
+
+def _continuous_rate(G, seconds, lens):
+    """continuous self-play (finished games restart at once, agz_arena_selfplay) keeps all G slots busy: one arena ply costs the same
+    whether a slot holds a live game or not (the batch is fixed), so its rate is G games per (mean length x seconds per arena ply)"""
+    lens = np.asarray(lens)
+    per_ply = seconds / max(1, int(lens.max()))
+    return {"seconds_per_arena_ply": per_ply, "games_per_s_continuous": G / (float(lens.mean()) * per_ply),
+            "games_per_s_continuous_note": "G / (mean game length x seconds per arena ply): the rate with every slot restarted as it finishes; "
+                                           "both factors measured in this run"}
 
 
 def go9_leg(ctx, compute="wino_h2"):
@@ -242,8 +252,10 @@ def go9_leg(ctx, compute="wino_h2"):
     net.commit()
     net.set_compute_mode(MODES[compute])
     # RandomCount = 8: the first eight moves drawn from the visit distribution (see games_leg) — 512 different games, not 512 copies of one
+    # (node pools: the default holds two searches' worth of expansions; a re-rooted NARROW tree keeps most of its nodes move after move, and
+    # with 512 different games one of them outgrew it in round 6's first run — six searches' worth here, peak use reported)
     arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337, Budget=sims, RandomCount=8,
-                    RandomMinVisits=1, RandomTemperature=1.0)
+                    RandomMinVisits=1, RandomTemperature=1.0, max_nodes=6 * (sims + 2) * 82)
     arena.set_inferencer(0, capi.INF_NET, net)
     arena.set_inferencer(1, capi.INF_NET, net)
     arena.reset()
@@ -261,7 +273,7 @@ def go9_leg(ctx, compute="wino_h2"):
            "sims_per_s": st["sims_nonnull"] / dt, "moves_per_s": st["moves_played"] / dt,
            "moves_per_game": st["moves_played"] / max(st["games_finished"], 1), "game_length": _length_stats(lens), "termination": ends,
            "distinct_games": len({arena.history(g).tobytes() for g in range(G)}), "examples": st["examples"],
-           "examples_dropped": st["examples_dropped"], "tree_full": st["tree_full"],
+           "examples_dropped": st["examples_dropped"], "tree_full": st["tree_full"], **_continuous_rate(G, dt, lens),
            "note": "the arena runs until its LONGEST game ends (finished games idle in the batch): games_per_s is a lower bound of the continuous-self-play rate"}
     arena.close()
     net.close()
@@ -301,12 +313,12 @@ def complete_19x19_leg(ctx, net, G=512, budget=16, S=19):
     dt = time.perf_counter() - t0
     st = arena.stats()
     lens = np.array([len(arena.history(g)) for g in range(G)])
-    aw, bw, dr = arena.results()
+    res = arena.results()
     out = {"workload": "%d complete 19x19 games (each once, to Ended()), K=256, 20 blocks, %d sims/move, RandomCount 16" % (G, budget),
            "games_finished": st["games_finished"], "seconds": dt, "moves_played": st["moves_played"], "sims": st["sims_nonnull"],
            "game_length": _length_stats(lens), "termination": _termination_mix(arena, G, 2 * S * S),
            "distinct_games": len({arena.history(g).tobytes() for g in range(G)}),
-           "results": {"a_wins": aw, "b_wins": bw, "draws": dr}, "examples": st["examples"], "examples_dropped": st["examples_dropped"],
+           "results": res, "examples": st["examples"], "examples_dropped": st["examples_dropped"],
            "tree_full": st["tree_full"]}
     arena.close()
     return out
@@ -418,7 +430,7 @@ def deep_tree_leg(ctx, S, K, L, G, budget, compute, target_max_prior=0.5, zero_v
            "k_select_ms_per_step": (sel_ms / sel_n) if sel_n else None, "k_expand_ms_per_step": (exp_ms / exp_n) if exp_n else None,
            "ms_per_step": dt / budget * 1e3,
            "mcts_share_of_step": ((sel_ms / sel_n + exp_ms / exp_n) / (dt / budget * 1e3)) if sel_n and exp_n else None,
-           "max_tree_nodes_sampled": int(max(nodes)), "tree_full": s3["tree_full"],
+           "max_path_nodes": arena.max_path_nodes(), "max_tree_nodes_sampled": int(max(nodes)), "tree_full": s3["tree_full"],
            "note": "k_select / k_expand: HIP events on the last %d steps of the move (the deepest trees); ms_per_step: the whole move / Budget" % steps_prof}
     arena.close()
     net.close()
@@ -602,7 +614,9 @@ def main():
     ap.add_argument("--no-train-leg", action="store_true", help="skip the dual.Train step leg (SURVEY 8(f)-1)")
     ap.add_argument("--no-deep-leg", action="store_true", help="skip the deep-tree legs (the headline workload under a peaked policy head)")
     ap.add_argument("--no-complete-games-leg", action="store_true", help="skip the 512 complete 19x19 games at a small Budget (measured game length)")
-    ap.add_argument("--complete-games-budget", type=int, default=16, help="simulations per move of the complete-games leg")
+    ap.add_argument("--complete-games-budget", type=int, default=4,
+                    help="simulations per move of the complete-games leg (4: ~40 s; the 16-simulation run of the same leg — 168 s — is committed as "
+                         "profiles/r06/complete_games_19x19_budget16.json: mean length 692 of a 722-move cap, 473 of 512 games end at the cap)")
     ap.add_argument("--prof-stride", type=int, default=4,
                     help="inside the timed region every N-th launch of the dominant kernel is bracketed with HIP events (0: none)")
     ap.add_argument("--tower-queues", type=int, default=0, choices=[0, 1, 2],
@@ -742,6 +756,7 @@ def main():
         for n_ in nets:
             n_.set_tower_queues(args.tower_queues)
 
+    max_path_main = arena.max_path_nodes()
     sims = st1["sims_nonnull"] - st0["sims_nonnull"]
     sims_all = st1["sims_total"] - st0["sims_total"]
     evals = st1["nn_evals"] - st0["nn_evals"]
@@ -867,7 +882,7 @@ def main():
                         for k, v in json.load(open(os.path.join(ROOT, "profiles", "r05", "pmc_mcts_kernels.json")))["kernels"].items()}
         except Exception:
             pass
-        mcts_detail = {"mean_path_nodes": path_per_sim, "mean_children_per_select": kids_per_node,
+        mcts_detail = {"mean_path_nodes": path_per_sim, "mean_children_per_select": kids_per_node, "max_path_nodes": max_path_main,
                        "k_select": {"avg_ms": sel_ms, "algorithmic_bytes": sel_bytes, "GBps": (sel_bytes / (sel_ms * 1e-3) / 1e9) if sel_ms else None,
                                     "frac_of_8TBps": (sel_bytes / (sel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sel_ms else None},
                        "k_expand": {"avg_ms": exp_ms, "algorithmic_bytes": exp_bytes, "GBps": (exp_bytes / (exp_ms * 1e-3) / 1e9) if exp_ms else None,
@@ -1093,9 +1108,13 @@ def main():
                 out["extra"]["complete_games_19x19"] = {"error": repr(e)}
         if world == 1 and not args.no_deep_leg:
             try:
+                # two points: a policy as peaked as a trained one (largest prior 0.5 on average, ordinary value head), and the stress point — priors
+                # only (value output zeroed), largest prior 0.95: mean path ~ 1 / (1 - p) nodes, the deepest trees this family produces
+                # (the round's first run also measured 0.8 / priors only: profiles/r06/bench_n1_first.json)
                 dl = {"peaked_0.5": deep_tree_leg(ctx, S, K, L, G, args.budget, args.compute, 0.5, False),
-                      "priors_only_0.8": deep_tree_leg(ctx, S, K, L, G, args.budget, args.compute, 0.8, True)}
+                      "priors_only_0.95": deep_tree_leg(ctx, S, K, L, G, args.budget, args.compute, 0.95, True)}
                 dl["headline_for_comparison"] = {"sims_per_s": (full_move or {}).get("sims_per_s"), "mean_path_nodes": mcts_detail["mean_path_nodes"],
+                                                 "max_path_nodes": mcts_detail["max_path_nodes"],
                                                  "mean_children_per_select": mcts_detail["mean_children_per_select"],
                                                  "k_select_ms_per_step": mcts_detail["k_select"]["avg_ms"], "k_expand_ms_per_step": mcts_detail["k_expand"]["avg_ms"]}
                 out["extra"]["deep_tree_leg"] = dl

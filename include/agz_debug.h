@@ -72,13 +72,21 @@ int agz_arena_last_prep_batch(agz_arena* arena, int* boards, int* roots);
  * (diagnostic: per-kernel durations without overlap).  Bit 5 set: the DMA forward convolution with one tap per K step (k_conv_h2dma, 128 x 256
  * tile) instead of nine taps from one x image (k_conv_h2dma3, 256 x 128 tile; default where the image fits its 372 rows).  Same tolerance;
  * bits 3, 4 and 5 do not change a single product.  Bits 6, 7: decomposition runs of k_conv_h2dma3 (no x image after chunk 0 / no weight DMA):
- * WRONG results, timing only. */
+ * WRONG results, timing only.  Bit 8 (round 6): the weight gradient k_wgrad_h2t3 at two workgroups per CU as in round 5 (default: ONE — it then leaves
+ * half of every SIMD's registers to the main stream's chain, which runs beside it).  Bit 9: the side stream at the lowest priority (set before
+ * the first step; measured no different).  Bits 8 and 9 do not change a single product. */
 int agz_trainer_set_dma_forward(agz_trainer* t, int on);
 
 /* The smallest batch >= n that runs the kernels of a batch of G boards on this net in its current compute mode (agz_net::min_same_batch, what
  * prepareRoot's packed forward uses): per board the outputs of such a batch are those of the G-board batch bit for bit.  The parity tests
  * evaluate single leaves for the oracle with it instead of G copies of the board. */
 int agz_net_min_same_batch(agz_net* net, int n, int G, int* batch);
+
+/* Measurement: raw device counter `which` of an arena.  AGZ_CNT_PATHMAX: nodes on the LONGEST descent since the last reset (all games run
+ * one simulation per step in lock step: a step's k_select lasts as long as its longest path, so the maximum — not the mean that
+ * agz_arena_stats reports — is what prices the kernel on narrow, deep trees). */
+#define AGZ_CNT_PATHMAX 15
+int agz_arena_debug_counter(agz_arena* arena, int which, int64_t* value);
 
 /* Failure injection (tests): the data-parallel step of this communicator fails on THIS rank right before it would enter the collective of
  * slice k (0 = the heads, 1 .. = layer L .. 0; k < 0: off).  One shot: cleared by the step it hits.  What the test checks is the rule of

@@ -5,6 +5,7 @@ size the checks are size-independent properties: batch independence, determinism
 (a checksum of checksums), MCTS conservation laws (search.go:392-408, tree.go:110, node.go:70-76), plus a
 two-board spot check of the full-size network against the oracle.
 """
+import os
 import zlib
 
 import numpy as np
@@ -318,3 +319,53 @@ def test_engine_with_split_mode_network_bit_exact_vs_oracle(ctx, mode):
         # games with the same colour assignment are identical (same net, same seedless search)
         for g in range(2, G, 5):
             assert np.array_equal(arena.history(g), arena.history(g % 2))
+
+
+def test_complete_19x19_games_histories_labels_and_examples_match_the_oracle(ctx):
+    """Arena.Play to Ended() on 19x19 (arena.go:96-155) — what bench.py's complete-games leg runs (small Budget, RandomCount
+    16 with the per-tree RNG streams, DontPreferPass) — for 48 concurrent games; eight watched games against oracle arenas played the same
+    way: the whole move list (several hundred moves, randomised opening included), how the game ended, the winner, and every example row
+    with its final label (planes, one-hot policy, value +1 / -1 / 0 from the winner: arena.go:146-155) bit for bit."""
+    S, G, budget, seed = 19, 48, 16, 4242
+    kw = dict(Budget=budget, RandomCount=16, RandomMinVisits=1, RandomTemperature=1.0, DumbPass=True, PassPreference=capi.DONT_PREFER_PASS)
+    dev = A.Arena(ctx, capi.GAME_WQ, S, S, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=seed, **kw)
+    dev.set_inferencer(0, capi.INF_HASH)
+    dev.set_inferencer(1, capi.INF_HASH)
+    ab = np.array([(g % 2) == 0 for g in range(G)], np.uint8)
+    dev.reset(ab)
+    dev.play(0, record=True)
+    st = dev.stats()
+    assert st["games_finished"] == G and st["n_active"] == 0 and st["tree_full"] == 0
+    lens = np.array([len(dev.history(g)) for g in range(G)])
+    assert len({dev.history(g).tobytes() for g in range(G)}) == G            # every game its own (RandomCount)
+    dp, dpol, dval, dgi = dev.examples()
+    watch = (0, 1, 7, 13, 22, 31, 40, 47)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def oracle_game(g):
+        o = O.Arena(O.WQ, S, S, 0, 7.5, enc=O.ENC_WQ, seed=seed + g, **kw)
+        o.set_inferencer(0, O.INF_HASH)
+        o.set_inferencer(1, O.INF_HASH)
+        o.begin(int(ab[g]))
+        o.play(0, True)
+        return o
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        orcs = dict(zip(watch, ex.map(oracle_game, watch)))
+    ends = {"two_passes": 0, "cap": 0, "other": 0}
+    for g, o in orcs.items():
+        oh = o.history()
+        np.testing.assert_array_equal(dev.history(g), oh, err_msg="game %d" % g)
+        _, ost = o.state()
+        _, dst = dev.game(g)
+        assert ost["ended"] and dst["ended"] and dst["winner"] == ost["winner"], g
+        ob, op, ov = o.examples()
+        sel = dgi == g
+        assert sel.sum() == ob.shape[0] > 0
+        np.testing.assert_array_equal(dp[sel].view(np.uint32), ob.view(np.uint32))
+        np.testing.assert_array_equal(dpol[sel].view(np.uint32), op.view(np.uint32))
+        np.testing.assert_array_equal(dval[sel], ov)
+        assert set(np.unique(ov)) <= {-1.0, 0.0, 1.0}
+        ends["two_passes" if (len(oh) >= 2 and oh[-1] == capi.PASS and oh[-2] == capi.PASS) else "cap" if len(oh) >= 2 * S * S else "other"] += 1
+    print("\n[complete 19x19 games] lengths min %d mean %.1f max %d; watched endings %r" % (lens.min(), lens.mean(), lens.max(), ends))
+    dev.close()
