@@ -243,38 +243,61 @@ def _continuous_rate(G, seconds, lens):
 
 
 def go9_leg(ctx, compute="wino_h2"):
-    """Measured games/s on BASELINE config #3: 9x9 Go (wq), K=128, 10 blocks, 512 concurrent games, 400 sims/move,
-    continuous self-play until 512 complete games have finished (wino_h2 with F(5x5,3x3): 4 tiles x 49 positions per board, measured 15 % less time per 512-board pass than bf16x3 on this shape)."""
+    """BASELINE config #3: 9x9 Go (wq), K=128, 10 blocks, 512 concurrent games, 400 sims/move (wino_h2 with F(5x5,3x3): 4 tiles x 49 positions
+    per board, measured 15 % less time per 512-board pass than bf16x3 on this shape).  Two measurements, as for 19x19: (1) the MOVE RATE at the
+    configuration's own 400 simulations per move — 16 whole arena plies of all 512 games from per-game random openings; (2) the GAME LENGTH —
+    every one of 512 games played once to its end at 16 simulations per move (RandomCount 8: the first eight moves drawn from the visit
+    distribution by each tree's own RNG, the reference's mechanism for game diversity: tree.go:22, search.go:356).  games/s = (1) / mean of (2).
+    Round 5 played 512 COPIES of one deterministic game (64 moves); complete games at 400 simulations per move were measured once this round
+    (99 s: mean 131 moves, 340 of 512 at the 162-move cap, 5.1 games/s as a batch, 6.4 continuous: profiles/r06/go9_complete_games_400_sims.json)."""
     K, L, G, sims = 128, 10, 512, 400
     net = A.Net(ctx, K, L, 2 * K, 9, 9, 18, 82, bn_mode=capi.BN_IDENTITY)
     net.init_random(1337)
     standard_bn_init(net)
     net.commit()
     net.set_compute_mode(MODES[compute])
-    # RandomCount = 8: the first eight moves drawn from the visit distribution (see games_leg) — 512 different games, not 512 copies of one
-    # (node pools: the default holds two searches' worth of expansions; a re-rooted NARROW tree keeps most of its nodes move after move, and
-    # with 512 different games one of them outgrew it in round 6's first run — six searches' worth here, peak use reported)
-    arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337, Budget=sims, RandomCount=8,
-                    RandomMinVisits=1, RandomTemperature=1.0, max_nodes=6 * (sims + 2) * 82)
+    # (1) move rate at 400 simulations per move.  Node pools: the default holds two searches' worth of expansions; a re-rooted NARROW tree keeps
+    # most of its nodes move after move (one of 512 different games outgrew it in round 6's first run): six searches' worth
+    arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337, Budget=sims, max_nodes=6 * (sims + 2) * 82)
+    arena.set_inferencer(0, capi.INF_NET, net)
+    arena.set_inferencer(1, capi.INF_NET, net)
+    arena.reset()
+    arena.random_moves(np.random.default_rng(1337).integers(0, 41, size=G).astype(np.int32), 1337)
+    plies = 16
+    arena.play(1, record=True)            # (first ply: every root fresh)
+    ctx.sync()
+    s0 = arena.stats()
+    t0 = time.perf_counter()
+    arena.play(plies, record=True)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    s1 = arena.stats()
+    rate = {"plies": plies, "seconds": dt, "moves_per_s": (s1["moves_played"] - s0["moves_played"]) / dt,
+            "sims_per_s": (s1["sims_nonnull"] - s0["sims_nonnull"]) / dt, "active_games_at_end": s1["n_active"], "tree_full": s1["tree_full"]}
+    arena.close()
+    # (2) game length
+    arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337, Budget=16, RandomCount=8,
+                    RandomMinVisits=1, RandomTemperature=1.0)
     arena.set_inferencer(0, capi.INF_NET, net)
     arena.set_inferencer(1, capi.INF_NET, net)
     arena.reset()
     ctx.sync()
     t0 = time.perf_counter()
-    arena.play(0, record=True)          # every game once, to its end
+    arena.play(0, record=True)
     ctx.sync()
-    dt = time.perf_counter() - t0
+    dl = time.perf_counter() - t0
     st = arena.stats()
     lens = np.array([len(arena.history(g)) for g in range(G)])
-    ends = _termination_mix(arena, G, 2 * 81)
-    out = {"workload": "config #3: 9x9 Go (wq, komi 7.5), K=128, 10 blocks, 512 concurrent games, 400 sims/move, RandomCount 8: each game played once to its end",
-           "compute": compute,
-           "games_finished": st["games_finished"], "seconds": dt, "games_per_s": st["games_finished"] / dt,
-           "sims_per_s": st["sims_nonnull"] / dt, "moves_per_s": st["moves_played"] / dt,
-           "moves_per_game": st["moves_played"] / max(st["games_finished"], 1), "game_length": _length_stats(lens), "termination": ends,
-           "distinct_games": len({arena.history(g).tobytes() for g in range(G)}), "examples": st["examples"],
-           "examples_dropped": st["examples_dropped"], "tree_full": st["tree_full"], **_continuous_rate(G, dt, lens),
-           "note": "the arena runs until its LONGEST game ends (finished games idle in the batch): games_per_s is a lower bound of the continuous-self-play rate"}
+    out = {"workload": "config #3: 9x9 Go (wq, komi 7.5), K=128, 10 blocks, 512 concurrent games, 400 sims/move", "compute": compute,
+           "move_rate_at_400_sims": rate,
+           "complete_games_at_16_sims": {"games_finished": st["games_finished"], "seconds": dl, "game_length": _length_stats(lens),
+                                         "termination": _termination_mix(arena, G, 2 * 81),
+                                         "distinct_games": len({arena.history(g).tobytes() for g in range(G)}), "examples": st["examples"],
+                                         "examples_dropped": st["examples_dropped"], "tree_full": st["tree_full"]},
+           "games_per_s": rate["moves_per_s"] / float(lens.mean()), "sims_per_s": rate["sims_per_s"], "moves_per_s": rate["moves_per_s"],
+           "moves_per_game": float(lens.mean()),
+           "games_per_s_note": "moves/s of 16 arena plies at 400 simulations per move (all 512 games live) / the mean length of 512 complete games at 16 "
+                               "simulations per move; complete games AT 400 simulations: profiles/r06/go9_complete_games_400_sims.json (mean 131 moves)"}
     arena.close()
     net.close()
     return out
@@ -517,7 +540,7 @@ def latency_leg(ctx, lanes_list=(1, 8, 16), moves=3, sims=1600):
     return out
 
 
-def train_leg(ctx, steps=3):
+def train_leg(ctx, steps=10):
     """SURVEY 8(f)-1 under the driver's clock: one dual.Train batch (dualnet/meta.go:16-54) of the config #4 network —
     19x19, K=256, 20 blocks, BatchSize 256 — forward (training-mode BatchNorm), loss, backward, vanilla SGD step, in the trainer's
     AGZ_COMPUTE_WINO_H2 arithmetic (every gradient tensor within 2e-5 * max|g| of the oracle: tests/test_train_gpu.py); host batch in,
@@ -950,8 +973,9 @@ def main():
         if args.compute == "wino_h2" and capi.wino_h2_chained(S, S, K) == 1:
             pmc_name = "pmc_wino_h2c.json"   # the chained block's GEMM (wino_gemm_h2g_kernel), round 4
         pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-        if os.path.exists(os.path.join(ROOT, "profiles", "r05", pmc_name)):   # the newest pass of the same kernel (scripts/r5_pmc_tower.sh)
-            pmc_path = os.path.join(ROOT, "profiles", "r05", pmc_name)
+        for rd in ("r05", "r06"):   # the newest pass of the same kernel (scripts/r5_pmc_tower.sh, re-run by scripts/r6_evidence.sh)
+            if os.path.exists(os.path.join(ROOT, "profiles", rd, pmc_name)):
+                pmc_path = os.path.join(ROOT, "profiles", rd, pmc_name)
         if os.path.exists(pmc_path) and (S, K, L, G) == (19, 256, 20, 512):  # the PMC pass was taken on this exact shape
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
@@ -1017,7 +1041,7 @@ def main():
                        "tower_queues": 2 if two_queues else 1},
             "roofline": ({"bound": "hbm", "achieved": wino_detail["wino_gemm"]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": wino_detail["wino_gemm"]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                          "traffic_source": (traffic_source + " (separate rocprofv3 --pmc passes over this kernel on this shape, scripts/r5_pmc_tower.sh: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE; QUOTED, not collected in this run)") if traffic_source else None,
+                          "traffic_source": (traffic_source + " (separate rocprofv3 --pmc passes over this kernel on this shape, scripts/r5_pmc_tower.sh: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE; QUOTED from the committed pass, not collected in this run)") if traffic_source else None,
                           "measured_in_this_run": ["achieved", "frac", "avg_launch_ms", "launches", "block"],
                           "algorithmic_bytes_per_launch": wino_detail["wino_gemm"]["algorithmic_bytes"],
                           # the whole dual block (all its kernels, one-queue HIP events around the block): VERDICT r3 item 2

@@ -20,6 +20,12 @@ package agzhip
 #cgo LDFLAGS: -L${SRCDIR}/../../agogo_amd/lib -lagz
 #include <stdlib.h>
 #include "agz.h"
+
+// the host-inferencer trampoline (AGZ_INF_CALLBACK): exported from Go below, handed to libagz as an agz_infer_fn
+extern int agzGoInfer(void* user, agz_leaf_batch* batch);
+static inline int mctsSetGoInferencer(agz_mcts* m, void* user, int policy_len) {
+  return agz_mcts_set_inferencer_callback(m, (agz_infer_fn)agzGoInfer, user, policy_len);
+}
 */
 import "C"
 
@@ -27,6 +33,7 @@ import (
 	"errors"
 	"fmt"
 	"runtime"
+	"runtime/cgo"
 	"sync"
 	"time"
 	"unsafe"
@@ -366,11 +373,13 @@ func (a *BatchedArena) Opponent(moves []game.Single) error {
 // `a.MCTS.SetGame(g); return a.MCTS.Search(a.Player)`.  The game stays a Go game.State; SetGame ships the position (board,
 // to-move, hash, the moves since the start via LastMove/UndoLastMove on a clone, the last 8 historical boards for WQEncoder).
 type MCTS struct {
-	ctx     *Ctx
-	h       *C.agz_mcts
-	cells   int
-	action  int
-	current game.State
+	ctx        *Ctx
+	h          *C.agz_mcts
+	cells      int
+	action     int
+	current    game.State
+	host       *hostInferencer // NewMCTSInferer / NewMCTSInferencer: the caller's network behind AGZ_INF_CALLBACK
+	hostHandle cgo.Handle
 }
 
 // NewMCTS mirrors mcts.New(game, conf, nn) (tree.go:80-103): kind names the device implementation of g's rules, nn the
@@ -434,6 +443,118 @@ func poolNodes(conf mcts.Config, actionSpace int, withNet bool) int {
 		nodes = 8000000
 	}
 	return int(nodes)
+}
+
+// ---- mcts.New(game, conf, nn Inferencer) with ANY Inferencer (mcts/mcts.go:15-18) ---------------------------------------------------
+// The device search hands the leaves of a simulation to the host between its two kernels (AGZ_INF_CALLBACK, include/agz.h): the shim
+// turns each leaf into what the caller's network takes.
+//
+//	NewMCTSInferer    — an agogo.Inferer (datatypes.go:56-59): Infer(encoded planes) — the leaf arrives ENCODED (the tree's encoder ran on
+//	                    the device: what Agent.Infer computes with a.Enc(g), agent.go:60-74), so a gorgonia dualnet or any other
+//	                    network plugs in unchanged;
+//	NewMCTSInferencer — an mcts.Inferencer: Infer(state game.State) — the leaf arrives as a read-only game.State (LeafState below:
+//	                    Board, ToMove, MoveNumber, BoardSize, ActionSpace, Hash; the mutating methods panic), which is what the
+//	                    reference's own test inferencers read (mcts/example_test.go:40-72 switches on state.MoveNumber()).
+type hostInferencer struct {
+	byPlanes agogo.Inferer
+	byState  mcts.Inferencer
+	action   int
+	err      error
+}
+
+// LeafState is the game.State view of one leaf of a device search (read-only).
+type LeafState struct {
+	m, n, action int
+	board        []game.Colour
+	toMove       game.Player
+	moveNumber   int
+}
+
+func (l *LeafState) BoardSize() (int, int)   { return l.m, l.n }
+func (l *LeafState) Board() []game.Colour    { return l.board }
+func (l *LeafState) ActionSpace() int        { return l.action }
+func (l *LeafState) ToMove() game.Player     { return l.toMove }
+func (l *LeafState) MoveNumber() int         { return l.moveNumber }
+func (l *LeafState) Passes() int             { return 0 }
+func (l *LeafState) Handicap() int           { return 0 }
+func (l *LeafState) AdditionalScore() float32 { return 0 }
+func (l *LeafState) Hash() game.Zobrist { // FNV-1a over the cells (the device keeps its own zobrist key; a leaf's is not shipped)
+	h := uint32(2166136261)
+	for _, c := range l.board {
+		h = (h ^ uint32(c)) * 16777619
+	}
+	return game.Zobrist(h)
+}
+func (l *LeafState) LastMove() game.PlayerMove         { panic("agzhip.LeafState: LastMove is not available on a device leaf") }
+func (l *LeafState) Score(game.Player) float32         { panic("agzhip.LeafState: Score is not available on a device leaf") }
+func (l *LeafState) Ended() (bool, game.Player)        { return false, game.None }
+func (l *LeafState) SetToMove(game.Player)             { panic("agzhip.LeafState is read-only") }
+func (l *LeafState) Check(game.PlayerMove) bool        { panic("agzhip.LeafState is read-only") }
+func (l *LeafState) Apply(game.PlayerMove) game.State  { panic("agzhip.LeafState is read-only") }
+func (l *LeafState) Reset()                            { panic("agzhip.LeafState is read-only") }
+func (l *LeafState) Historical(int) []game.Colour      { panic("agzhip.LeafState: history is not shipped with a leaf (the encoded planes carry it)") }
+func (l *LeafState) UndoLastMove()                     { panic("agzhip.LeafState is read-only") }
+func (l *LeafState) Fwd()                              { panic("agzhip.LeafState is read-only") }
+func (l *LeafState) Eq(game.State) bool                { return false }
+func (l *LeafState) Clone() game.State                 { c := *l; c.board = append([]game.Colour(nil), l.board...); return &c }
+
+//export agzGoInfer
+func agzGoInfer(user unsafe.Pointer, b *C.agz_leaf_batch) C.int {
+	inf := cgo.Handle(uintptr(user)).Value().(*hostInferencer)
+	n, f, h, w, pl := int(b.n), int(b.features), int(b.height), int(b.width), int(b.policy_len)
+	planes := unsafe.Slice((*float32)(unsafe.Pointer(b.planes)), n*f*h*w)
+	boards := unsafe.Slice((*int32)(unsafe.Pointer(b.board)), n*h*w)
+	toMove := unsafe.Slice((*int32)(unsafe.Pointer(b.to_move)), n)
+	moveNo := unsafe.Slice((*int32)(unsafe.Pointer(b.move_number)), n)
+	polOut := unsafe.Slice((*float32)(unsafe.Pointer(b.policy)), n*pl)
+	valOut := unsafe.Slice((*float32)(unsafe.Pointer(b.value)), n)
+	for i := 0; i < n; i++ {
+		var policy []float32
+		var value float32
+		if inf.byPlanes != nil {
+			var err error
+			if policy, value, err = inf.byPlanes.Infer(planes[i*f*h*w : (i+1)*f*h*w]); err != nil {
+				inf.err = err
+				return 1 // the search aborts with AGZ_E_CALLBACK; Search reports inf.err
+			}
+		} else {
+			ls := &LeafState{m: h, n: w, action: inf.action, toMove: game.Player(toMove[i]), moveNumber: int(moveNo[i]), board: make([]game.Colour, h*w)}
+			for q := range ls.board {
+				ls.board[q] = game.Colour(boards[i*h*w+q])
+			}
+			policy, value = inf.byState.Infer(ls)
+		}
+		copy(polOut[i*pl:(i+1)*pl], policy) // (a shorter policy leaves zeros; the LAST entry of the row is the pass probability, search.go:276)
+		valOut[i] = value
+	}
+	return 0
+}
+
+func newMCTSHost(ctx *Ctx, kind GameKind, g game.State, k int, komi float32, encoder int, conf mcts.Config, inf *hostInferencer, policyLen int, seed uint64) (*MCTS, error) {
+	t, err := NewMCTS(ctx, kind, g, k, komi, encoder, conf, nil, seed)
+	if err != nil {
+		return nil, err
+	}
+	defer ctx.enter()()
+	inf.action = g.ActionSpace()
+	t.host = inf
+	t.hostHandle = cgo.NewHandle(inf)
+	if err := lastErr(C.mctsSetGoInferencer(t.h, unsafe.Pointer(uintptr(t.hostHandle)), C.int(policyLen))); err != nil {
+		t.hostHandle.Delete()
+		C.agz_mcts_destroy(t.h)
+		return nil, err
+	}
+	return t, nil
+}
+
+// NewMCTSInferer: mcts.New with an agogo.Inferer as the network (policyLen = the length of the policy it returns: ActionSpace + 1).
+func NewMCTSInferer(ctx *Ctx, kind GameKind, g game.State, k int, komi float32, encoder int, conf mcts.Config, nn agogo.Inferer, policyLen int, seed uint64) (*MCTS, error) {
+	return newMCTSHost(ctx, kind, g, k, komi, encoder, conf, &hostInferencer{byPlanes: nn}, policyLen, seed)
+}
+
+// NewMCTSInferencer: mcts.New(game, conf, nn) for any mcts.Inferencer (the reference's signature, tree.go:80).
+func NewMCTSInferencer(ctx *Ctx, kind GameKind, g game.State, k int, komi float32, encoder int, conf mcts.Config, nn mcts.Inferencer, policyLen int, seed uint64) (*MCTS, error) {
+	return newMCTSHost(ctx, kind, g, k, komi, encoder, conf, &hostInferencer{byState: nn}, policyLen, seed)
 }
 
 // timeoutMs: a positive duration below one millisecond is one millisecond (0 would silently mean "exactly Budget simulations").
@@ -594,7 +715,16 @@ func (t *MCTS) Children(of int) []Child {
 // Reset (tree.go:249-276), completed to "a fresh tree" (what Arena.Play does next, arena.go:140-141,175-176).
 func (t *MCTS) Reset() { defer t.ctx.enter()(); C.agz_mcts_reset(t.h) }
 
-func (t *MCTS) Close() error { defer t.ctx.enter()(); C.agz_mcts_destroy(t.h); t.h = nil; return nil }
+func (t *MCTS) Close() error {
+	defer t.ctx.enter()()
+	C.agz_mcts_destroy(t.h)
+	t.h = nil
+	if t.host != nil {
+		t.hostHandle.Delete()
+		t.host = nil
+	}
+	return nil
+}
 
 // ---- dual.Train (dualnet/meta.go:16-54) ----------------------------------------------------------------------------------
 // Trainer holds the training graph of a Dual (full batch-shaped learnables in Model() order, train.hip).

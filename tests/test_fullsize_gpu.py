@@ -323,10 +323,10 @@ def test_engine_with_split_mode_network_bit_exact_vs_oracle(ctx, mode):
 
 def test_complete_19x19_games_histories_labels_and_examples_match_the_oracle(ctx):
     """Arena.Play to Ended() on 19x19 (arena.go:96-155) — what bench.py's complete-games leg runs (small Budget, RandomCount
-    16 with the per-tree RNG streams, DontPreferPass) — for 48 concurrent games; eight watched games against oracle arenas played the same
+    16 with the per-tree RNG streams, DontPreferPass) — for 48 concurrent games; four watched games against oracle arenas played the same
     way: the whole move list (several hundred moves, randomised opening included), how the game ended, the winner, and every example row
     with its final label (planes, one-hot policy, value +1 / -1 / 0 from the winner: arena.go:146-155) bit for bit."""
-    S, G, budget, seed = 19, 48, 16, 4242
+    S, G, budget, seed = 19, 48, 8, 4242
     kw = dict(Budget=budget, RandomCount=16, RandomMinVisits=1, RandomTemperature=1.0, DumbPass=True, PassPreference=capi.DONT_PREFER_PASS)
     dev = A.Arena(ctx, capi.GAME_WQ, S, S, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=seed, **kw)
     dev.set_inferencer(0, capi.INF_HASH)
@@ -339,7 +339,7 @@ def test_complete_19x19_games_histories_labels_and_examples_match_the_oracle(ctx
     lens = np.array([len(dev.history(g)) for g in range(G)])
     assert len({dev.history(g).tobytes() for g in range(G)}) == G            # every game its own (RandomCount)
     dp, dpol, dval, dgi = dev.examples()
-    watch = (0, 1, 7, 13, 22, 31, 40, 47)
+    watch = (0, 13, 31, 47)
     from concurrent.futures import ThreadPoolExecutor
 
     def oracle_game(g):
