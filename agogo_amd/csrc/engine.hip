@@ -1631,10 +1631,11 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
   d.G = G; d.T = T;
   // (a single tree with Budget <= 0 = a search that stops on the wall clock, agz_mcts_set_timeout_ms: no simulation count to size by —
   // room for 65536 expansions, at most the 8 M-node ceiling; a full pool ends such a search, agz_mcts_search)
-  // (an arena of several games with neither a Budget nor a pool size has nothing to size its trees by: refused, not guessed — ADVICE r5)
-  AGZ_REQUIRE(mcts->Budget > 0 || n_games == 1 || max_nodes > 0, AGZ_E_INVALID,
-              "agz_arena_create: %d games with Budget <= 0 need an explicit max_nodes (node pool per tree)", n_games);
-  const long long size_by = mcts->Budget > 0 ? mcts->Budget : 65536;
+  // Budget <= 0, explicitly: a SINGLE tree may search by the wall clock (agz_mcts_set_timeout_ms) — no simulation count to size by,
+  // room for 65536 expansions unless the caller passes max_nodes (the Go shim derives it from the Timeout).  An arena of SEVERAL games has no
+  // wall-clock rule: Budget 0 there means exactly zero simulations per move — every move comes from prepareRoot's one expansion
+  // (tests/test_engine_edges_gpu.py) — and two expansions' worth of nodes is all its trees can ever hold.
+  const long long size_by = mcts->Budget > 0 ? mcts->Budget : (n_games == 1 ? 65536 : 0);
   long long cap = max_nodes > 0 ? max_nodes : (long long)(2 * (size_by + 2)) * (c.A + 1) + 16;
   if (cap > 8000000) cap = 8000000;
   d.cap = (int)cap;

@@ -262,7 +262,9 @@ def go9_leg(ctx, compute="wino_h2"):
     arena.set_inferencer(0, capi.INF_NET, net)
     arena.set_inferencer(1, capi.INF_NET, net)
     arena.reset()
-    arena.random_moves(np.random.default_rng(1337).integers(0, 41, size=G).astype(np.int32), 1337)
+    # (openings spread over the WHOLE length of a game — mean length 130 moves — not only its first moves: an arena ply late in the game costs
+    # ~1.5x an early one, and round 6's first form of this leg, openings of 0..40 moves, read 1284 moves/s where the complete games ran 834)
+    arena.random_moves(np.random.default_rng(1337).integers(0, 121, size=G).astype(np.int32), 1337)
     plies = 16
     arena.play(1, record=True)            # (first ply: every root fresh)
     ctx.sync()
@@ -563,10 +565,32 @@ def train_leg(ctx, steps=10):
     dt = (time.perf_counter() - t0) / steps
     hw = S * S
     flops = 3 * (2.0 * 18 * K * 9 * hw + L * 2 * 2.0 * K * K * 9 * hw) * B   # forward + data gradient + weight gradient, direct-equivalent
+    # the loop AZ.Learn runs (agogo.go:123-133 -> dual.Train, dualnet/meta.go:16-54) with the examples RESIDENT in HBM (agz_examples_* ->
+    # agz_train_dev): `steps` batches of one iteration, gathered device to device by the shuffled row index, no per-batch host round trip —
+    # the per-batch cost of dual.Train as the path runs it (the figure above pays a 27 MB pageable copy and a synchronisation per batch)
+    dev_ms = None
+    try:
+        ex = A.Examples(ctx, 18, S, S, S * S + 1)
+        for _ in range(steps):
+            ex.append_host(x, pi, v)
+        nb = ex.prepare(B, 0, seed=1)
+        xd, pd, vd, rows_d, bd = ex.tensors_dev()
+        t.train_dev(xd, pd, vd, 1, 1, seed=3)           # warm
+        ctx.sync()
+        t0 = time.perf_counter()
+        t.train_dev(xd, pd, vd, bd, 1, seed=3)
+        ctx.sync()
+        dev_ms = (time.perf_counter() - t0) / bd * 1e3
+        ex.close()
+    except Exception as e:   # the leg above stands on its own
+        dev_ms = {"error": repr(e)}
     t.close()
     return {"workload": "dual.Train batch: 19x19, K=256, 20 blocks, BatchSize 256 (config #4 network), trainer AGZ_COMPUTE_WINO_H2",
             "steps_timed": steps, "step_ms": dt * 1e3, "examples_per_s": B / dt, "direct_equivalent_tflops": flops / dt / 1e12,
-            "cost": float(c), "note": "includes the host -> device copy of the batch (27 MB) and the cost read-back: the boundary's agz_trainer_batch"}
+            "cost": float(c), "note": "includes the host -> device copy of the batch (27 MB) and the cost read-back: the boundary's agz_trainer_batch",
+            "step_ms_device_resident": dev_ms,
+            "step_ms_device_resident_note": "agz_train_dev over %d batches of examples resident in HBM (what AZ.Learn's dual.Train runs on): per batch, no host copy, "
+                                            "no per-batch synchronisation" % steps}
 
 
 def launcher_command(argv, gpus, environ, port=None):
