@@ -1204,7 +1204,9 @@ def main():
     if gather_hung:
         os._exit(0)   # a thread is stuck inside a collective: no clean teardown possible (the line is out)
     if world > 1:
-        dist.barrier()
+        # the closing rendezvous on HOST tensors (gloo): ranks 1 .. N-1 wait here while rank 0 times the CPU baseline — about a minute; a
+        # device-side barrier would park a spinning RCCL kernel on every other GPU for that long
+        adist.reduce_step_timing(0.0, [0.0], device=None)
         dist.destroy_process_group()
     arena.close()
     for n_ in nets:
