@@ -1327,6 +1327,7 @@ struct agz_arena {
   float* h_policy[2] = {nullptr, nullptr};           // [G*V][policy_len] in NN-slot order, uploaded for k_expand
   float* h_value[2] = {nullptr, nullptr};
   int64_t cb_calls = 0, cb_leaves = 0;
+  size_t h_pk_policy_cap = 0, h_policy_cap[2] = {0, 0}, h_value_cap[2] = {0, 0};
 
   template <typename T>
   int alloc(T** p, size_t n) {
@@ -1393,17 +1394,24 @@ int agz_arena::cb_setup() {
         (r = halloc(&h_pk_mn, rows)) != AGZ_OK || (r = halloc(&h_pk_game, rows)) != AGZ_OK)
       return r;
     cb_rows = rows;
+    h_pk_policy_cap = 0; h_policy_cap[0] = h_policy_cap[1] = 0; h_value_cap[0] = h_value_cap[1] = 0;   // (rows changed: size everything anew)
   }
-  { int r = halloc(&h_pk_policy, (size_t)rows * std::max(std::max(cb_plen[0], cb_plen[1]), 1)); if (r != AGZ_OK) return r; }
+  // (the row buffers grow only: a caller that re-registers its inferencer again and again does not accumulate page-locked memory)
+  const size_t pk_need = (size_t)rows * std::max(std::max(cb_plen[0], cb_plen[1]), 1);
+  if (pk_need > h_pk_policy_cap) { int r = halloc(&h_pk_policy, pk_need); if (r != AGZ_OK) return r; h_pk_policy_cap = pk_need; }
   for (int a = 0; a < 2; a++) {
     if (inf_kind[a] != AGZ_INF_CALLBACK) continue;
+    const size_t need = (size_t)rows * cb_plen[a];
     if (d_policy[a]) { hipFree(d_policy[a]); d_policy[a] = nullptr; }
     if (d_value[a]) { hipFree(d_value[a]); d_value[a] = nullptr; }
-    AGZ_HIP_TRY(hipMalloc(&d_policy[a], (size_t)rows * cb_plen[a] * sizeof(float)));
+    AGZ_HIP_TRY(hipMalloc(&d_policy[a], need * sizeof(float)));
     AGZ_HIP_TRY(hipMalloc(&d_value[a], (size_t)rows * sizeof(float)));
-    int r;
-    if ((r = halloc(&h_policy[a], (size_t)rows * cb_plen[a])) != AGZ_OK || (r = halloc(&h_value[a], rows)) != AGZ_OK) return r;
-    memset(h_policy[a], 0, (size_t)rows * cb_plen[a] * sizeof(float));
+    if (need > h_policy_cap[a] || (size_t)rows > h_value_cap[a]) {
+      int r;
+      if ((r = halloc(&h_policy[a], need)) != AGZ_OK || (r = halloc(&h_value[a], rows)) != AGZ_OK) return r;
+      h_policy_cap[a] = need; h_value_cap[a] = (size_t)rows;
+    }
+    memset(h_policy[a], 0, need * sizeof(float));
     memset(h_value[a], 0, (size_t)rows * sizeof(float));
   }
   return AGZ_OK;
