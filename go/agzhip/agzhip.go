@@ -22,10 +22,8 @@ package agzhip
 #include "agz.h"
 
 // the host-inferencer trampoline (AGZ_INF_CALLBACK): exported from Go below, handed to libagz as an agz_infer_fn
+// (declaration only: a cgo preamble next to //export directives may not hold definitions)
 extern int agzGoInfer(void* user, agz_leaf_batch* batch);
-static inline int mctsSetGoInferencer(agz_mcts* m, void* user, int policy_len) {
-  return agz_mcts_set_inferencer_callback(m, (agz_infer_fn)agzGoInfer, user, policy_len);
-}
 */
 import "C"
 
@@ -539,7 +537,7 @@ func newMCTSHost(ctx *Ctx, kind GameKind, g game.State, k int, komi float32, enc
 	inf.action = g.ActionSpace()
 	t.host = inf
 	t.hostHandle = cgo.NewHandle(inf)
-	if err := lastErr(C.mctsSetGoInferencer(t.h, unsafe.Pointer(uintptr(t.hostHandle)), C.int(policyLen))); err != nil {
+	if err := lastErr(C.agz_mcts_set_inferencer_callback(t.h, C.agz_infer_fn(C.agzGoInfer), unsafe.Pointer(uintptr(t.hostHandle)), C.int(policyLen))); err != nil {
 		t.hostHandle.Delete()
 		C.agz_mcts_destroy(t.h)
 		return nil, err
