@@ -245,9 +245,10 @@ def _continuous_rate(G, seconds, lens):
 def go9_leg(ctx, compute="wino_h2"):
     """BASELINE config #3: 9x9 Go (wq), K=128, 10 blocks, 512 concurrent games, 400 sims/move (wino_h2 with F(5x5,3x3): 4 tiles x 49 positions
     per board, measured 15 % less time per 512-board pass than bf16x3 on this shape).  Two measurements, as for 19x19: (1) the MOVE RATE at the
-    configuration's own 400 simulations per move — 16 whole arena plies of all 512 games from per-game random openings; (2) the GAME LENGTH —
-    every one of 512 games played once to its end at 16 simulations per move (RandomCount 8: the first eight moves drawn from the visit
-    distribution by each tree's own RNG, the reference's mechanism for game diversity: tree.go:22, search.go:356).  games/s = (1) / mean of (2).
+    configuration's own 400 simulations per move — 16 whole arena plies of all 512 games, each game standing at a uniformly drawn ply of a
+    game it really played; (2) the GAME LENGTH — every one of 512 games played once to its end at 16 simulations per move (RandomCount 8: the
+    first eight moves drawn from the visit distribution by each tree's own RNG, the reference's mechanism for game diversity: tree.go:22,
+    search.go:356).  games/s = (1) / mean of (2).
     Round 5 played 512 COPIES of one deterministic game (64 moves); complete games at 400 simulations per move were measured once this round
     (99 s: mean 131 moves, 340 of 512 at the 162-move cap, 5.1 games/s as a batch, 6.4 continuous: profiles/r06/go9_complete_games_400_sims.json)."""
     K, L, G, sims = 128, 10, 512, 400
@@ -256,28 +257,7 @@ def go9_leg(ctx, compute="wino_h2"):
     standard_bn_init(net)
     net.commit()
     net.set_compute_mode(MODES[compute])
-    # (1) move rate at 400 simulations per move.  Node pools: the default holds two searches' worth of expansions; a re-rooted NARROW tree keeps
-    # most of its nodes move after move (one of 512 different games outgrew it in round 6's first run): six searches' worth
-    arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337, Budget=sims, max_nodes=6 * (sims + 2) * 82)
-    arena.set_inferencer(0, capi.INF_NET, net)
-    arena.set_inferencer(1, capi.INF_NET, net)
-    arena.reset()
-    # (openings spread over the WHOLE length of a game — mean length 130 moves — not only its first moves: an arena ply late in the game costs
-    # ~1.5x an early one, and round 6's first form of this leg, openings of 0..40 moves, read 1284 moves/s where the complete games ran 834)
-    arena.random_moves(np.random.default_rng(1337).integers(0, 121, size=G).astype(np.int32), 1337)
-    plies = 16
-    arena.play(1, record=True)            # (first ply: every root fresh)
-    ctx.sync()
-    s0 = arena.stats()
-    t0 = time.perf_counter()
-    arena.play(plies, record=True)
-    ctx.sync()
-    dt = time.perf_counter() - t0
-    s1 = arena.stats()
-    rate = {"plies": plies, "seconds": dt, "moves_per_s": (s1["moves_played"] - s0["moves_played"]) / dt,
-            "sims_per_s": (s1["sims_nonnull"] - s0["sims_nonnull"]) / dt, "active_games_at_end": s1["n_active"], "tree_full": s1["tree_full"]}
-    arena.close()
-    # (2) game length
+    # (2) first: the GAME LENGTH — and the games themselves, whose positions (1) is then measured on
     arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337, Budget=16, RandomCount=8,
                     RandomMinVisits=1, RandomTemperature=1.0)
     arena.set_inferencer(0, capi.INF_NET, net)
@@ -289,18 +269,45 @@ def go9_leg(ctx, compute="wino_h2"):
     ctx.sync()
     dl = time.perf_counter() - t0
     st = arena.stats()
-    lens = np.array([len(arena.history(g)) for g in range(G)])
+    hist = [arena.history(g) for g in range(G)]
+    lens = np.array([len(h) for h in hist])
+    complete = {"games_finished": st["games_finished"], "seconds": dl, "game_length": _length_stats(lens),
+                "termination": _termination_mix(arena, G, 2 * 81),
+                "distinct_games": len({h.tobytes() for h in hist}), "examples": st["examples"],
+                "examples_dropped": st["examples_dropped"], "tree_full": st["tree_full"]}
+    arena.close()
+    # (1) move rate at 400 simulations per move, on positions of THOSE games: game g replayed up to a uniformly drawn ply of its own length (an
+    # arena ply late in a game costs ~1.5x an early one; uniformly random openings — round 6's first forms of this leg — are neither: 1284 and
+    # 533 moves/s where complete 400-simulation games ran 834).  Node pools: the default holds two searches' worth of expansions; a re-rooted
+    # NARROW tree keeps most of its nodes move after move (one of 512 different games outgrew it in round 6's first run): six searches' worth
+    arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337, Budget=sims, max_nodes=6 * (sims + 2) * 82)
+    arena.set_inferencer(0, capi.INF_NET, net)
+    arena.set_inferencer(1, capi.INF_NET, net)
+    arena.reset(np.array([1] * G, np.uint8))
+    plies = 16
+    prefix = np.array([int(np.random.default_rng(1337 + g).integers(0, max(1, len(hist[g]) - plies - 1))) for g in range(G)])
+    for ply in range(int(prefix.max())):
+        mv = np.array([int(hist[g][ply]) if ply < prefix[g] else capi.NO_MOVE for g in range(G)], np.int32)
+        arena.apply_moves(mv)
+    arena.play(1, record=True)            # (first ply: every root fresh)
+    ctx.sync()
+    s0 = arena.stats()
+    t0 = time.perf_counter()
+    arena.play(plies, record=True)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    s1 = arena.stats()
+    rate = {"plies": plies, "seconds": dt, "moves_per_s": (s1["moves_played"] - s0["moves_played"]) / dt,
+            "sims_per_s": (s1["sims_nonnull"] - s0["sims_nonnull"]) / dt, "active_games_at_end": s1["n_active"], "tree_full": s1["tree_full"],
+            "positions": "each game replayed to a uniformly drawn ply of its own (16-simulation) game: mean %.0f moves played" % float(prefix.mean())}
+    arena.close()
     out = {"workload": "config #3: 9x9 Go (wq, komi 7.5), K=128, 10 blocks, 512 concurrent games, 400 sims/move", "compute": compute,
            "move_rate_at_400_sims": rate,
-           "complete_games_at_16_sims": {"games_finished": st["games_finished"], "seconds": dl, "game_length": _length_stats(lens),
-                                         "termination": _termination_mix(arena, G, 2 * 81),
-                                         "distinct_games": len({arena.history(g).tobytes() for g in range(G)}), "examples": st["examples"],
-                                         "examples_dropped": st["examples_dropped"], "tree_full": st["tree_full"]},
+           "complete_games_at_16_sims": complete,
            "games_per_s": rate["moves_per_s"] / float(lens.mean()), "sims_per_s": rate["sims_per_s"], "moves_per_s": rate["moves_per_s"],
            "moves_per_game": float(lens.mean()),
            "games_per_s_note": "moves/s of 16 arena plies at 400 simulations per move (all 512 games live) / the mean length of 512 complete games at 16 "
                                "simulations per move; complete games AT 400 simulations: profiles/r06/go9_complete_games_400_sims.json (mean 131 moves)"}
-    arena.close()
     net.close()
     return out
 
