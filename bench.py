@@ -306,7 +306,7 @@ def go9_leg(ctx, compute="wino_h2"):
            "complete_games_at_16_sims": complete,
            "games_per_s": rate["moves_per_s"] / float(lens.mean()), "sims_per_s": rate["sims_per_s"], "moves_per_s": rate["moves_per_s"],
            "moves_per_game": float(lens.mean()),
-           "games_per_s_note": "moves/s of 16 arena plies at 400 simulations per move (all 512 games live) / the mean length of 512 complete games at 16 "
+           "games_per_s_note": "moves/s of 16 arena plies at 400 simulations per move (512 games on positions of games they really played; the few that end inside the window stop counting) / the mean length of 512 complete games at 16 "
                                "simulations per move; complete games AT 400 simulations: profiles/r06/go9_complete_games_400_sims.json (mean 131 moves)"}
     net.close()
     return out
