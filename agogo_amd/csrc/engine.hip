@@ -38,6 +38,23 @@ __device__ __forceinline__ float evaluate(float bs, uint32_t visits, int player)
   return score;
 }
 
+// Correctly rounded float32 square root.  On this toolchain (ROCm 7.2, __clang_hip_math.h) __fsqrt_rn IS __ocml_native_sqrt_f32 and sqrtf
+// compiles to the same 1-ulp instruction sequence whatever -fhip-fp32-correctly-rounded-divide-sqrt says: 2 526 173 of the integers 1 .. 2^24
+// come out one ulp off (scripts/probes/select_arith_probe.hip; sqrt(300.f) = 0x418a9066 instead of 0x418a9067) — and rounds 1-5 computed PUCT's
+// sqrt(parentVisits) with it.  One ulp in the numerator flips an argmax only at a near-tie: no test saw it until round 6's narrow-tree fuzz
+// (value 0, equal priors: 0.5 / 154 against (1/14) / 22 at 300 parent visits) did.  Here: the native estimate, bracketed with EXACT double
+// products (a 24-bit significand squared has 48 bits) so that r <= sqrt(x) < next(r), then x against the exact square of the midpoint
+// (25 bits -> 50): the nearer neighbour, for every x.  (float division IS correctly rounded on the device: the same probe, 4 M pairs.)
+__device__ __forceinline__ float sqrt_cr(float x) {
+  if (!(x > 0.f)) return x == 0.f ? x : __builtin_amdgcn_sqrtf(x);   // +-0 as they are, negatives / NaN -> NaN (visits sums never are)
+  float r = __builtin_amdgcn_sqrtf(x);
+  while ((double)r * (double)r > (double)x) r = __uint_as_float(__float_as_uint(r) - 1u);
+  float rn = __uint_as_float(__float_as_uint(r) + 1u);
+  while ((double)rn * (double)rn <= (double)x) { r = rn; rn = __uint_as_float(__float_as_uint(r) + 1u); }
+  const double mid = 0.5 * ((double)r + (double)rn);
+  return (double)x > mid * mid ? rn : r;
+}
+
 // Node.Select: mcts/node.go:170-237.  64 lanes over the contiguous child block; strict '>' keeps the first maximum.
 __device__ int select_child(const Dev& d, size_t base, int off, int n, int player, float PUCT, int lane, bool use_vl, int* move_out = nullptr) {
   // The whole child block goes to registers in ONE batch of loads (n <= CELLS_PAD: six children per lane): visits, sums, priors,
@@ -59,7 +76,7 @@ __device__ int select_child(const Dev& d, size_t base, int off, int n, int playe
 #pragma unroll
   for (int k = 0; k < PER; k++) pv += cv[k];
   for (int o = 32; o > 0; o >>= 1) pv += __shfl_xor(pv, o, 64);
-  float numerator = __fsqrt_rn((float)pv);
+  float numerator = sqrt_cr((float)pv);   // math32.Sqrt (node.go:209): correctly rounded — NOT __fsqrt_rn / sqrtf, see sqrt_cr above
   float best = -INFINITY;
   int idx = -1, mv = 0;
 #pragma unroll
@@ -1020,7 +1037,8 @@ __global__ __launch_bounds__(64) void k_end_move(Dev d, GameCfg c, MctsCfg mc, i
           if (norm == 0.f) { norm = (float)v; if (v <= mc.RandomMinVisits) bail = true; }
           if (!bail && v > mc.RandomMinVisits) {
             float ex = __fdiv_rn(1.f, mc.RandomTemperature), rt = __fdiv_rn((float)v, norm);
-            accum = __fadd_rn(accum, ex == 1.f ? rt : powf(rt, ex));  // pow(x, 1) == x exactly
+            // math32.Pow(x, y) = float32(math.Pow(float64(x), float64(y))) (tree.go:228): the power in DOUBLE, rounded once (powf differs in the last place)
+            accum = __fadd_rn(accum, ex == 1.f ? rt : (float)pow((double)rt, (double)ex));  // pow(x, 1) == x exactly
             s.libs[nacc++] = __float_as_int(accum);
           }
         }
@@ -1644,7 +1662,12 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
   // wall-clock rule: Budget 0 there means exactly zero simulations per move — every move comes from prepareRoot's one expansion
   // (tests/test_engine_edges_gpu.py) — and two expansions' worth of nodes is all its trees can ever hold.
   const long long size_by = mcts->Budget > 0 ? mcts->Budget : (n_games == 1 ? 65536 : 0);
-  long long cap = max_nodes > 0 ? max_nodes : (long long)(2 * (size_by + 2)) * (c.A + 1) + 16;
+  // default: FOUR searches' worth of expansions.  A search adds at most Budget + 1 expansions to the subtree kept from the one before; with
+  // a kept fraction f per move a tree settles at (Budget + 1)(A + 1) / (1 - f) nodes: two searches' worth (rounds 1-5) is f <= 0.5 — enough for
+  // the wide trees of near-uniform priors (the headline keeps < 5 %), NOT for the narrow trees of a peaked policy, which keep most of
+  // their nodes move after move (round 6: tests/test_deep_tree_fuzz_gpu.py overflowed it within five moves; one of 512 distinct 9x9 games
+  // did in bench.py).  Four is f <= 0.75; beyond that the caller passes max_nodes (the reference is unbounded up to MAXTREESIZE).
+  long long cap = max_nodes > 0 ? max_nodes : (long long)(4 * (size_by + 2)) * (c.A + 1) + 16;
   if (cap > 8000000) cap = 8000000;
   d.cap = (int)cap;
   d.moves_stride = c.max_moves + 4;

@@ -7,7 +7,7 @@
 //
 // Bit-exactness contract (tests/test_engine_gpu.py): visit counts, blackScores and chosen moves equal the
 // sequential CPU oracle.  All float arithmetic below mirrors the reference's operation order
-// (mcts/node.go:147-237, mcts/search.go:259-339) with correctly-rounded +,-,*,/,sqrt and NO fma
+// (mcts/node.go:147-237, mcts/search.go:259-339) with correctly-rounded +,-,*,/, a correctly rounded sqrt of OUR OWN (sqrt_cr, engine.hip: the toolchain's is not) and NO fma
 // contraction (this translation unit is built with -ffp-contract=off).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -278,8 +278,8 @@ def go9_leg(ctx, compute="wino_h2"):
     arena.close()
     # (1) move rate at 400 simulations per move, on positions of THOSE games: game g replayed up to a uniformly drawn ply of its own length (an
     # arena ply late in a game costs ~1.5x an early one; uniformly random openings — round 6's first forms of this leg — are neither: 1284 and
-    # 533 moves/s where complete 400-simulation games ran 834).  Node pools: the default holds two searches' worth of expansions; a re-rooted
-    # NARROW tree keeps most of its nodes move after move (one of 512 different games outgrew it in round 6's first run): six searches' worth
+    # 533 moves/s where complete 400-simulation games ran 834).  Node pools: six searches' worth of expansions (the default, four, covers trees that
+    # keep up to 3/4 of their nodes per move; round 5's default of two was outgrown by one of 512 different games in round 6's first run)
     arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337, Budget=sims, max_nodes=6 * (sims + 2) * 82)
     arena.set_inferencer(0, capi.INF_NET, net)
     arena.set_inferencer(1, capi.INF_NET, net)

@@ -299,11 +299,11 @@ typedef int (*agz_infer_fn)(void* user, const agz_leaf_batch* batch);
 
 /* MakeArena × n_games (arena.go:42-70): n_games independent games, each with agents A and B, each
  * agent with its own search tree (mcts.New, mcts/tree.go:80-103).  max_nodes = node-pool capacity per
- * tree; 0 = the default: two searches' worth of expansions, 2 * (Budget + 2) * (ActionSpace + 1) nodes (at most 8 M) — a search adds at most
- * Budget + 1 expansions to the subtree kept from the one before.  A NARROW tree keeps most of its nodes move after move and can outgrow that
- * (the reference's arena is unbounded up to MAXTREESIZE, search.go:23,78): a tree whose pool fills stops growing for that move,
- * agz_arena_stats.tree_full counts it and agz_arena_play / agz_arena_selfplay return AGZ_E_TREE_FULL — pass a larger max_nodes
- * (bench.py's 9x9 leg passes six searches' worth).  Examples: up to 2 * n_games * max_moves rows, at most 12 GiB per arena
+ * tree; 0 = the default: FOUR searches' worth of expansions, 4 * (Budget + 2) * (ActionSpace + 1) nodes (at most 8 M) — a search adds at most
+ * Budget + 1 expansions to the subtree kept from the one before, so a tree that keeps a fraction f of its nodes per move settles at
+ * (Budget + 1)(ActionSpace + 1) / (1 - f): the default covers f <= 0.75.  A very NARROW tree keeps more and can outgrow it (the reference's
+ * arena is unbounded up to MAXTREESIZE, search.go:23,78): a tree whose pool fills stops growing for that move, agz_arena_stats.tree_full
+ * counts it and agz_arena_play / agz_arena_selfplay return AGZ_E_TREE_FULL — pass a larger max_nodes.  Examples: up to 2 * n_games * max_moves rows, at most 12 GiB per arena
  * (agz_arena_stats.examples_dropped counts rows that did not fit).  Budget 0 with several games: no simulations at all, every move
  * comes from prepareRoot (search.go:392-408). */
 int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_conf* mcts, int n_games,

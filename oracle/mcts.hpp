@@ -429,7 +429,7 @@ struct MCTS {
         if (visits <= conf.RandomMinVisits) return;
       }
       if (visits > conf.RandomMinVisits) {
-        accum += std::pow((float)visits / norm, 1 / conf.RandomTemperature);
+        accum += (float)std::pow((double)((float)visits / norm), (double)(1 / conf.RandomTemperature));   // math32.Pow = float32(math.Pow(float64, float64))
         accumVector.push_back(accum);
       }
     }

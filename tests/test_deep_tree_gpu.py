@@ -64,8 +64,8 @@ def batched(one, plen):
     return f
 
 
-def run(ctx, kind, okind, m, n, komi, enc, one, plen, G, budget, plies, openings, lanes=1, PassPreference=capi.DONT_PREFER_PASS, max_moves=0):
-    dev = A.Arena(ctx, kind, m, n, 0, komi, encoder=enc, n_games=G, seed=11, Budget=budget, PassPreference=PassPreference, max_moves=max_moves)
+def run(ctx, kind, okind, m, n, komi, enc, one, plen, G, budget, plies, openings, lanes=1, PassPreference=capi.DONT_PREFER_PASS, max_moves=0, k=0, **kw):
+    dev = A.Arena(ctx, kind, m, n, k, komi, encoder=enc, n_games=G, seed=11, Budget=budget, PassPreference=PassPreference, max_moves=max_moves, **kw)
     if lanes > 1:
         dev.set_parallel(lanes)
     f = batched(one, plen)
@@ -76,7 +76,7 @@ def run(ctx, kind, okind, m, n, komi, enc, one, plen, G, budget, plies, openings
     dev.random_moves(np.asarray(openings, np.int32), 11)
     orcs = []
     for g in range(G):
-        o = O.Arena(okind, m, n, 0, komi, enc=enc, Budget=budget, seed=11 + g, PassPreference=PassPreference, max_moves=max_moves)
+        o = O.Arena(okind, m, n, k, komi, enc=enc, Budget=budget, seed=11 + g, PassPreference=PassPreference, max_moves=max_moves, **kw)
         o.set_callback(0, one, plen)
         o.set_callback(1, one, plen)
         if lanes > 1:
@@ -175,3 +175,51 @@ def test_narrow_deep_trees_on_19x19_220_simulations(ctx):
     assert st["path_nodes"] / st["sims_total"] > 4, st["path_nodes"] / st["sims_total"]
     assert dev.max_path_nodes() >= 12
     dev.close()
+
+
+def test_puct_near_tie_needs_a_correctly_rounded_sqrt(ctx):
+    """Round 6, found by the narrow-tree fuzz: Connect-4, a policy of 0.5 on one column and 1/14 on the others, value 0.  After 292 simulations
+    the root's children stand at 153 / 21 / 21 ... visits: 0.5 * sqrt(300) / 154 against (1/14) * sqrt(300) / 22 — equal in exact arithmetic
+    (0.5 / 154 = 1 / 308), two ulps apart in float32 in favour of the SECOND child when sqrt(300.f) is correctly rounded (0x418a9067), a tie — first
+    child — when it is one ulp low (0x418a9066: what __fsqrt_rn AND sqrtf return on this toolchain for 15 % of the integers up to 2^24,
+    scripts/probes/select_arith_probe.hip).  Simulation 293 is the witness; the sequential and the lane-round search both."""
+    cells, plen = 42, 8
+
+    def one(planes_flat):
+        x = np.ascontiguousarray(planes_flat, np.float32)
+        p = np.full(plen, 0.5 / 7, np.float32)
+        empt = np.where(np.abs(x[:cells]) < 0.5)[0]
+        p[zlib.crc32(x.tobytes()) % plen if plen <= cells else int(empt[0])] = 0.5
+        return p, 0.0
+
+    f = batched(one, plen)
+    for lanes, budget in ((1, 292), (1, 293), (1, 294), (2, 293), (2, 294)):
+        dev = A.Arena(ctx, capi.GAME_C4, 6, 7, 4, 0.0, encoder=capi.ENC_TWOPLANE, n_games=1, seed=11, Budget=budget, PassPreference=capi.DONT_RESIGN, max_moves=126)
+        if lanes > 1:
+            dev.set_parallel(lanes)
+        dev.set_inferencer_callback(0, f, plen)
+        dev.set_inferencer_callback(1, f, plen)
+        dev.reset(np.array([1], np.uint8))
+        dev.random_moves(np.array([2], np.int32), 11)
+        o = O.Arena(O.C4, 6, 7, 4, 0.0, enc=O.ENC_TWOPLANE, Budget=budget, seed=11, PassPreference=capi.DONT_RESIGN, max_moves=126)
+        o.set_callback(0, one, plen)
+        o.set_callback(1, one, plen)
+        if lanes > 1:
+            o.set_parallel(lanes)
+        o.begin(1)
+        for _ in range(2):
+            o.random_move(11, 0)
+        dev.begin_move()
+        dev.simulate(budget)
+        dev.end_move(True)
+        o.step(True)
+        omv, ovis, obs, opr = o.root_children(0)
+        dmv, dvis, dbs, dpr = dev.root_children(0, 0)
+        np.testing.assert_array_equal(dmv, omv, err_msg="lanes %d budget %d" % (lanes, budget))
+        np.testing.assert_array_equal(dvis, ovis, err_msg="lanes %d budget %d" % (lanes, budget))
+        np.testing.assert_array_equal(f32bits(dpr), f32bits(opr))
+        if (lanes, budget) == (1, 292):
+            assert sorted(dvis.tolist()) == [21] * 7 + [153]             # the near-tie position itself
+        if (lanes, budget) == (1, 293):
+            assert sorted(dvis.tolist()) == [21] * 6 + [22, 153]         # the second child took simulation 293 (a low sqrt gives 154 / 21)
+        dev.close()
