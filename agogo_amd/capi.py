@@ -21,6 +21,7 @@ COMPUTE_FORCE = 0x100
 PROF_CONV, PROF_HEADS, PROF_SELECT, PROF_EXPAND, PROF_MOVE, PROF_CONV_INIT = 0, 1, 2, 3, 4, 5
 PROF_WINO_IN, PROF_WINO_GEMM, PROF_WINO_OUT = 6, 7, 8
 DONT_PREFER_PASS, PREFER_PASS, DONT_RESIGN = 0, 1, 2
+POOL_STRICT, POOL_STOP_SEARCH = 0, 1
 
 
 class AgzError(RuntimeError):
@@ -232,6 +233,8 @@ def lib():
     sig("agz_mcts_set_inferencer", i32, vp, i32, vp)
     sig("agz_mcts_set_inferencer_callback", i32, vp, INFER_FN, vp, i32)
     sig("agz_arena_set_inferencer_callback", i32, vp, i32, INFER_FN, vp, i32)
+    sig("agz_arena_set_pool_policy", i32, vp, i32)
+    sig("agz_mcts_set_pool_policy", i32, vp, i32)
     sig("agz_mcts_set_parallel", i32, vp, i32)
     sig("agz_mcts_set_game", i32, vp, C.POINTER(State))
     sig("agz_mcts_search", i32, vp, i32, pi)
@@ -593,6 +596,10 @@ class Arena:
         _check(lib().agz_arena_set_inferencer_callback(self.h, agent, cfn, None, int(policy_len)), "agz_arena_set_inferencer_callback")
         self._nets.append(cfn)      # keeps the trampoline alive as long as the arena
 
+    def set_pool_policy(self, policy):
+        """POOL_STRICT (default: a full node pool fails play / selfplay) or POOL_STOP_SEARCH (the reference's MAXTREESIZE rule: the game goes on)"""
+        _check(lib().agz_arena_set_pool_policy(self.h, int(policy)), "agz_arena_set_pool_policy")
+
     def reset(self, a_is_black=None):
         if a_is_black is None:
             _check(lib().agz_arena_reset(self.h, None), "agz_arena_reset")
@@ -766,6 +773,9 @@ class Mcts:
         cfn = make_infer_fn(fn)
         _check(lib().agz_mcts_set_inferencer_callback(self.h, cfn, None, int(policy_len)), "agz_mcts_set_inferencer_callback")
         self._nets.append(cfn)
+
+    def set_pool_policy(self, policy):
+        _check(lib().agz_mcts_set_pool_policy(self.h, int(policy)), "agz_mcts_set_pool_policy")
 
     def set_parallel(self, lanes):
         _check(lib().agz_mcts_set_parallel(self.h, int(lanes)), "agz_mcts_set_parallel")

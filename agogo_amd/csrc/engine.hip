@@ -1345,6 +1345,7 @@ struct agz_arena {
   float* h_policy[2] = {nullptr, nullptr};           // [G*V][policy_len] in NN-slot order, uploaded for k_expand
   float* h_value[2] = {nullptr, nullptr};
   int64_t cb_calls = 0, cb_leaves = 0;
+  bool pool_stop = false;   // agz_arena_set_pool_policy: a full node pool stops that tree's search for the move (the reference's MAXTREESIZE rule) instead of failing the call
   size_t h_pk_policy_cap = 0, h_policy_cap[2] = {0, 0}, h_value_cap[2] = {0, 0};
 
   template <typename T>
@@ -1775,6 +1776,13 @@ int agz_arena_set_inferencer_callback(agz_arena* a, int agent, agz_infer_fn fn, 
   return a->update_slots();
 }
 
+int agz_arena_set_pool_policy(agz_arena* a, int policy) {
+  AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
+  AGZ_REQUIRE(policy == AGZ_POOL_STRICT || policy == AGZ_POOL_STOP_SEARCH, AGZ_E_INVALID, "agz_arena_set_pool_policy: policy %d", policy);
+  a->pool_stop = policy == AGZ_POOL_STOP_SEARCH;
+  return AGZ_OK;
+}
+
 int agz_arena_set_parallel(agz_arena* a, int lanes) {
   AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
   AGZ_REQUIRE(lanes >= 1 && lanes <= 16, AGZ_E_INVALID, "agz_arena_set_parallel: lanes must be in [1,16], got %d", lanes);
@@ -1944,7 +1952,7 @@ int agz_arena_play(agz_arena* a, int n_moves, int record) {
       agz_arena_stats st;
       int r = agz_arena_get_stats(a, &st);
       if (r != AGZ_OK) return r;
-      if (st.tree_full) { agz::set_error("agz_arena_play: %d tree pool(s) overflowed (max_nodes too small)", st.tree_full); return AGZ_E_TREE_FULL; }
+      if (st.tree_full && !a->pool_stop) { agz::set_error("agz_arena_play: %d tree pool(s) overflowed (max_nodes too small)", st.tree_full); return AGZ_E_TREE_FULL; }
       if (st.n_active == 0) break;
     }
     int r = agz_arena_begin_move(a);
@@ -1969,7 +1977,7 @@ int agz_arena_selfplay(agz_arena* a, int64_t n_games_target, int record) {
     if ((moves & 3) == 0) {
       agz_arena_stats st;
       if ((rc = agz_arena_get_stats(a, &st)) != AGZ_OK) break;
-      if (st.tree_full) { agz::set_error("agz_arena_selfplay: %d tree pool(s) overflowed", st.tree_full); rc = AGZ_E_TREE_FULL; break; }
+      if (st.tree_full && !a->pool_stop) { agz::set_error("agz_arena_selfplay: %d tree pool(s) overflowed", st.tree_full); rc = AGZ_E_TREE_FULL; break; }
       if (st.games_finished >= n_games_target) break;
     }
     if ((rc = agz_arena_begin_move(a)) != AGZ_OK) break;
@@ -2294,6 +2302,11 @@ int agz_mcts_set_inferencer_callback(agz_mcts* m, agz_infer_fn fn, void* user, i
   return agz_arena_set_inferencer_callback(m->arena, 1, fn, user, policy_len);
 }
 
+int agz_mcts_set_pool_policy(agz_mcts* m, int policy) {
+  AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
+  return agz_arena_set_pool_policy(m->arena, policy);
+}
+
 int agz_mcts_set_parallel(agz_mcts* m, int lanes) {
   AGZ_REQUIRE(m, AGZ_E_INVALID, "mcts is NULL");
   return agz_arena_set_parallel(m->arena, lanes);
@@ -2372,7 +2385,7 @@ int agz_mcts_search(agz_mcts* m, int player, int32_t* best) {
   AGZ_HIP_TRY(hipMemcpyAsync(&full, a->d.counters + CNT_FULL, 8, hipMemcpyDeviceToHost, s));
   AGZ_HIP_TRY(hipStreamSynchronize(s));
   *best = out[0];
-  AGZ_REQUIRE(full == full0 || pool_full_stop, AGZ_E_TREE_FULL, "agz_mcts_search: the node pool overflowed (max_nodes too small); the move is the best of the truncated search");
+  AGZ_REQUIRE(full == full0 || pool_full_stop || a->pool_stop, AGZ_E_TREE_FULL, "agz_mcts_search: the node pool overflowed (max_nodes too small); the move is the best of the truncated search");
   return AGZ_OK;
 }
 

@@ -351,6 +351,11 @@ func (a *BatchedArena) Search() ([]game.Single, error) {
 
 // SetParallel runs the simulations of every tree in rounds of `lanes` (1..16) whose leaves are one network batch: the
 // deterministic, lane-ordered form of the reference's NumCPU goroutines sharing a tree (search.go:112-131).  1 = sequential.
+func (a *BatchedArena) SetPoolPolicy(policy int) error {
+	defer a.ctx.enter()()
+	return lastErr(C.agz_arena_set_pool_policy(a.h, C.int(policy)))
+}
+
 func (a *BatchedArena) SetParallel(lanes int) error {
 	defer a.ctx.enter()()
 	return lastErr(C.agz_arena_set_parallel(a.h, C.int(lanes)))
@@ -578,6 +583,18 @@ func (t *MCTS) Log() string { return "" }
 
 // SetGame (tree.go:120-124).
 func (t *MCTS) SetGame(g game.State) { t.current = g }
+
+// SetPoolPolicy: what a full node pool means — PoolStrict (default: Search reports it) or PoolStopSearch (the reference's MAXTREESIZE rule:
+// the search of that move stops, the game goes on; search.go:23,78,229).
+const (
+	PoolStrict     = 0
+	PoolStopSearch = 1
+)
+
+func (t *MCTS) SetPoolPolicy(policy int) error {
+	defer t.ctx.enter()()
+	return lastErr(C.agz_mcts_set_pool_policy(t.h, C.int(policy)))
+}
 
 // SetParallel: lanes per round (see BatchedArena.SetParallel).
 func (t *MCTS) SetParallel(lanes int) error {

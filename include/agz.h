@@ -315,6 +315,14 @@ int agz_arena_set_inferencer(agz_arena* arena, int agent, int kind, agz_net* net
 /* agent `agent` holds a host inferencer (AGZ_INF_CALLBACK, above).  policy_len >= the game's ActionSpace (<= 4096).  Setting another
  * kind with agz_arena_set_inferencer removes it. */
 int agz_arena_set_inferencer_callback(agz_arena* arena, int agent, agz_infer_fn fn, void* user, int policy_len);
+/* What a FULL node pool means.  AGZ_POOL_STRICT (default): the tree stops growing, agz_arena_stats.tree_full counts it, and agz_arena_play /
+ * agz_arena_selfplay / agz_mcts_search fail with AGZ_E_TREE_FULL — nothing is silently truncated, and every parity test runs this way.
+ * AGZ_POOL_STOP_SEARCH: the reference's own rule — a tree at MAXTREESIZE stops being searched for that move and the game goes on
+ * (search.go:23,78,229) — with max_nodes in MAXTREESIZE's place: the move is the best of the truncated search, the next move re-roots into
+ * the free pool, tree_full still counts.  For long unattended self-play with a peaked network, where one narrow tree should not end the run. */
+#define AGZ_POOL_STRICT 0
+#define AGZ_POOL_STOP_SEARCH 1
+int agz_arena_set_pool_policy(agz_arena* arena, int policy);
 /* Start new games: fresh trees, empty boards, colour assignment.  a_is_black: per game 0/1, or NULL to
  * draw it from the arena RNG (arena.go:81-89 draws a.r.Intn(2)). */
 int agz_arena_reset(agz_arena* arena, const uint8_t* a_is_black);
@@ -439,6 +447,8 @@ int agz_mcts_set_inferencer(agz_mcts* mcts, int kind, agz_net* net);
 /* mcts.New(game, conf, nn) with a caller-supplied Inferencer: `fn` is called once per simulation with the one leaf state (lane rounds:
  * up to `lanes` leaves) — the reference's own dummyNN (mcts/example_test.go:40-72) runs through this as it runs through mcts.New */
 int agz_mcts_set_inferencer_callback(agz_mcts* mcts, agz_infer_fn fn, void* user, int policy_len);
+/* AGZ_POOL_* for a single tree (see agz_arena_set_pool_policy) */
+int agz_mcts_set_pool_policy(agz_mcts* mcts, int policy);
 /* lanes per round (BUILD EXTENSION, see agz_arena_set_parallel) */
 int agz_mcts_set_parallel(agz_mcts* mcts, int lanes);
 /* (*MCTS).SetGame (tree.go:120-124) */

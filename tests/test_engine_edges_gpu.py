@@ -151,3 +151,51 @@ def test_more_games_than_compute_units(ctx):
     assert st["games_finished"] == G
     r = dev.results()
     assert r["a_wins"] + r["b_wins"] + r["draws"] == G
+
+
+def test_full_pool_policy_strict_fails_stop_search_plays_on(ctx):
+    """agz_arena_set_pool_policy.  A pool of ~4 expansions on 5x5 Go at Budget 40 fills in every search.  AGZ_POOL_STRICT (default): agz_arena_play
+    fails with AGZ_E_TREE_FULL.  AGZ_POOL_STOP_SEARCH — the reference's MAXTREESIZE rule with max_nodes in its place (search.go:23,78,229: a full
+    tree stops being searched for that move, the game goes on): every game runs to its end, tree_full counts the truncated searches, and every
+    move played is legal in the oracle's rules; the single-tree handle returns the best move of the truncated search instead of failing."""
+    G = 6
+    kw = dict(encoder=capi.ENC_WQ, n_games=G, seed=5, Budget=40, max_nodes=110, max_moves=60)
+    dev = A.Arena(ctx, capi.GAME_WQ, 5, 5, 0, 0.5, **kw)
+    dev.set_inferencer(0, capi.INF_HASH)
+    dev.set_inferencer(1, capi.INF_HASH)
+    dev.reset()
+    with pytest.raises(A.AgzError, match="overflowed"):
+        dev.play(0, True)
+    dev.close()
+    dev = A.Arena(ctx, capi.GAME_WQ, 5, 5, 0, 0.5, **kw)
+    dev.set_inferencer(0, capi.INF_HASH)
+    dev.set_inferencer(1, capi.INF_HASH)
+    dev.set_pool_policy(capi.POOL_STOP_SEARCH)
+    dev.reset()
+    dev.play(0, True)
+    st = dev.stats()
+    assert st["games_finished"] == G and st["n_active"] == 0 and st["tree_full"] > 0
+    for g in range(G):
+        og = O.Game(O.WQ, 5, 5, 0, 0.5)
+        player = O.BLACK
+        og.set_to_move(player)
+        for mv in dev.history(g):
+            if mv == capi.RESIGN:
+                break
+            assert mv == capi.PASS or og.check(player, int(mv)), (g, mv)
+            og.apply(player, int(mv))
+            player = O.WHITE if player == O.BLACK else O.BLACK
+            og.set_to_move(player)
+    with pytest.raises(A.AgzError):
+        dev.set_pool_policy(7)
+    dev.close()
+    m = A.Mcts(ctx, capi.GAME_WQ, 5, 5, 0, 0.5, encoder=capi.ENC_WQ, Budget=40, max_nodes=110)
+    m.set_inferencer(capi.INF_HASH)
+    m.set_pool_policy(capi.POOL_STOP_SEARCH)
+    og = O.Game(O.WQ, 5, 5, 0, 0.5)
+    og.set_to_move(O.BLACK)
+    m.set_game(board=og.board(), to_move=O.BLACK, n_moves=0, passes=0, hash=og.hash(), last_moves=[], historical=np.zeros((0, 25), np.int32))
+    mv = m.search(O.BLACK)                  # no AgzError
+    assert mv == capi.PASS or og.check(O.BLACK, mv)
+    assert m.stats()["tree_full"] > 0
+    m.close()
