@@ -648,6 +648,7 @@ def main():
     ap.add_argument("--K", type=int, default=256)
     ap.add_argument("--L", type=int, default=20)
     ap.add_argument("--budget", type=int, default=800, help="simulations per move")
+    ap.add_argument("--max-nodes", type=int, default=0, help="node pool per tree (0: the library default, four searches' worth of expansions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=64, help="threads of the cpu_baseline legs (0 = every host core: slower in aggregate and ~7 minutes)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=30.0, help="size of the cpu_baseline's 19x19 leg (seconds of wall time it is sized for)")
@@ -717,7 +718,7 @@ def main():
         net.set_compute_mode(MODES[args.compute])
         net.set_tower_queues(args.tower_queues)
         nets.append(net)
-    arena = A.Arena(ctx, capi.GAME_WQ, S, S, komi=7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337 + rank,
+    arena = A.Arena(ctx, capi.GAME_WQ, S, S, komi=7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337 + rank, max_nodes=args.max_nodes,
                     Budget=args.budget, PUCT=1.0, RandomCount=0, DumbPass=True,
                     PassPreference=capi.DONT_PREFER_PASS)
     arena.set_inferencer(0, capi.INF_NET, nets[0])
