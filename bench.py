@@ -570,6 +570,18 @@ def train_leg(ctx, steps=10):
         c = t.batch(x, pi, v)
     ctx.sync()
     dt = (time.perf_counter() - t0) / steps
+    # the same call with the batch in page-locked host memory (agz_host_alloc: what the Go shim's staging uses)
+    xp, pp, vp = ctx.host_array(x.shape), ctx.host_array(pi.shape), ctx.host_array(v.shape)
+    xp[...], pp[...], vp[...] = x, pi, v
+    t.batch(xp, pp, vp)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t.batch(xp, pp, vp)
+    ctx.sync()
+    dt_pinned = (time.perf_counter() - t0) / steps
+    for a_ in (xp, pp, vp):
+        ctx.host_free(a_)
     hw = S * S
     flops = 3 * (2.0 * 18 * K * 9 * hw + L * 2 * 2.0 * K * K * 9 * hw) * B   # forward + data gradient + weight gradient, direct-equivalent
     # the loop AZ.Learn runs (agogo.go:123-133 -> dual.Train, dualnet/meta.go:16-54) with the examples RESIDENT in HBM (agz_examples_* ->
@@ -595,6 +607,7 @@ def train_leg(ctx, steps=10):
     return {"workload": "dual.Train batch: 19x19, K=256, 20 blocks, BatchSize 256 (config #4 network), trainer AGZ_COMPUTE_WINO_H2",
             "steps_timed": steps, "step_ms": dt * 1e3, "examples_per_s": B / dt, "direct_equivalent_tflops": flops / dt / 1e12,
             "cost": float(c), "note": "includes the host -> device copy of the batch (27 MB) and the cost read-back: the boundary's agz_trainer_batch",
+            "step_ms_pinned_host_batch": dt_pinned * 1e3,
             "step_ms_device_resident": dev_ms,
             "step_ms_device_resident_note": "agz_train_dev over %d batches of examples resident in HBM (what AZ.Learn's dual.Train runs on): per batch, no host copy, "
                                             "no per-batch synchronisation" % steps}
