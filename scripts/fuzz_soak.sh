@@ -7,4 +7,6 @@ LOG=gpurun_out/fuzz_soak_$BASE.log
 : > $LOG
 AGZ_FUZZ_BASE=$BASE AGZ_FUZZ_N=$NE timeout 300 python -m pytest tests/test_engine_fuzz_gpu.py -q -m gpu -p no:cacheprovider --tb=line 2>&1 | grep -v "^\.*  *\[" | tail -60 >> $LOG
 AGZ_FUZZ_BASE=$BASE AGZ_FUZZ_N=$NO timeout 200 python -m pytest tests/test_net_fuzz_gpu.py tests/test_train_fuzz_gpu.py tests/test_tournament_gpu.py -q -m gpu -p no:cacheprovider --tb=line -k "fuzz or random" 2>&1 | grep -v "^\.*  *\[" | tail -60 >> $LOG
+# the tie-heavy family (round 6): narrow trees through host inferencers on both sides
+AGZ_FUZZ_BASE=$BASE AGZ_FUZZ_N=$NE timeout 600 python -m pytest tests/test_deep_tree_fuzz_gpu.py -q -m gpu -p no:cacheprovider --tb=line 2>&1 | grep -v "^\.*  *\[" | tail -20 >> $LOG
 cat $LOG | tail -60
