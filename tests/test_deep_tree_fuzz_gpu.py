@@ -36,7 +36,23 @@ def peaked(plen, cells, peak, value_amp, among_empty, twoplane):
     return one
 
 
+WIDE = bool(os.environ.get("AGZ_FUZZ_WIDE"))   # soak runs: bigger boards, budgets, more lanes and games
+
+
 def draw(rng):
+    c = _draw(rng)
+    if WIDE:
+        if c["kind"] == capi.GAME_WQ:
+            s = int(rng.choice([5, 7, 9, 13, 19]))
+            c.update(m=s, n=s)
+        c["budget"] = int(rng.choice([30, 120, 300, 600]))
+        c["lanes"] = int(rng.choice([1, 1, 2, 3, 7, 16]))
+        c["G"] = int(rng.integers(1, 9))
+        c["peak"] = float(rng.choice([0.5, 0.8, 0.95, 0.99, 0.999]))
+    return c
+
+
+def _draw(rng):
     kind = int(rng.choice([capi.GAME_MNK, capi.GAME_C4, capi.GAME_KOMI, capi.GAME_WQ, capi.GAME_WQ]))
     c = dict(kind=kind, k=0, komi=0.0)
     if kind == capi.GAME_MNK:
@@ -76,6 +92,9 @@ def test_random_narrow_tree_configuration(ctx, seed):
     openings = [int(x) for x in rng.integers(0, max(1, cells // 3), size=c["G"])]
     dev, orcs = run(ctx, c["kind"], KINDS[c["kind"]], c["m"], c["n"], c["komi"], c["enc"], one, plen, G=c["G"], budget=c["budget"], plies=c["plies"],
                     openings=openings, lanes=c["lanes"], PassPreference=c["PassPreference"], max_moves=3 * cells, k=c["k"], DumbPass=c["DumbPass"],
+                    # (pools for EVERY search's expansions: a 0.999-peaked tree keeps nearly all its nodes move after move — the default, four
+                    #  searches' worth, is a sizing rule for kept fractions up to 3/4, include/agz.h; parity is what is tested here)
+                    max_nodes=(c["plies"] + 2) * (c["budget"] + 2) * (plen + 1),
                     ResignPercentage=c["ResignPercentage"], PUCT=c["PUCT"], RandomCount=c["RandomCount"], RandomTemperature=1.0, RandomMinVisits=0)
     dp, dpol, dval, dgi = dev.examples()
     for g in range(c["G"]):
@@ -87,7 +106,7 @@ def test_random_narrow_tree_configuration(ctx, seed):
             np.testing.assert_array_equal(f32bits(dp[sel]), f32bits(ob))
             np.testing.assert_array_equal(f32bits(dpol[sel]), f32bits(op))
     st = dev.stats()
-    assert st["tree_full"] == 0      # (default pools: four searches' worth of expansions — two, rounds 1-5's default, overflowed here within five moves)
+    assert st["tree_full"] == 0
     tot_e = sum(o.tree_stats(a)["nn_evals"] for o in orcs for a in (0, 1))
     tot_p = sum(o.tree_stats(a)["playouts"] for o in orcs for a in (0, 1))
     assert st["sims_nonnull"] == tot_p, c

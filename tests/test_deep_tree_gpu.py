@@ -64,8 +64,9 @@ def batched(one, plen):
     return f
 
 
-def run(ctx, kind, okind, m, n, komi, enc, one, plen, G, budget, plies, openings, lanes=1, PassPreference=capi.DONT_PREFER_PASS, max_moves=0, k=0, **kw):
-    dev = A.Arena(ctx, kind, m, n, k, komi, encoder=enc, n_games=G, seed=11, Budget=budget, PassPreference=PassPreference, max_moves=max_moves, **kw)
+def run(ctx, kind, okind, m, n, komi, enc, one, plen, G, budget, plies, openings, lanes=1, PassPreference=capi.DONT_PREFER_PASS, max_moves=0, k=0, max_nodes=0, **kw):
+    dev = A.Arena(ctx, kind, m, n, k, komi, encoder=enc, n_games=G, seed=11, Budget=budget, PassPreference=PassPreference, max_moves=max_moves,
+                  max_nodes=max_nodes, **kw)
     if lanes > 1:
         dev.set_parallel(lanes)
     f = batched(one, plen)
