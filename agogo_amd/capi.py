@@ -21,7 +21,7 @@ COMPUTE_FORCE = 0x100
 PROF_CONV, PROF_HEADS, PROF_SELECT, PROF_EXPAND, PROF_MOVE, PROF_CONV_INIT = 0, 1, 2, 3, 4, 5
 PROF_WINO_IN, PROF_WINO_GEMM, PROF_WINO_OUT = 6, 7, 8
 DONT_PREFER_PASS, PREFER_PASS, DONT_RESIGN = 0, 1, 2
-POOL_STRICT, POOL_STOP_SEARCH = 0, 1
+POOL_STRICT, POOL_STOP_SEARCH, POOL_GROW = 0, 1, 2
 
 
 class AgzError(RuntimeError):
@@ -224,6 +224,7 @@ def lib():
     sig("agz_trainer_set_dma_forward", i32, vp, i32)
     sig("agz_arena_last_prep_batch", i32, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
     sig("agz_arena_debug_counter", i32, vp, i32, C.POINTER(C.c_int64))
+    sig("agz_arena_pool_capacity", i32, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
     sig("agz_wino_h2_chained", i32, i32, i32, i32)
     sig("agz_arena_random_moves", i32, vp, pi, u64)
     sig("agz_arena_set_state", i32, vp, i32, C.POINTER(State))
@@ -686,6 +687,12 @@ class Arena:
         b, r = C.c_int(0), C.c_int(0)
         _check(lib().agz_arena_last_prep_batch(self.h, C.byref(b), C.byref(r)), "agz_arena_last_prep_batch")
         return b.value, r.value
+
+    def pool_capacity(self):
+        """agz_debug.h: (nodes per pool, re-allocations by POOL_GROW)"""
+        c, g = C.c_int(0), C.c_int(0)
+        _check(lib().agz_arena_pool_capacity(self.h, C.byref(c), C.byref(g)), "agz_arena_pool_capacity")
+        return c.value, g.value
 
     def max_path_nodes(self):
         """agz_debug.h AGZ_CNT_PATHMAX: nodes on the longest descent since the last reset"""

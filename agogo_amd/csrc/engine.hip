@@ -1345,6 +1345,10 @@ struct agz_arena {
   float* h_policy[2] = {nullptr, nullptr};           // [G*V][policy_len] in NN-slot order, uploaded for k_expand
   float* h_value[2] = {nullptr, nullptr};
   int64_t cb_calls = 0, cb_leaves = 0;
+  bool pool_grow = false;   // AGZ_POOL_GROW: before every search the pools are made large enough for it (ensure_pool_room)
+  long long room_sims = 0, sims_this_move = 0;   // simulations the current capacity is guaranteed for / enqueued since begin_move
+  int pool_grows = 0;       // how often the pools were re-allocated
+  int ensure_pool_room(long long sims);
   bool pool_stop = false;   // agz_arena_set_pool_policy: a full node pool stops that tree's search for the move (the reference's MAXTREESIZE rule) instead of failing the call
   size_t h_pk_policy_cap = 0, h_policy_cap[2] = {0, 0}, h_value_cap[2] = {0, 0};
 
@@ -1389,6 +1393,61 @@ __global__ __launch_bounds__(256) void k_prep_compact(Dev d, float* act, int slo
     if (src != rank && i < slot_f4) a4[(size_t)rank * slot_f4 + i] = a4[(size_t)src * slot_f4 + i];
     rank++;
   }
+}
+
+// ---- AGZ_POOL_GROW -----------------------------------------------------------------------------------------------------------------
+// Node pools that cannot overflow.  A search of `sims` simulations adds at most (sims + 1) expansions of at most A + 1 children each to a
+// tree (prepareRoot's included); before the search the host reads every tree's node count (T words, one synchronisation per move) and, if the
+// fullest tree could outgrow the pool, re-allocates ALL pools at a larger capacity (trees keep one stride: pool_base) and copies every
+// tree's live pool over — node indices, child offsets and therefore every result stay what they were.  Rare (a narrow tree that keeps most of
+// its nodes move after move), tens of milliseconds when it happens; memory follows the fullest tree.
+__global__ __launch_bounds__(256) void k_pool_copy(Dev o, Dev n) {
+  const int t = blockIdx.y;
+  const int pool = o.cur_pool[t], cnt = o.n_nodes[t];
+  const size_t so = ((size_t)t * 2 + pool) * o.cap, sn = ((size_t)t * 2 + pool) * n.cap;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) {
+    n.prior[sn + i] = o.prior[so + i]; n.visits[sn + i] = o.visits[so + i]; n.bsum[sn + i] = o.bsum[so + i];
+    n.kids_off[sn + i] = o.kids_off[so + i]; n.kids_n[sn + i] = o.kids_n[so + i]; n.nmove[sn + i] = o.nmove[so + i];
+  }
+}
+
+int agz_arena::ensure_pool_room(long long sims) {
+  hipStream_t s = ctx->stream;
+  const int T = d.T;
+  std::vector<int32_t> nn(T);
+  AGZ_HIP_TRY(hipMemcpyAsync(nn.data(), d.n_nodes, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  long long most = 0;
+  for (int t = 0; t < T; t++) most = std::max<long long>(most, nn[t]);
+  const long long need = most + (sims + 2) * (long long)(gc.A + 1) + 16;
+  if (need <= d.cap) return AGZ_OK;
+  long long ncap = std::max(need + need / 2, 2ll * d.cap);
+  size_t free_b = 0, total_b = 0;
+  AGZ_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const size_t per_node = 4 + 4 + 4 + 4 + 2 + 2 + 1;
+  auto bytes = [&](long long c) { return (size_t)T * 2 * (size_t)c * per_node; };
+  if (bytes(ncap) + (1ull << 30) > free_b) ncap = need;                      // (the old pools stay allocated until the copy is done)
+  AGZ_REQUIRE(ncap < (1ll << 30) && bytes(ncap) + (256ull << 20) <= free_b, AGZ_E_NOMEM,
+              "AGZ_POOL_GROW: the fullest tree holds %lld nodes, the next search may need %lld per pool — %zu MB for %d trees do not fit the free device memory (%zu MB)",
+              most, need, bytes(need) >> 20, T, free_b >> 20);
+  Dev nd = d;
+  nd.cap = (int)ncap;
+  const size_t pool = (size_t)T * 2 * (size_t)ncap;
+  void* old[7] = {d.prior, d.visits, d.bsum, d.kids_off, d.kids_n, d.nmove, d.vl};
+  int r;
+  if ((r = alloc(&nd.prior, pool)) != AGZ_OK || (r = alloc(&nd.visits, pool)) != AGZ_OK || (r = alloc(&nd.bsum, pool)) != AGZ_OK ||
+      (r = alloc(&nd.kids_off, pool)) != AGZ_OK || (r = alloc(&nd.kids_n, pool)) != AGZ_OK || (r = alloc(&nd.nmove, pool)) != AGZ_OK ||
+      (r = alloc(&nd.vl, pool)) != AGZ_OK)
+    return r;                                                                  // (whatever was allocated is on the arena's list and goes with it)
+  hipLaunchKernelGGL(k_pool_copy, dim3(64, T), dim3(256), 0, s, d, nd);
+  AGZ_HIP_TRY(hipStreamSynchronize(s));
+  for (void* p : old) {
+    allocs.erase(std::remove(allocs.begin(), allocs.end(), p), allocs.end());
+    hipFree(p);
+  }
+  d = nd;
+  pool_grows++;
+  return AGZ_OK;
 }
 
 // ---- AGZ_INF_CALLBACK ------------------------------------------------------------------------------------------------------------
@@ -1778,8 +1837,10 @@ int agz_arena_set_inferencer_callback(agz_arena* a, int agent, agz_infer_fn fn, 
 
 int agz_arena_set_pool_policy(agz_arena* a, int policy) {
   AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
-  AGZ_REQUIRE(policy == AGZ_POOL_STRICT || policy == AGZ_POOL_STOP_SEARCH, AGZ_E_INVALID, "agz_arena_set_pool_policy: policy %d", policy);
+  AGZ_REQUIRE(policy == AGZ_POOL_STRICT || policy == AGZ_POOL_STOP_SEARCH || policy == AGZ_POOL_GROW, AGZ_E_INVALID, "agz_arena_set_pool_policy: policy %d", policy);
+  AGZ_REQUIRE(!a->in_move, AGZ_E_STATE, "agz_arena_set_pool_policy: a search is in progress");
   a->pool_stop = policy == AGZ_POOL_STOP_SEARCH;
+  a->pool_grow = policy == AGZ_POOL_GROW;
   return AGZ_OK;
 }
 
@@ -1841,6 +1902,13 @@ int agz_arena_begin_move(agz_arena* a) {
     hipLaunchKernelGGL(k_begin_move, dim3(a->G), dim3(64), 0, a->ctx->stream, a->d, a->gc, a->mc);
   }
   a->in_move = true;
+  a->sims_this_move = 0; a->room_sims = 0;
+  if (a->pool_grow) {   // room for this move's search before its first expansion (prepareRoot's): AGZ_POOL_GROW
+    const long long sims = a->mc.Budget > 0 ? a->mc.Budget : 0;
+    int r = a->ensure_pool_room(sims);
+    if (r != AGZ_OK) { a->in_move = false; return r; }
+    a->room_sims = sims;
+  }
   return a->nn_step(1);  // prepareRoot
 }
 
@@ -1851,6 +1919,12 @@ int agz_arena_debug_counter(agz_arena* a, int which, int64_t* value) {
   AGZ_HIP_TRY(hipMemcpyAsync(&v, a->d.counters + which, 8, hipMemcpyDeviceToHost, a->ctx->stream));
   AGZ_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
   *value = (int64_t)v;
+  return AGZ_OK;
+}
+
+int agz_arena_pool_capacity(agz_arena* a, int* nodes_per_pool, int* grows) {
+  AGZ_REQUIRE(a && nodes_per_pool && grows, AGZ_E_INVALID, "agz_arena_pool_capacity: NULL argument");
+  *nodes_per_pool = a->d.cap; *grows = a->pool_grows;
   return AGZ_OK;
 }
 
@@ -1870,6 +1944,12 @@ int agz_arena_simulate(agz_arena* a, int k) {
   AGZ_REQUIRE(a, AGZ_E_INVALID, "arena is NULL");
   AGZ_REQUIRE(a->in_move, AGZ_E_STATE, "agz_arena_simulate: call agz_arena_begin_move first");
   AGZ_HIP_TRY(hipSetDevice(a->ctx->device));
+  if (a->pool_grow && a->sims_this_move + k > a->room_sims) {   // more simulations than the move's Budget promised (or a wall-clock search): room for these
+    int r = a->ensure_pool_room(k);
+    if (r != AGZ_OK) return r;
+    a->room_sims = a->sims_this_move + k;
+  }
+  a->sims_this_move += k;
   // k simulations per tree, in rounds of up to V lanes (agz_arena_set_parallel; V = 1: one at a time)
   for (int done = 0; done < k;) {
     int nl = std::min(a->d.V, k - done);

@@ -278,11 +278,12 @@ def go9_leg(ctx, compute="wino_h2"):
     arena.close()
     # (1) move rate at 400 simulations per move, on positions of THOSE games: game g replayed up to a uniformly drawn ply of its own length (an
     # arena ply late in a game costs ~1.5x an early one; uniformly random openings — round 6's first forms of this leg — are neither: 1284 and
-    # 533 moves/s where complete 400-simulation games ran 834).  Node pools: six searches' worth of expansions (the default, four, covers trees that
-    # keep up to 3/4 of their nodes per move; round 5's default of two was outgrown by one of 512 different games in round 6's first run)
-    arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337, Budget=sims, max_nodes=6 * (sims + 2) * 82)
+    # 533 moves/s where complete 400-simulation games ran 834).  Node pools: the default with AGZ_POOL_GROW (round 5's default of two searches'
+    # worth was outgrown by one of 512 different games in round 6's first run)
+    arena = A.Arena(ctx, capi.GAME_WQ, 9, 9, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=1337, Budget=sims)
     arena.set_inferencer(0, capi.INF_NET, net)
     arena.set_inferencer(1, capi.INF_NET, net)
+    arena.set_pool_policy(capi.POOL_GROW)     # default pools (four searches' worth) that grow if a narrow tree needs more
     arena.reset(np.array([1] * G, np.uint8))
     plies = 16
     prefix = np.array([int(np.random.default_rng(1337 + g).integers(0, max(1, len(hist[g]) - plies - 1))) for g in range(G)])
@@ -299,7 +300,8 @@ def go9_leg(ctx, compute="wino_h2"):
     s1 = arena.stats()
     rate = {"plies": plies, "seconds": dt, "moves_per_s": (s1["moves_played"] - s0["moves_played"]) / dt,
             "sims_per_s": (s1["sims_nonnull"] - s0["sims_nonnull"]) / dt, "active_games_at_end": s1["n_active"], "tree_full": s1["tree_full"],
-            "positions": "each game replayed to a uniformly drawn ply of its own (16-simulation) game: mean %.0f moves played" % float(prefix.mean())}
+            "positions": "each game replayed to a uniformly drawn ply of its own (16-simulation) game: mean %.0f moves played" % float(prefix.mean()),
+            "node_pool": dict(zip(("nodes_per_pool", "grows"), arena.pool_capacity()))}
     arena.close()
     out = {"workload": "config #3: 9x9 Go (wq, komi 7.5), K=128, 10 blocks, 512 concurrent games, 400 sims/move", "compute": compute,
            "move_rate_at_400_sims": rate,

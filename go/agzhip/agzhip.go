@@ -589,6 +589,7 @@ func (t *MCTS) SetGame(g game.State) { t.current = g }
 const (
 	PoolStrict     = 0
 	PoolStopSearch = 1
+	PoolGrow       = 2 // pools re-allocated before a search could outgrow them: results unchanged, no max_nodes to choose
 )
 
 func (t *MCTS) SetPoolPolicy(policy int) error {

@@ -320,8 +320,15 @@ int agz_arena_set_inferencer_callback(agz_arena* arena, int agent, agz_infer_fn 
  * AGZ_POOL_STOP_SEARCH: the reference's own rule — a tree at MAXTREESIZE stops being searched for that move and the game goes on
  * (search.go:23,78,229) — with max_nodes in MAXTREESIZE's place: the move is the best of the truncated search, the next move re-roots into
  * the free pool, tree_full still counts.  For long unattended self-play with a peaked network, where one narrow tree should not end the run. */
+/* AGZ_POOL_GROW: pools that cannot overflow.  Before every search (agz_arena_begin_move; again inside agz_arena_simulate when a move runs more
+ * simulations than its Budget) the host reads every tree's node count and, when the fullest tree could outgrow its pool — a search adds at
+ * most (simulations + 1) x (ActionSpace + 1) nodes — re-allocates all pools at a larger capacity and copies the live trees over: node indices
+ * and every result stay what they were (bit-exact against AGZ_POOL_STRICT with a large enough max_nodes).  One small read-back per move; a
+ * re-allocation takes tens of milliseconds and is rare.  AGZ_E_NOMEM when the device cannot hold the larger pools.  A wall-clock search
+ * (Budget <= 0) is covered slice by slice. */
 #define AGZ_POOL_STRICT 0
 #define AGZ_POOL_STOP_SEARCH 1
+#define AGZ_POOL_GROW 2
 int agz_arena_set_pool_policy(agz_arena* arena, int policy);
 /* Start new games: fresh trees, empty boards, colour assignment.  a_is_black: per game 0/1, or NULL to
  * draw it from the arena RNG (arena.go:81-89 draws a.r.Intn(2)). */

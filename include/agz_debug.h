@@ -88,6 +88,9 @@ int agz_net_min_same_batch(agz_net* net, int n, int G, int* batch);
 #define AGZ_CNT_PATHMAX 15
 int agz_arena_debug_counter(agz_arena* arena, int which, int64_t* value);
 
+/* Measurement: the node-pool capacity of an arena's trees and how often AGZ_POOL_GROW has re-allocated them */
+int agz_arena_pool_capacity(agz_arena* arena, int* nodes_per_pool, int* grows);
+
 /* Failure injection (tests): the data-parallel step of this communicator fails on THIS rank right before it would enter the collective of
  * slice k (0 = the heads, 1 .. = layer L .. 0; k < 0: off).  One shot: cleared by the step it hits.  What the test checks is the rule of
  * agz_trainer_forward_backward_allreduce: the failing rank still enters every collective, every rank's call fails (AGZ_E_PEER on the

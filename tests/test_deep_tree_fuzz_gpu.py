@@ -90,11 +90,13 @@ def test_random_narrow_tree_configuration(ctx, seed):
     plen = A_ + 1
     one = peaked(plen, cells, c["peak"], c["value_amp"], c["among_empty"], c["enc"] == capi.ENC_TWOPLANE)
     openings = [int(x) for x in rng.integers(0, max(1, cells // 3), size=c["G"])]
+    grow = bool(seed & 1)
     dev, orcs = run(ctx, c["kind"], KINDS[c["kind"]], c["m"], c["n"], c["komi"], c["enc"], one, plen, G=c["G"], budget=c["budget"], plies=c["plies"],
                     openings=openings, lanes=c["lanes"], PassPreference=c["PassPreference"], max_moves=3 * cells, k=c["k"], DumbPass=c["DumbPass"],
                     # (pools for EVERY search's expansions: a 0.999-peaked tree keeps nearly all its nodes move after move — the default, four
                     #  searches' worth, is a sizing rule for kept fractions up to 3/4, include/agz.h; parity is what is tested here)
-                    max_nodes=(c["plies"] + 2) * (c["budget"] + 2) * (plen + 1),
+                    # ... or, every other configuration, pools of ONE search's worth that grow (AGZ_POOL_GROW): the same results
+                    max_nodes=((c["plies"] + 2) if not grow else 1) * (c["budget"] + 2) * (plen + 1), pool_policy=capi.POOL_GROW if grow else None,
                     ResignPercentage=c["ResignPercentage"], PUCT=c["PUCT"], RandomCount=c["RandomCount"], RandomTemperature=1.0, RandomMinVisits=0)
     dp, dpol, dval, dgi = dev.examples()
     for g in range(c["G"]):

@@ -64,7 +64,7 @@ def batched(one, plen):
     return f
 
 
-def run(ctx, kind, okind, m, n, komi, enc, one, plen, G, budget, plies, openings, lanes=1, PassPreference=capi.DONT_PREFER_PASS, max_moves=0, k=0, max_nodes=0, **kw):
+def run(ctx, kind, okind, m, n, komi, enc, one, plen, G, budget, plies, openings, lanes=1, PassPreference=capi.DONT_PREFER_PASS, max_moves=0, k=0, max_nodes=0, pool_policy=None, **kw):
     dev = A.Arena(ctx, kind, m, n, k, komi, encoder=enc, n_games=G, seed=11, Budget=budget, PassPreference=PassPreference, max_moves=max_moves,
                   max_nodes=max_nodes, **kw)
     if lanes > 1:
@@ -72,6 +72,8 @@ def run(ctx, kind, okind, m, n, komi, enc, one, plen, G, budget, plies, openings
     f = batched(one, plen)
     dev.set_inferencer_callback(0, f, plen)
     dev.set_inferencer_callback(1, f, plen)
+    if pool_policy is not None:
+        dev.set_pool_policy(pool_policy)
     ab = np.array([(g % 2) == 0 for g in range(G)], np.uint8)
     dev.reset(ab)
     dev.random_moves(np.asarray(openings, np.int32), 11)
@@ -223,4 +225,68 @@ def test_puct_near_tie_needs_a_correctly_rounded_sqrt(ctx):
             assert sorted(dvis.tolist()) == [21] * 7 + [153]             # the near-tie position itself
         if (lanes, budget) == (1, 293):
             assert sorted(dvis.tolist()) == [21] * 6 + [22, 153]         # the second child took simulation 293 (a low sqrt gives 154 / 21)
+        dev.close()
+
+
+def test_growing_pools_never_overflow_and_change_nothing(ctx):
+    """AGZ_POOL_GROW.  13x13 Go, a 0.999-peaked policy, value 0: the tree keeps nearly all its nodes move after move and outgrows ANY fixed
+    multiple of a search's expansions (the wide narrow-tree soak's one default-pool failure).  Two arenas on the same seeds: pools that
+    start at ONE search's worth and grow, and strict pools sized for every search of the run — identical roots,
+    histories and counters after every ply, all equal to the oracle's; the growing pools re-allocated at least twice, nothing overflowed."""
+    S, G, budget, plies = 13, 4, 40, 10
+    plen = S * S + 1
+    one = peaked_by_hash(plen, 0.999)
+    f = batched(one, plen)
+    one_search = (budget + 2) * (plen + 1)
+    arenas = []
+    for policy, cap in ((capi.POOL_GROW, one_search), (capi.POOL_STRICT, (plies + 2) * one_search)):
+        dev = A.Arena(ctx, capi.GAME_WQ, S, S, 0, 0.5, encoder=capi.ENC_TWOPLANE, n_games=G, seed=11, Budget=budget, max_nodes=cap, max_moves=3 * S * S)
+        dev.set_inferencer_callback(0, f, plen)
+        dev.set_inferencer_callback(1, f, plen)
+        dev.set_pool_policy(policy)
+        ab = np.array([(g % 2) == 0 for g in range(G)], np.uint8)
+        dev.reset(ab)
+        dev.random_moves(np.array([0, 4, 9, 15], np.int32), 11)
+        arenas.append(dev)
+    orcs = []
+    for g in range(G):
+        o = O.Arena(O.WQ, S, S, 0, 0.5, enc=O.ENC_TWOPLANE, Budget=budget, seed=11 + g, max_moves=3 * S * S)
+        o.set_callback(0, one, plen)
+        o.set_callback(1, one, plen)
+        o.begin(int(ab[g]))
+        for _ in range([0, 4, 9, 15][g]):
+            o.random_move(11, g)
+        orcs.append(o)
+    for ply in range(plies):
+        for dev in arenas:
+            dev.begin_move()
+            dev.simulate(budget // 2)          # (the move's simulations in two calls: the room was made for all of them at begin_move)
+            dev.simulate(budget - budget // 2)
+            dev.end_move(True)
+        for g, o in enumerate(orcs):
+            _, st0 = o.state()
+            agent = 0 if ((st0["to_move"] == O.BLACK) == bool(ab[g])) else 1
+            o.step(True)
+            ref = o.root_children(agent)
+            for dev in arenas:
+                got = dev.root_children(g, agent)
+                np.testing.assert_array_equal(got[0], ref[0], err_msg="game %d ply %d" % (g, ply))
+                np.testing.assert_array_equal(got[1], ref[1], err_msg="game %d ply %d" % (g, ply))
+                np.testing.assert_array_equal(f32bits(got[2]), f32bits(ref[2]))
+                np.testing.assert_array_equal(f32bits(got[3]), f32bits(ref[3]))
+                assert dev.history(g)[-1] == o.history()[-1]
+    cap, grows = arenas[0].pool_capacity()
+    nodes = max(arenas[0].tree_nodes(g, a) for g in range(G) for a in (0, 1))
+    print("\n[growing pools] capacity %d -> %d nodes per pool in %d re-allocations; fullest tree %d nodes (one search's worth: %d)" % (one_search, cap, grows, nodes, one_search))
+    assert grows >= 2 and cap > one_search and nodes > 2 * one_search
+    assert arenas[1].pool_capacity() == ((plies + 2) * one_search, 0)
+    for dev in arenas:
+        assert dev.stats()["tree_full"] == 0
+    # more simulations in a move than its Budget promised: room is made inside agz_arena_simulate
+    dev = arenas[0]
+    dev.begin_move()
+    dev.simulate(5 * budget)
+    dev.end_move(True)
+    assert dev.stats()["tree_full"] == 0
+    for dev in arenas:
         dev.close()
