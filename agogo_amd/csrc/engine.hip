@@ -1697,6 +1697,7 @@ int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_con
   AGZ_HIP_TRY(hipSetDevice(ctx->device));
   agz_arena* a = new agz_arena();
   a->ctx = ctx; a->G = n_games; a->seed = seed; a->seed0 = seed;
+  a->pool_grow = max_nodes <= 0;   // the library chose the pool size: it also keeps it sufficient (AGZ_POOL_GROW); an explicit max_nodes is the caller's budget (AGZ_POOL_STRICT)
   GameCfg& c = a->gc;
   c.kind = game->kind; c.m = game->m; c.n = game->n; c.k = game->k; c.cells = c.m * c.n;
   c.A = c.kind == AGZ_GAME_C4 ? c.n : c.cells;

@@ -302,8 +302,10 @@ typedef int (*agz_infer_fn)(void* user, const agz_leaf_batch* batch);
  * tree; 0 = the default: FOUR searches' worth of expansions, 4 * (Budget + 2) * (ActionSpace + 1) nodes (at most 8 M) — a search adds at most
  * Budget + 1 expansions to the subtree kept from the one before, so a tree that keeps a fraction f of its nodes per move settles at
  * (Budget + 1)(ActionSpace + 1) / (1 - f): the default covers f <= 0.75.  A very NARROW tree keeps more and can outgrow it (the reference's
- * arena is unbounded up to MAXTREESIZE, search.go:23,78): a tree whose pool fills stops growing for that move, agz_arena_stats.tree_full
- * counts it and agz_arena_play / agz_arena_selfplay return AGZ_E_TREE_FULL — pass a larger max_nodes.  Examples: up to 2 * n_games * max_moves rows, at most 12 GiB per arena
+ * arena is unbounded up to MAXTREESIZE, search.go:23,78).  With max_nodes = 0 — the library chose the size — the pools therefore GROW when a
+ * search could outgrow them (AGZ_POOL_GROW below is the default policy then: results unchanged, overflow impossible short of AGZ_E_NOMEM).  An
+ * explicit max_nodes > 0 is the caller's memory budget (AGZ_POOL_STRICT): a tree whose pool fills stops growing for that move,
+ * agz_arena_stats.tree_full counts it and agz_arena_play / agz_arena_selfplay return AGZ_E_TREE_FULL.  Examples: up to 2 * n_games * max_moves rows, at most 12 GiB per arena
  * (agz_arena_stats.examples_dropped counts rows that did not fit).  Budget 0 with several games: no simulations at all, every move
  * comes from prepareRoot (search.go:392-408). */
 int agz_arena_create(agz_ctx* ctx, const agz_game_conf* game, const agz_mcts_conf* mcts, int n_games,
@@ -315,7 +317,8 @@ int agz_arena_set_inferencer(agz_arena* arena, int agent, int kind, agz_net* net
 /* agent `agent` holds a host inferencer (AGZ_INF_CALLBACK, above).  policy_len >= the game's ActionSpace (<= 4096).  Setting another
  * kind with agz_arena_set_inferencer removes it. */
 int agz_arena_set_inferencer_callback(agz_arena* arena, int agent, agz_infer_fn fn, void* user, int policy_len);
-/* What a FULL node pool means.  AGZ_POOL_STRICT (default): the tree stops growing, agz_arena_stats.tree_full counts it, and agz_arena_play /
+/* What a FULL node pool means (default: AGZ_POOL_GROW when the arena was created with max_nodes = 0, AGZ_POOL_STRICT with an explicit
+ * max_nodes).  AGZ_POOL_STRICT: the tree stops growing, agz_arena_stats.tree_full counts it, and agz_arena_play /
  * agz_arena_selfplay / agz_mcts_search fail with AGZ_E_TREE_FULL — nothing is silently truncated, and every parity test runs this way.
  * AGZ_POOL_STOP_SEARCH: the reference's own rule — a tree at MAXTREESIZE stops being searched for that move and the game goes on
  * (search.go:23,78,229) — with max_nodes in MAXTREESIZE's place: the move is the best of the truncated search, the next move re-roots into
