@@ -46,6 +46,7 @@ FP16X2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
 MODES = {"f32": capi.COMPUTE_F32_MFMA, "bf16x3": capi.COMPUTE_BF16X3, "fp16x2": capi.COMPUTE_FP16X2, "wino": capi.COMPUTE_WINO,
          "wino_h2": capi.COMPUTE_WINO_H2}
 HBM_PEAK_GBS = 8000.0          # same guide: HBM3E ~8 TB/s
+N_ONE_QUEUE_STEPS = 24         # bracketed one-queue steps after the timed region: the roofline's per-kernel durations (round 5: 6 — 120 launches, a noisy sample)
 
 
 def standard_bn_init(net):
@@ -817,8 +818,11 @@ def main():
     if two_queues:
         for n_ in nets:
             n_.set_tower_queues(1)
+    for _ in range(2):      # (settle on the one-queue plan before the bracketed steps)
+        step()
+    fence()
     ctx.prof_enable(True)
-    for _ in range(6):
+    for _ in range(N_ONE_QUEUE_STEPS):
         step()
     fence()
     ctx.prof_enable(False)
@@ -841,8 +845,8 @@ def main():
         prof[name] = {"launches": n, "avg_ms": (ms / n) if n else None, "total_ms": ms}
     dom_name = "wino_gemm" if args.compute in ("wino", "wino_h2") else "conv_dual"
     prof[dom_name + "_timed_region"] = {"launches": dom_n, "avg_ms": (dom_ms / dom_n) if dom_n else None, "total_ms": dom_ms}
-    prof["breakdown_note"] = ("all classes: six extra steps after the timed region%s; *_timed_region: HIP events inside the timed region"
-                              % (" on ONE queue (the timed region runs the tower on two)" if two_queues else ""))
+    prof["breakdown_note"] = ("all classes: %d extra steps after the timed region%s; *_timed_region: HIP events inside the timed region"
+                              % (N_ONE_QUEUE_STEPS, " on ONE queue (the timed region runs the tower on two)" if two_queues else ""))
     if not in_region_prof:
         prof[dom_name + "_timed_region"] = {"launches": 0, "avg_ms": None, "total_ms": 0.0}
 
@@ -1124,7 +1128,7 @@ def main():
                          "launches": n_launch,
                          "timing": ("HIP events on the launch stream around every %d-th launch of the kernel inside the timed region "
                                     "(%d launches bracketed)" % (args.prof_stride, n_launch)) if in_region_prof else
-                                   ("HIP events on the launch stream around every launch of the kernel on six ONE-queue steps right after "
+                                   ("HIP events on the launch stream around every launch of the kernel on 24 ONE-queue steps right after "
                                     "the timed region (%d launches): the timed region runs the tower on two queues (agz_net_set_tower_queues), "
                                     "where the half-batch chains overlap and a kernel's own duration is not defined; "
                                     "`bench.py --tower-queues 1` measures the same kernel inside the timed region" % n_launch) if two_queues else
