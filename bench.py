@@ -697,6 +697,7 @@ def main():
                     help="debug: all ranks use GPU 0 and gloo collectives (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--print-launch", action="store_true", help="print the re-launch command for --gpus N (JSON list) and exit")
     args = ap.parse_args()
+    t_process = time.perf_counter()
 
     # `python bench.py --gpus N` (N > 1) outside a launcher: become the N-rank job (one process per GPU over RCCL)
     cmd = launcher_command([a_ for a_ in sys.argv[1:] if a_ != "--print-launch"], args.gpus, os.environ)
@@ -1226,6 +1227,8 @@ def main():
                 out["cpu_baseline"]["ran_on"] = "rank 0 only, once, after the timed region (the other %d rank(s) idle in a barrier)" % (world - 1)
             except Exception as e:  # the oracle is only the baseline leg; never the measured path
                 out["cpu_baseline"] = {"value": None, "unit": "sims/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        # this process's own clock from argument parsing to the line (the legs outside the timed region included; imports excluded)
+        out["extra"]["bench_wall_seconds"] = time.perf_counter() - t_process
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if gather_hung:
