@@ -519,6 +519,8 @@ def test_headline_budget_800_hash_inferencer_24_watched_games_bit_exact(ctx):
     oracle's cost is then MCTS only — and 24 watched games spread over the opening depths (0 .. 216 moves) and both colours: every watched
     root after every ply (children, visits, blackScores bits, prior bits), every move, and the finished examples of the watched games."""
     G, budget, seed = 512, 800, 99
+    # (soak knobs: AGZ_HEADLINE_PLIES / AGZ_HEADLINE_WATCH run the same comparison longer and wider — profiles/r06/headline_depth_soak.txt)
+    plies, n_watch = int(os.environ.get("AGZ_HEADLINE_PLIES", "3")), int(os.environ.get("AGZ_HEADLINE_WATCH", "24"))
     dev = A.Arena(ctx, capi.GAME_WQ, S, S, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=seed, Budget=budget)
     dev.set_inferencer(0, capi.INF_HASH)
     dev.set_inferencer(1, capi.INF_HASH)
@@ -527,8 +529,8 @@ def test_headline_budget_800_hash_inferencer_24_watched_games_bit_exact(ctx):
     rng = np.random.default_rng(seed)
     n_moves = rng.integers(0, 217, size=G).astype(np.int32)
     order = np.argsort(n_moves, kind="stable")
-    watch = sorted(set(int(order[i]) for i in np.linspace(0, G - 1, 24).round().astype(int)))
-    assert len(watch) == 24
+    watch = sorted(set(int(order[i]) for i in np.linspace(0, G - 1, n_watch).round().astype(int)))
+    assert len(watch) == n_watch
     dev.random_moves(n_moves, seed)
     orcs = {}
     for g in watch:
@@ -540,7 +542,7 @@ def test_headline_budget_800_hash_inferencer_24_watched_games_bit_exact(ctx):
         np.testing.assert_array_equal(dev.history(g), o.history())
         orcs[g] = o
     from concurrent.futures import ThreadPoolExecutor
-    for ply in range(3):
+    for ply in range(plies):
         dev.begin_move()
         dev.simulate(budget)
         dev.end_move(True)
@@ -561,7 +563,8 @@ def test_headline_budget_800_hash_inferencer_24_watched_games_bit_exact(ctx):
             if ply == 2:
                 assert int(ovis.sum()) > budget + len(ovis)          # the re-rooted tree kept visits from ply 0
     st = dev.stats()
-    assert st["tree_full"] == 0 and st["sims_total"] == 3 * G * budget
+    assert st["tree_full"] == 0 and st["sims_total"] == plies * G * budget
+    print("\n[headline depth, hash] %d plies x %d watched games of %d at Budget %d: bit-exact; nodes per pool now %r" % (plies, n_watch, G, budget, dev.pool_capacity()))
     dev.close()
 
 

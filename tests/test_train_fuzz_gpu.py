@@ -46,12 +46,17 @@ def test_random_trainer_shape(ctx, seed):
         # (profiles/r05/fuzz_soak.txt, seed 560359): 1e-4 there
         cost_tol = 4e-5 if B * H * W >= 64 else 1e-4
         assert abs(cd - co) <= cost_tol * max(1.0, abs(co)), (cd, co, shape)
+        # gradients: 2e-5 of a tensor's maximum — except under the same fewer-than-64-samples BatchNorm, where the ORACLE's own fp32
+        # gradients sit 3.0e-5 / 3.5e-5 from float64 autograd (seed 2100290: BatchSize 1 on a 3x3 board, statistics over 9 values, true-fp32
+        # device path 3.4e-5 from the oracle on both draws; scripts/debug/oracle_train_vs_f64.py, profiles/r06/fuzz_soak.txt): two fp32
+        # evaluations each that far from the exact value -> 8e-5 between them
+        grad_tol = 2e-5 if B * H * W >= 64 else 8e-5
         bad = []
         for i in range(ot.num_params()):
             go, gd = ot.get_grad(i), dt.get_grad(i)
             scale = float(np.abs(go).max())
             err = float(np.abs(gd - go).max())
-            if err > 2e-5 * scale + 1e-7:
+            if err > grad_tol * scale + 1e-7:
                 bad.append((ot.param_name(i), err, scale))
         if not bad:
             return
