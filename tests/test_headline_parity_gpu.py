@@ -550,7 +550,7 @@ def test_headline_budget_800_hash_inferencer_24_watched_games_bit_exact(ctx):
         for g, o in orcs.items():
             _, st0 = o.state()
             agents[g] = 0 if ((st0["to_move"] == O.BLACK) == bool(ab[g])) else 1
-        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:      # (the oracle calls run outside the GIL)
+        with ThreadPoolExecutor(max_workers=min(int(os.environ.get("AGZ_HEADLINE_THREADS", "8")), os.cpu_count() or 2)) as ex:      # (the oracle calls run outside the GIL)
             list(ex.map(lambda o: o.step(True), orcs.values()))
         for g, o in orcs.items():
             omv, ovis, obs, opr = o.root_children(agents[g])
@@ -562,8 +562,10 @@ def test_headline_budget_800_hash_inferencer_24_watched_games_bit_exact(ctx):
             assert dev.history(g)[-1] == o.history()[-1]
             if ply == 2:
                 assert int(ovis.sum()) > budget + len(ovis)          # the re-rooted tree kept visits from ply 0
+        if plies > 3 and ply % 8 == 7:
+            print("[headline depth, hash] ply %d: %d watched games equal so far" % (ply + 1, len(orcs)), flush=True)
     st = dev.stats()
-    assert st["tree_full"] == 0 and st["sims_total"] == plies * G * budget
+    assert st["tree_full"] == 0 and (st["sims_total"] == plies * G * budget if plies == 3 else st["sims_total"] <= plies * G * budget)   # (a long soak sees games end)
     print("\n[headline depth, hash] %d plies x %d watched games of %d at Budget %d: bit-exact; nodes per pool now %r" % (plies, n_watch, G, budget, dev.pool_capacity()))
     dev.close()
 
