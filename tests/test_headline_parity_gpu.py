@@ -480,36 +480,47 @@ def test_headline_budget_800_three_plies_on_the_measured_network_bit_exact(ctx):
         p, v = net.infer(np.repeat(planes.reshape(1, F, S, S), nb, axis=0))
         return p[0], float(v[0])
 
-    o = O.Arena(O.WQ, S, S, 0, 7.5, enc=O.ENC_WQ, Budget=budget, seed=seed + g)
-    o.set_callback(0, cb, ASPACE)
-    o.set_callback(1, cb, ASPACE)
-    o.begin(int(ab[g]))
-    _replay_opening(o, seed, g, n_moves[g])
-    np.testing.assert_array_equal(dev.history(g), o.history())
+    # (soak knobs: AGZ_HEADLINE_NET_PLIES plies, AGZ_HEADLINE_NET_WATCH further watched games besides game 137 — profiles/r06/headline_depth_soak.txt)
+    plies = int(os.environ.get("AGZ_HEADLINE_NET_PLIES", "3"))
+    extra = int(os.environ.get("AGZ_HEADLINE_NET_WATCH", "0"))
+    watch = [g] + [w for w in range(5, G, max(1, G // max(extra, 1)))if w != g][:extra]
+    orcs = {}
+    for w in watch:
+        o = O.Arena(O.WQ, S, S, 0, 7.5, enc=O.ENC_WQ, Budget=budget, seed=seed + w)
+        o.set_callback(0, cb, ASPACE)
+        o.set_callback(1, cb, ASPACE)
+        o.begin(int(ab[w]))
+        _replay_opening(o, seed, w, n_moves[w])
+        np.testing.assert_array_equal(dev.history(w), o.history())
+        orcs[w] = o
     root_visits, nodes, preps = [], [], []
-    for ply in range(3):
+    for ply in range(plies):
         dev.begin_move()
         preps.append(dev.last_prep_batch())
         dev.simulate(budget)
         dev.end_move(True)
-        _, st0 = o.state()
-        agent = 0 if ((st0["to_move"] == O.BLACK) == bool(ab[g])) else 1
-        o.step(True)
-        omv, ovis, obs, opr = o.root_children(agent)
-        dmv, dvis, dbs, dpr = dev.root_children(g, agent)
-        np.testing.assert_array_equal(dmv, omv, err_msg="ply %d" % ply)
-        np.testing.assert_array_equal(dvis, ovis, err_msg="ply %d" % ply)
-        np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
-        np.testing.assert_array_equal(dpr.view(np.uint32), opr.view(np.uint32))
-        assert dev.history(g)[-1] == o.history()[-1]
-        root_visits.append(int(ovis.sum()))
-        nodes.append(dev.tree_nodes(g, agent))
+        for w, o in orcs.items():
+            _, st0 = o.state()
+            agent = 0 if ((st0["to_move"] == O.BLACK) == bool(ab[w])) else 1
+            o.step(True)
+            omv, ovis, obs, opr = o.root_children(agent)
+            dmv, dvis, dbs, dpr = dev.root_children(w, agent)
+            np.testing.assert_array_equal(dmv, omv, err_msg="game %d ply %d" % (w, ply))
+            np.testing.assert_array_equal(dvis, ovis, err_msg="game %d ply %d" % (w, ply))
+            np.testing.assert_array_equal(dbs.view(np.uint32), obs.view(np.uint32))
+            np.testing.assert_array_equal(dpr.view(np.uint32), opr.view(np.uint32))
+            assert dev.history(w)[-1] == o.history()[-1]
+            if w == g:
+                root_visits.append(int(ovis.sum()))
+                nodes.append(dev.tree_nodes(g, agent))
+        if plies > 3:
+            print("[headline depth, network] ply %d: %d watched games equal so far" % (ply + 1, len(orcs)), flush=True)
     st = dev.stats()
-    assert st["tree_full"] == 0 and st["sims_total"] == 3 * G * budget
+    assert st["tree_full"] == 0 and (st["sims_total"] == plies * G * budget if plies == 3 else st["sims_total"] <= plies * G * budget)
     assert root_visits[0] >= budget and root_visits[2] > root_visits[0], root_visits   # ply 3: this search's 800 on top of the kept subtree
     assert min(nodes) > 100000, nodes
     assert preps[0] == (G, G) and 0 < preps[2][1] < G and preps[2][0] <= G, preps     # the re-rooted ply: only the roots without children
-    print("\n[headline depth] budget 800 x 3 plies: root visits %r, tree nodes %r, prepareRoot batches %r" % (root_visits, nodes, preps))
+    print("\n[headline depth] budget 800 x %d plies, %d watched game(s): root visits %r, tree nodes %r, prepareRoot batches %r" % (plies, len(watch), root_visits, nodes, preps))
     dev.close()
     net.close()
 
