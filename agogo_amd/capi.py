@@ -598,7 +598,9 @@ class Arena:
         self._nets.append(cfn)      # keeps the trampoline alive as long as the arena
 
     def set_pool_policy(self, policy):
-        """POOL_STRICT (default: a full node pool fails play / selfplay) or POOL_STOP_SEARCH (the reference's MAXTREESIZE rule: the game goes on)"""
+        """POOL_STRICT (a full node pool fails play / selfplay; the default with an explicit max_nodes), POOL_STOP_SEARCH (the reference's
+        MAXTREESIZE rule: the search ends early, the game goes on) or POOL_GROW (pools re-allocated before a search could outgrow them; the default
+        when the library sized the pools, max_nodes = 0) — include/agz.h"""
         _check(lib().agz_arena_set_pool_policy(self.h, int(policy)), "agz_arena_set_pool_policy")
 
     def reset(self, a_is_black=None):
