@@ -615,7 +615,8 @@ def test_config4_budget_1600_one_tree_bit_exact_vs_oracle(ctx, lanes, forced):
 
     orc.set_callback(cb, ASPACE)
     vis_sum = []
-    for turn in range(2):
+    turns = int(os.environ.get("AGZ_CONFIG4_TURNS", "2"))     # (soak knob: more turns on the same handle — profiles/r06/headline_depth_soak.txt)
+    for turn in range(turns):
         dev.set_game(board=g.board(), to_move=player, n_moves=len(moves), passes=0, hash=g.hash(), last_moves=moves,
                      historical=np.array(boards[-8:], np.int32))
         orc.set_game(g)
@@ -636,5 +637,7 @@ def test_config4_budget_1600_one_tree_bit_exact_vs_oracle(ctx, lanes, forced):
     assert vis_sum[1] > budget + 362      # turn 2 searched a re-rooted tree (the kept subtree's visits on top of its own 1600)
     assert dev.stats()["tree_full"] == 0
     assert dev.nodes() > 100000
+    if turns > 2:
+        print("\n[configs[4] depth] lanes %d: %d turns at Budget %d bit-exact; root visits %r" % (lanes, turns, budget, vis_sum))
     dev.close()
     net.close()
