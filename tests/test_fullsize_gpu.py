@@ -326,7 +326,7 @@ def test_complete_19x19_games_histories_labels_and_examples_match_the_oracle(ctx
     16 with the per-tree RNG streams, DontPreferPass) — for 48 concurrent games; four watched games against oracle arenas played the same
     way: the whole move list (several hundred moves, randomised opening included), how the game ended, the winner, and every example row
     with its final label (planes, one-hot policy, value +1 / -1 / 0 from the winner: arena.go:146-155) bit for bit."""
-    S, G, budget, seed = 19, 48, 8, 4242
+    S, G, budget, seed = 19, 48, int(os.environ.get("AGZ_COMPLETE_BUDGET", "8")), 4242     # (soak knobs: Budget, watched games, oracle threads)
     kw = dict(Budget=budget, RandomCount=16, RandomMinVisits=1, RandomTemperature=1.0, DumbPass=True, PassPreference=capi.DONT_PREFER_PASS)
     dev = A.Arena(ctx, capi.GAME_WQ, S, S, 0, 7.5, encoder=capi.ENC_WQ, n_games=G, seed=seed, **kw)
     dev.set_inferencer(0, capi.INF_HASH)
@@ -339,7 +339,7 @@ def test_complete_19x19_games_histories_labels_and_examples_match_the_oracle(ctx
     lens = np.array([len(dev.history(g)) for g in range(G)])
     assert len({dev.history(g).tobytes() for g in range(G)}) == G            # every game its own (RandomCount)
     dp, dpol, dval, dgi = dev.examples()
-    watch = (0, 13, 31, 47)
+    watch = (0, 13, 31, 47) if "AGZ_COMPLETE_WATCH" not in os.environ else tuple(range(0, G, max(1, G // int(os.environ["AGZ_COMPLETE_WATCH"]))))
     from concurrent.futures import ThreadPoolExecutor
 
     def oracle_game(g):
@@ -350,7 +350,7 @@ def test_complete_19x19_games_histories_labels_and_examples_match_the_oracle(ctx
         o.play(0, True)
         return o
 
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+    with ThreadPoolExecutor(max_workers=min(int(os.environ.get("AGZ_HEADLINE_THREADS", "8")), os.cpu_count() or 2)) as ex:
         orcs = dict(zip(watch, ex.map(oracle_game, watch)))
     ends = {"two_passes": 0, "cap": 0, "other": 0}
     for g, o in orcs.items():
@@ -367,5 +367,5 @@ def test_complete_19x19_games_histories_labels_and_examples_match_the_oracle(ctx
         np.testing.assert_array_equal(dval[sel], ov)
         assert set(np.unique(ov)) <= {-1.0, 0.0, 1.0}
         ends["two_passes" if (len(oh) >= 2 and oh[-1] == capi.PASS and oh[-2] == capi.PASS) else "cap" if len(oh) >= 2 * S * S else "other"] += 1
-    print("\n[complete 19x19 games] lengths min %d mean %.1f max %d; watched endings %r" % (lens.min(), lens.mean(), lens.max(), ends))
+    print("\n[complete 19x19 games] Budget %d, %d watched of %d: lengths min %d mean %.1f max %d; watched endings %r" % (budget, len(watch), G, lens.min(), lens.mean(), lens.max(), ends))
     dev.close()
